@@ -1,0 +1,167 @@
+/*
+ * mtadgat.h -- C ABI of the MI355X-native MTAD-GAT per-window forward path.
+ *
+ * The reference (ML4ITS/mtad-gat-pytorch) is pure Python on PyTorch and has no
+ * FFI of its own; the interface this library replaces is the Python call
+ *
+ *     predictions, recons = MTAD_GAT.forward(x)          reference mtad_gat.py:64-79
+ *
+ * and, stage by stage, the nn.Module.forward() methods it is made of
+ * (reference modules.py, cited per entry point below).  The Python module
+ * `mtad-gat-pytorch_amd/mtad_gat.py` mirrors the reference class on top of this
+ * ABI through ctypes; any other host language binds the
+ * same symbols.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a
+ *     negative mtadgat_status; mtadgat_last_error() gives the message
+ *     (thread-local).  Nothing throws across the boundary.
+ *   - all tensors are float32, row-major contiguous, in the reference's own
+ *     shapes; `*_dev` pointers are device (HBM) pointers owned by the caller,
+ *     `*_host` pointers are host pointers.
+ *   - every launch goes to the HIP stream the caller passes (a hipStream_t cast
+ *     to void*; NULL = the null stream) and nothing synchronises the device.
+ *   - the library keeps no per-call state besides the packed weights held by
+ *     the handle; one handle may be used from one thread at a time.
+ *   - gfx950 only.  There is no CPU implementation behind this ABI.
+ */
+#ifndef MTADGAT_H
+#define MTADGAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTADGAT_ABI_VERSION 1
+#define MTADGAT_MAX_LAYERS 8
+
+typedef enum mtadgat_status {
+    MTADGAT_OK = 0,
+    MTADGAT_ERR_INVALID = -1,      /* bad argument / inconsistent shapes         */
+    MTADGAT_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels cover       */
+    MTADGAT_ERR_HIP = -3,          /* a HIP runtime call failed                  */
+    MTADGAT_ERR_NOWEIGHTS = -4,    /* forward before mtadgat_load_weights        */
+    MTADGAT_ERR_WORKSPACE = -5     /* workspace pointer NULL or too small        */
+} mtadgat_status;
+
+/* Model hyper-parameters: the constructor arguments of reference
+ * MTAD_GAT.__init__ (mtad_gat.py:37-54) after the defaulting that
+ * modules.py:36-63 / :137-164 apply. */
+typedef struct mtadgat_config {
+    int32_t n_features;       /* F  (mtad_gat.py:39)                                   */
+    int32_t window_size;      /* W  (mtad_gat.py:40)                                   */
+    int32_t out_dim;          /* mtad_gat.py:41                                        */
+    int32_t kernel_size;      /* odd; ConvLayer pads (k-1)/2, modules.py:14            */
+    int32_t use_gatv2;        /* 1: GATv2 (modules.py:74-77), 0: GAT (modules.py:80-83)*/
+    int32_t feat_embed;       /* rows of feature_gat.lin.weight  (doubled already for v2, modules.py:47-50) */
+    int32_t time_embed;       /* rows of temporal_gat.lin.weight (modules.py:148-151)  */
+    int32_t gru_n_layers;     /* modules.py:233                                        */
+    int32_t gru_hid_dim;
+    int32_t forecast_n_linear;/* number of nn.Linear in Forecasting_Model = n_layers+1 (modules.py:297-301) */
+    int32_t forecast_hid_dim;
+    int32_t recon_n_layers;   /* modules.py:253                                        */
+    int32_t recon_hid_dim;
+    float   alpha;            /* LeakyReLU negative slope (modules.py:62,163)          */
+} mtadgat_config;
+
+/* The reference's parameters (its state_dict, mtad_gat.py:56-62), as host
+ * pointers to float32 arrays in the reference's own shapes. */
+typedef struct mtadgat_params {
+    const float* conv_weight;      /* conv.conv.weight   (F, F, k)                     */
+    const float* conv_bias;        /* conv.conv.bias     (F)                           */
+    const float* feat_lin_weight;  /* feature_gat.lin.weight  v2 (E_f, 2W)  v1 (E_f, W)*/
+    const float* feat_lin_bias;    /* feature_gat.lin.bias    (E_f)                    */
+    const float* feat_a;           /* feature_gat.a           v2 (E_f,1)   v1 (2E_f,1) */
+    const float* feat_bias;        /* feature_gat.bias        (F, F)                   */
+    const float* temp_lin_weight;  /* temporal_gat.lin.weight v2 (E_t, 2F)  v1 (E_t, F)*/
+    const float* temp_lin_bias;    /* temporal_gat.lin.bias   (E_t)                    */
+    const float* temp_a;           /* temporal_gat.a          v2 (E_t,1)   v1 (2E_t,1) */
+    const float* temp_bias;        /* temporal_gat.bias       (W, W)                   */
+    /* gru.gru.{weight_ih,weight_hh,bias_ih,bias_hh}_l<i>; gate order r|z|n            */
+    const float* gru_w_ih[MTADGAT_MAX_LAYERS];   /* (3H, 3F) for l0, (3H, H) after     */
+    const float* gru_w_hh[MTADGAT_MAX_LAYERS];   /* (3H, H)                            */
+    const float* gru_b_ih[MTADGAT_MAX_LAYERS];   /* (3H)                               */
+    const float* gru_b_hh[MTADGAT_MAX_LAYERS];   /* (3H)                               */
+    /* forecasting_model.layers.<i>.{weight,bias}                                      */
+    const float* fc_weight[MTADGAT_MAX_LAYERS];
+    const float* fc_bias[MTADGAT_MAX_LAYERS];
+    /* recon_model.decoder.rnn.*_l<i>                                                  */
+    const float* rec_w_ih[MTADGAT_MAX_LAYERS];   /* (3Hr, H) for l0, (3Hr, Hr) after   */
+    const float* rec_w_hh[MTADGAT_MAX_LAYERS];
+    const float* rec_b_ih[MTADGAT_MAX_LAYERS];
+    const float* rec_b_hh[MTADGAT_MAX_LAYERS];
+    const float* rec_fc_weight;    /* recon_model.fc.weight (out, Hr)                  */
+    const float* rec_fc_bias;      /* recon_model.fc.bias   (out)                      */
+} mtadgat_params;
+
+typedef struct mtadgat_handle_s* mtadgat_handle;
+
+int         mtadgat_abi_version(void);
+const char* mtadgat_last_error(void);
+
+/* Replaces MTAD_GAT.__init__ (mtad_gat.py:37-62): validates the configuration. */
+int mtadgat_create(const mtadgat_config* cfg, mtadgat_handle* out);
+int mtadgat_destroy(mtadgat_handle h);
+
+/* Replaces load_state_dict / the in-place parameter update seen by forward()
+ * (training.py:127, :248; utils.py:189): re-packs the parameters into the
+ * kernels' tile format on the host and uploads them on `stream`.  Call again
+ * whenever a parameter changed. */
+int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, void* stream);
+
+/* Bytes of device scratch forward() needs for a batch of `batch` windows
+ * (intermediates of at most mtadgat_chunk_windows() windows are live at once). */
+size_t  mtadgat_workspace_bytes(mtadgat_handle h, int64_t batch);
+int64_t mtadgat_chunk_windows(mtadgat_handle h);
+int     mtadgat_set_chunk_windows(mtadgat_handle h, int64_t windows);
+
+/* Replaces MTAD_GAT.forward (mtad_gat.py:64-79), eval mode.
+ *   x_dev      (batch, W, F)          in, not modified
+ *   preds_dev  (batch, out_dim)       out   (may be NULL: skip both heads if recons_dev is NULL too)
+ *   recons_dev (batch, W, out_dim)    out
+ *   hend_dev   (batch, gru_hid_dim)   out, optional (NULL to skip): h_end of mtad_gat.py:74 */
+int mtadgat_forward(mtadgat_handle h, const float* x_dev, int64_t batch,
+                    float* preds_dev, float* recons_dev, float* hend_dev,
+                    void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- stage entry points (the reference's sub-module forward() calls) ---------
+ * Same workspace / stream contract; each is what forward() runs for that stage. */
+
+/* ConvLayer.forward, modules.py:18-22: x (batch,W,F) -> y (batch,W,F). */
+int mtadgat_conv(mtadgat_handle h, const float* x_dev, int64_t batch, float* y_dev,
+                 void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* FeatureAttentionLayer.forward (modules.py:65-95) when which == 0,
+ * TemporalAttentionLayer.forward (modules.py:166-193) when which == 1:
+ * xc (batch,W,F) -> h (batch,W,F). */
+int mtadgat_gat(mtadgat_handle h, int which, const float* xc_dev, int64_t batch, float* h_dev,
+                void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* GRULayer.forward, modules.py:235-238: h_cat (batch,W,3F) -> h_end (batch,H)
+ * (the h[-1] the reference keeps; its out[-1] is discarded by mtad_gat.py:73). */
+int mtadgat_gru(mtadgat_handle h, const float* hcat_dev, int64_t batch, float* hend_dev,
+                void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Forecasting_Model.forward (modules.py:307-311) and ReconstructionModel.forward
+ * (modules.py:276-283): h_end (batch,H) -> preds (batch,out), recons (batch,W,out). */
+int mtadgat_heads(mtadgat_handle h, const float* hend_dev, int64_t batch,
+                  float* preds_dev, float* recons_dev,
+                  void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Per-kernel launch timing for bench.py's roofline leg: when enabled, forward()
+ * brackets each kernel family with hipEvents on `stream`; mtadgat_profile_read
+ * synchronises those events and returns accumulated milliseconds + launch counts
+ * since the last read.  names: "conv","proj","attend","gru","fc","recon". */
+#define MTADGAT_PROFILE_SLOTS 6
+int mtadgat_profile_enable(mtadgat_handle h, int on);
+int mtadgat_profile_read(mtadgat_handle h, double ms[MTADGAT_PROFILE_SLOTS],
+                         int64_t launches[MTADGAT_PROFILE_SLOTS]);
+const char* mtadgat_profile_name(int slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTADGAT_H */

@@ -1,0 +1,232 @@
+"""ctypes binding of the C ABI in include/mtadgat.h (libmtadgat.so, gfx950 HIP kernels).
+
+PyTorch is used for device memory and the current HIP stream only.  There is no
+fallback: if the library is missing or the tensors are not on a HIP device the
+calls raise.
+"""
+import ctypes
+import os
+
+import torch  # must be imported before the library: both bind libamdhip64.so.7, torch's copy wins
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmtadgat.so")
+MAX_LAYERS = 8
+PROFILE_SLOTS = 6
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+
+
+class Config(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "n_features", "window_size", "out_dim", "kernel_size", "use_gatv2", "feat_embed", "time_embed",
+        "gru_n_layers", "gru_hid_dim", "forecast_n_linear", "forecast_hid_dim", "recon_n_layers",
+        "recon_hid_dim")] + [("alpha", ctypes.c_float)]
+
+
+class Params(ctypes.Structure):
+    _fields_ = (
+        [(n, ctypes.c_void_p) for n in (
+            "conv_weight", "conv_bias", "feat_lin_weight", "feat_lin_bias", "feat_a", "feat_bias",
+            "temp_lin_weight", "temp_lin_bias", "temp_a", "temp_bias")]
+        + [(n, ctypes.c_void_p * MAX_LAYERS) for n in (
+            "gru_w_ih", "gru_w_hh", "gru_b_ih", "gru_b_hh", "fc_weight", "fc_bias",
+            "rec_w_ih", "rec_w_hh", "rec_b_ih", "rec_b_hh")]
+        + [("rec_fc_weight", ctypes.c_void_p), ("rec_fc_bias", ctypes.c_void_p)])
+
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libmtadgat.so (raises with build instructions if it is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: the MI355X HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`python mtad-gat-pytorch_amd/build.py`). There is no non-HIP implementation.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp, i64, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t
+    lib.mtadgat_abi_version.restype = ctypes.c_int
+    lib.mtadgat_last_error.restype = ctypes.c_char_p
+    lib.mtadgat_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+    lib.mtadgat_destroy.argtypes = [vp]
+    lib.mtadgat_load_weights.argtypes = [vp, ctypes.POINTER(Params), vp]
+    lib.mtadgat_workspace_bytes.argtypes = [vp, i64]
+    lib.mtadgat_workspace_bytes.restype = sz
+    lib.mtadgat_chunk_windows.argtypes = [vp]
+    lib.mtadgat_chunk_windows.restype = i64
+    lib.mtadgat_set_chunk_windows.argtypes = [vp, i64]
+    lib.mtadgat_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp, sz, vp]
+    lib.mtadgat_conv.argtypes = [vp, vp, i64, vp, vp, sz, vp]
+    lib.mtadgat_gat.argtypes = [vp, ctypes.c_int, vp, i64, vp, vp, sz, vp]
+    lib.mtadgat_gru.argtypes = [vp, vp, i64, vp, vp, sz, vp]
+    lib.mtadgat_heads.argtypes = [vp, vp, i64, vp, vp, vp, sz, vp]
+    lib.mtadgat_profile_enable.argtypes = [vp, ctypes.c_int]
+    lib.mtadgat_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+    lib.mtadgat_profile_name.argtypes = [ctypes.c_int]
+    lib.mtadgat_profile_name.restype = ctypes.c_char_p
+    if lib.mtadgat_abi_version() != 1:
+        raise RuntimeError("libmtadgat.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().mtadgat_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"mtadgat {what} failed (status {rc}): {msg}")
+
+
+def _dev_ptr(t, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            f"{name} is on '{t.device}': the MI355X HIP path needs tensors on the GPU "
+            "('cuda' = HIP on PyTorch-ROCm); there is no CPU implementation")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One model instance on the native side: packed weights + launch plans."""
+
+    def __init__(self, cfg: dict):
+        self.lib = load_library()
+        self.cfg = Config(**cfg)
+        self.handle = ctypes.c_void_p()
+        _check(self.lib.mtadgat_create(ctypes.byref(self.cfg), ctypes.byref(self.handle)), "create")
+        self._ws = None
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.mtadgat_destroy(self.handle)
+                self.handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    # -- weights ------------------------------------------------------------------------------
+    def load_weights(self, sd, device):
+        """sd: reference-format state_dict (any device); packs on the host, uploads on the current stream."""
+        host = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in sd.items()}
+        p = Params()
+
+        def ptr(key):
+            return ctypes.c_void_p(host[key].data_ptr())
+
+        p.conv_weight, p.conv_bias = ptr("conv.conv.weight"), ptr("conv.conv.bias")
+        p.feat_lin_weight, p.feat_lin_bias = ptr("feature_gat.lin.weight"), ptr("feature_gat.lin.bias")
+        p.feat_a, p.feat_bias = ptr("feature_gat.a"), ptr("feature_gat.bias")
+        p.temp_lin_weight, p.temp_lin_bias = ptr("temporal_gat.lin.weight"), ptr("temporal_gat.lin.bias")
+        p.temp_a, p.temp_bias = ptr("temporal_gat.a"), ptr("temporal_gat.bias")
+        for l in range(self.cfg.gru_n_layers):
+            p.gru_w_ih[l], p.gru_w_hh[l] = ptr(f"gru.gru.weight_ih_l{l}").value, ptr(f"gru.gru.weight_hh_l{l}").value
+            p.gru_b_ih[l], p.gru_b_hh[l] = ptr(f"gru.gru.bias_ih_l{l}").value, ptr(f"gru.gru.bias_hh_l{l}").value
+        for i in range(self.cfg.forecast_n_linear):
+            p.fc_weight[i] = ptr(f"forecasting_model.layers.{i}.weight").value
+            p.fc_bias[i] = ptr(f"forecasting_model.layers.{i}.bias").value
+        for l in range(self.cfg.recon_n_layers):
+            pre = "recon_model.decoder.rnn."
+            p.rec_w_ih[l], p.rec_w_hh[l] = ptr(f"{pre}weight_ih_l{l}").value, ptr(f"{pre}weight_hh_l{l}").value
+            p.rec_b_ih[l], p.rec_b_hh[l] = ptr(f"{pre}bias_ih_l{l}").value, ptr(f"{pre}bias_hh_l{l}").value
+        p.rec_fc_weight, p.rec_fc_bias = ptr("recon_model.fc.weight"), ptr("recon_model.fc.bias")
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _check(self.lib.mtadgat_load_weights(self.handle, ctypes.byref(p), ctypes.c_void_p(stream)), "load_weights")
+        self._keep = host
+
+    # -- scratch ------------------------------------------------------------------------------
+    def _workspace(self, batch, device):
+        need = self.lib.mtadgat_workspace_bytes(self.handle, batch)
+        ws = self._ws
+        if ws is None or ws.device != device or ws.numel() * 4 < need:
+            self._ws = None
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+            self._ws = ws
+        return ws, need
+
+    def set_chunk_windows(self, n):
+        _check(self.lib.mtadgat_set_chunk_windows(self.handle, int(n)), "set_chunk_windows")
+        self._ws = None
+
+    def _call(self, fn, what, device, *args):
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _check(fn(self.handle, *args, stream), what)
+
+    # -- forward ------------------------------------------------------------------------------
+    def forward(self, x, want_hend=False):
+        c = self.cfg
+        b = x.shape[0]
+        xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
+        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=x.device)
+        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=x.device)
+        hend = torch.empty((b, c.gru_hid_dim), dtype=torch.float32, device=x.device) if want_hend else None
+        ws, need = self._workspace(b, x.device)
+        self._call(self.lib.mtadgat_forward, "forward", x.device, xp, b, _dev_ptr(preds, "preds"),
+                   _dev_ptr(recons, "recons"), _dev_ptr(hend, "hend") if want_hend else None,
+                   _dev_ptr(ws, "workspace"), need)
+        return (preds, recons, hend) if want_hend else (preds, recons)
+
+    def conv(self, x):
+        c = self.cfg
+        b = x.shape[0]
+        xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
+        y = torch.empty_like(x)
+        self._call(self.lib.mtadgat_conv, "conv", x.device, xp, b, _dev_ptr(y, "y"), None, 0)
+        return y
+
+    def gat(self, which, xc):
+        c = self.cfg
+        b = xc.shape[0]
+        xp = _dev_ptr(xc, "x", (b, c.window_size, c.n_features))
+        y = torch.empty_like(xc)
+        ws, need = self._workspace(b, xc.device)
+        self._call(self.lib.mtadgat_gat, "gat", xc.device, which, xp, b, _dev_ptr(y, "y"), _dev_ptr(ws, "workspace"), need)
+        return y
+
+    def gru(self, hcat):
+        c = self.cfg
+        b = hcat.shape[0]
+        xp = _dev_ptr(hcat, "h_cat", (b, c.window_size, 3 * c.n_features))
+        hend = torch.empty((b, c.gru_hid_dim), dtype=torch.float32, device=hcat.device)
+        ws, need = self._workspace(b, hcat.device)
+        self._call(self.lib.mtadgat_gru, "gru", hcat.device, xp, b, _dev_ptr(hend, "h_end"), _dev_ptr(ws, "workspace"), need)
+        return hend
+
+    def heads(self, hend, want_preds=True, want_recons=True):
+        c = self.cfg
+        b = hend.shape[0]
+        hp = _dev_ptr(hend, "h_end", (b, c.gru_hid_dim))
+        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=hend.device) if want_preds else None
+        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=hend.device) if want_recons else None
+        ws, need = self._workspace(b, hend.device)
+        self._call(self.lib.mtadgat_heads, "heads", hend.device, hp, b,
+                   _dev_ptr(preds, "preds") if want_preds else None,
+                   _dev_ptr(recons, "recons") if want_recons else None, _dev_ptr(ws, "workspace"), need)
+        return preds, recons
+
+    # -- per-kernel timing (bench.py) ------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _check(self.lib.mtadgat_profile_enable(self.handle, 1 if on else 0), "profile_enable")
+
+    def profile_read(self):
+        ms = (ctypes.c_double * PROFILE_SLOTS)()
+        n = (ctypes.c_int64 * PROFILE_SLOTS)()
+        _check(self.lib.mtadgat_profile_read(self.handle, ms, n), "profile_read")
+        return {self.lib.mtadgat_profile_name(i).decode(): (ms[i], n[i]) for i in range(PROFILE_SLOTS)}

@@ -1,0 +1,39 @@
+"""Build libmtadgat.so (gfx950) in-tree with hipcc.  No torch C++ extension, no JIT cache:
+the .so sits next to this file so it travels with the source tree to the GPU box."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["mtadgat_kernels.hip", "mtadgat_pack.cpp", "mtadgat_capi.cpp"]
+HEADERS = ["mtadgat_kernels.h", "mtadgat_host.h", os.path.join("..", "..", "include", "mtadgat.h")]
+LIB = os.path.join(HERE, "libmtadgat.so")
+# -fno-slp-vectorize: keep the attention inner loop as single-issue v_add_f32 (2 VALU/element);
+# SLP packing into v_pk_add_f32 costs 3 VALU/element there.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    """Compile the HIP kernels + C ABI into libmtadgat.so; returns the library path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print("[mtadgat] " + " ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,408 @@
+// C ABI (include/mtadgat.h) over the gfx950 kernels: handle lifetime, weight upload,
+// the forward() launch sequence and the per-stage entry points.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "mtadgat_host.h"
+
+using namespace mtadgat;
+
+struct mtadgat_handle_s {
+    Model m;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return MTADGAT_ERR_HIP;
+}
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t e__ = (expr);                             \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);  \
+    } while (0)
+#define K_TRY(expr, what)                                                                          \
+    do {                                                                                           \
+        int rc__ = (expr);                                                                         \
+        if (rc__ == -2) return fail(MTADGAT_ERR_UNSUPPORTED, std::string(what) + ": unsupported shape"); \
+        if (rc__ != 0) return hip_fail((hipError_t)rc__, what);                                    \
+    } while (0)
+
+enum Slot { S_CONV = 0, S_PROJ = 1, S_ATTEND = 2, S_GRU = 3, S_FC = 4, S_RECON = 5 };
+const char* kSlotNames[MTADGAT_PROFILE_SLOTS] = {"conv", "proj", "attend", "gru", "fc", "recon"};
+
+struct Scope {  // brackets a kernel family with events when profiling is on
+    Model& m;
+    int slot;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    Scope(Model& m_, int slot_, hipStream_t s_) : m(m_), slot(slot_), s(s_) {
+        if (m.profile) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~Scope() {
+        if (a && b) {
+            (void)hipEventRecord(b, s);
+            m.ev[slot].emplace_back(a, b);
+        }
+    }
+};
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- stage launch helpers; all pointers device, n windows ------------------------------------
+int run_conv(Model& m, const float* x, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s) {
+    Scope sc(m, S_CONV, s);
+    ConvArgs a{};
+    a.X = x; a.B = n; a.W = m.W; a.F = m.F; a.Fp = m.Fp; a.taps = m.taps; a.pad = m.pad;
+    a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w_off);
+    a.bias = m.packed_dev + m.conv_b_off;
+    a.NT = m.convNT;
+    a.XC = xc; a.XCT = xct; a.Wpad = m.Wp; a.HCAT = hcat; a.Dp = m.Dp; a.Y = y;
+    K_TRY(launch_conv(a, s), "conv");
+    return 0;
+}
+
+int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nrows, float* lr, hipStream_t s) {
+    Scope sc(m, S_PROJ, s);
+    RowGemmArgs a{};
+    a.X = rows; a.ldx = ld; a.Kvalid = g.D; a.Q = g.Q;
+    a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
+    a.bias = m.packed_dev + g.b_off;
+    a.Y = lr; a.ldy = g.ldo; a.Nvalid = g.ldo; a.vec_store = 1;
+    a.R = nrows; a.NT = g.NT; a.relu = 0;
+    K_TRY(launch_rowgemm(a, s), "gat projection");
+    return 0;
+}
+
+int run_attend(Model& m, const GatPlan& g, const float* lr, const float* v, int ldv, int64_t n, float* out, long so_w,
+               long so_i, long so_d, hipStream_t s) {
+    Scope sc(m, S_ATTEND, s);
+    AttendArgs a{};
+    a.LR = lr; a.ldo = g.ldo; a.PT = g.PT; a.P8 = g.P8;
+    a.bias = m.packed_dev + g.bias_off;
+    a.V = v; a.ldv = ldv; a.D = g.D;
+    a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
+    a.K = g.K; a.rows_per_blk = g.rows_per_blk; a.nblk = g.nblk;
+    a.total_blocks = n * g.nblk;
+    a.v1 = m.cfg.use_gatv2 ? 0 : 1;
+    a.alpha = m.cfg.alpha;
+    a.ATT = nullptr;
+    K_TRY(launch_attend(a, g.IB, s), "gat attention");
+    return 0;
+}
+
+// one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
+int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
+                  long ldhe, float* seq, const LinPlan* fc, float* yfc, hipStream_t s) {
+    Scope sc(m, slot, s);
+    GruArgs a{};
+    a.X = x; a.ldx = ldx; a.Kx = kx; a.Qx = g.Qx;
+    a.m0 = g.xmode == 1 ? reinterpret_cast<const int*>(m.packed_dev + g.m0_off) : nullptr;
+    a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx_off);
+    a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
+    a.bias = m.packed_dev + g.b_off;
+    a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
+    a.Hend = hend; a.ldhe = ldhe;
+    a.Seq = seq; a.ldseq = g.Hp;
+    if (fc) {
+        a.Wfc = reinterpret_cast<const f32x4*>(m.packed_dev + fc->w_off);
+        a.bfc = m.packed_dev + fc->b_off;
+        a.NTfc = fc->NT;
+        a.Yfc = yfc;
+        a.out_dim = fc->out_dim;
+    }
+    K_TRY(launch_gru(a, g.NCG, g.xmode, fc != nullptr, s), "gru");
+    return 0;
+}
+
+int run_gru_stack(Model& m, const float* hcat, long ldx, int64_t n, float* hend, long ldhe, float* ws, const Workspace& o,
+                  hipStream_t s) {
+    const int L = (int)m.gru.size();
+    const float* x = hcat;
+    long ld = ldx;
+    int kx = 3 * m.F;
+    for (int l = 0; l < L; ++l) {
+        const bool last = (l == L - 1);
+        float* seq = last ? nullptr : ws + ((l & 1) ? o.seq1 : o.seq0);
+        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, s);
+        if (rc) return rc;
+        x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;
+    }
+    return 0;
+}
+
+int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, float* recons, float* ws, const Workspace& o,
+              hipStream_t s) {
+    if (preds) {
+        Scope sc(m, S_FC, s);
+        const float* x = hend;
+        long ld = ldh;
+        const int nfc = (int)m.fc.size();
+        for (int i = 0; i < nfc; ++i) {
+            const LinPlan& p = m.fc[i];
+            const bool last = (i == nfc - 1);
+            RowGemmArgs a{};
+            a.X = x; a.ldx = ld; a.Kvalid = p.in_dim; a.Q = p.Q;
+            a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
+            a.bias = m.packed_dev + p.b_off;
+            a.R = n; a.NT = p.NT;
+            if (last) {
+                a.Y = preds; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
+                a.vec_store = (p.out_dim % 4 == 0 && aligned16(preds)) ? 1 : 0;
+                a.relu = 0;
+            } else {
+                a.Y = ws + ((i & 1) ? o.fc1 : o.fc0); a.ldy = p.NT * 32; a.Nvalid = p.NT * 32; a.vec_store = 1;
+                a.relu = 1;   // eval mode: dropout is the identity (reference modules.py:309-310)
+            }
+            K_TRY(launch_rowgemm(a, s), "forecasting head");
+            x = a.Y; ld = a.ldy;
+        }
+    }
+    if (recons) {
+        const int L = (int)m.rec.size();
+        const float* x = hend;
+        long ld = ldh;
+        int kx = m.cfg.gru_hid_dim;
+        for (int l = 0; l < L; ++l) {
+            const bool last = (l == L - 1);
+            float* seq = last ? nullptr : ws + ((l & 1) ? o.rseq1 : o.rseq0);
+            int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr,
+                                   last ? recons : nullptr, s);
+            if (rc) return rc;
+            x = seq; ld = m.rec[l].Hp; kx = m.rec[l].H;
+        }
+    }
+    return 0;
+}
+
+int check_common(mtadgat_handle h, int64_t batch, void* ws, size_t ws_bytes, bool need_ws) {
+    if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(MTADGAT_ERR_INVALID, "negative batch");
+    if (!h->m.have_weights) return fail(MTADGAT_ERR_NOWEIGHTS, "mtadgat_load_weights has not been called");
+    if (need_ws && batch > 0) {
+        if (!ws) return fail(MTADGAT_ERR_WORKSPACE, "workspace is NULL");
+        if (!aligned16(ws)) return fail(MTADGAT_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+        if (ws_bytes < mtadgat_workspace_bytes(h, batch)) return fail(MTADGAT_ERR_WORKSPACE, "workspace too small");
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtadgat_abi_version(void) { return MTADGAT_ABI_VERSION; }
+const char* mtadgat_last_error(void) { return g_err.c_str(); }
+
+int mtadgat_create(const mtadgat_config* cfg, mtadgat_handle* out) {
+    if (!cfg || !out) return fail(MTADGAT_ERR_INVALID, "null argument");
+    mtadgat_handle h = new (std::nothrow) mtadgat_handle_s();
+    if (!h) return fail(MTADGAT_ERR_INVALID, "out of host memory");
+    h->m.cfg = *cfg;
+    std::string err = validate_and_plan(h->m);
+    if (!err.empty()) {
+        delete h;
+        return fail(MTADGAT_ERR_UNSUPPORTED, err);
+    }
+    *out = h;
+    return 0;
+}
+
+int mtadgat_destroy(mtadgat_handle h) {
+    if (!h) return 0;
+    if (h->m.packed_dev) (void)hipFree(h->m.packed_dev);
+    for (auto& v : h->m.ev)
+        for (auto& p : v) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    delete h;
+    return 0;
+}
+
+int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream) {
+    if (!h || !p) return fail(MTADGAT_ERR_INVALID, "null argument");
+    Model& m = h->m;
+    std::vector<float> host;
+    std::string err = pack_weights(m, *p, host);
+    if (!err.empty()) return fail(MTADGAT_ERR_INVALID, err);
+    if (!m.packed_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.packed_dev), m.packed_floats * sizeof(float)));
+    hipStream_t s = (hipStream_t)stream;
+    // pageable source: the copy is staged before the call returns, `host` may die afterwards
+    HIP_TRY(hipMemcpyAsync(m.packed_dev, host.data(), m.packed_floats * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    m.have_weights = true;
+    return 0;
+}
+
+int64_t mtadgat_chunk_windows(mtadgat_handle h) { return h ? h->m.chunk : 0; }
+int mtadgat_set_chunk_windows(mtadgat_handle h, int64_t w) {
+    if (!h || w < 1) return fail(MTADGAT_ERR_INVALID, "chunk must be >= 1");
+    h->m.chunk = w;
+    return 0;
+}
+
+size_t mtadgat_workspace_bytes(mtadgat_handle h, int64_t batch) {
+    if (!h || batch <= 0) return 0;
+    Workspace o;
+    plan_workspace(h->m, std::min<int64_t>(batch, h->m.chunk), o);
+    return o.total * sizeof(float);
+}
+
+int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* preds, float* recons, float* hend_out,
+                    void* ws_, size_t ws_bytes, void* stream) {
+    int rc = check_common(h, batch, ws_, ws_bytes, true);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!x) return fail(MTADGAT_ERR_INVALID, "x is NULL");
+    Model& m = h->m;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = static_cast<float*>(ws_);
+    const int F = m.F, W = m.W;
+    for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
+        const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
+        Workspace o;
+        plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
+        const float* xc_in = x + c0 * (int64_t)W * F;
+        float* xc = ws + o.xc;
+        float* xct = ws + o.xct;
+        float* hcat = ws + o.hcat;
+        if ((rc = run_conv(m, xc_in, n, xc, xct, hcat, nullptr, s))) return rc;
+        // temporal layer: nodes = time steps, rows of xc
+        if ((rc = run_proj(m, m.temp, xc, m.Fp, n * W, ws + o.lrt, s))) return rc;
+        // feature layer: nodes = features, rows of xc^T
+        if ((rc = run_proj(m, m.feat, xct, m.Wp, n * F, ws + o.lrf, s))) return rc;
+        if ((rc = run_attend(m, m.temp, ws + o.lrt, xc, m.Fp, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
+        if ((rc = run_attend(m, m.feat, ws + o.lrf, xct, m.Wp, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
+        float* hend = ws + o.hend;
+        const long ldh = m.gru.back().Hp;
+        if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s))) return rc;
+        if (hend_out)
+            K_TRY(launch_copy2d(hend, ldh, hend_out + c0 * m.cfg.gru_hid_dim, m.cfg.gru_hid_dim, n, m.cfg.gru_hid_dim, s),
+                  "h_end copy");
+        if (preds || recons) {
+            if ((rc = run_heads(m, hend, ldh, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
+                                recons ? recons + c0 * (int64_t)W * m.cfg.out_dim : nullptr, ws, o, s)))
+                return rc;
+        }
+    }
+    return 0;
+}
+
+int mtadgat_conv(mtadgat_handle h, const float* x, int64_t batch, float* y, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(h, batch, ws, ws_bytes, false);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!x || !y) return fail(MTADGAT_ERR_INVALID, "null tensor");
+    return run_conv(h->m, x, batch, nullptr, nullptr, nullptr, y, (hipStream_t)stream);
+}
+
+int mtadgat_gat(mtadgat_handle h, int which, const float* xc_in, int64_t batch, float* out, void* ws_, size_t ws_bytes,
+                void* stream) {
+    int rc = check_common(h, batch, ws_, ws_bytes, true);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!xc_in || !out) return fail(MTADGAT_ERR_INVALID, "null tensor");
+    if (which != 0 && which != 1) return fail(MTADGAT_ERR_INVALID, "which must be 0 (feature) or 1 (temporal)");
+    Model& m = h->m;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = static_cast<float*>(ws_);
+    const int F = m.F, W = m.W;
+    for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
+        const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
+        Workspace o;
+        plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
+        const float* xin = xc_in + c0 * (int64_t)W * F;
+        float* o_c = out + c0 * (int64_t)W * F;
+        if (which == 1) {
+            K_TRY(launch_copy2d(xin, F, ws + o.xc, m.Fp, n * W, F, s), "pad copy");
+            if ((rc = run_proj(m, m.temp, ws + o.xc, m.Fp, n * W, ws + o.lrt, s))) return rc;
+            if ((rc = run_attend(m, m.temp, ws + o.lrt, ws + o.xc, m.Fp, n, o_c, (long)W * F, F, 1, s))) return rc;
+        } else {
+            K_TRY(launch_transpose_win(xin, F, ws + o.xct, m.Wp, n, W, F, s), "transpose");
+            if ((rc = run_proj(m, m.feat, ws + o.xct, m.Wp, n * F, ws + o.lrf, s))) return rc;
+            if ((rc = run_attend(m, m.feat, ws + o.lrf, ws + o.xct, m.Wp, n, o_c, (long)W * F, 1, F, s))) return rc;
+        }
+    }
+    return 0;
+}
+
+int mtadgat_gru(mtadgat_handle h, const float* hcat, int64_t batch, float* hend, void* ws_, size_t ws_bytes, void* stream) {
+    int rc = check_common(h, batch, ws_, ws_bytes, true);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!hcat || !hend) return fail(MTADGAT_ERR_INVALID, "null tensor");
+    Model& m = h->m;
+    float* ws = static_cast<float*>(ws_);
+    const int D = 3 * m.F, H = m.cfg.gru_hid_dim;
+    for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
+        const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
+        Workspace o;
+        plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
+        if ((rc = run_gru_stack(m, hcat + c0 * (int64_t)m.W * D, D, n, hend + c0 * H, H, ws, o, (hipStream_t)stream))) return rc;
+    }
+    return 0;
+}
+
+int mtadgat_heads(mtadgat_handle h, const float* hend, int64_t batch, float* preds, float* recons, void* ws_, size_t ws_bytes,
+                  void* stream) {
+    int rc = check_common(h, batch, ws_, ws_bytes, true);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!hend) return fail(MTADGAT_ERR_INVALID, "null tensor");
+    Model& m = h->m;
+    float* ws = static_cast<float*>(ws_);
+    const int H = m.cfg.gru_hid_dim;
+    for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
+        const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
+        Workspace o;
+        plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
+        if ((rc = run_heads(m, hend + c0 * H, H, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
+                            recons ? recons + c0 * (int64_t)m.W * m.cfg.out_dim : nullptr, ws, o, (hipStream_t)stream)))
+            return rc;
+    }
+    return 0;
+}
+
+int mtadgat_profile_enable(mtadgat_handle h, int on) {
+    if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");
+    h->m.profile = on != 0;
+    return 0;
+}
+
+int mtadgat_profile_read(mtadgat_handle h, double ms[MTADGAT_PROFILE_SLOTS], int64_t launches[MTADGAT_PROFILE_SLOTS]) {
+    if (!h || !ms || !launches) return fail(MTADGAT_ERR_INVALID, "null argument");
+    for (int i = 0; i < MTADGAT_PROFILE_SLOTS; ++i) {
+        ms[i] = 0.0;
+        launches[i] = 0;
+        for (auto& p : h->m.ev[i]) {
+            HIP_TRY(hipEventSynchronize(p.second));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, p.first, p.second));
+            ms[i] += t;
+            launches[i] += 1;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        h->m.ev[i].clear();
+    }
+    return 0;
+}
+
+const char* mtadgat_profile_name(int slot) {
+    return (slot >= 0 && slot < MTADGAT_PROFILE_SLOTS) ? kSlotNames[slot] : "";
+}
+
+}  // extern "C"

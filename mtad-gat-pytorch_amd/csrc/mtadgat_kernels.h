@@ -1,0 +1,87 @@
+// Kernel argument blocks and launchers (internal; the public ABI is include/mtadgat.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mtadgat {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Y[r,:] = act(W X[r,:] + bias); W packed as tiles [NT][Q][64 lanes] of float4 (mtadgat_pack.cpp)
+struct RowGemmArgs {
+    const float* X;      // (R, ldx) data rows
+    long ldx;
+    int Kvalid;          // valid input features per row
+    int Q;               // ceil(Kvalid / 8)
+    const f32x4* Wp;     // packed weight tiles
+    const float* bias;   // NT*32 floats (zero padded)
+    float* Y;            // (R, ldy)
+    long ldy;
+    int Nvalid;          // columns stored: [0, Nvalid)
+    int vec_store;       // 1: ldy % 4 == 0 and Y 16-byte aligned
+    long R;
+    int NT;              // output tiles of 32 columns
+    int relu;
+};
+
+struct ConvArgs {
+    const float* X;      // (B, W, F)
+    long B;
+    int W, F, Fp, taps, pad;
+    const f32x4* Wp;     // packed (F x taps*Fp), NT tiles, Q = taps*Fp/8
+    const float* bias;   // NT*32
+    int NT;
+    float* XC;           // (B*W, Fp)   or null
+    float* XCT;          // (B*F, Wp)   or null
+    int Wpad;            // row stride of XCT
+    float* HCAT;         // (B*W, Dp) columns [0,F)   or null
+    int Dp;
+    float* Y;            // (B*W, F) plain output   or null
+};
+
+struct AttendArgs {
+    const float* LR;     // (B*K, ldo): [L'(PT) | R'(PT) | c | d | pad]
+    int ldo, PT, P8;
+    const float* bias;   // (K, K) or null
+    const float* V;      // (B*K, ldv) node feature rows
+    int ldv, D;
+    float* out;          // out[win*so_w + i*so_i + d*so_d]
+    long so_w, so_i, so_d;
+    int K, rows_per_blk, nblk;
+    long total_blocks;   // B * nblk
+    int v1;
+    float alpha;
+    float* ATT;          // optional (B, K, K) dump of the attention matrix
+};
+
+struct GruArgs {
+    const float* X;      // XMODE 0: (B*T, ldx) input rows; XMODE 1: (B, ldx) hin rows
+    long ldx;
+    int Kx;              // valid input features (XMODE 1: valid hin entries)
+    int Qx;              // input chunks per step
+    const int* m0;       // XMODE 1: first hin index used at step t
+    const f32x4* Wx;     // [c][Qx][3][64]  (XMODE 1: [t][c][Qx][3][64])
+    const f32x4* Wh;     // [c][4*NCG][3][64]
+    const float* bias;   // [4][Hp]: b_ir+b_hr | b_iz+b_hz | b_in | b_hn
+    int Hp, H, T;
+    long B;
+    float* Hend;         // (B, ldhe) or null
+    long ldhe;
+    float* Seq;          // (B*T, ldseq) or null
+    long ldseq;
+    const f32x4* Wfc;    // [NTfc][4*NCG][64]
+    const float* bfc;    // NTfc*32
+    int NTfc;
+    float* Yfc;          // (B*T, out_dim)
+    int out_dim;
+};
+
+int launch_rowgemm(const RowGemmArgs& a, hipStream_t s);
+int launch_conv(const ConvArgs& a, hipStream_t s);
+void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
+int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
+int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
+int launch_copy2d(const float* src, long lds, float* dst, long ldd, long R, int ncols, hipStream_t s);
+int launch_transpose_win(const float* src, long lds, float* dst, long ldd, long B, int R, int C, hipStream_t s);
+
+}  // namespace mtadgat

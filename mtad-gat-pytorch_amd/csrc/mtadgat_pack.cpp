@@ -1,0 +1,321 @@
+// Host-side planning and weight packing: reference-format parameters -> the tile
+// streams the gfx950 kernels consume (mtadgat_kernels.hip).  Pure host C++.
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+#include "mtadgat_host.h"
+
+namespace mtadgat {
+
+namespace {
+
+size_t align64(size_t v) { return (v + 63) / 64 * 64; }
+
+// tile format: [NT][Q][64 lanes][4]; lane (j = lane&31, g = lane>>5), element s holds
+// M[32n + j][8q + 4g + s] (zero outside the matrix)
+void pack_tiles(float* out, int NT, int Q, const std::function<float(int, int)>& get) {
+    for (int n = 0; n < NT; ++n)
+        for (int q = 0; q < Q; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 4; ++s)
+                    out[(((size_t)n * Q + q) * 64 + lane) * 4 + s] = get(32 * n + (lane & 31), 8 * q + 4 * (lane >> 5) + s);
+}
+
+// GRU stream format: [NCG][Q][3 gates][64 lanes][4]
+void pack_gru_tiles(float* out, int NCG, int Q, const std::function<float(int, int, int)>& get /*(gate,row,k)*/) {
+    for (int c = 0; c < NCG; ++c)
+        for (int q = 0; q < Q; ++q)
+            for (int st = 0; st < 3; ++st)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s)
+                        out[((((size_t)c * Q + q) * 3 + st) * 64 + lane) * 4 + s] =
+                            get(st, 32 * c + (lane & 31), 8 * q + 4 * (lane >> 5) + s);
+}
+
+}  // namespace
+
+std::string validate_and_plan(Model& m) {
+    const mtadgat_config& c = m.cfg;
+    if (c.n_features < 1 || c.window_size < 1 || c.out_dim < 1) return "n_features, window_size and out_dim must be >= 1";
+    if (c.kernel_size < 1 || (c.kernel_size & 1) == 0) return "kernel_size must be odd (the reference's ConvLayer shortens the window otherwise)";
+    if (c.feat_embed < 1 || c.time_embed < 1) return "embedding dims must be >= 1";
+    if (c.n_features > 512 || c.window_size > 512) return "n_features and window_size up to 512 nodes are supported";
+    if (c.gru_n_layers < 1 || c.gru_n_layers > MTADGAT_MAX_LAYERS) return "gru_n_layers out of range";
+    if (c.recon_n_layers < 1 || c.recon_n_layers > MTADGAT_MAX_LAYERS) return "recon_n_layers out of range";
+    if (c.forecast_n_linear < 1 || c.forecast_n_linear > MTADGAT_MAX_LAYERS) return "forecast_n_linear out of range";
+    if (c.gru_hid_dim < 1 || c.gru_hid_dim > 256 || c.recon_hid_dim < 1 || c.recon_hid_dim > 256)
+        return "GRU hidden sizes 1..256 are supported";
+    if (c.forecast_hid_dim < 1) return "forecast_hid_dim must be >= 1";
+
+    m.F = c.n_features;
+    m.W = c.window_size;
+    m.Fp = round_up(m.F, 8);
+    m.Wp = round_up(m.W, 8);
+    m.Dp = round_up(3 * m.F, 8);
+    m.taps = c.kernel_size;
+    m.pad = (c.kernel_size - 1) / 2;
+
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        size_t o = off;
+        off = align64(off + n);
+        return o;
+    };
+    // conv
+    m.convNT = (m.F + 31) / 32;
+    {
+        const int Q = m.taps * m.Fp / 8;
+        m.conv_w_off = take((size_t)m.convNT * Q * 256);
+        m.conv_b_off = take((size_t)m.convNT * 32);
+    }
+    // GAT layers
+    auto plan_gat = [&](GatPlan& g, int K, int D, int E) {
+        g.K = K; g.D = D; g.E = E;
+        const int ptcap = c.use_gatv2 ? round_up(E, 8) + 8 : 0;
+        g.ldo = round_up(2 * ptcap + 2, 32);
+        g.NT = g.ldo / 32;
+        g.Q = (D + 7) / 8;
+        g.PT = g.P8 = 0;
+        g.w_off = take((size_t)g.NT * g.Q * 256);
+        g.b_off = take((size_t)g.ldo);
+        g.bias_off = take((size_t)K * K);
+        attend_plan(K, &g.rows_per_blk, &g.nblk, &g.IB);
+    };
+    plan_gat(m.feat, m.F, m.W, c.feat_embed);
+    plan_gat(m.temp, m.W, m.F, c.time_embed);
+    // GRU stack
+    m.gru.assign(c.gru_n_layers, GruPlan());
+    for (int l = 0; l < c.gru_n_layers; ++l) {
+        GruPlan& g = m.gru[l];
+        g.in_dim = (l == 0) ? 3 * m.F : c.gru_hid_dim;
+        g.H = c.gru_hid_dim;
+        g.Hp = round_up(g.H, 32);
+        g.NCG = g.Hp / 32;
+        g.Qx = (g.in_dim + 7) / 8;
+        g.xmode = 0;
+        g.wx_off = take((size_t)g.NCG * g.Qx * 3 * 256);
+        g.wh_off = take((size_t)g.NCG * 4 * g.NCG * 3 * 256);
+        g.b_off = take((size_t)4 * g.Hp);
+    }
+    // forecasting head
+    m.fc.assign(c.forecast_n_linear, LinPlan());
+    for (int i = 0; i < c.forecast_n_linear; ++i) {
+        LinPlan& p = m.fc[i];
+        p.in_dim = (i == 0) ? c.gru_hid_dim : c.forecast_hid_dim;
+        p.out_dim = (i == c.forecast_n_linear - 1) ? c.out_dim : c.forecast_hid_dim;
+        p.NT = (p.out_dim + 31) / 32;
+        p.Q = (p.in_dim + 7) / 8;
+        p.w_off = take((size_t)p.NT * p.Q * 256);
+        p.b_off = take((size_t)p.NT * 32);
+    }
+    // reconstruction decoder
+    m.rec.assign(c.recon_n_layers, GruPlan());
+    for (int l = 0; l < c.recon_n_layers; ++l) {
+        GruPlan& g = m.rec[l];
+        g.H = c.recon_hid_dim;
+        g.Hp = round_up(g.H, 32);
+        g.NCG = g.Hp / 32;
+        if (l == 0) {
+            // decoder input (t, j) = h_end[(t*H + j) / W]  (reference modules.py:279)
+            const int Hin = c.gru_hid_dim, T = m.W;
+            int nm = 1;
+            for (int t = 0; t < T; ++t) {
+                const int lo = (int)(((long)t * Hin) / T), hi = (int)(((long)t * Hin + Hin - 1) / T);
+                if (hi - lo + 1 > nm) nm = hi - lo + 1;
+            }
+            g.in_dim = Hin;
+            g.xmode = 1;
+            g.Qx = (nm + 7) / 8;
+            g.wx_off = take((size_t)T * g.NCG * g.Qx * 3 * 256);
+            g.m0_off = take((size_t)T);
+        } else {
+            g.in_dim = c.recon_hid_dim;
+            g.xmode = 0;
+            g.Qx = (g.in_dim + 7) / 8;
+            g.wx_off = take((size_t)g.NCG * g.Qx * 3 * 256);
+        }
+        g.wh_off = take((size_t)g.NCG * 4 * g.NCG * 3 * 256);
+        g.b_off = take((size_t)4 * g.Hp);
+    }
+    {
+        LinPlan& p = m.rec_fc;
+        p.in_dim = c.recon_hid_dim;
+        p.out_dim = c.out_dim;
+        p.NT = (p.out_dim + 31) / 32;
+        p.Q = m.rec.back().Hp / 8;
+        p.w_off = take((size_t)p.NT * p.Q * 256);
+        p.b_off = take((size_t)p.NT * 32);
+    }
+    m.packed_floats = off;
+    return "";
+}
+
+void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
+    size_t off = 0;
+    auto take = [&](size_t cnt) {
+        size_t o = off;
+        off = align64(off + cnt);
+        return o;
+    };
+    const size_t N = (size_t)n;
+    ws.xc = take(N * m.W * m.Fp);
+    ws.xct = take(N * m.F * m.Wp);
+    ws.lrt = take(N * m.W * m.temp.ldo);
+    ws.lrf = take(N * m.F * m.feat.ldo);
+    ws.hcat = take(N * m.W * m.Dp);
+    ws.hend = take(N * m.gru.back().Hp);
+    const bool gseq = m.gru.size() > 1;
+    ws.seq0 = take(gseq ? N * m.W * m.gru[0].Hp : 0);
+    ws.seq1 = take(m.gru.size() > 2 ? N * m.W * m.gru[0].Hp : 0);
+    size_t fcw = 0;
+    for (const LinPlan& p : m.fc) fcw = std::max(fcw, (size_t)p.NT * 32);
+    ws.fc0 = take(N * fcw);
+    ws.fc1 = take(N * fcw);
+    const bool rseq = m.rec.size() > 1;
+    ws.rseq0 = take(rseq ? N * m.W * m.rec[0].Hp : 0);
+    ws.rseq1 = take(m.rec.size() > 2 ? N * m.W * m.rec[0].Hp : 0);
+    ws.total = off;
+}
+
+static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_b, const float* a, const float* bias,
+                     std::vector<float>& out) {
+    const int E = g.E, D = g.D;
+    const double alpha = m.cfg.alpha;
+    std::vector<double> rows((size_t)g.ldo * D, 0.0), bvec(g.ldo, 0.0);
+    if (m.cfg.use_gatv2) {
+        // e_ij = a . LeakyReLU(W_l v_i + W_r v_j + b)          (reference modules.py:74-77, :174-177)
+        //      = c_i + d_j + sum_k a'_k |L_ik + R_jk|,  LeakyReLU(u) = (1+alpha)/2 u + (1-alpha)/2 |u|
+        const int lin_in = 2 * D;
+        std::vector<int> pos, neg;
+        for (int k = 0; k < E; ++k) (((1.0 - alpha) * 0.5 * (double)a[k]) >= 0.0 ? pos : neg).push_back(k);
+        g.P8 = round_up((int)pos.size(), 8);
+        const int N8 = round_up((int)neg.size(), 8);
+        g.PT = g.P8 + N8;
+        std::vector<int> colk(g.PT, -1);
+        for (size_t n = 0; n < pos.size(); ++n) colk[n] = pos[n];
+        for (size_t n = 0; n < neg.size(); ++n) colk[g.P8 + n] = neg[n];
+        for (int n = 0; n < g.PT; ++n) {
+            const int k = colk[n];
+            if (k < 0) continue;
+            const double s = std::fabs((1.0 - alpha) * 0.5 * (double)a[k]);
+            for (int cidx = 0; cidx < D; ++cidx) {
+                rows[(size_t)n * D + cidx] = s * (double)lin_w[(size_t)k * lin_in + cidx];
+                rows[(size_t)(g.PT + n) * D + cidx] = s * (double)lin_w[(size_t)k * lin_in + D + cidx];
+            }
+            bvec[n] = s * (double)lin_b[k];
+        }
+        const double hl = (1.0 + alpha) * 0.5;
+        for (int k = 0; k < E; ++k) {
+            for (int cidx = 0; cidx < D; ++cidx) {
+                rows[(size_t)(2 * g.PT) * D + cidx] += hl * (double)a[k] * (double)lin_w[(size_t)k * lin_in + cidx];
+                rows[(size_t)(2 * g.PT + 1) * D + cidx] += hl * (double)a[k] * (double)lin_w[(size_t)k * lin_in + D + cidx];
+            }
+            bvec[2 * g.PT] += hl * (double)a[k] * (double)lin_b[k];
+        }
+    } else {
+        // e_ij = LeakyReLU(a1 . (W v_i + b) + a2 . (W v_j + b))   (reference modules.py:80-83, :180-183)
+        g.PT = g.P8 = 0;
+        for (int k = 0; k < E; ++k) {
+            for (int cidx = 0; cidx < D; ++cidx) {
+                rows[(size_t)0 * D + cidx] += (double)a[k] * (double)lin_w[(size_t)k * D + cidx];
+                rows[(size_t)1 * D + cidx] += (double)a[E + k] * (double)lin_w[(size_t)k * D + cidx];
+            }
+            bvec[0] += (double)a[k] * (double)lin_b[k];
+            bvec[1] += (double)a[E + k] * (double)lin_b[k];
+        }
+    }
+    pack_tiles(out.data() + g.w_off, g.NT, g.Q, [&](int n, int k) -> float {
+        return (n < g.ldo && k < D) ? (float)rows[(size_t)n * D + k] : 0.f;
+    });
+    for (int n = 0; n < g.ldo; ++n) out[g.b_off + n] = (float)bvec[n];
+    std::memcpy(out.data() + g.bias_off, bias, sizeof(float) * (size_t)g.K * g.K);
+}
+
+static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                           std::vector<float>& out) {
+    const int H = g.H, in = g.in_dim;
+    if (g.xmode == 0) {
+        pack_gru_tiles(out.data() + g.wx_off, g.NCG, g.Qx, [&](int st, int r, int k) -> float {
+            return (r < H && k < in) ? w_ih[((size_t)st * H + r) * in + k] : 0.f;
+        });
+    }
+    pack_gru_tiles(out.data() + g.wh_off, g.NCG, 4 * g.NCG, [&](int st, int r, int k) -> float {
+        return (r < H && k < H) ? w_hh[((size_t)st * H + r) * H + k] : 0.f;
+    });
+    float* b = out.data() + g.b_off;
+    for (int j = 0; j < g.Hp; ++j) {
+        b[0 * g.Hp + j] = j < H ? b_ih[j] + b_hh[j] : 0.f;
+        b[1 * g.Hp + j] = j < H ? b_ih[H + j] + b_hh[H + j] : 0.f;
+        b[2 * g.Hp + j] = j < H ? b_ih[2 * H + j] : 0.f;
+        b[3 * g.Hp + j] = j < H ? b_hh[2 * H + j] : 0.f;
+    }
+}
+
+std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& out) {
+    const mtadgat_config& c = m.cfg;
+    out.assign(m.packed_floats, 0.f);
+    if (!p.conv_weight || !p.conv_bias || !p.feat_lin_weight || !p.feat_lin_bias || !p.feat_a || !p.feat_bias ||
+        !p.temp_lin_weight || !p.temp_lin_bias || !p.temp_a || !p.temp_bias || !p.rec_fc_weight || !p.rec_fc_bias)
+        return "null parameter pointer";
+    // conv: K index = tap*Fp + channel   (reference weight (F_out, F_in, k), modules.py:15)
+    {
+        const int F = m.F, Fp = m.Fp, taps = m.taps;
+        pack_tiles(out.data() + m.conv_w_off, m.convNT, taps * Fp / 8, [&](int n, int k) -> float {
+            const int tap = k / Fp, ch = k % Fp;
+            return (n < F && ch < F && tap < taps) ? p.conv_weight[((size_t)n * F + ch) * taps + tap] : 0.f;
+        });
+        for (int n = 0; n < F; ++n) out[m.conv_b_off + n] = p.conv_bias[n];
+    }
+    pack_gat(m, m.feat, p.feat_lin_weight, p.feat_lin_bias, p.feat_a, p.feat_bias, out);
+    pack_gat(m, m.temp, p.temp_lin_weight, p.temp_lin_bias, p.temp_a, p.temp_bias, out);
+    for (int l = 0; l < c.gru_n_layers; ++l) {
+        if (!p.gru_w_ih[l] || !p.gru_w_hh[l] || !p.gru_b_ih[l] || !p.gru_b_hh[l]) return "null GRU parameter pointer";
+        pack_gru_layer(m.gru[l], p.gru_w_ih[l], p.gru_w_hh[l], p.gru_b_ih[l], p.gru_b_hh[l], out);
+    }
+    for (int i = 0; i < c.forecast_n_linear; ++i) {
+        if (!p.fc_weight[i] || !p.fc_bias[i]) return "null forecasting parameter pointer";
+        const LinPlan& lp = m.fc[i];
+        const float* w = p.fc_weight[i];
+        pack_tiles(out.data() + lp.w_off, lp.NT, lp.Q, [&](int n, int k) -> float {
+            return (n < lp.out_dim && k < lp.in_dim) ? w[(size_t)n * lp.in_dim + k] : 0.f;
+        });
+        for (int n = 0; n < lp.out_dim; ++n) out[lp.b_off + n] = p.fc_bias[i][n];
+    }
+    for (int l = 0; l < c.recon_n_layers; ++l) {
+        if (!p.rec_w_ih[l] || !p.rec_w_hh[l] || !p.rec_b_ih[l] || !p.rec_b_hh[l]) return "null decoder parameter pointer";
+        const GruPlan& g = m.rec[l];
+        if (g.xmode == 1) {
+            // x_t[j] = h_end[(t*Hin + j) / T]: fold W_ih over the j that share an h_end entry
+            const int Hin = g.in_dim, T = m.W, H = g.H;
+            const int NMp = 8 * g.Qx;
+            std::vector<double> csum((size_t)3 * H * NMp);
+            int* m0 = reinterpret_cast<int*>(out.data() + g.m0_off);
+            for (int t = 0; t < T; ++t) {
+                const int lo = (int)(((long)t * Hin) / T);
+                m0[t] = lo;
+                std::fill(csum.begin(), csum.end(), 0.0);
+                for (int r = 0; r < 3 * H; ++r)
+                    for (int j = 0; j < Hin; ++j) {
+                        const int cc = (int)(((long)t * Hin + j) / T) - lo;
+                        csum[(size_t)r * NMp + cc] += (double)p.rec_w_ih[l][(size_t)r * Hin + j];
+                    }
+                pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qx * 3 * 256, g.NCG, g.Qx,
+                               [&](int st, int r, int k) -> float {
+                                   return (r < H && k < NMp) ? (float)csum[((size_t)st * H + r) * NMp + k] : 0.f;
+                               });
+            }
+        }
+        pack_gru_layer(g, p.rec_w_ih[l], p.rec_w_hh[l], p.rec_b_ih[l], p.rec_b_hh[l], out);
+    }
+    {
+        const LinPlan& lp = m.rec_fc;
+        pack_tiles(out.data() + lp.w_off, lp.NT, lp.Q, [&](int n, int k) -> float {
+            return (n < lp.out_dim && k < lp.in_dim) ? p.rec_fc_weight[(size_t)n * lp.in_dim + k] : 0.f;
+        });
+        for (int n = 0; n < lp.out_dim; ++n) out[lp.b_off + n] = p.rec_fc_bias[n];
+    }
+    return "";
+}
+
+}  // namespace mtadgat

@@ -1,0 +1,245 @@
+"""Drop-in `mtad_gat` module: `MTAD_GAT` with the reference's constructor, parameter
+names and `forward(x) -> (predictions, recons)` contract (reference
+`mtad_gat.py:14-79`), whose forward pass runs on hand-written HIP kernels for
+MI355X (gfx950) through the C ABI in `include/mtadgat.h`.
+
+Put this directory ahead of the reference on `sys.path` and the reference's own
+`train.py` / `predict.py` pick it up through `from mtad_gat import MTAD_GAT`
+(`train.py:7`, `predict.py:7`); see INTEGRATION.md.
+
+The sub-modules below only *hold* the parameters -- under the reference's
+attribute names, created in the reference's order with the reference's
+initialisers, so `state_dict()` keys/shapes, strict `load_state_dict` of the
+shipped checkpoints, `.cuda()`, optimisers and seeded initialisation behave
+exactly as with the reference classes (`modules.py:5-311`).  Their `forward`
+methods call the corresponding stage entry point of the native library; there
+is no PyTorch implementation of the arithmetic anywhere in this package and no
+CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+import _native
+
+
+class ConvLayer(nn.Module):
+    """Parameters of reference `ConvLayer` (`modules.py:12-16`): `conv.weight (F,F,k)`, `conv.bias (F)`."""
+
+    def __init__(self, n_features, kernel_size=7):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.conv = nn.Conv1d(in_channels=n_features, out_channels=n_features, kernel_size=kernel_size)
+
+    def forward(self, x):
+        return self._owner()._stage("conv", x)
+
+
+class _AttentionParams(nn.Module):
+    """Parameters shared by the two graph-attention layers (`modules.py:36-63`, `:137-164`)."""
+
+    def __init__(self, num_nodes, node_dim, default_embed, dropout, alpha, embed_dim, use_gatv2, use_bias):
+        super().__init__()
+        self.dropout = dropout
+        self.alpha = alpha
+        self.use_gatv2 = use_gatv2
+        self.use_bias = use_bias
+        self.num_nodes = num_nodes
+        self.embed_dim = embed_dim if embed_dim is not None else default_embed
+        if use_gatv2:   # GATv2 applies `lin` to the concatenated pair, so both dims double
+            self.embed_dim *= 2
+            lin_in, a_in = 2 * node_dim, self.embed_dim
+        else:
+            lin_in, a_in = node_dim, 2 * self.embed_dim
+        self.lin = nn.Linear(lin_in, self.embed_dim)
+        self.a = nn.Parameter(torch.empty((a_in, 1)))
+        nn.init.xavier_uniform_(self.a.data, gain=1.414)
+        if use_bias:
+            self.bias = nn.Parameter(torch.zeros(num_nodes, num_nodes))
+
+
+class FeatureAttentionLayer(_AttentionParams):
+    """Feature-oriented GAT/GATv2: nodes = features (reference `modules.py:25-122`)."""
+
+    def __init__(self, n_features, window_size, dropout, alpha, embed_dim=None, use_gatv2=True, use_bias=True):
+        super().__init__(n_features, window_size, window_size, dropout, alpha, embed_dim, use_gatv2, use_bias)
+        self.n_features, self.window_size = n_features, window_size
+
+    def forward(self, x):
+        return self._owner()._stage("feature_gat", x)
+
+
+class TemporalAttentionLayer(_AttentionParams):
+    """Time-oriented GAT/GATv2: nodes = time steps (reference `modules.py:125-217`)."""
+
+    def __init__(self, n_features, window_size, dropout, alpha, embed_dim=None, use_gatv2=True, use_bias=True):
+        super().__init__(window_size, n_features, n_features, dropout, alpha, embed_dim, use_gatv2, use_bias)
+        self.n_features, self.window_size = n_features, window_size
+
+    def forward(self, x):
+        return self._owner()._stage("temporal_gat", x)
+
+
+class GRULayer(nn.Module):
+    """Parameters of reference `GRULayer` (`modules.py:228-233`); forward returns (None, h_end)."""
+
+    def __init__(self, in_dim, hid_dim, n_layers, dropout):
+        super().__init__()
+        self.hid_dim, self.n_layers = hid_dim, n_layers
+        self.dropout = 0.0 if n_layers == 1 else dropout
+        self.gru = nn.GRU(in_dim, hid_dim, num_layers=n_layers, batch_first=True, dropout=self.dropout)
+
+    def forward(self, x):
+        # the reference also returns out[-1] (the last batch element's sequence, a batch_first
+        # quirk, modules.py:237) which MTAD_GAT.forward discards (mtad_gat.py:73): not produced.
+        return None, self._owner()._stage("gru", x)
+
+
+class RNNDecoder(nn.Module):
+    """Parameters of reference `RNNDecoder` (`modules.py:249-253`)."""
+
+    def __init__(self, in_dim, hid_dim, n_layers, dropout):
+        super().__init__()
+        self.in_dim = in_dim
+        self.dropout = 0.0 if n_layers == 1 else dropout
+        self.rnn = nn.GRU(in_dim, hid_dim, n_layers, batch_first=True, dropout=self.dropout)
+
+
+class ReconstructionModel(nn.Module):
+    """Parameters of reference `ReconstructionModel` (`modules.py:260-262`)."""
+
+    def __init__(self, window_size, in_dim, hid_dim, out_dim, n_layers, dropout):
+        super().__init__()
+        self.window_size = window_size
+        self.decoder = RNNDecoder(in_dim, hid_dim, n_layers, dropout)
+        self.fc = nn.Linear(hid_dim, out_dim)
+
+    def forward(self, x):
+        return self._owner()._stage("recon", x)
+
+
+class Forecasting_Model(nn.Module):
+    """Parameters of reference `Forecasting_Model` (`modules.py:295-305`): n_layers + 1 Linear."""
+
+    def __init__(self, in_dim, hid_dim, out_dim, n_layers, dropout):
+        super().__init__()
+        layers = [nn.Linear(in_dim, hid_dim)]
+        for _ in range(n_layers - 1):
+            layers.append(nn.Linear(hid_dim, hid_dim))
+        layers.append(nn.Linear(hid_dim, out_dim))
+        self.layers = nn.ModuleList(layers)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self._owner()._stage("forecast", x)
+
+
+class MTAD_GAT(nn.Module):
+    """MTAD-GAT model, reference signature (`mtad_gat.py:37-54`).
+
+    :param n_features: number of input features
+    :param window_size: length of the input sequence
+    :param out_dim: number of features to output
+    :param kernel_size: size of kernel to use in the 1-D convolution (odd)
+    :param feat_gat_embed_dim / time_gat_embed_dim: embedding dims of the two GAT layers
+    :param use_gatv2: GATv2 attention instead of standard GAT
+    :param gru_n_layers / gru_hid_dim: GRU layer
+    :param forecast_n_layers / forecast_hid_dim: FC forecasting model
+    :param recon_n_layers / recon_hid_dim: GRU reconstruction model
+    :param dropout: dropout rate
+    :param alpha: negative slope of the LeakyReLU
+    """
+
+    def __init__(
+        self,
+        n_features,
+        window_size,
+        out_dim,
+        kernel_size=7,
+        feat_gat_embed_dim=None,
+        time_gat_embed_dim=None,
+        use_gatv2=True,
+        gru_n_layers=1,
+        gru_hid_dim=150,
+        forecast_n_layers=1,
+        forecast_hid_dim=150,
+        recon_n_layers=1,
+        recon_hid_dim=150,
+        dropout=0.2,
+        alpha=0.2,
+    ):
+        super().__init__()
+        if kernel_size % 2 == 0:
+            raise ValueError("kernel_size must be odd: the reference's ConvLayer shortens the window otherwise")
+        self.n_features, self.window_size, self.out_dim = n_features, window_size, out_dim
+        self.alpha, self.dropout_p = alpha, dropout
+        # same construction order as the reference (mtad_gat.py:56-62) => same RNG consumption
+        self.conv = ConvLayer(n_features, kernel_size)
+        self.feature_gat = FeatureAttentionLayer(n_features, window_size, dropout, alpha, feat_gat_embed_dim, use_gatv2)
+        self.temporal_gat = TemporalAttentionLayer(n_features, window_size, dropout, alpha, time_gat_embed_dim, use_gatv2)
+        self.gru = GRULayer(3 * n_features, gru_hid_dim, gru_n_layers, dropout)
+        self.forecasting_model = Forecasting_Model(gru_hid_dim, forecast_hid_dim, out_dim, forecast_n_layers, dropout)
+        self.recon_model = ReconstructionModel(window_size, gru_hid_dim, recon_hid_dim, out_dim, recon_n_layers, dropout)
+        self._native_cfg = dict(
+            n_features=n_features, window_size=window_size, out_dim=out_dim, kernel_size=kernel_size,
+            use_gatv2=1 if use_gatv2 else 0, feat_embed=self.feature_gat.embed_dim,
+            time_embed=self.temporal_gat.embed_dim, gru_n_layers=gru_n_layers, gru_hid_dim=gru_hid_dim,
+            forecast_n_linear=forecast_n_layers + 1, forecast_hid_dim=forecast_hid_dim,
+            recon_n_layers=recon_n_layers, recon_hid_dim=recon_hid_dim, alpha=float(alpha))
+        # sub-modules reach the engine through a weak back-reference (not a registered child)
+        import weakref
+        ref = weakref.ref(self)
+        for mod in (self.conv, self.feature_gat, self.temporal_gat, self.gru, self.forecasting_model, self.recon_model):
+            object.__setattr__(mod, "_owner", ref)
+        object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_weights_key", None)
+
+    # -- native engine ----------------------------------------------------------------------------
+    def _sync_engine(self, device):
+        """Engine whose packed weights match the current parameters (repacked when any changed)."""
+        if self._engine is None:
+            object.__setattr__(self, "_engine", _native.Engine(self._native_cfg))
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key != self._weights_key:
+            self._engine.load_weights(self.state_dict(), device)
+            object.__setattr__(self, "_weights_key", key)
+        return self._engine
+
+    def _check_mode(self, x):
+        if x.device.type != "cuda":
+            raise RuntimeError(
+                f"MTAD_GAT (MI355X HIP path) got a tensor on '{x.device}': move the model and the input to the GPU "
+                "(.cuda() / .to('cuda')); there is no CPU implementation in this package")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError(
+                "MTAD_GAT HIP path: training-mode forward (attention/MLP dropout + backward) is not implemented; "
+                "call model.eval() and run under torch.no_grad() (Trainer.evaluate / Predictor do)")
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("MTAD_GAT HIP path: dropout (train mode) is not implemented; call model.eval()")
+
+    def _stage(self, name, x):
+        self._check_mode(x)
+        eng = self._sync_engine(x.device)
+        x = x.contiguous().float()
+        if name == "conv":
+            return eng.conv(x)
+        if name == "feature_gat":
+            return eng.gat(0, x)
+        if name == "temporal_gat":
+            return eng.gat(1, x)
+        if name == "gru":
+            return eng.gru(x)
+        if name == "forecast":
+            return eng.heads(x, True, False)[0]
+        if name == "recon":
+            return eng.heads(x, False, True)[1]
+        raise KeyError(name)
+
+    def forward(self, x):
+        """x (b, window_size, n_features) float32 on the GPU -> (predictions (b, out_dim),
+        recons (b, window_size, out_dim)); reference `mtad_gat.py:64-79`.  x is not modified."""
+        self._check_mode(x)
+        if x.dim() != 3 or x.shape[1] != self.window_size or x.shape[2] != self.n_features:
+            raise RuntimeError(f"expected input of shape (b, {self.window_size}, {self.n_features}), got {tuple(x.shape)}")
+        eng = self._sync_engine(x.device)
+        with torch.no_grad():
+            return eng.forward(x.contiguous().float())

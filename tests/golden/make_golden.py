@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the reference itself.
+
+Run in the build container (where /root/reference exists):
+
+    python -B tests/golden/make_golden.py
+
+It imports the *unmodified* reference modules (`/root/reference/mtad_gat.py`,
+`modules.py`), runs `MTAD_GAT.forward` on CPU in eval mode on seeded inputs and
+writes one `<case>.npz` per case with: the input, the reference-format
+state_dict (shipped checkpoints and small synthetic models) or the init seed
+(large synthetic models), the float32 outputs + per-stage intermediates, and
+the outputs of the same reference model run in float64 (used to judge
+rounding noise).
+
+The GPU box has no /root/reference: tests read only the .npz files.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("MTAD_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+from mtad_gat import MTAD_GAT as RefMTAD  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SHIPPED = {
+    "msl": ("output/MSL/27062021_111641/model.pt", dict(n_features=55, out_dim=1)),
+    "smap": ("output/SMAP/27062021_112545/model.pt", dict(n_features=25, out_dim=1)),
+    "smd_1_1": ("output/SMD/1-1/27062021_114402/model.pt", dict(n_features=38, out_dim=38)),
+}
+# ctor kwargs of the shipped runs (output/*/config.txt): fc_n_layers=3, rest default
+SHIPPED_KW = dict(window_size=100, kernel_size=7, use_gatv2=True, gru_n_layers=1, gru_hid_dim=150,
+                  forecast_n_layers=3, forecast_hid_dim=150, recon_n_layers=1, recon_hid_dim=150,
+                  dropout=0.3, alpha=0.2)
+
+# small / odd-shaped synthetic models: (name, ctor kwargs, batch, store_state_dict)
+SYNTH = [
+    ("syn_v1_small", dict(n_features=7, window_size=12, out_dim=7, kernel_size=3, use_gatv2=False,
+                          feat_gat_embed_dim=5, time_gat_embed_dim=6, gru_n_layers=2, gru_hid_dim=20,
+                          forecast_n_layers=2, forecast_hid_dim=24, recon_n_layers=2, recon_hid_dim=18,
+                          dropout=0.2, alpha=0.2), 5, True),
+    ("syn_v2_embed", dict(n_features=9, window_size=16, out_dim=3, kernel_size=5, use_gatv2=True,
+                          feat_gat_embed_dim=5, time_gat_embed_dim=3, gru_n_layers=1, gru_hid_dim=33,
+                          forecast_n_layers=1, forecast_hid_dim=40, recon_n_layers=1, recon_hid_dim=35,
+                          dropout=0.2, alpha=0.1), 37, True),
+    ("syn_v2_wide", dict(n_features=70, window_size=130, out_dim=70, kernel_size=7, use_gatv2=True,
+                         gru_n_layers=1, gru_hid_dim=150, forecast_n_layers=3, forecast_hid_dim=150,
+                         recon_n_layers=1, recon_hid_dim=150, dropout=0.3, alpha=0.2), 3, False),
+    ("syn_v1_default", dict(n_features=25, window_size=100, out_dim=1, kernel_size=7, use_gatv2=False,
+                            gru_n_layers=1, gru_hid_dim=150, forecast_n_layers=3, forecast_hid_dim=150,
+                            recon_n_layers=1, recon_hid_dim=150, dropout=0.3, alpha=0.2), 4, False),
+    # BASELINE.json configs[3] shape at oracle-able batch
+    ("syn_c4", dict(n_features=512, window_size=256, out_dim=512, kernel_size=7, use_gatv2=True,
+                    gru_n_layers=1, gru_hid_dim=150, forecast_n_layers=3, forecast_hid_dim=150,
+                    recon_n_layers=1, recon_hid_dim=150, dropout=0.3, alpha=0.2), 1, False),
+]
+INIT_SEED = 0
+X_SEED = 1234
+
+
+def sd_digest(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def stages(model, x):
+    """Intermediates, re-using the reference's own sub-modules (mtad_gat.py:64-79)."""
+    xc = model.conv(x)
+    h_feat = model.feature_gat(xc)
+    h_temp = model.temporal_gat(xc)
+    h_cat = torch.cat([xc, h_feat, h_temp], dim=2)
+    _, h_end = model.gru(h_cat)
+    h_end = h_end.view(x.shape[0], -1)
+    return dict(xc=xc, h_feat=h_feat, h_temp=h_temp, h_end=h_end)
+
+
+def run_case(name, model, kwargs, batch, store_sd, meta_extra):
+    model.eval()
+    g = torch.Generator().manual_seed(X_SEED)
+    x = torch.rand(batch, kwargs["window_size"], kwargs["n_features"], generator=g)
+    with torch.no_grad():
+        preds, recons = model(x)
+        st = stages(model, x)
+        m64 = RefMTAD(**{k: v for k, v in kwargs.items()}).double()
+        m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+        m64.eval()
+        p64, r64 = m64(x.double())
+        st64 = stages(m64, x.double())
+    out = dict(x=x.numpy(), preds=preds.numpy(), recons=recons.numpy(),
+               preds64=p64.numpy(), recons64=r64.numpy(), h_end64=st64["h_end"].numpy())
+    for k, v in st.items():
+        out["stage_" + k] = v.numpy()
+    sd = model.state_dict()
+    if store_sd:
+        for k, v in sd.items():
+            out["sd/" + k] = v.numpy()
+    meta = dict(name=name, kwargs=kwargs, batch=batch, x_seed=X_SEED, init_seed=INIT_SEED,
+                sd_sha256=sd_digest(sd), store_sd=store_sd, torch=torch.__version__, **meta_extra)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: b={batch} preds{tuple(preds.shape)} recons{tuple(recons.shape)} "
+          f"|p32-p64|={float((preds.double()-p64).abs().max()):.2e} "
+          f"|r32-r64|={float((recons.double()-r64).abs().max()):.2e} "
+          f"-> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    for name, (rel, dims) in SHIPPED.items():
+        kwargs = dict(SHIPPED_KW, **dims)
+        model = RefMTAD(**kwargs)
+        sd = torch.load(os.path.join(REF, rel), map_location="cpu")
+        model.load_state_dict(sd)           # strict
+        run_case(name, model, kwargs, 6, True, dict(source=rel))
+    for name, kwargs, batch, store in SYNTH:
+        torch.manual_seed(INIT_SEED)
+        model = RefMTAD(**kwargs)
+        # exercise the attention-bias path (reference initialises it to zeros, modules.py:60,161)
+        g = torch.Generator().manual_seed(INIT_SEED + 1)
+        with torch.no_grad():
+            model.feature_gat.bias.copy_(torch.randn(model.feature_gat.bias.shape, generator=g))
+            model.temporal_gat.bias.copy_(torch.randn(model.temporal_gat.bias.shape, generator=g))
+        run_case(name, model, kwargs, batch, store,
+                 dict(source="torch.manual_seed(%d) ctor init + randn GAT biases (seed %d)"
+                      % (INIT_SEED, INIT_SEED + 1)))
+
+
+if __name__ == "__main__":
+    main()

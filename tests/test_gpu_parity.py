@@ -1,0 +1,112 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in module) with the reference:
+golden vectors generated from the reference itself (tests/golden/make_golden.py)."""
+import pytest
+import torch
+
+from helpers import ALL_CASES, SHIPPED_CASES, Case, gate
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=ALL_CASES)
+def case_model(request, gpu_device):
+    case = Case(request.param)
+    model = case.build_model().to(gpu_device)
+    return case, model
+
+
+def test_forward_matches_reference(case_model, gpu_device):
+    case, model = case_model
+    with torch.no_grad():
+        preds, recons = model(case.x.to(gpu_device))
+    assert preds.shape == case.preds.shape and recons.shape == case.recons.shape
+    assert preds.dtype == torch.float32 and preds.device.type == "cuda"
+    dp = gate(preds, case.preds, case.preds64, what=f"{case.name} predictions")
+    dr = gate(recons, case.recons, case.recons64, what=f"{case.name} recons")
+    print(f"{case.name}: |preds-ref|={dp:.2e} |recons-ref|={dr:.2e}")
+
+
+def test_stages_match_reference(case_model, gpu_device):
+    case, model = case_model
+    x = case.x.to(gpu_device)
+    with torch.no_grad():
+        xc = model.conv(x)
+        gate(xc, case.stages["xc"], what=f"{case.name} conv")
+        xc_ref = case.stages["xc"].to(gpu_device)
+        hf = model.feature_gat(xc_ref)
+        gate(hf, case.stages["h_feat"], what=f"{case.name} feature_gat")
+        ht = model.temporal_gat(xc_ref)
+        gate(ht, case.stages["h_temp"], what=f"{case.name} temporal_gat")
+        hcat = torch.cat([case.stages["xc"], case.stages["h_feat"], case.stages["h_temp"]], dim=2).to(gpu_device)
+        _, h_end = model.gru(hcat)
+        gate(h_end, case.stages["h_end"], case.h_end64, what=f"{case.name} gru h_end")
+        h_ref = case.stages["h_end"].to(gpu_device)
+        p = model.forecasting_model(h_ref)
+        gate(p, case.preds, case.preds64, what=f"{case.name} forecasting head")
+        r = model.recon_model(h_ref)
+        gate(r, case.recons, case.recons64, what=f"{case.name} reconstruction head")
+
+
+def test_input_not_modified(case_model, gpu_device):
+    case, model = case_model
+    x = case.x.to(gpu_device)
+    x0 = x.clone()
+    with torch.no_grad():
+        model(x)
+    assert torch.equal(x, x0)
+
+
+@pytest.mark.parametrize("name", SHIPPED_CASES)
+def test_ragged_batches_and_chunking(name, gpu_device):
+    """Batch-split invariance (what data-parallel sharding relies on), batches that do not fill
+    a 32-window tile, and the internal chunk loop."""
+    case = Case(name)
+    model = case.build_model().to(gpu_device)
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(77, case.kwargs["window_size"], case.kwargs["n_features"], generator=g).to(gpu_device)
+    with torch.no_grad():
+        p_all, r_all = model(x)
+        # windows are independent: any split gives bit-identical rows
+        for lo, hi in [(0, 1), (1, 34), (34, 77)]:
+            p, r = model(x[lo:hi].contiguous())
+            assert torch.equal(p, p_all[lo:hi]) and torch.equal(r, r_all[lo:hi]), (lo, hi)
+        perm = torch.randperm(77, generator=g).to(gpu_device)
+        p, r = model(x[perm].contiguous())
+        assert torch.equal(p, p_all[perm]) and torch.equal(r, r_all[perm])
+        model._engine.set_chunk_windows(20)   # 77 = 20+20+20+17
+        p, r = model(x)
+        assert torch.equal(p, p_all) and torch.equal(r, r_all)
+        # the first 6 windows of the fixture still match the reference when embedded in a batch
+        xx = torch.cat([case.x.to(gpu_device), x], dim=0)
+        p, r = model(xx)
+        gate(p[:6], case.preds, case.preds64, what="embedded preds")
+        gate(r[:6], case.recons, case.recons64, what="embedded recons")
+    assert model(x[:0])[0].shape == (0, case.kwargs["out_dim"])
+
+
+def test_weight_update_is_seen(gpu_device):
+    """Parameters changed in place (optimizer.step, load_state_dict) must reach the kernels."""
+    a, b = Case("smap"), Case("syn_v1_default")   # same shapes except GAT flavour -> use smap twice
+    model = a.build_model().to(gpu_device)
+    x = a.x.to(gpu_device)
+    with torch.no_grad():
+        p0, _ = model(x)
+        model.forecasting_model.layers[3].bias.add_(1.0)
+        p1, _ = model(x)
+        assert torch.allclose(p1, p0 + 1.0, atol=1e-6)
+        model.load_state_dict(a.state_dict())
+        p2, _ = model(x)
+        assert torch.equal(p2, p0)
+
+
+def test_errors_are_loud(gpu_device):
+    case = Case("syn_v2_embed")
+    model = case.build_model()
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        model(case.x)                       # CPU tensors: no fallback
+    model = model.to(gpu_device)
+    with pytest.raises(RuntimeError, match="expected input of shape"):
+        model(case.x[:, :-1].to(gpu_device))
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(case.x.to(gpu_device))
