@@ -206,13 +206,24 @@ def gru_stack(x: Tensor, sd: Dict[str, Tensor], prefix: str, n_layers: int) -> T
     return seq, h
 
 
+def gru_stack_aten(x: Tensor, sd: Dict[str, Tensor], prefix: str, n_layers: int) -> Tuple[Tensor, Tensor]:
+    """Same contract as gru_stack, through ATen's fused `aten::gru` (what the reference's nn.GRU
+    dispatches to on CPU).  Used for the timed CPU baseline so the GRU costs what it costs the
+    reference; tests check it agrees with the explicit gate equations above."""
+    w_ih = sd[f"{prefix}weight_ih_l0"]
+    rnn = torch.nn.GRU(w_ih.shape[1], sd[f"{prefix}weight_hh_l0"].shape[1], n_layers, batch_first=True).to(x.dtype)
+    rnn.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
+    out, h = rnn(x)
+    return out, h[-1]
+
+
 def gru_layer(h_cat: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig) -> Tensor:
     """`GRULayer.forward`, reference `modules.py:235-238`; returns h[-1] (b, H).
 
     (The reference also returns out[-1] -- the last *batch element's* sequence,
     a `batch_first` quirk -- which `mtad_gat.py:73` discards.)
     """
-    _, h_end = gru_stack(h_cat, sd, "gru.gru.", cfg.gru_n_layers)
+    _, h_end = _GRU_IMPL[0](h_cat, sd, "gru.gru.", cfg.gru_n_layers)
     return h_end
 
 
@@ -237,15 +248,18 @@ def reconstruction_head(h_end: Tensor, sd: Dict[str, Tensor], cfg: OracleConfig)
     b = h_end.shape[0]
     W = cfg.window_size
     rep = h_end.repeat_interleave(W, dim=1).view(b, W, -1)
-    dec, _ = gru_stack(rep, sd, "recon_model.decoder.rnn.", cfg.recon_n_layers)
+    dec, _ = _GRU_IMPL[0](rep, sd, "recon_model.decoder.rnn.", cfg.recon_n_layers)
     return F.linear(dec, sd["recon_model.fc.weight"], sd["recon_model.fc.bias"])
+
+
+_GRU_IMPL = [gru_stack]
 
 
 # --------------------------------------------------------------------------
 # whole forward
 # --------------------------------------------------------------------------
 def forward(x: Tensor, sd: Dict[str, Tensor], alpha: float = 0.2,
-            return_stages: bool = False):
+            return_stages: bool = False, aten_gru: bool = False):
     """`MTAD_GAT.forward`, reference `mtad_gat.py:64-79` (eval mode).
 
     x (b, W, F) -> (predictions (b, out), recons (b, W, out)); with
@@ -253,6 +267,7 @@ def forward(x: Tensor, sd: Dict[str, Tensor], alpha: float = 0.2,
     """
     cfg = config_from_state_dict(sd, alpha)
     sd = {k: v.to(x.dtype) for k, v in sd.items()}
+    _GRU_IMPL[0] = gru_stack_aten if aten_gru else gru_stack
     xc = conv_layer(x, sd["conv.conv.weight"], sd["conv.conv.bias"])
     h_feat = feature_attention(xc, sd, cfg)
     h_temp = temporal_attention(xc, sd, cfg)
