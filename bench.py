@@ -162,10 +162,8 @@ def main():
         elapsed = time.perf_counter() - t0
         prof = eng.profile_read() if not args.no_profile else None
         eng.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from sharding import max_over_ranks
+    elapsed = max_over_ranks(elapsed, dev)      # the slowest rank's time is the job's time
     assert torch.isfinite(preds).all() and torch.isfinite(recons).all()
 
     if rank == 0:
@@ -195,8 +193,15 @@ def main():
             dom = max(fams, key=lambda k: fams[k]["ms_per_step"])
             ms_dom, n_dom = prof[dom]
             ach = flops[dom] * B * args.steps / (ms_dom * 1e-3) / 1e12
+            traffic = None   # HBM bytes per launch from the committed PMC pass (profiles/), scaled to this batch
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                if dom in tj["bytes_per_window"]:
+                    traffic = int(tj["bytes_per_window"][dom] * B * args.steps / n_dom)
+            except Exception:
+                pass
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "avg_launch_ms": round(ms_dom / n_dom, 3),
                                "alg_flop_per_window": flops[dom],
                                "note": "fp32-input MFMA (exact f32) peak; attend is VALU work (2 ops per pairwise element)"}

@@ -2,6 +2,7 @@
 // the forward() launch sequence and the per-stage entry points.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -74,28 +75,31 @@ int run_conv(Model& m, const float* x, int64_t n, float* xc, float* xct, float* 
     return 0;
 }
 
-int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nrows, float* lr, hipStream_t s) {
+int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nrows, float* lc, float* rt, hipStream_t s) {
     Scope sc(m, S_PROJ, s);
     RowGemmArgs a{};
     a.X = rows; a.ldx = ld; a.Kvalid = g.D; a.Q = g.Q;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
     a.bias = m.packed_dev + g.b_off;
-    a.Y = lr; a.ldy = g.ldo; a.Nvalid = g.ldo; a.vec_store = 1;
+    a.Y = lc; a.ldy = g.ldl; a.Nvalid = g.ldl; a.vec_store = 1;
     a.R = nrows; a.NT = g.NT; a.relu = 0;
+    a.NT_rm = g.NT_L; a.YT = rt; a.group = g.K; a.YT_rows = g.rt_rows; a.YT_ld = g.Kp;
     K_TRY(launch_rowgemm(a, s), "gat projection");
     return 0;
 }
 
-int run_attend(Model& m, const GatPlan& g, const float* lr, const float* v, int ldv, int64_t n, float* out, long so_w,
-               long so_i, long so_d, hipStream_t s) {
+int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, const float* v, int ldv, int64_t n, float* out,
+               long so_w, long so_i, long so_d, hipStream_t s) {
     Scope sc(m, S_ATTEND, s);
     AttendArgs a{};
-    a.LR = lr; a.ldo = g.ldo; a.PT = g.PT; a.P8 = g.P8;
+    a.LC = lc; a.RT = rt; a.ldl = g.ldl; a.rt_rows = g.rt_rows; a.Kp = g.Kp; a.PT = g.PT; a.P8 = g.P8;
     a.bias = m.packed_dev + g.bias_off;
     a.V = v; a.ldv = ldv; a.D = g.D;
     a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
     a.K = g.K; a.rows_per_blk = g.rows_per_blk; a.nblk = g.nblk;
-    a.total_blocks = n * g.nblk;
+    a.nwin = n;
+    { const char* e = getenv("MTADGAT_XCD"); a.xcd_map = e ? atoi(e) : 1; }
+    a.total_blocks = ((n + 7) / 8 * 8) * g.nblk;
     a.v1 = m.cfg.use_gatv2 ? 0 : 1;
     a.alpha = m.cfg.alpha;
     a.ATT = nullptr;
@@ -157,7 +161,7 @@ int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, fl
             a.X = x; a.ldx = ld; a.Kvalid = p.in_dim; a.Q = p.Q;
             a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
             a.bias = m.packed_dev + p.b_off;
-            a.R = n; a.NT = p.NT;
+            a.R = n; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1;
             if (last) {
                 a.Y = preds; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
                 a.vec_store = (p.out_dim % 4 == 0 && aligned16(preds)) ? 1 : 0;
@@ -281,11 +285,11 @@ int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* pred
         float* hcat = ws + o.hcat;
         if ((rc = run_conv(m, xc_in, n, xc, xct, hcat, nullptr, s))) return rc;
         // temporal layer: nodes = time steps, rows of xc
-        if ((rc = run_proj(m, m.temp, xc, m.Fp, n * W, ws + o.lrt, s))) return rc;
+        if ((rc = run_proj(m, m.temp, xc, m.Fp, n * W, ws + o.lct, ws + o.rtt, s))) return rc;
         // feature layer: nodes = features, rows of xc^T
-        if ((rc = run_proj(m, m.feat, xct, m.Wp, n * F, ws + o.lrf, s))) return rc;
-        if ((rc = run_attend(m, m.temp, ws + o.lrt, xc, m.Fp, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
-        if ((rc = run_attend(m, m.feat, ws + o.lrf, xct, m.Wp, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
+        if ((rc = run_proj(m, m.feat, xct, m.Wp, n * F, ws + o.lcf, ws + o.rtf, s))) return rc;
+        if ((rc = run_attend(m, m.temp, ws + o.lct, ws + o.rtt, xc, m.Fp, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
+        if ((rc = run_attend(m, m.feat, ws + o.lcf, ws + o.rtf, xct, m.Wp, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
         float* hend = ws + o.hend;
         const long ldh = m.gru.back().Hp;
         if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s))) return rc;
@@ -328,12 +332,12 @@ int mtadgat_gat(mtadgat_handle h, int which, const float* xc_in, int64_t batch, 
         float* o_c = out + c0 * (int64_t)W * F;
         if (which == 1) {
             K_TRY(launch_copy2d(xin, F, ws + o.xc, m.Fp, n * W, F, s), "pad copy");
-            if ((rc = run_proj(m, m.temp, ws + o.xc, m.Fp, n * W, ws + o.lrt, s))) return rc;
-            if ((rc = run_attend(m, m.temp, ws + o.lrt, ws + o.xc, m.Fp, n, o_c, (long)W * F, F, 1, s))) return rc;
+            if ((rc = run_proj(m, m.temp, ws + o.xc, m.Fp, n * W, ws + o.lct, ws + o.rtt, s))) return rc;
+            if ((rc = run_attend(m, m.temp, ws + o.lct, ws + o.rtt, ws + o.xc, m.Fp, n, o_c, (long)W * F, F, 1, s))) return rc;
         } else {
             K_TRY(launch_transpose_win(xin, F, ws + o.xct, m.Wp, n, W, F, s), "transpose");
-            if ((rc = run_proj(m, m.feat, ws + o.xct, m.Wp, n * F, ws + o.lrf, s))) return rc;
-            if ((rc = run_attend(m, m.feat, ws + o.lrf, ws + o.xct, m.Wp, n, o_c, (long)W * F, 1, F, s))) return rc;
+            if ((rc = run_proj(m, m.feat, ws + o.xct, m.Wp, n * F, ws + o.lcf, ws + o.rtf, s))) return rc;
+            if ((rc = run_attend(m, m.feat, ws + o.lcf, ws + o.rtf, ws + o.xct, m.Wp, n, o_c, (long)W * F, 1, F, s))) return rc;
         }
     }
     return 0;

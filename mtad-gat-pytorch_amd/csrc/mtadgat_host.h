@@ -19,7 +19,10 @@ struct GatPlan {
     int E = 0;      // rows of lin.weight
     int PT = 0;     // pairwise columns (pos + neg groups, each padded to 8)
     int P8 = 0;     // columns of the positive group
-    int ldo = 0;    // row stride of the projected rows [L' | R' | c | d | pad], multiple of 32
+    int ldl = 0;    // row stride of the query-side rows [L'(PT) | c | pad], multiple of 32
+    int rt_rows = 0;// rows per window of the key-side block R'^T: [R'(PT) ; d ; pad], multiple of 32
+    int Kp = 0;     // row stride of R'^T (K padded to 4)
+    int NT_L = 0;   // tiles of the query side; the key-side tiles follow (stored transposed)
     int NT = 0, Q = 0;
     size_t w_off = 0, b_off = 0, bias_off = 0;   // offsets (floats) into the packed buffer
     int rows_per_blk = 0, nblk = 0, IB = 0;      // attend launch plan
@@ -57,7 +60,7 @@ struct Model {
 
 struct Workspace {
     // offsets in floats for a chunk of `n` windows
-    size_t xc, xct, lrt, lrf, hcat, hend, seq0, seq1, fc0, fc1, rseq0, rseq1, total;
+    size_t xc, xct, lct, rtt, lcf, rtf, hcat, hend, seq0, seq1, fc0, fc1, rseq0, rseq1, total;
 };
 
 std::string validate_and_plan(Model& m);                       // "" on success

@@ -22,6 +22,11 @@ struct RowGemmArgs {
     long R;
     int NT;              // output tiles of 32 columns
     int relu;
+    // tiles n >= NT_rm are stored transposed per group of `group` consecutive rows:
+    //   YT[(row / group) * YT_rows + (col - 32*NT_rm)) * YT_ld + row % group]
+    int NT_rm;           // number of leading row-major tiles (== NT when nothing is transposed)
+    float* YT;
+    int group, YT_rows, YT_ld;
 };
 
 struct ConvArgs {
@@ -40,15 +45,18 @@ struct ConvArgs {
 };
 
 struct AttendArgs {
-    const float* LR;     // (B*K, ldo): [L'(PT) | R'(PT) | c | d | pad]
-    int ldo, PT, P8;
+    const float* LC;     // (B*K, ldl) per query node: [L'(PT) | c | pad]
+    const float* RT;     // (B, rt_rows, Kp) per window, key-node-minor: rows [0,PT) = R', row PT = d
+    int ldl, rt_rows, Kp, PT, P8;
     const float* bias;   // (K, K) or null
     const float* V;      // (B*K, ldv) node feature rows
     int ldv, D;
     float* out;          // out[win*so_w + i*so_i + d*so_d]
     long so_w, so_i, so_d;
     int K, rows_per_blk, nblk;
-    long total_blocks;   // B * nblk
+    long total_blocks;   // round_up(B, 8) * nblk
+    long nwin;           // B
+    int xcd_map;         // 1: XCD-aware block -> (window, row block) map
     int v1;
     float alpha;
     float* ATT;          // optional (B, K, K) dump of the attention matrix

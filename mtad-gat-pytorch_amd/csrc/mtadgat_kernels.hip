@@ -25,7 +25,13 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mtadgat_kernels.h"
+
+#ifndef MTADGAT_ATTEND_DEPTH
+#define MTADGAT_ATTEND_DEPTH 2
+#endif
 
 namespace mtadgat {
 
@@ -54,6 +60,29 @@ __device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ row, int k
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// GRU gate non-linearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each):
+// ~8 VALU ops per gate instead of ~40 for the libm versions; the product x*log2(e) is formed in
+// two pieces so the exponent keeps float accuracy for |x| up to ~40.
+#ifndef MTADGAT_ACCURATE_GATES
+__device__ __forceinline__ float exp_fast(float x) {   // e^x, argument clamped to [-88, 88] (no inf/NaN in, none out)
+    x = __builtin_amdgcn_fmed3f(x, -88.0f, 88.0f);
+    const float c_hi = 1.4426950216293335f;             // log2(e) rounded to float
+    const float c_lo = 1.9259629911266175e-08f;          // log2(e) - c_hi
+    const float hi = x * c_hi;
+    const float lo = __builtin_fmaf(x, c_hi, -hi) + x * c_lo;
+    return __builtin_amdgcn_exp2f(hi) * (1.0f + 0.6931471805599453f * lo);
+}
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(exp_fast(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float soft_exp(float x) { return exp_fast(x); }
+__device__ __forceinline__ float soft_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+__device__ __forceinline__ float gate_sigmoid(float x) { return sigmoidf_(x); }
+__device__ __forceinline__ float gate_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ float soft_exp(float x) { return expf(x); }
+__device__ __forceinline__ float soft_rcp(float x) { return 1.0f / x; }
+#endif
 
 // ---------------------------------------------------------------------------
 // rowgemm: Y[r, :] = act(W * X[r, :] + bias) for R data rows, 32 rows per wave.
@@ -105,6 +134,9 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
             if (n0 + nb >= a.NT) break;
+            const bool transposed = (n0 + nb) >= a.NT_rm;
+            const long grp = row / a.group;
+            const int member = (int)(row - grp * a.group);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int col = 32 * (n0 + nb) + 8 * m + 4 * g;
@@ -116,13 +148,19 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
                     v[s] = a.relu ? fmaxf(t, 0.f) : t;
                 }
                 if (row < a.R) {
-                    float* yp = a.Y + row * a.ldy + col;
-                    if (a.vec_store && col + 3 < a.Nvalid) {
-                        *reinterpret_cast<f32x4*>(yp) = v;
-                    } else {
+                    if (transposed) {   // lanes i <-> consecutive group members: coalesced 4-byte stores
+                        float* tp = a.YT + (grp * a.YT_rows + (col - 32 * a.NT_rm)) * (long)a.YT_ld + member;
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (col + s < a.Nvalid) yp[s] = v[s];
+                        for (int s = 0; s < 4; ++s) tp[(long)s * a.YT_ld] = v[s];
+                    } else {
+                        float* yp = a.Y + row * a.ldy + col;
+                        if (a.vec_store && col + 3 < a.Nvalid) {
+                            *reinterpret_cast<f32x4*>(yp) = v;
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                if (col + s < a.Nvalid) yp[s] = v[s];
+                        }
                     }
                 }
             }
@@ -234,64 +272,100 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
 // The softmax'd rows are staged through LDS into MFMA B-operand order and the
 // aggregation att @ V runs on the matrix pipe.
 // ---------------------------------------------------------------------------
-template <int JPL, int IB, bool NEG>
-__device__ __forceinline__ void attend_tile(float (&acc)[IB][JPL], const float* __restrict__ Lrow0, const int (&loff)[IB],
-                                            const float* (&Rp)[JPL], int k0) {
-    f32x4 r0[JPL], r1[JPL];
-#pragma unroll
-    for (int jj = 0; jj < JPL; ++jj) {
-        r0[jj] = *reinterpret_cast<const f32x4*>(Rp[jj] + k0);
-        r1[jj] = *reinterpret_cast<const f32x4*>(Rp[jj] + k0 + 4);
+// compile-time loop (DPP controls must be immediates)
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
     }
-    // branch-free over the IB query rows (rows past the block end are clamped duplicates whose
-    // results are dropped) so the scalar loads of L' can be scheduled ahead of the VALU work
+}
+// value of lane N of this lane's 16-lane row (gfx90a+ DPP row_newbcast); folds into the consuming VALU op
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
+}
+
+// one 8-wide k tile of the pairwise term for all IB query rows.
+//   r[jj][e]  : R'[k0+e][j]  for this lane's key nodes j (one VGPR each)
+//   lt[x]     : L' tile, lane n of every 16-lane row holds L'[row 2x + (n>>3)][k0 + (n&7)]
+// so L'_ik reaches all lanes through a DPP row broadcast fused into the add: 2 VALU ops/element
+// (v_add_f32_dpp + v_add_f32 |t|), no scalar loads, no LDS.  Measured on MI355X (scratch
+// microbenchmark): DPP add 4.3 cycles, |abs| accumulate 2.7 cycles per wave64
+// instruction with >= 2 waves/SIMD.  A software-pipelined variant (no back-to-back dependent pair,
+// no s_nop) measured slower because its extra live temporaries cost a wave of occupancy.
+template <int JPL, int IB, bool NEG>
+__device__ __forceinline__ void attend_tile(float (&acc)[IB][JPL], const float (&r)[JPL][8], const float (&lt)[IB / 2]) {
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) {
-        const float* __restrict__ Lp = Lrow0 + loff[ib] + k0;  // wave-uniform -> s_load_dwordx8
-        float l[8];
+    for (int x = 0; x < IB / 2; ++x) {
+        const float lv = lt[x];
+        static_for<0, 16>([&](auto nn) {
+            constexpr int N = decltype(nn)::value;
+            constexpr int e = N & 7;
+            const int ib = 2 * x + (N >> 3);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) l[e] = Lp[e];
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t0 = l[e] + r0[jj][e];
-                const float t1 = l[4 + e] + r1[jj][e];
-                if (NEG) {
-                    acc[ib][jj] -= fabsf(t0);
-                    acc[ib][jj] -= fabsf(t1);
-                } else {
-                    acc[ib][jj] += fabsf(t0);
-                    acc[ib][jj] += fabsf(t1);
-                }
+            for (int jj = 0; jj < JPL; ++jj) {
+                const float t = row_bcast<N>(lv) + r[jj][e];
+                if (NEG)
+                    acc[ib][jj] -= fabsf(t);
+                else
+                    acc[ib][jj] += fabsf(t);
             }
-        }
+        });
     }
 }
 
+// wave-wide all-reduce without LDS: butterfly inside each 16-lane row with DPP (fused into the
+// v_max / v_add), then the four row results meet through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_move<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_move<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_move<0x140>(v));   // row_mirror
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 template <int JPL, int IB>
-__global__ __launch_bounds__(64) void k_attend(const AttendArgs a) {
+__global__ __launch_bounds__(64, (JPL <= 2 ? 3 : 2)) void k_attend(const AttendArgs a) {
     __shared__ __attribute__((aligned(16))) float att_s[32][68];
+    static_assert(IB % 2 == 0 && IB <= 32, "IB");
+    constexpr int NL = IB / 2;
     const int lane = threadIdx.x;
+    // XCD-aware block -> (window, row block) map: dispatch ids b, b+8, b+16, ... run on the same
+    // XCD (b % 8), so giving them the row blocks of ONE window lets that window's R'^T / V tiles be
+    // fetched from HBM once and served to the other row blocks from that XCD's L2.
     const long blk = blockIdx.x;
-    const long win = blk / a.nblk;
-    const int rb = (int)(blk - win * a.nblk);
+    long win;
+    int rb;
+    if (a.xcd_map) {
+        const long grp = blk / (8 * a.nblk);
+        const int within = (int)(blk - grp * (8 * a.nblk));
+        win = grp * 8 + (within & 7);
+        rb = within >> 3;
+    } else {
+        win = blk / a.nblk;
+        rb = (int)(blk - win * a.nblk);
+    }
+    if (win >= a.nwin) return;
     const int i0 = rb * a.rows_per_blk;
     const int nrows = min(a.rows_per_blk, a.K - i0);
-    const int K = a.K, ldo = a.ldo, PT = a.PT;
-    const float* __restrict__ LR = a.LR;
-    const float* __restrict__ Lrow0 = LR + (win * K + i0) * (long)ldo;
+    const int K = a.K, ldl = a.ldl, PT = a.PT, Kp = a.Kp;
+    const float* __restrict__ Lrow0 = a.LC + (win * K + i0) * (long)ldl;
+    const float* __restrict__ RTw = a.RT + win * (long)a.rt_rows * Kp;
 
     float acc[IB][JPL];
 #pragma unroll
@@ -304,51 +378,93 @@ __global__ __launch_bounds__(64) void k_attend(const AttendArgs a) {
     for (int jj = 0; jj < JPL; ++jj) {
         int j = jj * 64 + lane;
         j = j < K ? j : K - 1;
-        Rp[jj] = LR + (win * K + j) * (long)ldo + PT;
+        Rp[jj] = RTw + j;
     }
-    int loff[IB];
+    // rows past the end of the block are clamped duplicates; their results are dropped below
+    int loff[NL];
+    {
+        const int n16 = lane & 15;
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) loff[ib] = (ib < nrows ? ib : nrows - 1) * ldo;
-    for (int k0 = 0; k0 < a.P8; k0 += 8) attend_tile<JPL, IB, false>(acc, Lrow0, loff, Rp, k0);
-    for (int k0 = a.P8; k0 < PT; k0 += 8) attend_tile<JPL, IB, true>(acc, Lrow0, loff, Rp, k0);
+        for (int x = 0; x < NL; ++x) {
+            const int i = 2 * x + (n16 >> 3);
+            loff[x] = (i < nrows ? i : nrows - 1) * ldl + (n16 & 7);
+        }
+    }
+    if (PT > 0) {
+        // 3-deep register ring over the k tiles: tile t+2 is requested before tile t is consumed, so two
+        // tiles of VALU work (~2.5k cycles) plus the other resident waves cover the HBM/L2 latency
+        constexpr int DEPTH = JPL <= 2 ? MTADGAT_ATTEND_DEPTH : 2;   // JPL >= 4: the tiles themselves fill the register file
+        float rr[DEPTH][JPL][8], lr[DEPTH][NL];
+        const int ntile = PT >> 3;
+        auto fetch = [&](int st, int tile) {
+            const int k1 = (tile < ntile ? tile : ntile - 1) << 3;
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rr[st][jj][e] = Rp[jj][(long)(k1 + e) * Kp];
+#pragma unroll
+            for (int x = 0; x < NL; ++x) lr[st][x] = Lrow0[loff[x] + k1];
+        };
+#pragma unroll
+        for (int st = 0; st < DEPTH - 1; ++st) fetch(st, st);
+        const int ptile = a.P8 >> 3;
+        for (int t0 = 0; t0 < ntile; t0 += DEPTH) {
+#pragma unroll
+            for (int st = 0; st < DEPTH; ++st) {
+                const int t = t0 + st;
+                if (t < ntile) {
+                    fetch((st + DEPTH - 1) % DEPTH, t + DEPTH - 1);
+                    if (t < ptile)
+                        attend_tile<JPL, IB, false>(acc, rr[st], lr[st]);
+                    else
+                        attend_tile<JPL, IB, true>(acc, rr[st], lr[st]);
+                }
+            }
+        }
+    }
 
-    // scores -> softmax over j (reference modules.py:85-89 / :184-188)
+    // scores -> softmax over j (reference modules.py:85-89 / :184-188); branch-free over rows
     float dj[JPL];
 #pragma unroll
-    for (int jj = 0; jj < JPL; ++jj) dj[jj] = Rp[jj][PT + 1];
+    for (int jj = 0; jj < JPL; ++jj) dj[jj] = Rp[jj][(long)PT * Kp];
+    const float cvec = Lrow0[(long)(lane < nrows ? lane : nrows - 1) * ldl + PT];   // lane ib holds c_ib
+    float bv[IB][JPL];
 #pragma unroll
     for (int ib = 0; ib < IB; ++ib) {
-        if (ib < nrows) {
-            const float ci = Lrow0[(long)ib * ldo + 2 * PT];
-            float e[JPL];
-            float m = -INFINITY;
+        const int irow = i0 + (ib < nrows ? ib : nrows - 1);
 #pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) {
-                const int j = jj * 64 + lane;
-                float v = acc[ib][jj] + ci + dj[jj];
-                if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
-                if (j < K) {
-                    if (a.bias) v += a.bias[(long)(i0 + ib) * K + j];
-                } else {
-                    v = -INFINITY;
-                }
-                e[jj] = v;
-                m = fmaxf(m, v);
-            }
-            m = wave_max(m);
-            float s = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) {
-                e[jj] = expf(e[jj] - m);
-                s += e[jj];
-            }
-            s = wave_sum(s);
-#pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) acc[ib][jj] = e[jj] / s;
-        } else {
-#pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) acc[ib][jj] = 0.f;
+        for (int jj = 0; jj < JPL; ++jj) {
+            int j = jj * 64 + lane;
+            j = j < K ? j : K - 1;
+            bv[ib][jj] = a.bias ? a.bias[(long)irow * K + j] : 0.f;
         }
+    }
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+        const float ci = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cvec), ib));
+        float e[JPL];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            const int j = jj * 64 + lane;
+            float v = acc[ib][jj] + ci + dj[jj];
+            if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
+            v += bv[ib][jj];
+            v = j < K ? v : -INFINITY;
+            e[jj] = v;
+            m = fmaxf(m, v);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            e[jj] = (jj * 64 + lane < K) ? soft_exp(e[jj] - m) : 0.f;
+            sum += e[jj];
+        }
+        sum = wave_sum(sum);
+        const float inv = soft_rcp(sum);
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ib][jj] = ib < nrows ? e[jj] * inv : 0.f;
     }
     if (a.ATT) {  // optional dump of the attention matrix (tests)
 #pragma unroll
@@ -375,6 +491,14 @@ __global__ __launch_bounds__(64) void k_attend(const AttendArgs a) {
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+        int dcl[2];
+        bool dok[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int d = 32 * (dt0 + nb) + i;
+            dok[nb] = d < a.D;
+            dcl[nb] = dok[nb] ? d : a.D - 1;
+        }
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
             if (jj * 64 < K) {
@@ -382,20 +506,31 @@ __global__ __launch_bounds__(64) void k_attend(const AttendArgs a) {
 #pragma unroll
                 for (int ib = 0; ib < IB; ++ib) att_s[ib][lane] = acc[ib][jj];
                 __syncthreads();
+                // rolled loop over the chunks of this 64-node block, operands of chunk q+1 fetched before
+                // chunk q's MFMAs (att is 0 past K; V loads are clamped + masked, no divergent control flow)
                 const int jn = min(64, K - jj * 64);
                 const int nq = (jn + 7) >> 3;
-                for (int q = 0; q < nq; ++q) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(&att_s[i][8 * q + 4 * g]);
+                auto fetch = [&](int q, f32x4& bq, f32x4 (&av)[2]) {
+                    bq = *reinterpret_cast<const f32x4*>(&att_s[i][8 * q + 4 * g]);
                     const int jb = jj * 64 + 8 * q + 4 * g;
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        const int d = 32 * (dt0 + nb) + i;
-                        f32x4 av;
+                    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            av[s] = (jb + s < K && d < a.D) ? Vw[(long)(jb + s) * a.ldv + d] : 0.f;
-                        o[nb] = mfma4(av, bv, o[nb]);
-                    }
+                        for (int s = 0; s < 4; ++s) {
+                            const int jc = jb + s < K ? jb + s : K - 1;
+                            const float v = Vw[(long)jc * a.ldv + dcl[nb]];
+                            av[nb][s] = (jb + s < K && dok[nb]) ? v : 0.f;
+                        }
+                };
+                f32x4 bq, av[2];
+                fetch(0, bq, av);
+#pragma unroll 1
+                for (int q = 0; q < nq; ++q) {
+                    f32x4 bn, an[2];
+                    fetch(q + 1 < nq ? q + 1 : q, bn, an);
+                    o[0] = mfma4(av[0], bq, o[0]);
+                    o[1] = mfma4(av[1], bq, o[1]);
+                    bq = bn; av[0] = an[0]; av[1] = an[1];
                 }
             }
         }
@@ -405,7 +540,7 @@ __global__ __launch_bounds__(64) void k_attend(const AttendArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int d = 32 * (dt0 + nb) + (r & 3) + 8 * (r >> 2) + 4 * g;
                 if (i < nrows && d < a.D)
-                    a.out[win * a.so_w + (long)(i0 + i) * a.so_i + (long)d * a.so_d] = sigmoidf_(o[nb][r]);
+                    a.out[win * a.so_w + (long)(i0 + i) * a.so_i + (long)d * a.so_d] = gate_sigmoid(o[nb][r]);
             }
         }
     }
@@ -424,7 +559,7 @@ __global__ __launch_bounds__(64) void k_attend(const AttendArgs a) {
 //            step t holds W_ih summed over the j that map to each of them.
 // ---------------------------------------------------------------------------
 template <int NCG, int XMODE, bool FC>
-__global__ __launch_bounds__(64) void k_gru(const GruArgs a) {
+__global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a) {
     __shared__ float hn_s[NCG][16][64];
     const int lane = threadIdx.x;
     const int i = lane & 31, g = lane >> 5;
@@ -467,41 +602,54 @@ __global__ __launch_bounds__(64) void k_gru(const GruArgs a) {
                     anh[4 * m + s] = b3[s];
                 }
             }
-            // ---- input part: W_i{r,z,n} x_t
+            // ---- input part: W_i{r,z,n} x_t.  3-deep register ring: the loads of chunk q+3 are issued
+            // right after chunk q's MFMAs, i.e. two chunks (24 MFMAs ~ 1.5k cycles) ahead of their use
             {
                 const f32x4* __restrict__ wp = Wx + ((long)c * Qx) * 3 * 64 + lane;
-                f32x4 xv = loadx(0);
-                f32x4 w0 = wp[0], w1 = wp[64], w2 = wp[128];
-                for (int q = 0; q < Qx; ++q) {
-                    const int qn = (q + 1 < Qx) ? q + 1 : q;
-                    const f32x4 xn = loadx(qn);
-                    const f32x4* __restrict__ wq = wp + (long)qn * 3 * 64;
-                    const f32x4 n0 = wq[0], n1 = wq[64], n2 = wq[128];
-                    ar = mfma4(w0, xv, ar);
-                    az = mfma4(w1, xv, az);
-                    anx = mfma4(w2, xv, anx);
-                    xv = xn; w0 = n0; w1 = n1; w2 = n2;
+                f32x4 xs[3], ws[3][3];
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+                    const int q = st < Qx ? st : Qx - 1;
+                    xs[st] = loadx(q);
+                    ws[st][0] = wp[(long)q * 192]; ws[st][1] = wp[(long)q * 192 + 64]; ws[st][2] = wp[(long)q * 192 + 128];
+                }
+                for (int q0 = 0; q0 < Qx; q0 += 3) {
+#pragma unroll
+                    for (int st = 0; st < 3; ++st) {
+                        if (q0 + st < Qx) {
+                            ar = mfma4(ws[st][0], xs[st], ar);
+                            az = mfma4(ws[st][1], xs[st], az);
+                            anx = mfma4(ws[st][2], xs[st], anx);
+                            const int qn = (q0 + st + 3 < Qx) ? q0 + st + 3 : Qx - 1;
+                            xs[st] = loadx(qn);
+                            ws[st][0] = wp[(long)qn * 192]; ws[st][1] = wp[(long)qn * 192 + 64];
+                            ws[st][2] = wp[(long)qn * 192 + 128];
+                        }
+                    }
                 }
             }
             // ---- recurrent part: W_h{r,z,n} h_{t-1}   (h_0 = 0: skipped at t = 0)
             if (t > 0) {
                 const f32x4* __restrict__ wp = Wh + ((long)c * Qh) * 3 * 64 + lane;
-                f32x4 w0 = wp[0], w1 = wp[64], w2 = wp[128];
+                f32x4 ws[3][3];
 #pragma unroll
-                for (int cq = 0; cq < NCG; ++cq) {
+                for (int st = 0; st < 3; ++st) {
+                    const int q = st < Qh ? st : Qh - 1;
+                    ws[st][0] = wp[(long)q * 192]; ws[st][1] = wp[(long)q * 192 + 64]; ws[st][2] = wp[(long)q * 192 + 128];
+                }
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const int q = 4 * cq + m;
-                        const int qn = (q + 1 < Qh) ? q + 1 : q;
-                        const f32x4* __restrict__ wq = wp + (long)qn * 3 * 64;
-                        const f32x4 n0 = wq[0], n1 = wq[64], n2 = wq[128];
-                        f32x4 hv;
-                        hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
-                        hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
-                        ar = mfma4(w0, hv, ar);
-                        az = mfma4(w1, hv, az);
-                        anh = mfma4(w2, hv, anh);
-                        w0 = n0; w1 = n1; w2 = n2;
+                for (int q = 0; q < Qh; ++q) {
+                    const int cq = q >> 2, m = q & 3, st = q % 3;
+                    f32x4 hv;
+                    hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
+                    hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
+                    ar = mfma4(ws[st][0], hv, ar);
+                    az = mfma4(ws[st][1], hv, az);
+                    anh = mfma4(ws[st][2], hv, anh);
+                    if (q + 3 < Qh) {
+                        const int qn = q + 3;
+                        ws[st][0] = wp[(long)qn * 192]; ws[st][1] = wp[(long)qn * 192 + 64];
+                        ws[st][2] = wp[(long)qn * 192 + 128];
                     }
                 }
             }
@@ -509,9 +657,9 @@ __global__ __launch_bounds__(64) void k_gru(const GruArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float hold = (t > 0) ? hn_s[c][r][lane] : 0.f;
-                const float rg = sigmoidf_(ar[r]);
-                const float zg = sigmoidf_(az[r]);
-                const float ng = tanhf(anx[r] + rg * anh[r]);
+                const float rg = gate_sigmoid(ar[r]);
+                const float zg = gate_sigmoid(az[r]);
+                const float ng = gate_tanh(anx[r] + rg * anh[r]);
                 ar[r] = (1.0f - zg) * ng + zg * hold;
             }
             // every lane reads and writes only its own slots -> no cross-lane hazard
@@ -639,7 +787,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
 // and pick the kernel's unrolled row count IB >= rows_per_blk that wastes the fewest rows.
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB) {
     const int jpl = (K + 63) / 64;
-    const int ibmax = jpl <= 2 ? 32 : (jpl <= 4 ? 16 : 8);
+    const int ibmax = jpl <= 1 ? 32 : (jpl <= 2 ? 20 : (jpl <= 4 ? 16 : 8));   // register budget (no spills)
     const int step = jpl <= 2 ? 4 : 8;
     const int nb0 = (K + ibmax - 1) / ibmax;
     long best = -1;

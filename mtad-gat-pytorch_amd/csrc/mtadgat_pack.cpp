@@ -73,12 +73,15 @@ std::string validate_and_plan(Model& m) {
     auto plan_gat = [&](GatPlan& g, int K, int D, int E) {
         g.K = K; g.D = D; g.E = E;
         const int ptcap = c.use_gatv2 ? round_up(E, 8) + 8 : 0;
-        g.ldo = round_up(2 * ptcap + 2, 32);
-        g.NT = g.ldo / 32;
+        g.ldl = round_up(ptcap + 1, 32);
+        g.rt_rows = g.ldl;
+        g.Kp = round_up(K, 4);
+        g.NT_L = g.ldl / 32;
+        g.NT = 2 * g.NT_L;
         g.Q = (D + 7) / 8;
         g.PT = g.P8 = 0;
         g.w_off = take((size_t)g.NT * g.Q * 256);
-        g.b_off = take((size_t)g.ldo);
+        g.b_off = take((size_t)g.NT * 32);
         g.bias_off = take((size_t)K * K);
         attend_plan(K, &g.rows_per_blk, &g.nblk, &g.IB);
     };
@@ -161,8 +164,10 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     const size_t N = (size_t)n;
     ws.xc = take(N * m.W * m.Fp);
     ws.xct = take(N * m.F * m.Wp);
-    ws.lrt = take(N * m.W * m.temp.ldo);
-    ws.lrf = take(N * m.F * m.feat.ldo);
+    ws.lct = take(N * m.W * m.temp.ldl);
+    ws.rtt = take(N * m.temp.rt_rows * m.temp.Kp);
+    ws.lcf = take(N * m.F * m.feat.ldl);
+    ws.rtf = take(N * m.feat.rt_rows * m.feat.Kp);
     ws.hcat = take(N * m.W * m.Dp);
     ws.hend = take(N * m.gru.back().Hp);
     const bool gseq = m.gru.size() > 1;
@@ -182,7 +187,9 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
                      std::vector<float>& out) {
     const int E = g.E, D = g.D;
     const double alpha = m.cfg.alpha;
-    std::vector<double> rows((size_t)g.ldo * D, 0.0), bvec(g.ldo, 0.0);
+    // projected columns: query side [0, ldl) = [L'(PT) | c | 0..], key side [ldl, 2 ldl) = [R'(PT) | d | 0..]
+    const int NC = 2 * g.ldl, KS = g.ldl;
+    std::vector<double> rows((size_t)NC * D, 0.0), bvec(NC, 0.0);
     if (m.cfg.use_gatv2) {
         // e_ij = a . LeakyReLU(W_l v_i + W_r v_j + b)          (reference modules.py:74-77, :174-177)
         //      = c_i + d_j + sum_k a'_k |L_ik + R_jk|,  LeakyReLU(u) = (1+alpha)/2 u + (1-alpha)/2 |u|
@@ -201,17 +208,17 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
             const double s = std::fabs((1.0 - alpha) * 0.5 * (double)a[k]);
             for (int cidx = 0; cidx < D; ++cidx) {
                 rows[(size_t)n * D + cidx] = s * (double)lin_w[(size_t)k * lin_in + cidx];
-                rows[(size_t)(g.PT + n) * D + cidx] = s * (double)lin_w[(size_t)k * lin_in + D + cidx];
+                rows[(size_t)(KS + n) * D + cidx] = s * (double)lin_w[(size_t)k * lin_in + D + cidx];
             }
             bvec[n] = s * (double)lin_b[k];
         }
         const double hl = (1.0 + alpha) * 0.5;
         for (int k = 0; k < E; ++k) {
             for (int cidx = 0; cidx < D; ++cidx) {
-                rows[(size_t)(2 * g.PT) * D + cidx] += hl * (double)a[k] * (double)lin_w[(size_t)k * lin_in + cidx];
-                rows[(size_t)(2 * g.PT + 1) * D + cidx] += hl * (double)a[k] * (double)lin_w[(size_t)k * lin_in + D + cidx];
+                rows[(size_t)(g.PT) * D + cidx] += hl * (double)a[k] * (double)lin_w[(size_t)k * lin_in + cidx];
+                rows[(size_t)(KS + g.PT) * D + cidx] += hl * (double)a[k] * (double)lin_w[(size_t)k * lin_in + D + cidx];
             }
-            bvec[2 * g.PT] += hl * (double)a[k] * (double)lin_b[k];
+            bvec[g.PT] += hl * (double)a[k] * (double)lin_b[k];
         }
     } else {
         // e_ij = LeakyReLU(a1 . (W v_i + b) + a2 . (W v_j + b))   (reference modules.py:80-83, :180-183)
@@ -219,16 +226,16 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
         for (int k = 0; k < E; ++k) {
             for (int cidx = 0; cidx < D; ++cidx) {
                 rows[(size_t)0 * D + cidx] += (double)a[k] * (double)lin_w[(size_t)k * D + cidx];
-                rows[(size_t)1 * D + cidx] += (double)a[E + k] * (double)lin_w[(size_t)k * D + cidx];
+                rows[(size_t)KS * D + cidx] += (double)a[E + k] * (double)lin_w[(size_t)k * D + cidx];
             }
             bvec[0] += (double)a[k] * (double)lin_b[k];
-            bvec[1] += (double)a[E + k] * (double)lin_b[k];
+            bvec[KS] += (double)a[E + k] * (double)lin_b[k];
         }
     }
     pack_tiles(out.data() + g.w_off, g.NT, g.Q, [&](int n, int k) -> float {
-        return (n < g.ldo && k < D) ? (float)rows[(size_t)n * D + k] : 0.f;
+        return (n < NC && k < D) ? (float)rows[(size_t)n * D + k] : 0.f;
     });
-    for (int n = 0; n < g.ldo; ++n) out[g.b_off + n] = (float)bvec[n];
+    for (int n = 0; n < NC; ++n) out[g.b_off + n] = (float)bvec[n];
     std::memcpy(out.data() + g.bias_off, bias, sizeof(float) * (size_t)g.K * g.K);
 }
 
