@@ -118,6 +118,8 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
     a.bias = m.packed_dev + g.b_off;
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
+    a.Qh_eff = (g.H + 7) / 8;
+    { const char* e = getenv("MTADGAT_STAGGER"); a.stagger = e ? atoi(e) : 2; }
     a.Hend = hend; a.ldhe = ldhe;
     a.Seq = seq; a.ldseq = g.Hp;
     if (fc) {

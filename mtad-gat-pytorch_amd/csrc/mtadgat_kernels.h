@@ -72,6 +72,8 @@ struct GruArgs {
     const f32x4* Wh;     // [c][4*NCG][3][64]
     const float* bias;   // [4][Hp]: b_ir+b_hr | b_iz+b_hz | b_in | b_hn
     int Hp, H, T;
+    int Qh_eff;          // ceil(H / 8): recurrent chunks that can be non-zero
+    int stagger;         // s_sleep(127) repetitions for odd wave slots (0 = off)
     long B;
     float* Hend;         // (B, ldhe) or null
     long ldhe;

@@ -565,10 +565,17 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
     const int i = lane & 31, g = lane >> 5;
     const long win = (long)blockIdx.x * 32 + i;
     const long winc = win < a.B ? win : a.B - 1;
-    const int T = a.T, Qx = a.Qx;
+    const int T = a.T, Qx = a.Qx, Qhe = a.Qh_eff;
     constexpr int Qh = 4 * NCG;
+    const int S = Qx + Qhe;                       // weight chunks per hidden tile and step
     const bool xvec = (a.ldx & 3) == 0;
-    const f32x4* __restrict__ Wh = a.Wh;
+
+    // The two waves that share a SIMD run the same instruction stream from the same start and would
+    // stall (gate math, h reload) in lock-step, leaving the matrix pipe idle ~1/3 of the time (PMC:
+    // SQ_VALU_MFMA_BUSY 63 %).  Delay the odd wave slots by about half a hidden-tile iteration once.
+    if (a.stagger && (__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 1)) {
+        for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    }
 
     f32x16 h[NCG];
 #pragma unroll
@@ -576,15 +583,44 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[c][r] = 0.f;
 
-    for (int t = 0; t < T; ++t) {
-        const float* __restrict__ xrow = (XMODE == 0) ? a.X + (winc * T + t) * a.ldx : a.X + winc * a.ldx;
-        const int m0 = (XMODE == 1) ? a.m0[t] : 0;
-        const f32x4* __restrict__ Wx = a.Wx + ((XMODE == 1) ? (long)t * NCG * Qx * 3 * 64 : 0);
-        auto loadx = [&](int q) -> f32x4 {
-            if (XMODE == 0) return load_feat4(xrow, 8 * q + 4 * g, a.Kx, xvec);
-            return load_feat4(xrow, m0 + 8 * q + 4 * g, a.Kx, false);
-        };
+    // ---- weight stream: one continuous sequence of chunks [tile c][x chunks 0..Qx) [h chunks 0..Qhe)
+    // per step, fetched through a 3-stage register ring that never drains: the cursor runs 3 chunks
+    // (36 MFMAs ~ 2.3k cycles) ahead of the MFMAs across the x/h, tile and step boundaries.
+    int pc = 0, ps = 0, pt = 0;                   // prefetch cursor (wave-uniform)
+    auto wload = [&](f32x4 (&dst)[3]) {
+        const f32x4* __restrict__ p;
+        if (ps < Qx) {
+            const long tt = (XMODE == 1) ? (long)(pt < T ? pt : T - 1) * NCG * Qx : 0;
+            p = a.Wx + (tt + (long)pc * Qx + ps) * 192 + lane;
+        } else {
+            p = a.Wh + ((long)pc * Qh + (ps - Qx)) * 192 + lane;
+        }
+        dst[0] = p[0]; dst[1] = p[64]; dst[2] = p[128];
+        if (++ps == S) { ps = 0; if (++pc == NCG) { pc = 0; ++pt; } }
+    };
+    auto rotate = [&](f32x4 (&r)[3][3], int m) {   // (r0,r1,r2) <- (r_m, r_m+1, r_m+2); branch-free selects
+        const bool m1 = (m == 1), m2 = (m == 2);    // (a branchy version gets merged into dynamically indexed scratch)
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = r[0][u][e], a1 = r[1][u][e], a2 = r[2][u][e];
+                r[0][u][e] = m1 ? a1 : (m2 ? a2 : a0);
+                r[1][u][e] = m1 ? a2 : (m2 ? a0 : a1);
+                r[2][u][e] = m1 ? a0 : (m2 ? a1 : a2);
+            }
+    };
+    auto loadx_t = [&](int t, int q) -> f32x4 {
+        if (XMODE == 0) return load_feat4(a.X + (winc * T + t) * a.ldx, 8 * q + 4 * g, a.Kx, xvec);
+        return load_feat4(a.X + winc * a.ldx, a.m0[t] + 8 * q + 4 * g, a.Kx, false);
+    };
 
+    f32x4 wr[3][3], xr[3];
+    wload(wr[0]); wload(wr[1]); wload(wr[2]);
+#pragma unroll
+    for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st < Qx ? st : Qx - 1);
+
+    for (int t = 0; t < T; ++t) {
         for (int c = 0; c < NCG; ++c) {
             f32x16 ar, az, anx, anh;
 #pragma unroll
@@ -595,63 +631,49 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                 const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias + 2 * a.Hp + col);
                 const f32x4 b3 = *reinterpret_cast<const f32x4*>(a.bias + 3 * a.Hp + col);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    ar[4 * m + s] = b0[s];
-                    az[4 * m + s] = b1[s];
-                    anx[4 * m + s] = b2[s];
-                    anh[4 * m + s] = b3[s];
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    ar[4 * m + s4] = b0[s4];
+                    az[4 * m + s4] = b1[s4];
+                    anx[4 * m + s4] = b2[s4];
+                    anh[4 * m + s4] = b3[s4];
                 }
             }
-            // ---- input part: W_i{r,z,n} x_t.  3-deep register ring: the loads of chunk q+3 are issued
-            // right after chunk q's MFMAs, i.e. two chunks (24 MFMAs ~ 1.5k cycles) ahead of their use
-            {
-                const f32x4* __restrict__ wp = Wx + ((long)c * Qx) * 3 * 64 + lane;
-                f32x4 xs[3], ws[3][3];
+            // ---- input part: W_i{r,z,n} x_t
+            for (int q0 = 0; q0 < Qx; q0 += 3) {
 #pragma unroll
                 for (int st = 0; st < 3; ++st) {
-                    const int q = st < Qx ? st : Qx - 1;
-                    xs[st] = loadx(q);
-                    ws[st][0] = wp[(long)q * 192]; ws[st][1] = wp[(long)q * 192 + 64]; ws[st][2] = wp[(long)q * 192 + 128];
-                }
-                for (int q0 = 0; q0 < Qx; q0 += 3) {
-#pragma unroll
-                    for (int st = 0; st < 3; ++st) {
-                        if (q0 + st < Qx) {
-                            ar = mfma4(ws[st][0], xs[st], ar);
-                            az = mfma4(ws[st][1], xs[st], az);
-                            anx = mfma4(ws[st][2], xs[st], anx);
-                            const int qn = (q0 + st + 3 < Qx) ? q0 + st + 3 : Qx - 1;
-                            xs[st] = loadx(qn);
-                            ws[st][0] = wp[(long)qn * 192]; ws[st][1] = wp[(long)qn * 192 + 64];
-                            ws[st][2] = wp[(long)qn * 192 + 128];
-                        }
+                    if (q0 + st < Qx) {
+                        ar = mfma4(wr[st][0], xr[st], ar);
+                        az = mfma4(wr[st][1], xr[st], az);
+                        anx = mfma4(wr[st][2], xr[st], anx);
+                        wload(wr[st]);
+                        const int qn = q0 + st + 3;
+                        xr[st] = loadx_t(t, qn < Qx ? qn : Qx - 1);
                     }
                 }
             }
-            // ---- recurrent part: W_h{r,z,n} h_{t-1}   (h_0 = 0: skipped at t = 0)
-            if (t > 0) {
-                const f32x4* __restrict__ wp = Wh + ((long)c * Qh) * 3 * 64 + lane;
-                f32x4 ws[3][3];
+            rotate(wr, Qx % 3);
+            // ---- recurrent part: W_h{r,z,n} h_{t-1}  (h_0 = 0 contributes nothing at t = 0; kept so the
+            // weight stream stays continuous).  Only the ceil(H/8) chunks that can be non-zero.
 #pragma unroll
-                for (int st = 0; st < 3; ++st) {
-                    const int q = st < Qh ? st : Qh - 1;
-                    ws[st][0] = wp[(long)q * 192]; ws[st][1] = wp[(long)q * 192 + 64]; ws[st][2] = wp[(long)q * 192 + 128];
-                }
-#pragma unroll
-                for (int q = 0; q < Qh; ++q) {
+            for (int q = 0; q < Qh; ++q) {
+                if (q < Qhe) {
                     const int cq = q >> 2, m = q & 3, st = q % 3;
                     f32x4 hv;
                     hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
                     hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
-                    ar = mfma4(ws[st][0], hv, ar);
-                    az = mfma4(ws[st][1], hv, az);
-                    anh = mfma4(ws[st][2], hv, anh);
-                    if (q + 3 < Qh) {
-                        const int qn = q + 3;
-                        ws[st][0] = wp[(long)qn * 192]; ws[st][1] = wp[(long)qn * 192 + 64];
-                        ws[st][2] = wp[(long)qn * 192 + 128];
-                    }
+                    ar = mfma4(wr[st][0], hv, ar);
+                    az = mfma4(wr[st][1], hv, az);
+                    anh = mfma4(wr[st][2], hv, anh);
+                    wload(wr[st]);
                 }
+            }
+            rotate(wr, Qhe % 3);
+            // x chunks 0..2 of the next tile / step: their latency hides under the gate math
+            {
+                const int tn = (c == NCG - 1) ? (t + 1 < T ? t + 1 : t) : t;
+#pragma unroll
+                for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st < Qx ? st : Qx - 1);
             }
             // ---- gates.  h_old for this tile comes back from LDS (written at the end of step t-1)
 #pragma unroll
@@ -690,17 +712,17 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                 for (int m = 0; m < 4; ++m) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bfc + 32 * n + 8 * m + 4 * g);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) y[4 * m + s] = bv[s];
+                    for (int s4 = 0; s4 < 4; ++s4) y[4 * m + s4] = bv[s4];
                 }
                 const f32x4* __restrict__ wp = a.Wfc + ((long)n * Qh) * 64 + lane;
 #pragma unroll
-                for (int cq = 0; cq < NCG; ++cq)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
+                for (int q = 0; q < Qh; ++q)
+                    if (q < Qhe) {
+                        const int cq = q >> 2, m = q & 3;
                         f32x4 hv;
                         hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
                         hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
-                        y = mfma4(wp[(4 * cq + m) * 64], hv, y);
+                        y = mfma4(wp[q * 64], hv, y);
                     }
                 if (win < a.B) {
                     float* yp = a.Yfc + (win * T + t) * (long)a.out_dim;
