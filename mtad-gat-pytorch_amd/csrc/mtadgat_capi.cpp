@@ -107,6 +107,38 @@ int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, con
     return 0;
 }
 
+bool use_fused(const GatPlan& g) {
+    const char* e = getenv("MTADGAT_FUSED");
+    return g.fused && !(e && atoi(e) == 0);
+}
+
+// fused layer: V rows (n*K, ldv) -> out, nothing but V read from / out written to HBM
+int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n, float* out, long so_w, long so_i,
+                  long so_d, hipStream_t s) {
+    Scope sc(m, S_ATTEND, s);
+    GatArgs a{};
+    a.V = v; a.ldv = ldv; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.rld = g.f_rld;
+    a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
+    a.pbias = m.packed_dev + g.b_off;
+    a.NT_L = g.NT_L; a.Q = g.Q; a.PT = g.PT; a.P8 = g.P8;
+    a.bias = m.packed_dev + g.bias_off;
+    a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
+    a.rows_per_blk = g.f_rows; a.nwin = n;
+    a.v1 = m.cfg.use_gatv2 ? 0 : 1;
+    a.alpha = m.cfg.alpha;
+    K_TRY(launch_gat(a, g.f_IB, g.f_KPT, g.f_nw, g.f_lds_bytes, s), "fused gat");
+    return 0;
+}
+
+// one graph-attention layer from its node rows, fused when the plan allows
+int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n, float* lc, float* rt, float* out, long so_w,
+                  long so_i, long so_d, hipStream_t s) {
+    if (use_fused(g)) return run_gat_fused(m, g, v, ldv, n, out, so_w, so_i, so_d, s);
+    int rc = run_proj(m, g, v, ldv, n * g.K, lc, rt, s);
+    if (rc) return rc;
+    return run_attend(m, g, lc, rt, v, ldv, n, out, so_w, so_i, so_d, s);
+}
+
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
 int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
                   long ldhe, float* seq, const LinPlan* fc, float* yfc, hipStream_t s) {
@@ -287,11 +319,9 @@ int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* pred
         float* hcat = ws + o.hcat;
         if ((rc = run_conv(m, xc_in, n, xc, xct, hcat, nullptr, s))) return rc;
         // temporal layer: nodes = time steps, rows of xc
-        if ((rc = run_proj(m, m.temp, xc, m.Fp, n * W, ws + o.lct, ws + o.rtt, s))) return rc;
+        if ((rc = run_gat_layer(m, m.temp, xc, m.Fp, n, ws + o.lct, ws + o.rtt, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
         // feature layer: nodes = features, rows of xc^T
-        if ((rc = run_proj(m, m.feat, xct, m.Wp, n * F, ws + o.lcf, ws + o.rtf, s))) return rc;
-        if ((rc = run_attend(m, m.temp, ws + o.lct, ws + o.rtt, xc, m.Fp, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
-        if ((rc = run_attend(m, m.feat, ws + o.lcf, ws + o.rtf, xct, m.Wp, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
+        if ((rc = run_gat_layer(m, m.feat, xct, m.Wp, n, ws + o.lcf, ws + o.rtf, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
         float* hend = ws + o.hend;
         const long ldh = m.gru.back().Hp;
         if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s))) return rc;
@@ -334,12 +364,10 @@ int mtadgat_gat(mtadgat_handle h, int which, const float* xc_in, int64_t batch, 
         float* o_c = out + c0 * (int64_t)W * F;
         if (which == 1) {
             K_TRY(launch_copy2d(xin, F, ws + o.xc, m.Fp, n * W, F, s), "pad copy");
-            if ((rc = run_proj(m, m.temp, ws + o.xc, m.Fp, n * W, ws + o.lct, ws + o.rtt, s))) return rc;
-            if ((rc = run_attend(m, m.temp, ws + o.lct, ws + o.rtt, ws + o.xc, m.Fp, n, o_c, (long)W * F, F, 1, s))) return rc;
+            if ((rc = run_gat_layer(m, m.temp, ws + o.xc, m.Fp, n, ws + o.lct, ws + o.rtt, o_c, (long)W * F, F, 1, s))) return rc;
         } else {
             K_TRY(launch_transpose_win(xin, F, ws + o.xct, m.Wp, n, W, F, s), "transpose");
-            if ((rc = run_proj(m, m.feat, ws + o.xct, m.Wp, n * F, ws + o.lcf, ws + o.rtf, s))) return rc;
-            if ((rc = run_attend(m, m.feat, ws + o.lcf, ws + o.rtf, ws + o.xct, m.Wp, n, o_c, (long)W * F, 1, F, s))) return rc;
+            if ((rc = run_gat_layer(m, m.feat, ws + o.xct, m.Wp, n, ws + o.lcf, ws + o.rtf, o_c, (long)W * F, 1, F, s))) return rc;
         }
     }
     return 0;

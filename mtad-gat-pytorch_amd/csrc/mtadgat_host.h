@@ -25,7 +25,11 @@ struct GatPlan {
     int NT_L = 0;   // tiles of the query side; the key-side tiles follow (stored transposed)
     int NT = 0, Q = 0;
     size_t w_off = 0, b_off = 0, bias_off = 0;   // offsets (floats) into the packed buffer
-    int rows_per_blk = 0, nblk = 0, IB = 0;      // attend launch plan
+    int rows_per_blk = 0, nblk = 0, IB = 0;      // attend launch plan (un-fused path)
+    // fused per-window kernel (k_gat) plan; fused == false -> k_rowgemm + k_attend through HBM
+    bool fused = false;
+    int f_nw = 0, f_rows = 0, f_IB = 0, f_KPT = 0, f_vld = 0, f_rld = 0;
+    size_t f_lds_bytes = 0;
 };
 
 struct GruPlan {

@@ -547,6 +547,275 @@ __global__ __launch_bounds__(64, (JPL <= 2 ? 3 : 2)) void k_attend(const AttendA
 }
 
 // ---------------------------------------------------------------------------
+// gat (fused): one workgroup per window does the whole graph-attention layer -- projection,
+// pairwise scores, softmax, aggregation, sigmoid -- with the node features V, the projected L' and
+// R'^T never leaving the CU.  Same algebra and packed weights as k_rowgemm + k_attend (which remain
+// the path for node counts / dims whose tiles do not fit in LDS).
+//   LDS:  Vs [K][vld]            node feature rows of this window (zero padded columns)
+//         Ls [K][lld]            L' columns of the current part, row-major (+ c when it is in the part)
+//         Rs [32*KPT][rld]       R'^T rows of the current part, key-node-minor (+ d)
+//         att[NW][IB][68]        softmax rows restaged for the aggregation MFMA (aliases Ls/Rs)
+// The embedding is processed in parts of KPT 32-column tiles: MFMA phase (projection of the part
+// into Ls/Rs) -> barrier -> VALU phase (|L'+R'| accumulation, 2 plain VALU ops per element: L'_ik is
+// a wave-uniform LDS broadcast read, R'_jk a per-lane LDS read) -> barrier.  Several workgroups per CU
+// are in different phases, so the matrix and vector pipes overlap across workgroups.
+// ---------------------------------------------------------------------------
+template <int JPL, int IB, bool NEG>
+__device__ __forceinline__ void gat_tile(float (&acc)[IB][JPL], const float* __restrict__ Ls, int lld, int row0, int nrows,
+                                         const float* __restrict__ Rs, int rld, const int (&jc)[JPL], int k0) {
+    float r[JPL][8];
+#pragma unroll
+    for (int jj = 0; jj < JPL; ++jj)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[jj][e] = Rs[(k0 + e) * rld + jc[jj]];
+    // L' rows are fetched one row ahead of their use (LDS latency ~100+ cycles would otherwise be
+    // exposed once per row: 32 VALU instructions)
+    auto lrow = [&](int ib) { return Ls + (row0 + (ib < nrows ? ib : nrows - 1)) * lld + k0; };   // wave-uniform
+    f32x4 l0 = *reinterpret_cast<const f32x4*>(lrow(0));
+    f32x4 l1 = *reinterpret_cast<const f32x4*>(lrow(0) + 4);
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+        f32x4 n0 = l0, n1 = l1;
+        if (ib + 1 < IB) {
+            n0 = *reinterpret_cast<const f32x4*>(lrow(ib + 1));
+            n1 = *reinterpret_cast<const f32x4*>(lrow(ib + 1) + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const float t0 = l0[e] + r[jj][e];
+                const float t1 = l1[e] + r[jj][4 + e];
+                if (NEG) {
+                    acc[ib][jj] -= fabsf(t0);
+                    acc[ib][jj] -= fabsf(t1);
+                } else {
+                    acc[ib][jj] += fabsf(t0);
+                    acc[ib][jj] += fabsf(t1);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        l0 = n0;
+        l1 = n1;
+    }
+}
+
+template <int JPL, int IB, int KPT>
+__global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const long win = blockIdx.x;
+    const int K = a.K, D = a.D, PT = a.PT;
+    const int vld = a.vld, lld = 32 * KPT + 4, rld = a.rld;
+    float* __restrict__ Vs = smem;
+    float* __restrict__ Ls = Vs + K * vld;
+    float* __restrict__ Rs = Ls + K * lld;
+    const int i = lane & 31, g = lane >> 5;
+
+    // ---- stage the window's node rows (one row per wave pass, coalesced), zero the padding columns
+    {
+        const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
+        for (int row = wave; row < K; row += NW)
+            for (int col = lane; col < vld; col += 64) Vs[row * vld + col] = col < D ? vsrc[(long)row * a.ldv + col] : 0.f;
+    }
+    __syncthreads();
+
+    const int i0 = wave * a.rows_per_blk;
+    int nrows = K - i0;
+    nrows = nrows < a.rows_per_blk ? nrows : a.rows_per_blk;
+    const bool active = nrows > 0;      // trailing waves of a short last block idle through the barriers
+    if (!active) nrows = 1;
+    const int row0 = active ? i0 : 0;
+
+    float acc[IB][JPL];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib)
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ib][jj] = 0.f;
+    int jc[JPL];
+#pragma unroll
+    for (int jj = 0; jj < JPL; ++jj) {
+        const int j = jj * 64 + lane;
+        jc[jj] = j < K ? j : K - 1;
+    }
+    float cvec = 0.f, dj[JPL];
+#pragma unroll
+    for (int jj = 0; jj < JPL; ++jj) dj[jj] = 0.f;
+
+    const int NTn = (K + 31) >> 5;                    // node tiles
+    const int nparts = (a.NT_L + KPT - 1) / KPT;
+    const int Q = a.Q;
+    const int ptile = a.P8 >> 3, ntile = PT >> 3;
+    for (int part = 0; part < nparts; ++part) {
+        // ---- MFMA phase: project this part's columns for all nodes into Ls / Rs
+        const int ntask = NTn * 2 * KPT;
+        for (int task = wave; task < ntask; task += NW) {
+            const int nt = task % NTn;
+            const int ft = task / NTn;                 // 0..KPT-1 query side, KPT..2KPT-1 key side
+            const bool keyside = ft >= KPT;
+            const int lt = keyside ? ft - KPT : ft;     // local 32-column tile inside the part
+            const int gt = part * KPT + lt;             // global tile on its side
+            if (gt >= a.NT_L) continue;
+            const int wtile = keyside ? a.NT_L + gt : gt;
+            const int node = nt * 32 + i;
+            const float* __restrict__ vrow = Vs + (node < K ? node : K - 1) * vld;
+            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+            f32x16 o;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.pbias + 32 * wtile + 8 * m + 4 * g);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) o[4 * m + s4] = bv[s4];
+            }
+            // all weight chunks of the task are requested at once (one L2 latency per task, not per chunk)
+            constexpr int QB = 8;
+            for (int qb = 0; qb < Q; qb += QB) {
+                f32x4 w[QB];
+#pragma unroll
+                for (int u = 0; u < QB; ++u) w[u] = wp[(long)(qb + u < Q ? qb + u : Q - 1) * 64];
+#pragma unroll
+                for (int u = 0; u < QB; ++u)
+                    if (qb + u < Q) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * (qb + u) + 4 * g);
+                        o = mfma4(w[u], xv, o);
+                    }
+            }
+            if (node < K) {
+                if (!keyside) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 v;
+                        v[0] = o[4 * m + 0]; v[1] = o[4 * m + 1]; v[2] = o[4 * m + 2]; v[3] = o[4 * m + 3];
+                        *reinterpret_cast<f32x4*>(Ls + node * lld + 32 * lt + 8 * m + 4 * g) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = 32 * lt + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        Rs[f * rld + node] = o[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- VALU phase: pairwise term over this part's k tiles
+        const int t0 = part * 4 * KPT;
+        for (int kt = 0; kt < 4 * KPT; ++kt) {
+            const int gtile = t0 + kt;
+            if (gtile >= ntile) break;
+            if (gtile < ptile)
+                gat_tile<JPL, IB, false>(acc, Ls, lld, row0, nrows, Rs, rld, jc, 8 * kt);
+            else
+                gat_tile<JPL, IB, true>(acc, Ls, lld, row0, nrows, Rs, rld, jc, 8 * kt);
+        }
+        // rank-1 terms c_i (query column PT) and d_j (key row PT) live in the tile that holds column PT
+        if (PT / (32 * KPT) == part) {
+            const int col = PT - part * 32 * KPT;
+            cvec = Ls[(row0 + (lane < nrows ? lane : nrows - 1)) * lld + col];
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) dj[jj] = Rs[col * rld + jc[jj]];
+        }
+        __syncthreads();
+    }
+
+    // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); branch-free over rows
+    float bvv[IB][JPL];
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+        const int irow = row0 + (ib < nrows ? ib : nrows - 1);
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) bvv[ib][jj] = a.bias ? a.bias[(long)irow * K + jc[jj]] : 0.f;
+    }
+#pragma unroll
+    for (int ib = 0; ib < IB; ++ib) {
+        const float ci = lane_value(cvec, ib);
+        float e[JPL];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            const int j = jj * 64 + lane;
+            float v = acc[ib][jj] + ci + dj[jj];
+            if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
+            v += bvv[ib][jj];
+            v = j < K ? v : -INFINITY;
+            e[jj] = v;
+            m = fmaxf(m, v);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            e[jj] = (jj * 64 + lane < K) ? soft_exp(e[jj] - m) : 0.f;
+            sum += e[jj];
+        }
+        sum = wave_sum(sum);
+        const float inv = soft_rcp(sum);
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ib][jj] = (active && ib < nrows) ? e[jj] * inv : 0.f;
+    }
+
+    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) on the matrix pipe; att restaged through this
+    // wave's slice of the (now free) Ls/Rs region.  Rows >= IB of the B operand read neighbouring
+    // (finite) data; they only feed output columns that are never stored.
+    float* __restrict__ att = Ls + wave * (IB * 68);
+    const int DT = (D + 31) >> 5;
+    for (int dt0 = 0; dt0 < DT; dt0 += 2) {
+        f32x16 o[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
+        int dcl[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int d = 32 * (dt0 + nb) + i;
+            dcl[nb] = d < vld ? d : vld - 1;          // columns >= D of Vs are zero
+        }
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            if (jj * 64 < K) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ib = 0; ib < IB; ++ib) att[ib * 68 + lane] = acc[ib][jj];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const int jn = min(64, K - jj * 64);
+                const int nq = (jn + 7) >> 3;
+                const int arow = i < IB ? i : IB - 1;
+                for (int q = 0; q < nq; ++q) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(att + arow * 68 + 8 * q + 4 * g);
+                    const int jb = jj * 64 + 8 * q + 4 * g;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        f32x4 av;
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const int jr = jb + s4 < K ? jb + s4 : K - 1;
+                            const float v = Vs[jr * vld + dcl[nb]];
+                            av[s4] = jb + s4 < K ? v : 0.f;
+                        }
+                        o[nb] = mfma4(av, bq, o[nb]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = 32 * (dt0 + nb) + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (active && i < nrows && d < D)
+                    a.out[win * a.so_w + (long)(i0 + i) * a.so_i + (long)d * a.so_d] = gate_sigmoid(o[nb][r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // GRU: 32 windows per wave, hidden state resident in registers in F-layout for
 // all T steps; W_ih / W_hh streamed from L2 in packed order; gates r|z|n as
 // torch.nn.GRU (reference GRULayer.forward modules.py:235-238, RNNDecoder
@@ -846,6 +1115,31 @@ int launch_attend(const AttendArgs& a, int IB, hipStream_t s) {
     ATTEND_CASE(2, 24) ATTEND_CASE(2, 28) ATTEND_CASE(2, 32)
     ATTEND_CASE(4, 8) ATTEND_CASE(4, 16)
     ATTEND_CASE(8, 8)
+    if (!launched) return -2;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+#define GAT_CASE(J, I, KP)                                                                      \
+    if (jpl == J && IB == I && KPT == KP) {                                                     \
+        if (lds_bytes > 64 * 1024) {                                                            \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat<J, I, KP>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e_ != hipSuccess) return (int)e_;                                               \
+        }                                                                                       \
+        hipLaunchKernelGGL((k_gat<J, I, KP>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);      \
+        launched = true;                                                                        \
+    }
+
+int launch_gat(const GatArgs& a, int IB, int KPT, int nw, size_t lds_bytes, hipStream_t s) {
+    if (a.nwin <= 0) return 0;
+    const int jpl = (a.K + 63) / 64;
+    const unsigned grid = (unsigned)a.nwin;
+    bool launched = false;
+    GAT_CASE(1, 8, 1) GAT_CASE(1, 12, 1) GAT_CASE(1, 16, 1) GAT_CASE(1, 20, 1)
+    GAT_CASE(2, 8, 1) GAT_CASE(2, 12, 1) GAT_CASE(2, 16, 1) GAT_CASE(2, 20, 1)
+    GAT_CASE(1, 8, 2) GAT_CASE(1, 12, 2) GAT_CASE(1, 16, 2) GAT_CASE(1, 20, 2)
+    GAT_CASE(2, 8, 2) GAT_CASE(2, 12, 2) GAT_CASE(2, 16, 2) GAT_CASE(2, 20, 2)
     if (!launched) return -2;
     LAUNCH_CHECK();
     return 0;

@@ -1,5 +1,6 @@
 // Host-side planning and weight packing: reference-format parameters -> the tile
 // streams the gfx950 kernels consume (mtadgat_kernels.hip).  Pure host C++.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <functional>
@@ -84,6 +85,27 @@ std::string validate_and_plan(Model& m) {
         g.b_off = take((size_t)g.NT * 32);
         g.bias_off = take((size_t)K * K);
         attend_plan(K, &g.rows_per_blk, &g.nblk, &g.IB);
+        // fused plan: one workgroup (f_nw waves) per window, tiles of the layer resident in LDS
+        g.fused = false;
+        if (K <= 128) {
+            int nw = (K + 19) / 20;
+            nw = nw < 4 ? 4 : (nw > 8 ? 8 : nw);
+            const int rows = (K + nw - 1) / nw;
+            int ib = round_up(rows, 4);
+            if (ib < 8) ib = 8;
+            if (ib <= 20) {
+                g.f_vld = round_up(D, 8) + 4;
+                g.f_rld = round_up(K, 4);
+                for (int kpt = 2; kpt >= 1 && !g.fused; --kpt) {
+                    const size_t lr = (size_t)K * (32 * kpt + 4) + (size_t)32 * kpt * g.f_rld;
+                    const size_t att = (size_t)nw * ib * 68;
+                    const size_t bytes = ((size_t)K * g.f_vld + std::max(lr, att)) * sizeof(float);
+                    if (bytes <= 52 * 1024) {   // three workgroups per CU (160 KiB LDS)
+                        g.fused = true; g.f_nw = nw; g.f_rows = rows; g.f_IB = ib; g.f_KPT = kpt; g.f_lds_bytes = bytes;
+                    }
+                }
+            }
+        }
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
