@@ -113,11 +113,11 @@ bool use_fused(const GatPlan& g) {
 }
 
 // fused layer: V rows (n*K, ldv) -> out, nothing but V read from / out written to HBM
-int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n, float* out, long so_w, long so_i,
+int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, int64_t n, float* out, long so_w, long so_i,
                   long so_d, hipStream_t s) {
     Scope sc(m, S_ATTEND, s);
     GatArgs a{};
-    a.V = v; a.ldv = ldv; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.rld = g.f_rld;
+    a.V = v; a.ldv = ldv; a.vt = vt; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.rld = g.f_rld;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
     a.pbias = m.packed_dev + g.b_off;
     a.NT_L = g.NT_L; a.Q = g.Q; a.PT = g.PT; a.P8 = g.P8;
@@ -133,7 +133,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 // one graph-attention layer from its node rows, fused when the plan allows
 int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n, float* lc, float* rt, float* out, long so_w,
                   long so_i, long so_d, hipStream_t s) {
-    if (use_fused(g)) return run_gat_fused(m, g, v, ldv, n, out, so_w, so_i, so_d, s);
+    if (use_fused(g)) return run_gat_fused(m, g, v, ldv, 0, n, out, so_w, so_i, so_d, s);
     int rc = run_proj(m, g, v, ldv, n * g.K, lc, rt, s);
     if (rc) return rc;
     return run_attend(m, g, lc, rt, v, ldv, n, out, so_w, so_i, so_d, s);
@@ -317,11 +317,19 @@ int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* pred
         float* xc = ws + o.xc;
         float* xct = ws + o.xct;
         float* hcat = ws + o.hcat;
-        if ((rc = run_conv(m, xc_in, n, xc, xct, hcat, nullptr, s))) return rc;
-        // temporal layer: nodes = time steps, rows of xc
-        if ((rc = run_gat_layer(m, m.temp, xc, m.Fp, n, ws + o.lct, ws + o.rtt, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
-        // feature layer: nodes = features, rows of xc^T
-        if ((rc = run_gat_layer(m, m.feat, xct, m.Wp, n, ws + o.lcf, ws + o.rtf, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
+        if (use_fused(m.temp) && use_fused(m.feat)) {
+            // fused front: conv writes only h_cat[:, :F]; each layer's workgroup stages its window from
+            // there (the feature layer transposes on the way into LDS) -- no xc / xc^T / L' / R' in HBM
+            if ((rc = run_conv(m, xc_in, n, nullptr, nullptr, hcat, nullptr, s))) return rc;
+            if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
+            if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
+        } else {
+            if ((rc = run_conv(m, xc_in, n, xc, xct, hcat, nullptr, s))) return rc;
+            // temporal layer: nodes = time steps, rows of xc
+            if ((rc = run_gat_layer(m, m.temp, xc, m.Fp, n, ws + o.lct, ws + o.rtt, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
+            // feature layer: nodes = features, rows of xc^T
+            if ((rc = run_gat_layer(m, m.feat, xct, m.Wp, n, ws + o.lcf, ws + o.rtf, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
+        }
         float* hend = ws + o.hend;
         const long ldh = m.gru.back().Hp;
         if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s))) return rc;

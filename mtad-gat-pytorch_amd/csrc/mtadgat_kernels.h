@@ -64,8 +64,9 @@ struct AttendArgs {
 
 // fused per-window graph-attention layer (projection + scores + softmax + aggregation in one workgroup)
 struct GatArgs {
-    const float* V;      // (B*K, ldv) node feature rows
+    const float* V;      // vt == 0: (B*K, ldv) node rows; vt == 1: (B*D, ldv) rows whose columns are the nodes
     int ldv, D, K;
+    int vt;
     int vld, rld;        // LDS row strides of the staged V rows and of R'^T
     const f32x4* Wp;     // packed projection tiles [2*NT_L][Q][64]: query-side tiles then key-side tiles
     const float* pbias;  // projection bias, 2*NT_L*32

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -249,6 +250,104 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
                         if (a.XCT) a.XCT[(win * a.F + o) * (long)a.Wpad + t] = v;
                         if (a.HCAT) a.HCAT[row * a.Dp + o] = v;
                         if (a.Y) a.Y[row * a.F + o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// conv, LDS-staged variant (used when 32+taps-1 input rows of Fp floats fit a wave's LDS budget):
+// the wave copies the input rows its 32 output rows touch into LDS once with coalesced loads and
+// takes every MFMA B operand from there -- the straight-from-global version above re-reads each
+// input row `taps` times with 4-byte gathers (PMC: 5-9x FETCH amplification, TA-bound).
+template <int NTB>
+__global__ __launch_bounds__(64) void k_conv_lds(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int lane = threadIdx.x;
+    const int i = lane & 31, g = lane >> 5;
+    const long R = a.B * a.W;
+    const long r0 = (long)blockIdx.x * 32;
+    const long row = r0 + i;
+    const long rowc = row < R ? row : R - 1;
+    const long win = rowc / a.W;
+    const int t = (int)(rowc - win * a.W);
+    const int Fld = a.Fp + 4;
+    const int nrow = 32 + a.taps - 1;
+    for (int rr = 0; rr < nrow; ++rr) {
+        const long flat = r0 - a.pad + rr;
+        const bool ok = flat >= 0 && flat < R;
+        const float* __restrict__ src = a.X + (ok ? flat : 0) * a.F;
+        for (int col = lane; col < Fld; col += 64) xs[rr * Fld + col] = (ok && col < a.F) ? src[col] : 0.f;
+    }
+    __syncthreads();
+    const int QF = a.Fp >> 3;
+    const int Q = a.taps * QF;
+    const f32x4* __restrict__ Wp = a.Wp;
+    auto loadx = [&](int q) -> f32x4 {
+        const int tap = q / QF;
+        const int cb = q - tap * QF;
+        const int tt = t + tap - a.pad;                     // zero padding is per window (modules.py:14,20)
+        f32x4 v = *reinterpret_cast<const f32x4*>(xs + (i + tap) * Fld + 8 * cb + 4 * g);
+        const bool ok = tt >= 0 && tt < a.W;
+        v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f;
+        return v;
+    };
+    for (int n0 = 0; n0 < a.NT; n0 += NTB) {
+        f32x16 acc[NTB];
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        f32x4 w[NTB];
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) {
+            const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
+            w[nb] = Wp[((long)n * Q) * 64 + lane];
+        }
+        for (int q = 0; q < Q; ++q) {
+            const int qn = (q + 1 < Q) ? q + 1 : q;
+            f32x4 wn[NTB];
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) {
+                const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
+                wn[nb] = Wp[((long)n * Q + qn) * 64 + lane];
+            }
+            const f32x4 xv = loadx(q);
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w[nb], xv, acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) w[nb] = wn[nb];
+        }
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) {
+            if (n0 + nb >= a.NT) break;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int col = 32 * (n0 + nb) + 8 * m + 4 * g;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+                f32x4 v;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) v[s4] = fmaxf(acc[nb][4 * m + s4] + bv[s4], 0.f);
+                if (row < R) {
+                    if (a.HCAT) {   // rows of h_cat are 16-byte aligned: one store per 4 channels
+                        float* hp = a.HCAT + row * a.Dp + col;
+                        if (col + 3 < a.F) {
+                            *reinterpret_cast<f32x4*>(hp) = v;
+                        } else {
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4)
+                                if (col + s4 < a.F) hp[s4] = v[s4];
+                        }
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int o = col + s4;
+                        if (o < a.F) {
+                            if (a.XC) a.XC[row * a.Fp + o] = v[s4];
+                            if (a.XCT) a.XCT[(win * a.F + o) * (long)a.Wpad + t] = v[s4];
+                            if (a.Y) a.Y[row * a.F + o] = v[s4];
+                        }
                     }
                 }
             }
@@ -615,11 +714,20 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     float* __restrict__ Rs = Ls + K * lld;
     const int i = lane & 31, g = lane >> 5;
 
-    // ---- stage the window's node rows (one row per wave pass, coalesced), zero the padding columns
+    // ---- stage the window's node rows (coalesced global reads), zero the padding columns.
+    // vt == 0: node rows are source rows (temporal layer: V = xc).  vt == 1: nodes are the source's
+    // columns (feature layer: V = xc^T), transposed on the way into LDS.
     {
-        const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
-        for (int row = wave; row < K; row += NW)
-            for (int col = lane; col < vld; col += 64) Vs[row * vld + col] = col < D ? vsrc[(long)row * a.ldv + col] : 0.f;
+        if (!a.vt) {
+            const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
+            for (int row = wave; row < K; row += NW)
+                for (int col = lane; col < vld; col += 64) Vs[row * vld + col] = col < D ? vsrc[(long)row * a.ldv + col] : 0.f;
+        } else {
+            const float* __restrict__ vsrc = a.V + win * (long)D * a.ldv;      // D source rows of K columns
+            for (int srow = wave; srow < vld; srow += NW)
+                for (int node = lane; node < K; node += 64)
+                    Vs[node * vld + srow] = srow < D ? vsrc[(long)srow * a.ldv + node] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -1066,7 +1174,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     const long R = a.B * a.W;
     if (R <= 0) return 0;
     const unsigned grid = (unsigned)((R + 31) / 32);
-    if (a.NT >= 2)
+    const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fp + 4) * sizeof(float);
+    const char* env = getenv("MTADGAT_CONV_LDS");
+    if (lds <= 20 * 1024 && !(env && atoi(env) == 0)) {       // >= 8 waves per CU keep their tile in LDS
+        if (a.NT >= 2)
+            hipLaunchKernelGGL(k_conv_lds<2>, dim3(grid), dim3(64), lds, s, a);
+        else
+            hipLaunchKernelGGL(k_conv_lds<1>, dim3(grid), dim3(64), lds, s, a);
+    } else if (a.NT >= 2)
         hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(k_conv<1>, dim3(grid), dim3(64), 0, s, a);

@@ -12,9 +12,13 @@ attribute names, created in the reference's order with the reference's
 initialisers, so `state_dict()` keys/shapes, strict `load_state_dict` of the
 shipped checkpoints, `.cuda()`, optimisers and seeded initialisation behave
 exactly as with the reference classes (`modules.py:5-311`).  Their `forward`
-methods call the corresponding stage entry point of the native library; there
-is no PyTorch implementation of the arithmetic anywhere in this package and no
-CPU fallback.
+methods call the corresponding stage entry point of the native library.
+
+Inference (`eval()`, any grad mode) always runs the HIP kernels and needs GPU
+tensors -- there is no CPU or PyTorch fallback for it.  The training step
+(`train()` with grad enabled, i.e. `Trainer.fit`) needs gradients, which the
+forward-only kernels do not provide yet: it is evaluated with differentiable
+torch ops over the same re-associated algebra (`_autograd.py`, interim).
 """
 import torch
 import torch.nn as nn
@@ -204,17 +208,19 @@ class MTAD_GAT(nn.Module):
             object.__setattr__(self, "_weights_key", key)
         return self._engine
 
+    def _needs_autograd(self):
+        """True when the caller will differentiate through the result (the training step)."""
+        return torch.is_grad_enabled() and self.training
+
     def _check_mode(self, x):
         if x.device.type != "cuda":
             raise RuntimeError(
                 f"MTAD_GAT (MI355X HIP path) got a tensor on '{x.device}': move the model and the input to the GPU "
-                "(.cuda() / .to('cuda')); there is no CPU implementation in this package")
-        if self.training and torch.is_grad_enabled():
+                "(.cuda() / .to('cuda')); there is no CPU implementation of the inference path in this package")
+        if self.training:
             raise NotImplementedError(
-                "MTAD_GAT HIP path: training-mode forward (attention/MLP dropout + backward) is not implemented; "
-                "call model.eval() and run under torch.no_grad() (Trainer.evaluate / Predictor do)")
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("MTAD_GAT HIP path: dropout (train mode) is not implemented; call model.eval()")
+                "MTAD_GAT HIP kernels implement the eval-mode forward; train-mode calls are only supported through "
+                "forward() with grad enabled (autograd path) -- call model.eval() for inference")
 
     def _stage(self, name, x):
         self._check_mode(x)
@@ -237,9 +243,14 @@ class MTAD_GAT(nn.Module):
     def forward(self, x):
         """x (b, window_size, n_features) float32 on the GPU -> (predictions (b, out_dim),
         recons (b, window_size, out_dim)); reference `mtad_gat.py:64-79`.  x is not modified."""
-        self._check_mode(x)
         if x.dim() != 3 or x.shape[1] != self.window_size or x.shape[2] != self.n_features:
             raise RuntimeError(f"expected input of shape (b, {self.window_size}, {self.n_features}), got {tuple(x.shape)}")
+        if self._needs_autograd():
+            # training step (Trainer.fit, training.py:100-130): differentiable torch ops over the same
+            # algebra (interim -- the HIP kernels are forward-only), dropout as in the reference
+            from _autograd import differentiable_forward
+            return differentiable_forward(self, x.float())
+        self._check_mode(x)
         eng = self._sync_engine(x.device)
         with torch.no_grad():
             return eng.forward(x.contiguous().float())

@@ -86,7 +86,7 @@ def test_ragged_batches_and_chunking(name, gpu_device):
 
 def test_weight_update_is_seen(gpu_device):
     """Parameters changed in place (optimizer.step, load_state_dict) must reach the kernels."""
-    a, b = Case("smap"), Case("syn_v1_default")   # same shapes except GAT flavour -> use smap twice
+    a = Case("smap")
     model = a.build_model().to(gpu_device)
     x = a.x.to(gpu_device)
     with torch.no_grad():
@@ -108,5 +108,5 @@ def test_errors_are_loud(gpu_device):
     with pytest.raises(RuntimeError, match="expected input of shape"):
         model(case.x[:, :-1].to(gpu_device))
     model.train()
-    with pytest.raises(NotImplementedError):
-        model(case.x.to(gpu_device))
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        model(case.x.to(gpu_device))          # train-mode (dropout) inference is not a HIP path

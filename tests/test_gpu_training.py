@@ -1,0 +1,39 @@
+"""Training step on the GPU (interim autograd path) next to the HIP inference path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import Case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_steps_then_hip_inference(gpu_device):
+    case = Case("syn_v2_embed")
+    model = case.build_model().to(gpu_device)
+    x = case.x.to(gpu_device)
+    y = torch.rand(x.shape[0], case.kwargs["out_dim"], device=gpu_device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)       # as train.py:92
+    with torch.no_grad():
+        p0, r0 = model.eval()(x)                               # HIP
+    model.train()
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        p, r = model(x)                                        # autograd path (dropout 0.2 active)
+        loss = torch.sqrt(F.mse_loss(y, p)) + torch.sqrt(F.mse_loss(x[:, :, : r.shape[2]], r))
+        loss.backward()
+        assert all(prm.grad is not None and torch.isfinite(prm.grad).all() for prm in model.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    # the optimizer updated the parameters in place: the HIP path must pick the new weights up,
+    # and agree with the autograd path evaluated in eval mode on the same weights
+    model.eval()
+    with torch.no_grad():
+        p1, r1 = model(x)
+    assert not torch.equal(p1, p0)
+    from _autograd import differentiable_forward
+    with torch.no_grad():
+        p2, r2 = differentiable_forward(model, x)
+    assert (p1 - p2).abs().max().item() <= 1e-5 and (r1 - r2).abs().max().item() <= 1e-5
