@@ -107,10 +107,7 @@ int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, con
     return 0;
 }
 
-bool use_fused(const GatPlan& g) {
-    const char* e = getenv("MTADGAT_FUSED");
-    return g.fused && !(e && atoi(e) == 0);
-}
+bool use_fused(const GatPlan& g) { return g.fused; }
 
 // fused layer: V rows (n*K, ldv) -> out, nothing but V read from / out written to HBM
 int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, int64_t n, float* out, long so_w, long so_i,
@@ -140,18 +137,17 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 }
 
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
-int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
+int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, bool xfast, int64_t n, float* hend,
                   long ldhe, float* seq, const LinPlan* fc, float* yfc, hipStream_t s) {
     Scope sc(m, slot, s);
     GruArgs a{};
-    a.X = x; a.ldx = ldx; a.Kx = kx; a.Qx = g.Qx;
+    a.X = x; a.ldx = ldx; a.Kx = kx; a.Qx = g.Qx; a.Qxp = g.Qxp;
+    (void)xfast;
     a.m0 = g.xmode == 1 ? reinterpret_cast<const int*>(m.packed_dev + g.m0_off) : nullptr;
     a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx_off);
     a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
     a.bias = m.packed_dev + g.b_off;
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
-    a.Qh_eff = (g.H + 7) / 8;
-    { const char* e = getenv("MTADGAT_STAGGER"); a.stagger = e ? atoi(e) : 2; }
     a.Hend = hend; a.ldhe = ldhe;
     a.Seq = seq; a.ldseq = g.Hp;
     if (fc) {
@@ -165,24 +161,28 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     return 0;
 }
 
-int run_gru_stack(Model& m, const float* hcat, long ldx, int64_t n, float* hend, long ldhe, float* ws, const Workspace& o,
-                  hipStream_t s) {
+// padded == true: hcat is the internal (n*W, Dp) buffer whose pad columns are zero
+int run_gru_stack(Model& m, const float* hcat, long ldx, bool padded, int64_t n, float* hend, long ldhe, float* ws,
+                  const Workspace& o, hipStream_t s) {
     const int L = (int)m.gru.size();
     const float* x = hcat;
     long ld = ldx;
     int kx = 3 * m.F;
+    bool fast = padded && (ldx % 4 == 0) && (8 * m.gru[0].Qx <= ldx);
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         float* seq = last ? nullptr : ws + ((l & 1) ? o.seq1 : o.seq0);
-        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, s);
+        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, fast, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, s);
         if (rc) return rc;
         x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;
+        fast = true;      // sequence buffers hold all Hp columns, padding lanes are exact zeros
     }
     return 0;
 }
 
-int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, float* recons, float* ws, const Workspace& o,
-              hipStream_t s) {
+// padded == true: hend is the internal (n, Hp) buffer with zero pad columns
+int run_heads(Model& m, const float* hend, long ldh, bool padded, int64_t n, float* preds, float* recons, float* ws,
+              const Workspace& o, hipStream_t s) {
     if (preds) {
         Scope sc(m, S_FC, s);
         const float* x = hend;
@@ -213,13 +213,16 @@ int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, fl
         const float* x = hend;
         long ld = ldh;
         int kx = m.cfg.gru_hid_dim;
+        // decoder layer 0 reads hend[m0(t) .. m0(t) + 8*Qx): inside the padded row?
+        bool fast = padded && ((long)((long)(m.W - 1) * m.cfg.gru_hid_dim / m.W) + 8 * m.rec[0].Qx <= ldh);
         for (int l = 0; l < L; ++l) {
             const bool last = (l == L - 1);
             float* seq = last ? nullptr : ws + ((l & 1) ? o.rseq1 : o.rseq0);
-            int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr,
+            int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, fast, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr,
                                    last ? recons : nullptr, s);
             if (rc) return rc;
             x = seq; ld = m.rec[l].Hp; kx = m.rec[l].H;
+            fast = true;
         }
     }
     return 0;
@@ -332,12 +335,12 @@ int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* pred
         }
         float* hend = ws + o.hend;
         const long ldh = m.gru.back().Hp;
-        if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s))) return rc;
+        if ((rc = run_gru_stack(m, hcat, m.Dp, true, n, hend, ldh, ws, o, s))) return rc;
         if (hend_out)
             K_TRY(launch_copy2d(hend, ldh, hend_out + c0 * m.cfg.gru_hid_dim, m.cfg.gru_hid_dim, n, m.cfg.gru_hid_dim, s),
                   "h_end copy");
         if (preds || recons) {
-            if ((rc = run_heads(m, hend, ldh, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
+            if ((rc = run_heads(m, hend, ldh, true, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
                                 recons ? recons + c0 * (int64_t)W * m.cfg.out_dim : nullptr, ws, o, s)))
                 return rc;
         }
@@ -393,7 +396,11 @@ int mtadgat_gru(mtadgat_handle h, const float* hcat, int64_t batch, float* hend,
         const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
         Workspace o;
         plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
-        if ((rc = run_gru_stack(m, hcat + c0 * (int64_t)m.W * D, D, n, hend + c0 * H, H, ws, o, (hipStream_t)stream))) return rc;
+        // the kernel wants 16-byte aligned, zero padded rows: stage the caller's (b, W, 3F) tensor into the padded buffer
+        hipStream_t s = (hipStream_t)stream;
+        HIP_TRY(hipMemsetAsync(ws + o.hcat, 0, (size_t)n * m.W * m.Dp * sizeof(float), s));
+        K_TRY(launch_copy2d(hcat + c0 * (int64_t)m.W * D, D, ws + o.hcat, m.Dp, n * m.W, D, s), "h_cat pad copy");
+        if ((rc = run_gru_stack(m, ws + o.hcat, m.Dp, true, n, hend + c0 * H, H, ws, o, s))) return rc;
     }
     return 0;
 }
@@ -411,8 +418,12 @@ int mtadgat_heads(mtadgat_handle h, const float* hend, int64_t batch, float* pre
         const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
         Workspace o;
         plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
-        if ((rc = run_heads(m, hend + c0 * H, H, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
-                            recons ? recons + c0 * (int64_t)m.W * m.cfg.out_dim : nullptr, ws, o, (hipStream_t)stream)))
+        hipStream_t s = (hipStream_t)stream;
+        const long ldh = m.gru.back().Hp;
+        HIP_TRY(hipMemsetAsync(ws + o.hend, 0, (size_t)n * ldh * sizeof(float), s));
+        K_TRY(launch_copy2d(hend + c0 * H, H, ws + o.hend, ldh, n, H, s), "h_end pad copy");
+        if ((rc = run_heads(m, ws + o.hend, ldh, true, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
+                            recons ? recons + c0 * (int64_t)m.W * m.cfg.out_dim : nullptr, ws, o, s)))
             return rc;
     }
     return 0;

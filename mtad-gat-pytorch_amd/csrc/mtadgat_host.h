@@ -33,7 +33,7 @@ struct GatPlan {
 };
 
 struct GruPlan {
-    int in_dim = 0, H = 0, Hp = 0, NCG = 0, Qx = 0;
+    int in_dim = 0, H = 0, Hp = 0, NCG = 0, Qx = 0, Qxp = 0;   // Qxp: packed x chunks (1 or a multiple of 3)
     int xmode = 0;          // 0 rows, 1 reference decoder input (modules.py:279)
     size_t wx_off = 0, wh_off = 0, b_off = 0, m0_off = 0;
 };

@@ -84,14 +84,13 @@ struct GruArgs {
     const float* X;      // XMODE 0: (B*T, ldx) input rows; XMODE 1: (B, ldx) hin rows
     long ldx;
     int Kx;              // valid input features (XMODE 1: valid hin entries)
-    int Qx;              // input chunks per step
+    int Qx;              // real input chunks per step
+    int Qxp;             // packed input chunks per step (1, or Qx rounded up to a multiple of 3 with zero chunks)
     const int* m0;       // XMODE 1: first hin index used at step t
-    const f32x4* Wx;     // [c][Qx][3][64]  (XMODE 1: [t][c][Qx][3][64])
+    const f32x4* Wx;     // [c][Qxp][3][64]  (decoder input: [t][c][Qxp][3][64])
     const f32x4* Wh;     // [c][4*NCG][3][64]
     const float* bias;   // [4][Hp]: b_ir+b_hr | b_iz+b_hz | b_in | b_hn
     int Hp, H, T;
-    int Qh_eff;          // ceil(H / 8): recurrent chunks that can be non-zero
-    int stagger;         // s_sleep(127) repetitions for odd wave slots (0 = off)
     long B;
     float* Hend;         // (B, ldhe) or null
     long ldhe;

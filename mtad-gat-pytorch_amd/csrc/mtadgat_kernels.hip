@@ -46,6 +46,17 @@ __device__ __forceinline__ f32x16 mfma4(const f32x4 w, const f32x4 x, f32x16 acc
     return acc;
 }
 
+// one chunk for three gate accumulators, k-steps interleaved across the accumulators so consecutive
+// MFMAs never depend on each other
+__device__ __forceinline__ void mfma4x3(const f32x4 (&w)[3], const f32x4 x, f32x16& a0, f32x16& a1, f32x16& a2) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0][s], x[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1][s], x[s], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2][s], x[s], a2, 0, 0, 0);
+    }
+}
+
 // four features k0..k0+3 of a row; zero beyond kvalid.  vec_ok: row base and k0 are 16-byte aligned
 __device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ row, int k0, int kvalid, bool vec_ok) {
     f32x4 v;
@@ -189,6 +200,8 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
     const int Q = a.taps * QF;
     const f32x4* __restrict__ Wp = a.Wp;
 
+    if (a.HCAT && row < R && g == 0)      // zero the alignment padding of the h_cat row (the GRU reads it unguarded)
+        for (int c = 3 * a.F; c < a.Dp; ++c) a.HCAT[row * a.Dp + c] = 0.f;
     auto loadx = [&](int q) -> f32x4 {
         const int tap = q / QF;
         const int cb = q - tap * QF;
@@ -284,6 +297,8 @@ __global__ __launch_bounds__(64) void k_conv_lds(const ConvArgs a) {
     const int QF = a.Fp >> 3;
     const int Q = a.taps * QF;
     const f32x4* __restrict__ Wp = a.Wp;
+    if (a.HCAT && row < R && g == 0)      // zero the alignment padding of the h_cat row (the GRU reads it unguarded)
+        for (int c = 3 * a.F; c < a.Dp; ++c) a.HCAT[row * a.Dp + c] = 0.f;
     auto loadx = [&](int q) -> f32x4 {
         const int tap = q / QF;
         const int cb = q - tap * QF;
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(64) void k_conv_lds(const ConvArgs a) {
                 wn[nb] = Wp[((long)n * Q + qn) * 64 + lane];
             }
             const f32x4 xv = loadx(q);
+            __builtin_amdgcn_sched_barrier(0);      // keep the next chunk's weight loads ahead of these MFMAs
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w[nb], xv, acc[nb]);
 #pragma unroll
@@ -935,24 +951,28 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 //            hin entries m0[t] .. m0[t]+NM-1 occur at step t, and the packed "Wx" for
 //            step t holds W_ih summed over the j that map to each of them.
 // ---------------------------------------------------------------------------
-template <int NCG, int XMODE, bool FC>
+// XMODE 0: input rows X[(win*T + t)*ldx + k], packed x part has Qxp = 3n chunks (zero chunks past Qx)
+// XMODE 1: decoder input (see above) with exactly one 8-wide chunk per step (NM <= 8)
+// XMODE 2: decoder input with Qxp = 3n chunks
+// DROP   : trailing all-padding chunks of the recurrent part that are skipped (H <= 8*(4*NCG - DROP))
+// Input rows must be 16-byte aligned (XMODE 0) and zero padded as far as the loads reach; every load
+// in the loop nest is unconditional and the nest has no data-dependent control flow, so the compiler
+// can count the outstanding loads exactly and waits with vmcnt(N > 0): the weight ring stays full.
+// (With guarded loads it fell back to vmcnt(0..2) before every MFMA group: 79k instead of 31k cycles
+// per hidden tile and step.)
+template <int NCG, int XMODE, bool FC, int DROP>
 __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a) {
     __shared__ float hn_s[NCG][16][64];
     const int lane = threadIdx.x;
     const int i = lane & 31, g = lane >> 5;
     const long win = (long)blockIdx.x * 32 + i;
     const long winc = win < a.B ? win : a.B - 1;
-    const int T = a.T, Qx = a.Qx, Qhe = a.Qh_eff;
-    constexpr int Qh = 4 * NCG;
-    const int S = Qx + Qhe;                       // weight chunks per hidden tile and step
-    const bool xvec = (a.ldx & 3) == 0;
-
-    // The two waves that share a SIMD run the same instruction stream from the same start and would
-    // stall (gate math, h reload) in lock-step, leaving the matrix pipe idle ~1/3 of the time (PMC:
-    // SQ_VALU_MFMA_BUSY 63 %).  Delay the odd wave slots by about half a hidden-tile iteration once.
-    if (a.stagger && (__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 1)) {
-        for (int k = 0; k < a.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-    }
+    const int T = a.T, Qx = a.Qx;
+    const int Qxp = (XMODE == 1) ? 1 : a.Qxp;
+    constexpr int Qh = 4 * NCG;                   // recurrent chunks as packed
+    constexpr int Qhe = Qh - DROP;                // ... and as used
+    constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % 3 : Qhe % 3;   // ring phase advance per hidden tile
+    const int S = Qxp + Qhe;
 
     f32x16 h[NCG];
 #pragma unroll
@@ -960,42 +980,39 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[c][r] = 0.f;
 
-    // ---- weight stream: one continuous sequence of chunks [tile c][x chunks 0..Qx) [h chunks 0..Qhe)
+    // ---- weight stream: one continuous sequence of chunks [tile c][x chunks 0..Qxp) [h chunks 0..Qhe)
     // per step, fetched through a 3-stage register ring that never drains: the cursor runs 3 chunks
     // (36 MFMAs ~ 2.3k cycles) ahead of the MFMAs across the x/h, tile and step boundaries.
-    int pc = 0, ps = 0, pt = 0;                   // prefetch cursor (wave-uniform)
+    // (A variant with per-tile base pointers + compile-time offsets instead of the cursor needed ~20 more
+    // VGPRs and measured slower.)
+    int pc = 0, ps = 0, pt = 0;                   // prefetch cursor (wave-uniform, branch-free updates)
     auto wload = [&](f32x4 (&dst)[3]) {
-        const f32x4* __restrict__ p;
-        if (ps < Qx) {
-            const long tt = (XMODE == 1) ? (long)(pt < T ? pt : T - 1) * NCG * Qx : 0;
-            p = a.Wx + (tt + (long)pc * Qx + ps) * 192 + lane;
-        } else {
-            p = a.Wh + ((long)pc * Qh + (ps - Qx)) * 192 + lane;
-        }
+        const long tt = (XMODE != 0) ? (long)(pt < T ? pt : T - 1) * NCG * Qxp : 0;
+        const f32x4* __restrict__ px = a.Wx + (tt + (long)pc * Qxp + ps) * 192 + lane;
+        const f32x4* __restrict__ ph = a.Wh + ((long)pc * Qh + (ps - Qxp)) * 192 + lane;
+        const f32x4* __restrict__ p = (ps < Qxp) ? px : ph;
         dst[0] = p[0]; dst[1] = p[64]; dst[2] = p[128];
-        if (++ps == S) { ps = 0; if (++pc == NCG) { pc = 0; ++pt; } }
-    };
-    auto rotate = [&](f32x4 (&r)[3][3], int m) {   // (r0,r1,r2) <- (r_m, r_m+1, r_m+2); branch-free selects
-        const bool m1 = (m == 1), m2 = (m == 2);    // (a branchy version gets merged into dynamically indexed scratch)
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a0 = r[0][u][e], a1 = r[1][u][e], a2 = r[2][u][e];
-                r[0][u][e] = m1 ? a1 : (m2 ? a2 : a0);
-                r[1][u][e] = m1 ? a2 : (m2 ? a0 : a1);
-                r[2][u][e] = m1 ? a0 : (m2 ? a1 : a2);
-            }
+        const bool ws = (ps + 1 == S);
+        ps = ws ? 0 : ps + 1;
+        const bool wc = ws && (pc + 1 == NCG);
+        pc = ws ? (wc ? 0 : pc + 1) : pc;
+        pt = wc ? pt + 1 : pt;
     };
     auto loadx_t = [&](int t, int q) -> f32x4 {
-        if (XMODE == 0) return load_feat4(a.X + (winc * T + t) * a.ldx, 8 * q + 4 * g, a.Kx, xvec);
-        return load_feat4(a.X + winc * a.ldx, a.m0[t] + 8 * q + 4 * g, a.Kx, false);
+        const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
+        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(a.X + (winc * T + t) * a.ldx + 8 * qq + 4 * g);
+        const float* __restrict__ rowp = a.X + winc * a.ldx;
+        const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
+        f32x4 v;
+        v[0] = rowp[min(k0, kmax)]; v[1] = rowp[min(k0 + 1, kmax)];
+        v[2] = rowp[min(k0 + 2, kmax)]; v[3] = rowp[min(k0 + 3, kmax)];
+        return v;
     };
 
     f32x4 wr[3][3], xr[3];
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
 #pragma unroll
-    for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st < Qx ? st : Qx - 1);
+    for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st);
 
     for (int t = 0; t < T; ++t) {
         for (int c = 0; c < NCG; ++c) {
@@ -1015,42 +1032,50 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                     anh[4 * m + s4] = b3[s4];
                 }
             }
-            // ---- input part: W_i{r,z,n} x_t
-            for (int q0 = 0; q0 < Qx; q0 += 3) {
+            // ---- input part: W_i{r,z,n} x_t.  sched_barrier pins "MFMAs of chunk j, then the loads that
+            // refill its ring stage": left alone the scheduler sinks all loads of an iteration below its
+            // MFMAs and the next iteration waits for them.
+            if (XMODE == 1) {
+                mfma4x3(wr[0], xr[0], ar, az, anx);
+                wload(wr[0]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                for (int q0 = 0; q0 < Qxp; q0 += 3) {
 #pragma unroll
-                for (int st = 0; st < 3; ++st) {
-                    if (q0 + st < Qx) {
-                        ar = mfma4(wr[st][0], xr[st], ar);
-                        az = mfma4(wr[st][1], xr[st], az);
-                        anx = mfma4(wr[st][2], xr[st], anx);
+                    for (int st = 0; st < 3; ++st) {
+                        mfma4x3(wr[st], xr[st], ar, az, anx);
                         wload(wr[st]);
-                        const int qn = q0 + st + 3;
-                        xr[st] = loadx_t(t, qn < Qx ? qn : Qx - 1);
+                        xr[st] = loadx_t(t, q0 + st + 3);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            rotate(wr, Qx % 3);
             // ---- recurrent part: W_h{r,z,n} h_{t-1}  (h_0 = 0 contributes nothing at t = 0; kept so the
-            // weight stream stays continuous).  Only the ceil(H/8) chunks that can be non-zero.
+            // weight stream stays continuous).  Ring stage of h chunk q is static: (x chunks + q) % 3.
 #pragma unroll
-            for (int q = 0; q < Qh; ++q) {
-                if (q < Qhe) {
-                    const int cq = q >> 2, m = q & 3, st = q % 3;
-                    f32x4 hv;
-                    hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
-                    hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
-                    ar = mfma4(wr[st][0], hv, ar);
-                    az = mfma4(wr[st][1], hv, az);
-                    anh = mfma4(wr[st][2], hv, anh);
-                    wload(wr[st]);
-                }
+            for (int q = 0; q < Qhe; ++q) {
+                constexpr int X0 = (XMODE == 1) ? 1 : 0;
+                const int cq = q >> 2, m = q & 3, st = (X0 + q) % 3;
+                f32x4 hv;
+                hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
+                hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
+                mfma4x3(wr[st], hv, ar, az, anh);
+                wload(wr[st]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            rotate(wr, Qhe % 3);
+            // bring the ring back to phase 0 for the next tile: a compile-time register renaming
+            if (ROT == 1) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { const f32x4 t0 = wr[0][u]; wr[0][u] = wr[1][u]; wr[1][u] = wr[2][u]; wr[2][u] = t0; }
+            } else if (ROT == 2) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { const f32x4 t0 = wr[0][u]; wr[0][u] = wr[2][u]; wr[2][u] = wr[1][u]; wr[1][u] = t0; }
+            }
             // x chunks 0..2 of the next tile / step: their latency hides under the gate math
             {
                 const int tn = (c == NCG - 1) ? (t + 1 < T ? t + 1 : t) : t;
 #pragma unroll
-                for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st < Qx ? st : Qx - 1);
+                for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st);
             }
             // ---- gates.  h_old for this tile comes back from LDS (written at the end of step t-1)
 #pragma unroll
@@ -1093,14 +1118,13 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                 }
                 const f32x4* __restrict__ wp = a.Wfc + ((long)n * Qh) * 64 + lane;
 #pragma unroll
-                for (int q = 0; q < Qh; ++q)
-                    if (q < Qhe) {
-                        const int cq = q >> 2, m = q & 3;
-                        f32x4 hv;
-                        hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
-                        hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
-                        y = mfma4(wp[q * 64], hv, y);
-                    }
+                for (int q = 0; q < Qhe; ++q) {
+                    const int cq = q >> 2, m = q & 3;
+                    f32x4 hv;
+                    hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
+                    hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
+                    y = mfma4(wp[q * 64], hv, y);
+                }
                 if (win < a.B) {
                     float* yp = a.Yfc + (win * T + t) * (long)a.out_dim;
 #pragma unroll
@@ -1114,13 +1138,24 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
     }
     if (a.Hend && win < a.B) {
         float* hp = a.Hend + win * a.ldhe;
+        if (a.ldhe >= a.Hp) {        // internal buffer: all Hp columns (the padding lanes of h are exact zeros)
 #pragma unroll
-        for (int c = 0; c < NCG; ++c)
+            for (int c = 0; c < NCG; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (j < a.H) hp[j] = h[c][r];
-            }
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 v;
+                    v[0] = h[c][4 * m + 0]; v[1] = h[c][4 * m + 1]; v[2] = h[c][4 * m + 2]; v[3] = h[c][4 * m + 3];
+                    *reinterpret_cast<f32x4*>(hp + 32 * c + 8 * m + 4 * g) = v;
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCG; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (j < a.H) hp[j] = h[c][r];
+                }
+        }
     }
 }
 
@@ -1260,23 +1295,34 @@ int launch_gat(const GatArgs& a, int IB, int KPT, int nw, size_t lds_bytes, hipS
     return 0;
 }
 
-template <int NCG>
-static int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, hipStream_t s) {
+template <int NCG, int XMODE>
+static int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + 31) / 32);
-    if (xmode == 0 && !fc)
-        hipLaunchKernelGGL((k_gru<NCG, 0, false>), dim3(grid), dim3(64), 0, s, a);
-    else if (xmode == 0 && fc)
-        hipLaunchKernelGGL((k_gru<NCG, 0, true>), dim3(grid), dim3(64), 0, s, a);
-    else if (xmode == 1 && !fc)
-        hipLaunchKernelGGL((k_gru<NCG, 1, false>), dim3(grid), dim3(64), 0, s, a);
+    if (!fc && drop == 0)
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 0>), dim3(grid), dim3(64), 0, s, a);
+    else if (!fc)
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 1>), dim3(grid), dim3(64), 0, s, a);
+    else if (drop == 0)
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 0>), dim3(grid), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((k_gru<NCG, 1, true>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 1>), dim3(grid), dim3(64), 0, s, a);
     LAUNCH_CHECK();
     return 0;
 }
 
+template <int NCG>
+static int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, hipStream_t s) {
+    // trailing recurrent chunks that are pure padding: skip one when H <= 8*(4*NCG - 1)
+    const int drop = (a.H <= 8 * (4 * NCG - 1)) ? 1 : 0;
+    if (xmode == 0) return launch_gru_mode<NCG, 0>(a, fc, drop, s);
+    if (a.Qxp == 1) return launch_gru_mode<NCG, 1>(a, fc, drop, s);
+    return launch_gru_mode<NCG, 2>(a, fc, drop, s);
+}
+
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     if (a.B <= 0) return 0;
+    if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
+    if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
     switch (ncg) {
         case 1: return launch_gru_ncg<1>(a, xmode, fc, s);
         case 2: return launch_gru_ncg<2>(a, xmode, fc, s);

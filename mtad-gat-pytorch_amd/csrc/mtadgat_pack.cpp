@@ -118,8 +118,9 @@ std::string validate_and_plan(Model& m) {
         g.Hp = round_up(g.H, 32);
         g.NCG = g.Hp / 32;
         g.Qx = (g.in_dim + 7) / 8;
+        g.Qxp = round_up(g.Qx, 3);
         g.xmode = 0;
-        g.wx_off = take((size_t)g.NCG * g.Qx * 3 * 256);
+        g.wx_off = take((size_t)g.NCG * g.Qxp * 3 * 256);
         g.wh_off = take((size_t)g.NCG * 4 * g.NCG * 3 * 256);
         g.b_off = take((size_t)4 * g.Hp);
     }
@@ -152,13 +153,15 @@ std::string validate_and_plan(Model& m) {
             g.in_dim = Hin;
             g.xmode = 1;
             g.Qx = (nm + 7) / 8;
-            g.wx_off = take((size_t)T * g.NCG * g.Qx * 3 * 256);
+            g.Qxp = g.Qx == 1 ? 1 : round_up(g.Qx, 3);
+            g.wx_off = take((size_t)T * g.NCG * g.Qxp * 3 * 256);
             g.m0_off = take((size_t)T);
         } else {
             g.in_dim = c.recon_hid_dim;
             g.xmode = 0;
             g.Qx = (g.in_dim + 7) / 8;
-            g.wx_off = take((size_t)g.NCG * g.Qx * 3 * 256);
+            g.Qxp = round_up(g.Qx, 3);
+            g.wx_off = take((size_t)g.NCG * g.Qxp * 3 * 256);
         }
         g.wh_off = take((size_t)g.NCG * 4 * g.NCG * 3 * 256);
         g.b_off = take((size_t)4 * g.Hp);
@@ -184,12 +187,14 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
         return o;
     };
     const size_t N = (size_t)n;
+    // un-fused path intermediates (also used by the stage entry point mtadgat_gat, which copies its input
+    // into xc / xcT): the projected L'/R'^T only exist when a layer's tiles do not fit in LDS
     ws.xc = take(N * m.W * m.Fp);
     ws.xct = take(N * m.F * m.Wp);
-    ws.lct = take(N * m.W * m.temp.ldl);
-    ws.rtt = take(N * m.temp.rt_rows * m.temp.Kp);
-    ws.lcf = take(N * m.F * m.feat.ldl);
-    ws.rtf = take(N * m.feat.rt_rows * m.feat.Kp);
+    ws.lct = take(m.temp.fused ? 0 : N * m.W * m.temp.ldl);
+    ws.rtt = take(m.temp.fused ? 0 : N * m.temp.rt_rows * m.temp.Kp);
+    ws.lcf = take(m.feat.fused ? 0 : N * m.F * m.feat.ldl);
+    ws.rtf = take(m.feat.fused ? 0 : N * m.feat.rt_rows * m.feat.Kp);
     ws.hcat = take(N * m.W * m.Dp);
     ws.hend = take(N * m.gru.back().Hp);
     const bool gseq = m.gru.size() > 1;
@@ -265,7 +270,7 @@ static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_h
                            std::vector<float>& out) {
     const int H = g.H, in = g.in_dim;
     if (g.xmode == 0) {
-        pack_gru_tiles(out.data() + g.wx_off, g.NCG, g.Qx, [&](int st, int r, int k) -> float {
+        pack_gru_tiles(out.data() + g.wx_off, g.NCG, g.Qxp, [&](int st, int r, int k) -> float {
             return (r < H && k < in) ? w_ih[((size_t)st * H + r) * in + k] : 0.f;
         });
     }
@@ -329,7 +334,7 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
                         const int cc = (int)(((long)t * Hin + j) / T) - lo;
                         csum[(size_t)r * NMp + cc] += (double)p.rec_w_ih[l][(size_t)r * Hin + j];
                     }
-                pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qx * 3 * 256, g.NCG, g.Qx,
+                pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qxp * 3 * 256, g.NCG, g.Qxp,
                                [&](int st, int r, int k) -> float {
                                    return (r < H && k < NMp) ? (float)csum[((size_t)st * H + r) * NMp + k] : 0.f;
                                });
