@@ -795,7 +795,7 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
                 for (int s4 = 0; s4 < 4; ++s4) o[4 * m + s4] = bv[s4];
             }
             // all weight chunks of the task are requested at once (one L2 latency per task, not per chunk)
-            constexpr int QB = 8;
+            constexpr int QB = 4;
             for (int qb = 0; qb < Q; qb += QB) {
                 f32x4 w[QB];
 #pragma unroll
