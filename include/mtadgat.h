@@ -127,6 +127,19 @@ int mtadgat_forward(mtadgat_handle h, const float* x_dev, int64_t batch,
                     float* preds_dev, float* recons_dev, float* hend_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Same as mtadgat_forward, with the windows gathered on the GPU from a device-resident series instead of
+ * materialised by the caller: window w = series rows [s_w, s_w + W), s_w = starts_dev[w] when starts_dev is
+ * not NULL, else start0 + w * stride.  Replaces SlidingWindowDataset.__getitem__ + default collate feeding
+ * forward() (utils.py:107-120, prediction.py:43-44, 51-55): consecutive windows share W-1 rows, so the input
+ * read from HBM shrinks ~W-fold.
+ *   series_dev (n_rows, F) float32;  starts_dev (batch) int64 or NULL;  every window must lie inside the series.
+ *   recons_last_dev (batch, out_dim), optional: recons[:, -1, :] only (what Predictor.get_score keeps,
+ *   prediction.py:63); recons_dev may then be NULL and the full (batch, W, out_dim) tensor is never written. */
+int mtadgat_forward_series(mtadgat_handle h, const float* series_dev, int64_t n_rows,
+                           const int64_t* starts_dev, int64_t start0, int64_t stride, int64_t batch,
+                           float* preds_dev, float* recons_dev, float* recons_last_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* ---- stage entry points (the reference's sub-module forward() calls) ---------
  * Same workspace / stream contract; each is what forward() runs for that stage. */
 

@@ -65,6 +65,7 @@ def load_library():
     lib.mtadgat_chunk_windows.restype = i64
     lib.mtadgat_set_chunk_windows.argtypes = [vp, i64]
     lib.mtadgat_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp, sz, vp]
+    lib.mtadgat_forward_series.argtypes = [vp, vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, sz, vp]
     lib.mtadgat_conv.argtypes = [vp, vp, i64, vp, vp, sz, vp]
     lib.mtadgat_gat.argtypes = [vp, ctypes.c_int, vp, i64, vp, vp, sz, vp]
     lib.mtadgat_gru.argtypes = [vp, vp, i64, vp, vp, sz, vp]
@@ -182,6 +183,34 @@ class Engine:
                    _dev_ptr(recons, "recons"), _dev_ptr(hend, "hend") if want_hend else None,
                    _dev_ptr(ws, "workspace"), need)
         return (preds, recons, hend) if want_hend else (preds, recons)
+
+    def forward_series(self, series, starts=None, start0=0, stride=1, count=None, want_recons=True, want_last=False):
+        """Windows gathered on the GPU from the device-resident series (n_rows, F); returns
+        (preds, recons or None, recons[:, -1] or None)."""
+        c = self.cfg
+        if series.dim() != 2 or series.shape[1] != c.n_features:
+            raise RuntimeError(f"series must have shape (n_rows, {c.n_features}), got {tuple(series.shape)}")
+        sp = _dev_ptr(series, "series")
+        n_rows = series.shape[0]
+        if starts is not None:
+            if starts.dtype != torch.int64 or starts.device != series.device or not starts.is_contiguous() or starts.dim() != 1:
+                raise RuntimeError("starts must be a contiguous 1-D int64 tensor on the series' device")
+            b = starts.shape[0]
+            if b and (int(starts.min()) < 0 or int(starts.max()) + c.window_size > n_rows):
+                raise RuntimeError("a window does not lie inside the series")
+            stp = ctypes.c_void_p(starts.data_ptr())
+        else:
+            b = count if count is not None else max(0, (n_rows - c.window_size - start0) // max(stride, 1) + 1)
+            stp = None
+        dev = series.device
+        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=dev)
+        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=dev) if want_recons else None
+        last = torch.empty((b, c.out_dim), dtype=torch.float32, device=dev) if want_last else None
+        ws, need = self._workspace(b, dev)
+        self._call(self.lib.mtadgat_forward_series, "forward_series", dev, sp, n_rows, stp, int(start0), int(stride), b,
+                   _dev_ptr(preds, "preds"), _dev_ptr(recons, "recons") if want_recons else None,
+                   _dev_ptr(last, "recons_last") if want_last else None, _dev_ptr(ws, "workspace") if b else None, need)
+        return preds, recons, last
 
     def conv(self, x):
         c = self.cfg

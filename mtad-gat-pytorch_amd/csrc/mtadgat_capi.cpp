@@ -63,10 +63,25 @@ struct Scope {  // brackets a kernel family with events when profiling is on
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- stage launch helpers; all pointers device, n windows ------------------------------------
-int run_conv(Model& m, const float* x, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s) {
+// where the windows come from: a materialised (n, W, F) tensor, or views of a device-resident series
+struct XSource {
+    const float* x = nullptr;        // windows (n, W, F) -- or the series when gather != 0
+    int gather = 0;
+    const int64_t* starts = nullptr;
+    int64_t start0 = 0, stride = 1;
+};
+
+int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s) {
     Scope sc(m, S_CONV, s);
     ConvArgs a{};
-    a.X = x; a.B = n; a.W = m.W; a.F = m.F; a.Fp = m.Fp; a.taps = m.taps; a.pad = m.pad;
+    if (src.gather) {
+        a.X = src.x; a.gather = 1;
+        a.starts = src.starts ? reinterpret_cast<const long*>(src.starts + c0) : nullptr;
+        a.start0 = src.start0 + c0 * src.stride; a.stride = src.stride;
+    } else {
+        a.X = src.x + c0 * (int64_t)m.W * m.F;
+    }
+    a.B = n; a.W = m.W; a.F = m.F; a.Fp = m.Fp; a.taps = m.taps; a.pad = m.pad;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w_off);
     a.bias = m.packed_dev + m.conv_b_off;
     a.NT = m.convNT;
@@ -138,7 +153,7 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
 int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, bool xfast, int64_t n, float* hend,
-                  long ldhe, float* seq, const LinPlan* fc, float* yfc, hipStream_t s) {
+                  long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s) {
     Scope sc(m, slot, s);
     GruArgs a{};
     a.X = x; a.ldx = ldx; a.Kx = kx; a.Qx = g.Qx; a.Qxp = g.Qxp;
@@ -155,6 +170,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.bfc = m.packed_dev + fc->b_off;
         a.NTfc = fc->NT;
         a.Yfc = yfc;
+        a.Ylast = ylast;
         a.out_dim = fc->out_dim;
     }
     K_TRY(launch_gru(a, g.NCG, g.xmode, fc != nullptr, s), "gru");
@@ -172,7 +188,7 @@ int run_gru_stack(Model& m, const float* hcat, long ldx, bool padded, int64_t n,
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         float* seq = last ? nullptr : ws + ((l & 1) ? o.seq1 : o.seq0);
-        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, fast, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, s);
+        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, fast, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s);
         if (rc) return rc;
         x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;
         fast = true;      // sequence buffers hold all Hp columns, padding lanes are exact zeros
@@ -181,8 +197,8 @@ int run_gru_stack(Model& m, const float* hcat, long ldx, bool padded, int64_t n,
 }
 
 // padded == true: hend is the internal (n, Hp) buffer with zero pad columns
-int run_heads(Model& m, const float* hend, long ldh, bool padded, int64_t n, float* preds, float* recons, float* ws,
-              const Workspace& o, hipStream_t s) {
+int run_heads(Model& m, const float* hend, long ldh, bool padded, int64_t n, float* preds, float* recons, float* recons_last,
+              float* ws, const Workspace& o, hipStream_t s) {
     if (preds) {
         Scope sc(m, S_FC, s);
         const float* x = hend;
@@ -208,7 +224,7 @@ int run_heads(Model& m, const float* hend, long ldh, bool padded, int64_t n, flo
             x = a.Y; ld = a.ldy;
         }
     }
-    if (recons) {
+    if (recons || recons_last) {
         const int L = (int)m.rec.size();
         const float* x = hend;
         long ld = ldh;
@@ -219,7 +235,7 @@ int run_heads(Model& m, const float* hend, long ldh, bool padded, int64_t n, flo
             const bool last = (l == L - 1);
             float* seq = last ? nullptr : ws + ((l & 1) ? o.rseq1 : o.rseq0);
             int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, fast, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr,
-                                   last ? recons : nullptr, s);
+                                   last ? recons : nullptr, last ? recons_last : nullptr, s);
             if (rc) return rc;
             x = seq; ld = m.rec[l].Hp; kx = m.rec[l].H;
             fast = true;
@@ -302,12 +318,12 @@ size_t mtadgat_workspace_bytes(mtadgat_handle h, int64_t batch) {
     return o.total * sizeof(float);
 }
 
-int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* preds, float* recons, float* hend_out,
-                    void* ws_, size_t ws_bytes, void* stream) {
+static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, float* preds, float* recons, float* recons_last,
+                        float* hend_out, void* ws_, size_t ws_bytes, void* stream) {
     int rc = check_common(h, batch, ws_, ws_bytes, true);
     if (rc) return rc;
     if (batch == 0) return 0;
-    if (!x) return fail(MTADGAT_ERR_INVALID, "x is NULL");
+    if (!src.x) return fail(MTADGAT_ERR_INVALID, "input is NULL");
     Model& m = h->m;
     hipStream_t s = (hipStream_t)stream;
     float* ws = static_cast<float*>(ws_);
@@ -316,18 +332,17 @@ int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* pred
         const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
         Workspace o;
         plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
-        const float* xc_in = x + c0 * (int64_t)W * F;
         float* xc = ws + o.xc;
         float* xct = ws + o.xct;
         float* hcat = ws + o.hcat;
         if (use_fused(m.temp) && use_fused(m.feat)) {
             // fused front: conv writes only h_cat[:, :F]; each layer's workgroup stages its window from
             // there (the feature layer transposes on the way into LDS) -- no xc / xc^T / L' / R' in HBM
-            if ((rc = run_conv(m, xc_in, n, nullptr, nullptr, hcat, nullptr, s))) return rc;
+            if ((rc = run_conv(m, src, c0, n, nullptr, nullptr, hcat, nullptr, s))) return rc;
             if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
             if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
         } else {
-            if ((rc = run_conv(m, xc_in, n, xc, xct, hcat, nullptr, s))) return rc;
+            if ((rc = run_conv(m, src, c0, n, xc, xct, hcat, nullptr, s))) return rc;
             // temporal layer: nodes = time steps, rows of xc
             if ((rc = run_gat_layer(m, m.temp, xc, m.Fp, n, ws + o.lct, ws + o.rtt, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
             // feature layer: nodes = features, rows of xc^T
@@ -339,13 +354,35 @@ int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* pred
         if (hend_out)
             K_TRY(launch_copy2d(hend, ldh, hend_out + c0 * m.cfg.gru_hid_dim, m.cfg.gru_hid_dim, n, m.cfg.gru_hid_dim, s),
                   "h_end copy");
-        if (preds || recons) {
+        if (preds || recons || recons_last) {
             if ((rc = run_heads(m, hend, ldh, true, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
-                                recons ? recons + c0 * (int64_t)W * m.cfg.out_dim : nullptr, ws, o, s)))
+                                recons ? recons + c0 * (int64_t)W * m.cfg.out_dim : nullptr,
+                                recons_last ? recons_last + c0 * m.cfg.out_dim : nullptr, ws, o, s)))
                 return rc;
         }
     }
     return 0;
+}
+
+int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* preds, float* recons, float* hend_out,
+                    void* ws_, size_t ws_bytes, void* stream) {
+    XSource src;
+    src.x = x;
+    return forward_impl(h, src, batch, preds, recons, nullptr, hend_out, ws_, ws_bytes, stream);
+}
+
+int mtadgat_forward_series(mtadgat_handle h, const float* series, int64_t n_rows, const int64_t* starts, int64_t start0,
+                           int64_t stride, int64_t batch, float* preds, float* recons, float* recons_last, void* ws_,
+                           size_t ws_bytes, void* stream) {
+    if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");
+    if (n_rows < h->m.W) return fail(MTADGAT_ERR_INVALID, "series shorter than one window");
+    if (!starts) {   // starts_dev cannot be checked on the host; the arithmetic progression can
+        if (stride < 0 || start0 < 0 || (batch > 0 && start0 + (batch - 1) * stride + h->m.W > n_rows))
+            return fail(MTADGAT_ERR_INVALID, "windows start0 + w*stride .. +W do not lie inside the series");
+    }
+    XSource src;
+    src.x = series; src.gather = 1; src.starts = starts; src.start0 = start0; src.stride = stride;
+    return forward_impl(h, src, batch, preds, recons, recons_last, nullptr, ws_, ws_bytes, stream);
 }
 
 int mtadgat_conv(mtadgat_handle h, const float* x, int64_t batch, float* y, void* ws, size_t ws_bytes, void* stream) {
@@ -353,7 +390,9 @@ int mtadgat_conv(mtadgat_handle h, const float* x, int64_t batch, float* y, void
     if (rc) return rc;
     if (batch == 0) return 0;
     if (!x || !y) return fail(MTADGAT_ERR_INVALID, "null tensor");
-    return run_conv(h->m, x, batch, nullptr, nullptr, nullptr, y, (hipStream_t)stream);
+    XSource src;
+    src.x = x;
+    return run_conv(h->m, src, 0, batch, nullptr, nullptr, nullptr, y, (hipStream_t)stream);
 }
 
 int mtadgat_gat(mtadgat_handle h, int which, const float* xc_in, int64_t batch, float* out, void* ws_, size_t ws_bytes,
@@ -423,7 +462,7 @@ int mtadgat_heads(mtadgat_handle h, const float* hend, int64_t batch, float* pre
         HIP_TRY(hipMemsetAsync(ws + o.hend, 0, (size_t)n * ldh * sizeof(float), s));
         K_TRY(launch_copy2d(hend + c0 * H, H, ws + o.hend, ldh, n, H, s), "h_end pad copy");
         if ((rc = run_heads(m, ws + o.hend, ldh, true, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
-                            recons ? recons + c0 * (int64_t)m.W * m.cfg.out_dim : nullptr, ws, o, s)))
+                            recons ? recons + c0 * (int64_t)m.W * m.cfg.out_dim : nullptr, nullptr, ws, o, s)))
             return rc;
     }
     return 0;

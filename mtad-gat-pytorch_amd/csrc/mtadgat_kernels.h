@@ -30,7 +30,12 @@ struct RowGemmArgs {
 };
 
 struct ConvArgs {
-    const float* X;      // (B, W, F)
+    const float* X;      // (B, W, F) windows, or -- gather mode -- the series (n_rows, F)
+    // gather mode (starts != null or stride > 0): window w = series rows [s_w, s_w + W), s_w = starts[w] or
+    // start0 + w*stride  (reference: SlidingWindowDataset.__getitem__, utils.py:114-117)
+    const long* starts;
+    long start0, stride;
+    int gather;
     long B;
     int W, F, Fp, taps, pad;
     const f32x4* Wp;     // packed (F x taps*Fp), NT tiles, Q = taps*Fp/8
@@ -99,7 +104,8 @@ struct GruArgs {
     const f32x4* Wfc;    // [NTfc][4*NCG][64]
     const float* bfc;    // NTfc*32
     int NTfc;
-    float* Yfc;          // (B*T, out_dim)
+    float* Yfc;          // (B*T, out_dim) or null (then only the last step is produced)
+    float* Ylast;        // (B, out_dim): the per-step Linear at the last step only, or null
     int out_dim;
 };
 

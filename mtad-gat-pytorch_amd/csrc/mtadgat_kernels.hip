@@ -290,7 +290,13 @@ __global__ __launch_bounds__(64) void k_conv_lds(const ConvArgs a) {
     for (int rr = 0; rr < nrow; ++rr) {
         const long flat = r0 - a.pad + rr;
         const bool ok = flat >= 0 && flat < R;
-        const float* __restrict__ src = a.X + (ok ? flat : 0) * a.F;
+        long srow = ok ? flat : 0;
+        if (a.gather) {          // windows are views of the device-resident series: no (b, W, F) copy exists
+            const long w = srow / a.W;
+            const long s0 = a.starts ? a.starts[w] : a.start0 + w * a.stride;
+            srow = s0 + (srow - w * a.W);
+        }
+        const float* __restrict__ src = a.X + srow * a.F;
         for (int col = lane; col < Fld; col += 64) xs[rr * Fld + col] = (ok && col < a.F) ? src[col] : 0.f;
     }
     __syncthreads();
@@ -1107,7 +1113,7 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                     *reinterpret_cast<f32x4*>(sp + 32 * c + 8 * m + 4 * g) = v;
                 }
         }
-        if (FC) {
+        if (FC && (a.Yfc != nullptr || t == T - 1)) {
             for (int n = 0; n < a.NTfc; ++n) {
                 f32x16 y;
 #pragma unroll
@@ -1126,11 +1132,15 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                     y = mfma4(wp[q * 64], hv, y);
                 }
                 if (win < a.B) {
-                    float* yp = a.Yfc + (win * T + t) * (long)a.out_dim;
+                    float* yp = a.Yfc ? a.Yfc + (win * T + t) * (long)a.out_dim : nullptr;
+                    float* yl = (a.Ylast && t == T - 1) ? a.Ylast + win * (long)a.out_dim : nullptr;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        if (o < a.out_dim) yp[o] = y[r];
+                        if (o < a.out_dim) {
+                            if (yp) yp[o] = y[r];
+                            if (yl) yl[o] = y[r];
+                        }
                     }
                 }
             }

@@ -254,3 +254,34 @@ class MTAD_GAT(nn.Module):
         eng = self._sync_engine(x.device)
         with torch.no_grad():
             return eng.forward(x.contiguous().float())
+
+    # -- beyond the reference's module API: the callers' data path on the GPU -------
+    def forward_series(self, series, starts=None, start=0, stride=1, count=None):
+        """forward() over sliding windows of a device-resident series (n_rows, F) without materialising
+        them: window w = series[s_w : s_w + W], s_w = starts[w] or start + w*stride.  Equivalent to
+        `SlidingWindowDataset` + default collate + `model(x)` (reference utils.py:107-120,
+        prediction.py:43-55); consecutive windows share W-1 rows, so ~W times fewer input bytes are read.
+        Returns (predictions (b, out_dim), recons (b, W, out_dim))."""
+        self._check_mode(series)
+        eng = self._sync_engine(series.device)
+        with torch.no_grad():
+            p, r, _ = eng.forward_series(series.contiguous().float(), starts, start, stride, count)
+        return p, r
+
+    def score_series(self, values):
+        """The model evaluations of `Predictor.get_score` (reference prediction.py:51-63) for a whole
+        series (N, F), fused: for every i in [0, N-W)
+            y_hat_i  = forward(values[i : i+W])[0]                  (forecast of row i+W)
+            recon_i  = forward(values[i+1 : i+W+1])[1][:, -1]       (reconstruction of row i+W)
+        The reference runs two full forwards per window and throws half of each away; both outputs of
+        window j are the forecast for i = j and the reconstruction for i = j-1, so ONE forward per window
+        over windows 0..N-W is enough, and only the last reconstruction step is ever written.
+        Returns (preds (N-W, out_dim), recons_last (N-W, out_dim))."""
+        self._check_mode(values)
+        n = values.shape[0] - self.window_size
+        if n <= 0:
+            raise RuntimeError("series shorter than window_size + 1")
+        eng = self._sync_engine(values.device)
+        with torch.no_grad():
+            p, _, last = eng.forward_series(values.contiguous().float(), None, 0, 1, n + 1, want_recons=False, want_last=True)
+        return p[:n], last[1:n + 1]

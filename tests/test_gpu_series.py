@@ -1,0 +1,73 @@
+"""GPU-side sliding-window gather and the fused Predictor scoring pass,
+against the materialised-window forward (bit-exact: same kernels, same values) and the oracle."""
+import pytest
+import torch
+
+from helpers import Case, gate
+from oracle import mtad_gat_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(gpu_device):
+    case = Case("smap")
+    model = case.build_model().to(gpu_device)
+    g = torch.Generator().manual_seed(3)
+    series = torch.rand(100 + 77, case.kwargs["n_features"], generator=g)
+    return case, model, series
+
+
+def _windows(series, starts, w):
+    # what SlidingWindowDataset.__getitem__ + default collate produce (reference utils.py:114-117)
+    return torch.stack([series[s:s + w] for s in starts])
+
+
+def test_forward_series_equals_materialised_windows(setup, gpu_device):
+    case, model, series = setup
+    w = case.kwargs["window_size"]
+    sd = series.to(gpu_device)
+    with torch.no_grad():
+        for starts in (list(range(0, 78)), list(range(2, 78, 3)), [5, 5, 70, 0, 33, 77]):
+            x = _windows(series, starts, w).to(gpu_device)
+            p_ref, r_ref = model(x)
+            if starts == list(range(0, 78)):
+                p, r = model.forward_series(sd)
+            elif starts == list(range(2, 78, 3)):
+                p, r = model.forward_series(sd, start=2, stride=3)
+            else:
+                p, r = model.forward_series(sd, starts=torch.tensor(starts, dtype=torch.int64, device=gpu_device))
+            assert torch.equal(p, p_ref) and torch.equal(r, r_ref), starts
+    with pytest.raises(RuntimeError):
+        model.forward_series(sd, start=0, stride=1, count=79)          # window 78 would end past the series
+    with pytest.raises(RuntimeError):
+        model.forward_series(sd, starts=torch.tensor([78], dtype=torch.int64, device=gpu_device))
+
+
+def test_score_series_equals_predictor_double_forward(setup, gpu_device):
+    case, model, series = setup
+    w = case.kwargs["window_size"]
+    n = series.shape[0] - w
+    sd = series.to(gpu_device)
+    with torch.no_grad():
+        preds, last = model.score_series(sd)
+        assert preds.shape == (n, case.kwargs["out_dim"]) and last.shape == (n, case.kwargs["out_dim"])
+        # the reference's loop (prediction.py:51-63), batch by batch, through the same module
+        ref_p, ref_l = [], []
+        for lo in range(0, n, 32):
+            idx = list(range(lo, min(lo + 32, n)))
+            x = _windows(series, idx, w).to(gpu_device)
+            y = torch.stack([series[i + w:i + w + 1] for i in idx]).to(gpu_device)
+            y_hat, _ = model(x)
+            recon_x = torch.cat((x[:, 1:, :], y), dim=1)
+            _, window_recon = model(recon_x)
+            ref_p.append(y_hat)
+            ref_l.append(window_recon[:, -1, :])
+        assert torch.equal(preds, torch.cat(ref_p)) and torch.equal(last, torch.cat(ref_l))
+        # and against the oracle (reference formulation on CPU) on a slice
+        x = _windows(series, list(range(0, 12)), w)
+        y = torch.stack([series[i + w:i + w + 1] for i in range(0, 12)])
+        p_o, _ = oracle.forward(x, case.state_dict(), alpha=case.kwargs["alpha"])
+        _, r_o = oracle.forward(torch.cat((x[:, 1:, :], y), dim=1), case.state_dict(), alpha=case.kwargs["alpha"])
+    gate(preds[:12], p_o, what="score_series forecasts")
+    gate(last[:12], r_o[:, -1, :], what="score_series reconstructions")
