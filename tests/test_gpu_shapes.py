@@ -1,0 +1,50 @@
+"""Odd and tiny shapes straight against the oracle (which is pinned by the golden vectors): single
+feature / tiny windows / kernel wider than the window / non-multiple-of-anything dims / ragged node
+blocks, v1 and v2 attention.  Tolerance 1e-5 (north_star)."""
+import pytest
+import torch
+
+from helpers import gate
+from oracle import mtad_gat_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    dict(n_features=1, window_size=3, out_dim=1, kernel_size=3, gru_hid_dim=5, forecast_hid_dim=4, recon_hid_dim=3),
+    dict(n_features=2, window_size=5, out_dim=2, kernel_size=9, gru_hid_dim=32, forecast_hid_dim=33, recon_hid_dim=31),
+    dict(n_features=3, window_size=64, out_dim=1, kernel_size=1, gru_hid_dim=64, forecast_n_layers=2, recon_hid_dim=96),
+    dict(n_features=64, window_size=65, out_dim=64, kernel_size=3, use_gatv2=False, gru_hid_dim=17, recon_hid_dim=150),
+    dict(n_features=33, window_size=31, out_dim=5, kernel_size=5, feat_gat_embed_dim=1, time_gat_embed_dim=1,
+         gru_hid_dim=97, recon_hid_dim=129, recon_n_layers=3, gru_n_layers=3),
+    dict(n_features=20, window_size=128, out_dim=20, kernel_size=7, gru_hid_dim=256, recon_hid_dim=200, alpha=0.7),
+    dict(n_features=129, window_size=40, out_dim=3, kernel_size=3, gru_hid_dim=40, recon_hid_dim=40),   # un-fused path (K > 128)
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES, ids=lambda k: f"F{k['n_features']}W{k['window_size']}")
+def test_shape_against_oracle(kw, gpu_device):
+    from mtad_gat import MTAD_GAT
+    torch.manual_seed(17)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+    for b in (1, 35):
+        x = torch.rand(b, kw["window_size"], kw["n_features"])
+        with torch.no_grad():
+            p_ref, r_ref = oracle.forward(x, model.state_dict(), alpha=kw.get("alpha", 0.2))
+            m = model.to(gpu_device)
+            p, r = m(x.to(gpu_device))
+            model = m.cpu()
+        gate(p, p_ref, what=f"preds b={b}")
+        gate(r, r_ref, what=f"recons b={b}")
+
+
+def test_unsupported_shapes_fail_loudly(gpu_device):
+    from mtad_gat import MTAD_GAT
+    model = MTAD_GAT(n_features=4, window_size=600, out_dim=1).eval().to(gpu_device)
+    with pytest.raises(RuntimeError, match="512"):
+        model(torch.rand(1, 600, 4, device=gpu_device))
+    model = MTAD_GAT(n_features=4, window_size=10, out_dim=1, gru_hid_dim=300).eval().to(gpu_device)
+    with pytest.raises(RuntimeError, match="hidden"):
+        model(torch.rand(1, 10, 4, device=gpu_device))
