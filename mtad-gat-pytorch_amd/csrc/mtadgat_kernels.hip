@@ -991,27 +991,35 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
     // (36 MFMAs ~ 2.3k cycles) ahead of the MFMAs across the x/h, tile and step boundaries.
     // (A variant with per-tile base pointers + compile-time offsets instead of the cursor needed ~20 more
     // VGPRs and measured slower.)
-    int pc = 0, ps = 0, pt = 0;                   // prefetch cursor (wave-uniform, branch-free updates)
+    // prefetch cursor: wave-uniform running pointers into the two packed streams (they stay in SGPRs; the
+    // per-lane part of every weight address is the constant lane*16 bytes), advanced by one chunk per fetch
+    int pc = 0, ps = 0, pt = 0;
+    const f32x4* __restrict__ pwx = a.Wx;          // next input-part chunk to fetch
+    const f32x4* __restrict__ pwh = a.Wh;          // next recurrent-part chunk to fetch
     auto wload = [&](f32x4 (&dst)[3]) {
-        const long tt = (XMODE != 0) ? (long)(pt < T ? pt : T - 1) * NCG * Qxp : 0;
-        const f32x4* __restrict__ px = a.Wx + (tt + (long)pc * Qxp + ps) * 192 + lane;
-        const f32x4* __restrict__ ph = a.Wh + ((long)pc * Qh + (ps - Qxp)) * 192 + lane;
-        const f32x4* __restrict__ p = (ps < Qxp) ? px : ph;
+        const bool isx = ps < Qxp;
+        const f32x4* __restrict__ p = (isx ? pwx : pwh) + lane;
         dst[0] = p[0]; dst[1] = p[64]; dst[2] = p[128];
-        const bool ws = (ps + 1 == S);
+        pwx += isx ? 192 : 0;
+        pwh += isx ? 0 : 192;
+        const bool ws = (ps + 1 == S);             // end of this tile's chunk sequence
         ps = ws ? 0 : ps + 1;
-        const bool wc = ws && (pc + 1 == NCG);
+        pwh += ws ? (Qh - Qhe) * 192 : 0;          // skip the dropped all-padding chunks of the tile
+        const bool wc = ws && (pc + 1 == NCG);     // end of the step
         pc = ws ? (wc ? 0 : pc + 1) : pc;
         pt = wc ? pt + 1 : pt;
+        pwh = wc ? a.Wh : pwh;
+        // input-part weights: per step for the decoder ([t][c][Qxp], contiguous), shared by all steps otherwise
+        pwx = wc ? ((XMODE == 0 || pt >= T) ? a.Wx : pwx) : pwx;
     };
+    const float* __restrict__ xbase = (XMODE == 0) ? a.X + winc * T * a.ldx + 4 * g : a.X + winc * a.ldx;
     auto loadx_t = [&](int t, int q) -> f32x4 {
         const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
-        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(a.X + (winc * T + t) * a.ldx + 8 * qq + 4 * g);
-        const float* __restrict__ rowp = a.X + winc * a.ldx;
+        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase + (long)t * a.ldx + 8 * qq);
         const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
         f32x4 v;
-        v[0] = rowp[min(k0, kmax)]; v[1] = rowp[min(k0 + 1, kmax)];
-        v[2] = rowp[min(k0 + 2, kmax)]; v[3] = rowp[min(k0 + 3, kmax)];
+        v[0] = xbase[min(k0, kmax)]; v[1] = xbase[min(k0 + 1, kmax)];
+        v[2] = xbase[min(k0 + 2, kmax)]; v[3] = xbase[min(k0 + 3, kmax)];
         return v;
     };
 
