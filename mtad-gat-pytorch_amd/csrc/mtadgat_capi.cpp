@@ -113,7 +113,7 @@ int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, con
     a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
     a.K = g.K; a.rows_per_blk = g.rows_per_blk; a.nblk = g.nblk;
     a.nwin = n;
-    { const char* e = getenv("MTADGAT_XCD"); a.xcd_map = e ? atoi(e) : 1; }
+    a.xcd_map = 1;
     a.total_blocks = ((n + 7) / 8 * 8) * g.nblk;
     a.v1 = m.cfg.use_gatv2 ? 0 : 1;
     a.alpha = m.cfg.alpha;

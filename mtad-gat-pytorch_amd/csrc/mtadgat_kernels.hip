@@ -1228,8 +1228,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     if (R <= 0) return 0;
     const unsigned grid = (unsigned)((R + 31) / 32);
     const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fp + 4) * sizeof(float);
-    const char* env = getenv("MTADGAT_CONV_LDS");
-    if (lds <= 20 * 1024 && !(env && atoi(env) == 0)) {       // >= 8 waves per CU keep their tile in LDS
+    if (lds <= 20 * 1024) {       // >= 8 waves per CU keep their tile in LDS
         if (a.NT >= 2)
             hipLaunchKernelGGL(k_conv_lds<2>, dim3(grid), dim3(64), lds, s, a);
         else

@@ -91,7 +91,6 @@ std::string validate_and_plan(Model& m) {
         if (K <= 128) {
             int nw = (K + 19) / 20;
             nw = nw < 4 ? 4 : (nw > 8 ? 8 : nw);
-            if (const char* e = getenv(K == c.window_size ? "MTADGAT_NW_T" : "MTADGAT_NW_F")) nw = atoi(e);   // tuning knob
             const int rows = (K + nw - 1) / nw;
             int ib = round_up(rows, 4);
             if (ib < 8) ib = 8;
