@@ -129,16 +129,16 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
                   long so_d, hipStream_t s) {
     Scope sc(m, S_ATTEND, s);
     GatArgs a{};
-    a.V = v; a.ldv = ldv; a.vt = vt; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.rld = g.f_rld;
+    a.V = v; a.ldv = ldv; a.vt = vt; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.lr_floats = g.f_lr;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
     a.pbias = m.packed_dev + g.b_off;
     a.NT_L = g.NT_L; a.Q = g.Q; a.PT = g.PT; a.P8 = g.P8;
     a.bias = m.packed_dev + g.bias_off;
     a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
-    a.rows_per_blk = g.f_rows; a.nwin = n;
+    a.nwin = n;
     a.v1 = m.cfg.use_gatv2 ? 0 : 1;
     a.alpha = m.cfg.alpha;
-    K_TRY(launch_gat(a, g.f_IB, g.f_KPT, g.f_nw, g.f_lds_bytes, s), "fused gat");
+    K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_nw, g.f_lds_bytes, s), "fused gat");
     return 0;
 }
 

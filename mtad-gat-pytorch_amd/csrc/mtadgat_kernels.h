@@ -72,14 +72,14 @@ struct GatArgs {
     const float* V;      // vt == 0: (B*K, ldv) node rows; vt == 1: (B*D, ldv) rows whose columns are the nodes
     int ldv, D, K;
     int vt;
-    int vld, rld;        // LDS row strides of the staged V rows and of R'^T
+    int vld;             // LDS row stride of the staged V rows
+    int lr_floats;       // LDS floats reserved for L' / R' (and the aliased softmax rows) ahead of the V rows
     const f32x4* Wp;     // packed projection tiles [2*NT_L][Q][64]: query-side tiles then key-side tiles
     const float* pbias;  // projection bias, 2*NT_L*32
     int NT_L, Q, PT, P8;
     const float* bias;   // (K, K) attention bias or null
     float* out;          // out[win*so_w + i*so_i + d*so_d]
     long so_w, so_i, so_d;
-    int rows_per_blk;    // query rows per wave
     long nwin;
     int v1;
     float alpha;
@@ -113,7 +113,7 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s);
 int launch_conv(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
-int launch_gat(const GatArgs& a, int IB, int KPT, int nw, size_t lds_bytes, hipStream_t s);
+int launch_gat(const GatArgs& a, int IBL, int JPL, int nw, size_t lds_bytes, hipStream_t s);
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_copy2d(const float* src, long lds, float* dst, long ldd, long R, int ncols, hipStream_t s);
 int launch_transpose_win(const float* src, long lds, float* dst, long ldd, long B, int R, int C, hipStream_t s);

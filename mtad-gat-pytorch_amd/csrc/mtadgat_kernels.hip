@@ -37,6 +37,7 @@
 namespace mtadgat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16 mfma4(const f32x4 w, const f32x4 x, f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[0], acc, 0, 0, 0);
@@ -670,228 +671,319 @@ __global__ __launch_bounds__(64, (JPL <= 2 ? 3 : 2)) void k_attend(const AttendA
 // ---------------------------------------------------------------------------
 // gat (fused): one workgroup per window does the whole graph-attention layer -- projection,
 // pairwise scores, softmax, aggregation, sigmoid -- with the node features V, the projected L' and
-// R'^T never leaving the CU.  Same algebra and packed weights as k_rowgemm + k_attend (which remain
+// R' never leaving the CU.  Same algebra and packed weights as k_rowgemm + k_attend (which remain
 // the path for node counts / dims whose tiles do not fit in LDS).
-//   LDS:  Vs [K][vld]            node feature rows of this window (zero padded columns)
-//         Ls [K][lld]            L' columns of the current part, row-major (+ c when it is in the part)
-//         Rs [32*KPT][rld]       R'^T rows of the current part, key-node-minor (+ d)
-//         att[NW][IB][68]        softmax rows restaged for the aggregation MFMA (aliases Ls/Rs)
-// The embedding is processed in parts of KPT 32-column tiles: MFMA phase (projection of the part
-// into Ls/Rs) -> barrier -> VALU phase (|L'+R'| accumulation, 2 plain VALU ops per element: L'_ik is
-// a wave-uniform LDS broadcast read, R'_jk a per-lane LDS read) -> barrier.  Several workgroups per CU
-// are in different phases, so the matrix and vector pipes overlap across workgroups.
+//   LDS:  Vs [Kp8][vld]          node feature rows of this window (zero padded rows and columns)
+//         Ls [NW*4*IBL][36]      L' columns of the current part, row-major (+ c when it is in the part)
+//         Rs [16*JPL][36]        R' columns of the current part, row-major (+ d)
+//         att[NW][4*IBL][68]     softmax rows restaged for the aggregation MFMA (aliases Ls/Rs)
+// The embedding is processed in parts of one 32-column tile per side: MFMA phase (projection of the
+// part into Ls/Rs) -> barrier -> VALU phase -> barrier.  Several workgroups per CU are in different
+// phases, so the matrix and vector pipes overlap across workgroups.
+//
+// VALU phase = 2-D register blocking of the K x K pair grid.  A wave owns 4*IBL query rows; lane
+// (li = lane>>4, lj = lane&15) accumulates the IBL x JPL pairs {rows li + 4 ii} x {keys lj + 16 jj}.
+// Per 2 embedding columns it reads IBL + JPL 8-byte LDS words (its rows of L', its keys of R') for
+// 4*IBL*JPL VALU instructions -- v_add_f32 t, l, r; v_add_f32 acc, acc, |t| -- so the LDS feeds
+// ~0.17 floats per VALU op (lane-per-key with wave-uniform broadcast rows needed 0.28-0.53 and was
+// LDS-return bound), no lane is spent on padding beyond 16*JPL keys, and all addresses are
+// base + immediate.  The two register sets A/B alternate: the loads of the next column pair are in
+// flight while the current pair is consumed.  Row strides of 36 floats keep every ds_read_b64 wave
+// access conflict-free (16 distinct keys x 2 banks each cover 32 bank pairs).
 // ---------------------------------------------------------------------------
-template <int JPL, int IB, bool NEG>
-__device__ __forceinline__ void gat_tile(float (&acc)[IB][JPL], const float* __restrict__ Ls, int lld, int row0, int nrows,
-                                         const float* __restrict__ Rs, int rld, const int (&jc)[JPL], int k0) {
-    float r[JPL][8];
+typedef const __attribute__((address_space(3))) float* lds_cptr;      // explicit LDS pointer (32-bit)
+constexpr int GAT_LLD = 34;     // 32 columns + 2: rows 8-byte aligned, 16 consecutive rows start on 16 distinct bank pairs
+constexpr int GAT_APITCH = 68;
+
+// lp[ii]: one base pointer per query row.  The pointers are made opaque to the compiler on purpose:
+// with a common base it merges row pairs into ds_read2_b64, which runs at half the LDS rate of two
+// ds_read_b64 (MI355X: 8 vs 2 x 2 LDS cycles per wave instruction).
+template <int IBL, int JPL>
+__device__ __forceinline__ void gat_load(f32x2 (&l)[IBL], f32x2 (&r)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp, int col) {
+    typedef const __attribute__((address_space(3))) f32x2* lds_c2;
 #pragma unroll
-    for (int jj = 0; jj < JPL; ++jj)
+    for (int ii = 0; ii < IBL; ++ii) l[ii] = *(lds_c2)(lp[ii] + col);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[jj][e] = Rs[(k0 + e) * rld + jc[jj]];
-    // L' rows are fetched one row ahead of their use (LDS latency ~100+ cycles would otherwise be
-    // exposed once per row: 32 VALU instructions)
-    auto lrow = [&](int ib) { return Ls + (row0 + (ib < nrows ? ib : nrows - 1)) * lld + k0; };   // wave-uniform
-    f32x4 l0 = *reinterpret_cast<const f32x4*>(lrow(0));
-    f32x4 l1 = *reinterpret_cast<const f32x4*>(lrow(0) + 4);
-#pragma unroll
-    for (int ib = 0; ib < IB; ++ib) {
-        f32x4 n0 = l0, n1 = l1;
-        if (ib + 1 < IB) {
-            n0 = *reinterpret_cast<const f32x4*>(lrow(ib + 1));
-            n1 = *reinterpret_cast<const f32x4*>(lrow(ib + 1) + 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) {
-                const float t0 = l0[e] + r[jj][e];
-                const float t1 = l1[e] + r[jj][4 + e];
-                if (NEG) {
-                    acc[ib][jj] -= fabsf(t0);
-                    acc[ib][jj] -= fabsf(t1);
-                } else {
-                    acc[ib][jj] += fabsf(t0);
-                    acc[ib][jj] += fabsf(t1);
-                }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        l0 = n0;
-        l1 = n1;
-    }
+    for (int jj = 0; jj < JPL; ++jj) r[jj] = *(lds_c2)(rp + jj * 16 * GAT_LLD + col);
 }
 
-template <int JPL, int IB, int KPT>
+// The two instructions per pair are written as (volatile) inline asm: left to itself the compiler packs
+// the column pair into v_pk_add_f32 (no faster) and schedules all sums of a step
+// ahead of their uses, which costs > 100 VGPRs of temporaries and spills the accumulators.
+template <int IBL, int JPL, bool NEG>
+__device__ __forceinline__ void gat_step(float (&acc)[IBL][JPL], const f32x2 (&l)[IBL], const f32x2 (&r)[JPL]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            float t[JPL];
+            const float lv = l[ii][e];
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const float rv = r[jj][e];
+                asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(t[jj]) : "v"(lv), "v"(rv));
+            }
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                if (NEG)
+                    asm volatile("v_sub_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t[jj]));
+                else
+                    asm volatile("v_add_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t[jj]));
+            }
+        }
+}
+
+// one 8-column k tile; on entry set A holds columns 0,1 of the tile (loads possibly still in flight),
+// on exit it holds columns 0,1 of the next tile (pad columns past the end of a part: never consumed)
+template <int IBL, int JPL, bool NEG>
+__device__ __forceinline__ void gat_tile(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], f32x2 (&lB)[IBL],
+                                         f32x2 (&rB)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
+    gat_load<IBL, JPL>(lB, rB, lp, rp, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lA, rA);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL>(lA, rA, lp, rp, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lB, rB);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL>(lB, rB, lp, rp, 6);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lA, rA);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL>(lA, rA, lp, rp, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lB, rB);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// all-reduce over the 16 lanes of a DPP row
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    return fmaxf(v, dpp_move<0x140>(v));
+}
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v + dpp_move<0x140>(v);
+}
+
+template <int IBL, int JPL>
 __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int IBW = 4 * IBL;                       // query rows per wave
+    constexpr int QB = 8;                              // weight chunks held in registers per task batch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
     const long win = blockIdx.x;
     const int K = a.K, D = a.D, PT = a.PT;
-    const int vld = a.vld, lld = 32 * KPT + 4, rld = a.rld;
-    float* __restrict__ Vs = smem;
-    float* __restrict__ Ls = Vs + K * vld;
-    float* __restrict__ Rs = Ls + K * lld;
-    const int i = lane & 31, g = lane >> 5;
+    const int vld = a.vld;
+    const int Kp8 = (K + 7) & ~7;
+    const int NWA = (K + IBW - 1) / IBW;               // waves that own query rows (the rest only project)
+    float* __restrict__ Ls = smem;
+    float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;     // K rows; lanes whose keys are >= K read on into Vs (never used)
+    float* __restrict__ Vs = smem + a.lr_floats;
+    const int i = lane & 31, g = lane >> 5;            // MFMA roles
+    const int lj = lane & 15, li = lane >> 4;          // pair-grid roles
 
-    // ---- stage the window's node rows (coalesced global reads), zero the padding columns.
+    const int NTn = (K + 31) >> 5;                    // node tiles
+    const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
+    const int Q = a.Q;
+    const int ptile = a.P8 >> 3, ntile = PT >> 3;
+    const int nparts = (PT >> 5) + 1;                 // the part holding column PT (c, d) is the last one with content
+
+    // The weights of this wave's first task of a part are requested one phase early -- before the barrier
+    // that ends the previous VALU phase, for part 0 before the window is staged -- so the L2 round trip is
+    // not on the critical path of the MFMA phase.  (The projection bias is row D of the packed weights,
+    // multiplied by a constant-one column of Vs: no separate bias loads.)
+    f32x4 w[QB];
+    auto prefetch = [&](int part) {
+        if (wave < ntask) {
+            const int wtile = wave >= NTn ? a.NT_L + part : part;
+            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < QB; ++u) w[u] = wp[(long)(u < Q ? u : Q - 1) * 64];
+        }
+    };
+    prefetch(0);
+
+    // ---- stage the window's node rows (coalesced global reads), zero the padding rows / columns.
     // vt == 0: node rows are source rows (temporal layer: V = xc).  vt == 1: nodes are the source's
     // columns (feature layer: V = xc^T), transposed on the way into LDS.
-    {
-        if (!a.vt) {
-            const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
-            for (int row = wave; row < K; row += NW)
-                for (int col = lane; col < vld; col += 64) Vs[row * vld + col] = col < D ? vsrc[(long)row * a.ldv + col] : 0.f;
+    if (!a.vt) {
+        const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
+        const int v4 = vld >> 2;                       // rows are 16-byte aligned in LDS and in the source
+        const bool vec = (a.ldv & 3) == 0 && 4 * v4 <= a.ldv + 3;
+        if (vec) {
+            for (int u = tid; u < Kp8 * v4; u += blockDim.x) {
+                const int row = u / v4, c4 = (u - row * v4) * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < K && c4 < D && c4 + 3 < a.ldv) {
+                    v = *reinterpret_cast<const f32x4*>(vsrc + (long)row * a.ldv + c4);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) v[s4] = c4 + s4 < D ? v[s4] : 0.f;
+                } else if (row < K && c4 < D) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) v[s4] = c4 + s4 < D ? vsrc[(long)row * a.ldv + c4 + s4] : 0.f;
+                }
+                if (row < K && D >= c4 && D < c4 + 4) v[D - c4] = 1.f;          // bias column
+                *reinterpret_cast<f32x4*>(Vs + row * vld + c4) = v;
+            }
         } else {
-            const float* __restrict__ vsrc = a.V + win * (long)D * a.ldv;      // D source rows of K columns
-            for (int srow = wave; srow < vld; srow += NW)
-                for (int node = lane; node < K; node += 64)
-                    Vs[node * vld + srow] = srow < D ? vsrc[(long)srow * a.ldv + node] : 0.f;
+            for (int row = wave; row < Kp8; row += NW)
+                for (int col = lane; col < vld; col += 64)
+                    Vs[row * vld + col] = (col < D && row < K) ? vsrc[(long)row * a.ldv + col] : ((col == D && row < K) ? 1.f : 0.f);
         }
+    } else {
+        const float* __restrict__ vsrc = a.V + win * (long)D * a.ldv;      // D source rows of K columns
+        for (int srow = wave; srow < vld; srow += NW)
+            for (int node = lane; node < Kp8; node += 64)
+                Vs[node * vld + srow] = (srow < D && node < K) ? vsrc[(long)srow * a.ldv + node] : ((srow == D && node < K) ? 1.f : 0.f);
     }
     __syncthreads();
 
-    const int i0 = wave * a.rows_per_blk;
-    int nrows = K - i0;
-    nrows = nrows < a.rows_per_blk ? nrows : a.rows_per_blk;
-    const bool active = nrows > 0;      // trailing waves of a short last block idle through the barriers
-    if (!active) nrows = 1;
-    const int row0 = active ? i0 : 0;
-
-    float acc[IB][JPL];
+    const bool rows_owner = wave < NWA;
+    const int i0 = (rows_owner ? wave : 0) * IBW;
+    lds_cptr lp[IBL];                                            // this lane's rows: i0 + li + 4 ii
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib)
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) acc[ib][jj] = 0.f;
-    int jc[JPL];
-#pragma unroll
-    for (int jj = 0; jj < JPL; ++jj) {
-        const int j = jj * 64 + lane;
-        jc[jj] = j < K ? j : K - 1;
+    for (int ii = 0; ii < IBL; ++ii) {
+        lp[ii] = (lds_cptr)(Ls + (i0 + li + 4 * ii) * GAT_LLD);
+        asm volatile("" : "+v"(lp[ii]));
     }
-    float cvec = 0.f, dj[JPL];
+    const lds_cptr rp = (lds_cptr)(Rs + lj * GAT_LLD);           // this lane's keys: lj + 16 jj
+    float acc[IBL][JPL];
 #pragma unroll
-    for (int jj = 0; jj < JPL; ++jj) dj[jj] = 0.f;
+    for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = 0.f;
 
-    const int NTn = (K + 31) >> 5;                    // node tiles
-    const int nparts = (a.NT_L + KPT - 1) / KPT;
-    const int Q = a.Q;
-    const int ptile = a.P8 >> 3, ntile = PT >> 3;
     for (int part = 0; part < nparts; ++part) {
-        // ---- MFMA phase: project this part's columns for all nodes into Ls / Rs
-        const int ntask = NTn * 2 * KPT;
+        // ---- MFMA phase: project this part's 32 + 32 columns for all nodes into Ls / Rs
         for (int task = wave; task < ntask; task += NW) {
-            const int nt = task % NTn;
-            const int ft = task / NTn;                 // 0..KPT-1 query side, KPT..2KPT-1 key side
-            const bool keyside = ft >= KPT;
-            const int lt = keyside ? ft - KPT : ft;     // local 32-column tile inside the part
-            const int gt = part * KPT + lt;             // global tile on its side
-            if (gt >= a.NT_L) continue;
-            const int wtile = keyside ? a.NT_L + gt : gt;
+            const bool keyside = task >= NTn;
+            const int nt = keyside ? task - NTn : task;
+            const int wtile = keyside ? a.NT_L + part : part;
             const int node = nt * 32 + i;
             const float* __restrict__ vrow = Vs + (node < K ? node : K - 1) * vld;
             const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+            if (task != wave) {                    // more tiles than waves: later tasks pay their own round trip
+#pragma unroll
+                for (int u = 0; u < QB; ++u) w[u] = wp[(long)(u < Q ? u : Q - 1) * 64];
+            }
             f32x16 o;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.pbias + 32 * wtile + 8 * m + 4 * g);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) o[4 * m + s4] = bv[s4];
-            }
-            // all weight chunks of the task are requested at once (one L2 latency per task, not per chunk)
-            constexpr int QB = 4;
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
             for (int qb = 0; qb < Q; qb += QB) {
-                f32x4 w[QB];
-#pragma unroll
-                for (int u = 0; u < QB; ++u) w[u] = wp[(long)(qb + u < Q ? qb + u : Q - 1) * 64];
 #pragma unroll
                 for (int u = 0; u < QB; ++u)
                     if (qb + u < Q) {
                         const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * (qb + u) + 4 * g);
                         o = mfma4(w[u], xv, o);
+                        // the chunk QB further on replaces this one as soon as it has been issued
+                        if (qb + QB + u < Q) w[u] = wp[(long)(qb + QB + u) * 64];
                     }
             }
             if (node < K) {
-                if (!keyside) {
+                float* __restrict__ dst = (keyside ? Rs : Ls) + node * GAT_LLD + 4 * g;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        f32x4 v;
-                        v[0] = o[4 * m + 0]; v[1] = o[4 * m + 1]; v[2] = o[4 * m + 2]; v[3] = o[4 * m + 3];
-                        *reinterpret_cast<f32x4*>(Ls + node * lld + 32 * lt + 8 * m + 4 * g) = v;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int f = 32 * lt + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        Rs[f * rld + node] = o[r];
-                    }
+                for (int m = 0; m < 4; ++m) {
+                    f32x2 v0, v1;
+                    v0[0] = o[4 * m + 0]; v0[1] = o[4 * m + 1]; v1[0] = o[4 * m + 2]; v1[1] = o[4 * m + 3];
+                    *reinterpret_cast<f32x2*>(dst + 8 * m) = v0;
+                    *reinterpret_cast<f32x2*>(dst + 8 * m + 2) = v1;
                 }
             }
         }
         __syncthreads();
-        // ---- VALU phase: pairwise term over this part's k tiles
-        const int t0 = part * 4 * KPT;
-        for (int kt = 0; kt < 4 * KPT; ++kt) {
-            const int gtile = t0 + kt;
-            if (gtile >= ntile) break;
-            if (gtile < ptile)
-                gat_tile<JPL, IB, false>(acc, Ls, lld, row0, nrows, Rs, rld, jc, 8 * kt);
-            else
-                gat_tile<JPL, IB, true>(acc, Ls, lld, row0, nrows, Rs, rld, jc, 8 * kt);
-        }
-        // rank-1 terms c_i (query column PT) and d_j (key row PT) live in the tile that holds column PT
-        if (PT / (32 * KPT) == part) {
-            const int col = PT - part * 32 * KPT;
-            cvec = Ls[(row0 + (lane < nrows ? lane : nrows - 1)) * lld + col];
+        // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
+        int ntl = ntile - 4 * part;
+        ntl = ntl > 4 ? 4 : ntl;
+        if (ntl > 0 && rows_owner) {
+            f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
+            lds_cptr lq[IBL];
 #pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) dj[jj] = Rs[col * rld + jc[jj]];
+            for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
+            lds_cptr rq = rp;
+            gat_load<IBL, JPL>(lA, rA, lq, rq, 0);
+            int npos = ptile - 4 * part;
+            npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
+            int kt = 0;
+            // two back-to-back loops rather than a sign branch inside one: with the diamond the compiler
+            // keeps two register copies of the accumulators (and spills)
+#pragma unroll 1
+            for (; kt < npos; ++kt) {
+                gat_tile<IBL, JPL, false>(acc, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                rq += 8;
+            }
+#pragma unroll 1
+            for (; kt < ntl; ++kt) {
+                gat_tile<IBL, JPL, true>(acc, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                rq += 8;
+            }
         }
-        __syncthreads();
+        if (part + 1 < nparts) {
+            prefetch(part + 1);
+            __syncthreads();
+        }
     }
+    // rank-1 terms c_i (query column PT) and d_j (key column PT) sit in the last part
+    float cv[IBL], dv[JPL];
+    {
+        const int col = PT & 31;
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) cv[ii] = lp[ii][col];
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * 16 * GAT_LLD + col];
+    }
+    __syncthreads();
+    if (!rows_owner) return;                           // no barrier below this point
 
-    // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); branch-free over rows
-    float bvv[IB][JPL];
+    // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); a query row lives in
+    // the 16 lanes of one DPP row (x JPL registers), so the reductions are row-local DPP butterflies
 #pragma unroll
-    for (int ib = 0; ib < IB; ++ib) {
-        const int irow = row0 + (ib < nrows ? ib : nrows - 1);
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) bvv[ib][jj] = a.bias ? a.bias[(long)irow * K + jc[jj]] : 0.f;
-    }
-#pragma unroll
-    for (int ib = 0; ib < IB; ++ib) {
-        const float ci = lane_value(cvec, ib);
+    for (int ii = 0; ii < IBL; ++ii) {
+        const int irow = i0 + li + 4 * ii;
+        const int irc = irow < K ? irow : K - 1;
         float e[JPL];
         float m = -INFINITY;
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
-            const int j = jj * 64 + lane;
-            float v = acc[ib][jj] + ci + dj[jj];
+            const int j = lj + 16 * jj;
+            const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
+            float v = acc[ii][jj] + cv[ii] + dv[jj];
             if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
-            v += bvv[ib][jj];
+            v += b;
             v = j < K ? v : -INFINITY;
             e[jj] = v;
             m = fmaxf(m, v);
         }
-        m = wave_max(m);
+        m = row_max(m);
         float sum = 0.f;
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
-            e[jj] = (jj * 64 + lane < K) ? soft_exp(e[jj] - m) : 0.f;
+            e[jj] = (lj + 16 * jj < K) ? soft_exp(e[jj] - m) : 0.f;
             sum += e[jj];
         }
-        sum = wave_sum(sum);
+        sum = row_sum(sum);
         const float inv = soft_rcp(sum);
 #pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) acc[ib][jj] = (active && ib < nrows) ? e[jj] * inv : 0.f;
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = irow < K ? e[jj] * inv : 0.f;
     }
 
-    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) on the matrix pipe; att restaged through this
-    // wave's slice of the (now free) Ls/Rs region.  Rows >= IB of the B operand read neighbouring
-    // (finite) data; they only feed output columns that are never stored.
-    float* __restrict__ att = Ls + wave * (IB * 68);
+    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) on the matrix pipe; att restaged, 64 keys at a
+    // time, through this wave's slice of the (now free) Ls/Rs region.  Rows >= 4*IBL of the B operand
+    // read a neighbouring (finite) row; they only feed output columns that are never stored.
+    float* __restrict__ att = Ls + wave * (IBW * GAT_APITCH);
     const int DT = (D + 31) >> 5;
+    const int arow = i < IBW ? i : IBW - 1;
+    constexpr int PASSES = (JPL + 3) / 4;
     for (int dt0 = 0; dt0 < DT; dt0 += 2) {
         f32x16 o[2];
 #pragma unroll
@@ -904,32 +996,44 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
             const int d = 32 * (dt0 + nb) + i;
             dcl[nb] = d < vld ? d : vld - 1;          // columns >= D of Vs are zero
         }
+        const bool two = dt0 + 1 < DT;
 #pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) {
-            if (jj * 64 < K) {
+        for (int pass = 0; pass < PASSES; ++pass) {
+            if (pass * 64 < K) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int ib = 0; ib < IB; ++ib) att[ib * 68 + lane] = acc[ib][jj];
+                for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4)
+                        if (4 * pass + j4 < JPL) att[(li + 4 * ii) * GAT_APITCH + lj + 16 * j4] = acc[ii][4 * pass + j4];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                const int jn = min(64, K - jj * 64);
-                const int nq = (jn + 7) >> 3;
-                const int arow = i < IB ? i : IB - 1;
+                const int jn = min(64, K - pass * 64);
+                const int nq = (jn + 7) >> 3;                     // rows < Kp8 of Vs: real or zero
+                const float* __restrict__ vcol0 = Vs + (pass * 64 + 4 * g) * vld + dcl[0];
+                const float* __restrict__ vcol1 = Vs + (pass * 64 + 4 * g) * vld + dcl[1];
+                const float* __restrict__ ab = att + arow * GAT_APITCH + 4 * g;
+                // operands of chunk q + 1 are read while the MFMAs of chunk q run
+                f32x4 bq = *reinterpret_cast<const f32x4*>(ab);
+                f32x4 av0, av1;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    av0[s4] = vcol0[s4 * vld];
+                    av1[s4] = vcol1[s4 * vld];
+                }
                 for (int q = 0; q < nq; ++q) {
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(att + arow * 68 + 8 * q + 4 * g);
-                    const int jb = jj * 64 + 8 * q + 4 * g;
+                    const int qn = q + 1 < nq ? q + 1 : q;
+                    const f32x4 bn = *reinterpret_cast<const f32x4*>(ab + 8 * qn);
+                    f32x4 an0, an1;
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        f32x4 av;
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            const int jr = jb + s4 < K ? jb + s4 : K - 1;
-                            const float v = Vs[jr * vld + dcl[nb]];
-                            av[s4] = jb + s4 < K ? v : 0.f;
-                        }
-                        o[nb] = mfma4(av, bq, o[nb]);
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        an0[s4] = vcol0[(8 * qn + s4) * vld];
+                        an1[s4] = vcol1[(8 * qn + s4) * vld];
                     }
+                    o[0] = mfma4(av0, bq, o[0]);
+                    if (two) o[1] = mfma4(av1, bq, o[1]);
+                    bq = bn; av0 = an0; av1 = an1;
                 }
             }
         }
@@ -938,7 +1042,7 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = 32 * (dt0 + nb) + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (active && i < nrows && d < D)
+                if (i < IBW && i0 + i < K && d < D)
                     a.out[win * a.so_w + (long)(i0 + i) * a.so_i + (long)d * a.so_d] = gate_sigmoid(o[nb][r]);
             }
         }
@@ -1287,26 +1391,24 @@ int launch_attend(const AttendArgs& a, int IB, hipStream_t s) {
     return 0;
 }
 
-#define GAT_CASE(J, I, KP)                                                                      \
-    if (jpl == J && IB == I && KPT == KP) {                                                     \
+#define GAT_CASE(I, J)                                                                          \
+    if (IBL == I && JPL == J) {                                                                 \
         if (lds_bytes > 64 * 1024) {                                                            \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat<J, I, KP>), \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat<I, J>),    \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e_ != hipSuccess) return (int)e_;                                               \
         }                                                                                       \
-        hipLaunchKernelGGL((k_gat<J, I, KP>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);      \
+        hipLaunchKernelGGL((k_gat<I, J>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);          \
         launched = true;                                                                        \
     }
 
-int launch_gat(const GatArgs& a, int IB, int KPT, int nw, size_t lds_bytes, hipStream_t s) {
+// IBL: query rows per lane (a wave owns 4*IBL rows), JPL: key nodes per lane (16*JPL >= K), nw waves
+int launch_gat(const GatArgs& a, int IBL, int JPL, int nw, size_t lds_bytes, hipStream_t s) {
     if (a.nwin <= 0) return 0;
-    const int jpl = (a.K + 63) / 64;
+    if (16 * JPL < a.K || nw * 4 * IBL < a.K || nw > 8) return -2;     // nw may exceed the row-owning waves: the rest only project
     const unsigned grid = (unsigned)a.nwin;
     bool launched = false;
-    GAT_CASE(1, 8, 1) GAT_CASE(1, 12, 1) GAT_CASE(1, 16, 1) GAT_CASE(1, 20, 1)
-    GAT_CASE(2, 8, 1) GAT_CASE(2, 12, 1) GAT_CASE(2, 16, 1) GAT_CASE(2, 20, 1)
-    GAT_CASE(1, 8, 2) GAT_CASE(1, 12, 2) GAT_CASE(1, 16, 2) GAT_CASE(1, 20, 2)
-    GAT_CASE(2, 8, 2) GAT_CASE(2, 12, 2) GAT_CASE(2, 16, 2) GAT_CASE(2, 20, 2)
+    GAT_CASE(4, 1) GAT_CASE(4, 2) GAT_CASE(4, 3) GAT_CASE(4, 4) GAT_CASE(4, 5) GAT_CASE(4, 6) GAT_CASE(4, 7) GAT_CASE(4, 8)
     if (!launched) return -2;
     LAUNCH_CHECK();
     return 0;

@@ -80,33 +80,32 @@ std::string validate_and_plan(Model& m) {
         g.Kp = round_up(K, 4);
         g.NT_L = g.ldl / 32;
         g.NT = 2 * g.NT_L;
-        g.Q = (D + 7) / 8;
         g.PT = g.P8 = 0;
+        attend_plan(K, &g.rows_per_blk, &g.nblk, &g.IB);
+        // fused plan: one workgroup (f_nw waves) per window, tiles of the layer resident in LDS.
+        // A wave owns 4*IBL query rows, a lane JPL key nodes (16*JPL >= K); see k_gat.
+        g.fused = false;
+        g.Q = (D + 7) / 8;
+        if (K <= 128) {
+            const int ibl = 4, ibw = 4 * ibl;
+            const int nwa = (K + ibw - 1) / ibw;                 // waves that own query rows
+            const int ntask = 2 * ((K + 31) / 32);               // projection tiles per part
+            int nw = nwa;
+            if (ntask > nwa) nw = std::min(8, std::max(nwa, std::min(ntask, round_up(nwa, 4))));   // extra waves only project
+            const int rows = nwa * ibw;
+            const int qf = (D + 8) / 8;                          // chunks incl. the bias row D (times the ones column of Vs)
+            const int vld = 8 * qf + 4;
+            const size_t lr = round_up((int)std::max((size_t)(rows + K) * 34, (size_t)rows * 68), 4);
+            const size_t bytes = ((size_t)round_up(K, 8) * vld + lr) * sizeof(float);
+            if (bytes <= 80 * 1024) {
+                g.fused = true; g.f_nw = nw; g.f_IBL = ibl; g.f_JPL = (K + 15) / 16; g.f_vld = vld; g.f_lr = (int)lr;
+                g.f_lds_bytes = bytes;
+                g.Q = qf;
+            }
+        }
         g.w_off = take((size_t)g.NT * g.Q * 256);
         g.b_off = take((size_t)g.NT * 32);
         g.bias_off = take((size_t)K * K);
-        attend_plan(K, &g.rows_per_blk, &g.nblk, &g.IB);
-        // fused plan: one workgroup (f_nw waves) per window, tiles of the layer resident in LDS
-        g.fused = false;
-        if (K <= 128) {
-            int nw = (K + 19) / 20;
-            nw = nw < 4 ? 4 : (nw > 8 ? 8 : nw);
-            const int rows = (K + nw - 1) / nw;
-            int ib = round_up(rows, 4);
-            if (ib < 8) ib = 8;
-            if (ib <= 20) {
-                g.f_vld = round_up(D, 8) + 4;
-                g.f_rld = round_up(K, 4);
-                for (int kpt = 2; kpt >= 1 && !g.fused; --kpt) {
-                    const size_t lr = (size_t)K * (32 * kpt + 4) + (size_t)32 * kpt * g.f_rld;
-                    const size_t att = (size_t)nw * ib * 68;
-                    const size_t bytes = ((size_t)K * g.f_vld + std::max(lr, att)) * sizeof(float);
-                    if (bytes <= 52 * 1024) {   // three workgroups per CU (160 KiB LDS)
-                        g.fused = true; g.f_nw = nw; g.f_rows = rows; g.f_IB = ib; g.f_KPT = kpt; g.f_lds_bytes = bytes;
-                    }
-                }
-            }
-        }
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
@@ -261,7 +260,9 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
         }
     }
     pack_tiles(out.data() + g.w_off, g.NT, g.Q, [&](int n, int k) -> float {
-        return (n < NC && k < D) ? (float)rows[(size_t)n * D + k] : 0.f;
+        if (n >= NC) return 0.f;
+        if (k < D) return (float)rows[(size_t)n * D + k];
+        return (g.fused && k == D) ? (float)bvec[n] : 0.f;       // fused kernel: bias = weight row D
     });
     for (int n = 0; n < NC; ++n) out[g.b_off + n] = (float)bvec[n];
     std::memcpy(out.data() + g.bias_off, bias, sizeof(float) * (size_t)g.K * g.K);
