@@ -781,7 +781,7 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     const long win = blockIdx.x;
     const int K = a.K, D = a.D, PT = a.PT;
     const int vld = a.vld;
-    const int Kp8 = (K + 7) & ~7;
+    const int Kp16 = (K + 15) & ~15;                   // rows of Vs: real nodes then zero rows
     const int NWA = (K + IBW - 1) / IBW;               // waves that own query rows (the rest only project)
     float* __restrict__ Ls = smem;
     float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;     // K rows; lanes whose keys are >= K read on into Vs (never used)
@@ -808,41 +808,70 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
             for (int u = 0; u < QB; ++u) w[u] = wp[(long)(u < Q ? u : Q - 1) * 64];
         }
     };
-    prefetch(0);
 
-    // ---- stage the window's node rows (coalesced global reads), zero the padding rows / columns.
-    // vt == 0: node rows are source rows (temporal layer: V = xc).  vt == 1: nodes are the source's
-    // columns (feature layer: V = xc^T), transposed on the way into LDS.
-    if (!a.vt) {
-        const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
-        const int v4 = vld >> 2;                       // rows are 16-byte aligned in LDS and in the source
-        const bool vec = (a.ldv & 3) == 0 && 4 * v4 <= a.ldv + 3;
-        if (vec) {
-            for (int u = tid; u < Kp8 * v4; u += blockDim.x) {
+    // ---- stage the window's node rows (coalesced global reads), zero the padding rows / columns, set
+    // the ones column D.  vt == 0: node rows are source rows (temporal layer: V = xc).  vt == 1: nodes
+    // are the source's columns (feature layer: V = xc^T), transposed on the way into LDS.  All global
+    // loads of a thread are issued before the first LDS store: one memory round trip per window, not one
+    // per loop iteration.
+    {
+        const int nthr = blockDim.x;
+        if (!a.vt && (a.ldv & 3) == 0 && ((D + 3) & ~3) <= a.ldv) {
+            // unit u = one float4 of a node row: row = u / v4 (exact through the float reciprocal: the
+            // fractional part of (u + 0.5) / v4 stays >= 0.5 / v4 away from an integer)
+            const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
+            constexpr int MAXU = 8;
+            const int v4 = vld >> 2, total = Kp16 * v4;
+            const float rinv = 1.0f / (float)v4;
+            f32x4 v[MAXU];
+            int off[MAXU];
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n) {
+                const int u = tid + n * nthr;
+                const int row = (int)(((float)u + 0.5f) * rinv), c4 = (u - row * v4) * 4;
+                off[n] = u < total ? row * vld + c4 : -1;
+                v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (u < total && row < K && c4 < D) v[n] = *reinterpret_cast<const f32x4*>(vsrc + (long)row * a.ldv + c4);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) v[n][s4] = (row < K && c4 + s4 < D) ? v[n][s4] : ((row < K && c4 + s4 == D) ? 1.f : 0.f);
+            }
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n)
+                if (off[n] >= 0) *reinterpret_cast<f32x4*>(Vs + off[n]) = v[n];
+            for (int u = tid + MAXU * nthr; u < total; u += nthr) {     // shapes beyond the register batch
                 const int row = u / v4, c4 = (u - row * v4) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (row < K && c4 < D && c4 + 3 < a.ldv) {
-                    v = *reinterpret_cast<const f32x4*>(vsrc + (long)row * a.ldv + c4);
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) v[s4] = c4 + s4 < D ? v[s4] : 0.f;
-                } else if (row < K && c4 < D) {
+                for (int s4 = 0; s4 < 4; ++s4)
+                    Vs[row * vld + c4 + s4] = (row < K && c4 + s4 < D) ? vsrc[(long)row * a.ldv + c4 + s4] : ((row < K && c4 + s4 == D) ? 1.f : 0.f);
+            }
+        } else if (a.vt) {
+            // a wave takes whole source rows (lane = node: coalesced), all its loads in flight at once
+            const float* __restrict__ vsrc = a.V + win * (long)D * a.ldv;
+            constexpr int MAXR = 36;
+            for (int nb = 0; nb < Kp16; nb += 64) {
+                const int node = nb + lane;
+                float v[MAXR];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) v[s4] = c4 + s4 < D ? vsrc[(long)row * a.ldv + c4 + s4] : 0.f;
+                for (int n = 0; n < MAXR; ++n) {
+                    const int srow = wave + n * NW;
+                    v[n] = (srow < D && node < K) ? vsrc[(long)srow * a.ldv + node] : ((srow == D && node < K) ? 1.f : 0.f);
                 }
-                if (row < K && D >= c4 && D < c4 + 4) v[D - c4] = 1.f;          // bias column
-                *reinterpret_cast<f32x4*>(Vs + row * vld + c4) = v;
+#pragma unroll
+                for (int n = 0; n < MAXR; ++n) {
+                    const int srow = wave + n * NW;
+                    if (srow < vld && node < Kp16) Vs[node * vld + srow] = v[n];
+                }
+                for (int srow = wave + MAXR * NW; srow < vld; srow += NW)
+                    if (node < Kp16) Vs[node * vld + srow] = (srow < D && node < K) ? vsrc[(long)srow * a.ldv + node] : ((srow == D && node < K) ? 1.f : 0.f);
             }
         } else {
-            for (int row = wave; row < Kp8; row += NW)
+            const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;     // unaligned caller tensor (stage entry point)
+            for (int row = wave; row < Kp16; row += NW)
                 for (int col = lane; col < vld; col += 64)
                     Vs[row * vld + col] = (col < D && row < K) ? vsrc[(long)row * a.ldv + col] : ((col == D && row < K) ? 1.f : 0.f);
         }
-    } else {
-        const float* __restrict__ vsrc = a.V + win * (long)D * a.ldv;      // D source rows of K columns
-        for (int srow = wave; srow < vld; srow += NW)
-            for (int node = lane; node < Kp8; node += 64)
-                Vs[node * vld + srow] = (srow < D && node < K) ? vsrc[(long)srow * a.ldv + node] : ((srow == D && node < K) ? 1.f : 0.f);
     }
+    prefetch(0);
     __syncthreads();
 
     const bool rows_owner = wave < NWA;
@@ -977,75 +1006,69 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
         for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = irow < K ? e[jj] * inv : 0.f;
     }
 
-    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) on the matrix pipe; att restaged, 64 keys at a
-    // time, through this wave's slice of the (now free) Ls/Rs region.  Rows >= 4*IBL of the B operand
-    // read a neighbouring (finite) row; they only feed output columns that are never stored.
+    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) on the matrix pipe, as out^T = V^T att^T with
+    // v_mfma_f32_16x16x4_f32 (M = 16 output features, N = this wave's 16 query rows, 4 keys per
+    // instruction): no padding to 32 rows, and each lane ends up with 4 consecutive features of one row.
+    // att is restaged, 64 keys at a time, through this wave's slice of the (now free) Ls/Rs region.
+    //   B operand: lane (n = lane&15, kb = lane>>4) = att[row n][key 4 kb + t]   (16-byte LDS read = 4 steps t)
+    //   A operand: lane (m = lane&15, kb)           = V[key 4 kb + t][16 dt + m]
+    //   D: register r of lane (n, mb = lane>>4)     = out[row n][16 dt + 4 mb + r]
+    static_assert(IBL == 4, "one 16-row MFMA group per wave");
+    constexpr int DTMAX = 8;                           // D <= 128 (plan)
     float* __restrict__ att = Ls + wave * (IBW * GAT_APITCH);
-    const int DT = (D + 31) >> 5;
-    const int arow = i < IBW ? i : IBW - 1;
+    const int DT = (D + 15) >> 4;
+    const int nr = lane & 15, kb = lane >> 4;
     constexpr int PASSES = (JPL + 3) / 4;
-    for (int dt0 = 0; dt0 < DT; dt0 += 2) {
-        f32x16 o[2];
+    f32x4 o[DTMAX];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int dcol[DTMAX];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[nb][r] = 0.f;
-        int dcl[2];
+    for (int dt = 0; dt < DTMAX; ++dt) {
+        const int d = 16 * dt + nr;
+        dcol[dt] = d < vld ? d : vld - 1;              // columns > D of Vs are zero
+    }
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int d = 32 * (dt0 + nb) + i;
-            dcl[nb] = d < vld ? d : vld - 1;          // columns >= D of Vs are zero
-        }
-        const bool two = dt0 + 1 < DT;
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass * 64 < K) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int pass = 0; pass < PASSES; ++pass) {
-            if (pass * 64 < K) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+            for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
-                for (int ii = 0; ii < IBL; ++ii)
+                for (int j4 = 0; j4 < 4; ++j4)
+                    if (4 * pass + j4 < JPL) att[(li + 4 * ii) * GAT_APITCH + lj + 16 * j4] = acc[ii][4 * pass + j4];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int jn = min(64, K - pass * 64);
+            const int ngrp = (jn + 15) >> 4;                   // rows < Kp16 of Vs: real or zero
+            for (int grp = 0; grp < ngrp; ++grp) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 16 * grp + 4 * kb);
+                const float* __restrict__ vk = Vs + (pass * 64 + 16 * grp + 4 * kb) * vld;
 #pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4)
-                        if (4 * pass + j4 < JPL) att[(li + 4 * ii) * GAT_APITCH + lj + 16 * j4] = acc[ii][4 * pass + j4];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const int jn = min(64, K - pass * 64);
-                const int nq = (jn + 7) >> 3;                     // rows < Kp8 of Vs: real or zero
-                const float* __restrict__ vcol0 = Vs + (pass * 64 + 4 * g) * vld + dcl[0];
-                const float* __restrict__ vcol1 = Vs + (pass * 64 + 4 * g) * vld + dcl[1];
-                const float* __restrict__ ab = att + arow * GAT_APITCH + 4 * g;
-                // operands of chunk q + 1 are read while the MFMAs of chunk q run
-                f32x4 bq = *reinterpret_cast<const f32x4*>(ab);
-                f32x4 av0, av1;
+                for (int dt = 0; dt < DTMAX; ++dt)
+                    if (dt < DT) {
+                        float av[4];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    av0[s4] = vcol0[s4 * vld];
-                    av1[s4] = vcol1[s4 * vld];
-                }
-                for (int q = 0; q < nq; ++q) {
-                    const int qn = q + 1 < nq ? q + 1 : q;
-                    const f32x4 bn = *reinterpret_cast<const f32x4*>(ab + 8 * qn);
-                    f32x4 an0, an1;
+                        for (int t = 0; t < 4; ++t) av[t] = vk[t * vld + dcol[dt]];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        an0[s4] = vcol0[(8 * qn + s4) * vld];
-                        an1[s4] = vcol1[(8 * qn + s4) * vld];
+                        for (int t = 0; t < 4; ++t) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bq[t], o[dt], 0, 0, 0);
                     }
-                    o[0] = mfma4(av0, bq, o[0]);
-                    if (two) o[1] = mfma4(av1, bq, o[1]);
-                    bq = bn; av0 = an0; av1 = an1;
+            }
+        }
+    }
+    {
+        const int row = i0 + nr;
+        float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
+#pragma unroll
+        for (int dt = 0; dt < DTMAX; ++dt)
+            if (dt < DT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = 16 * dt + 4 * kb + r;
+                    if (row < K && d < D) orow[(long)d * a.so_d] = gate_sigmoid(o[dt][r]);
                 }
             }
-        }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = 32 * (dt0 + nb) + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (i < IBW && i0 + i < K && d < D)
-                    a.out[win * a.so_w + (long)(i0 + i) * a.so_i + (long)d * a.so_d] = gate_sigmoid(o[nb][r]);
-            }
-        }
     }
 }
 

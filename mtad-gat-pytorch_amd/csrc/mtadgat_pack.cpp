@@ -86,7 +86,7 @@ std::string validate_and_plan(Model& m) {
         // A wave owns 4*IBL query rows, a lane JPL key nodes (16*JPL >= K); see k_gat.
         g.fused = false;
         g.Q = (D + 7) / 8;
-        if (K <= 128) {
+        if (K <= 128 && D <= 128) {
             const int ibl = 4, ibw = 4 * ibl;
             const int nwa = (K + ibw - 1) / ibw;                 // waves that own query rows
             const int ntask = 2 * ((K + 31) / 32);               // projection tiles per part
@@ -96,7 +96,7 @@ std::string validate_and_plan(Model& m) {
             const int qf = (D + 8) / 8;                          // chunks incl. the bias row D (times the ones column of Vs)
             const int vld = 8 * qf + 4;
             const size_t lr = round_up((int)std::max((size_t)(rows + K) * 34, (size_t)rows * 68), 4);
-            const size_t bytes = ((size_t)round_up(K, 8) * vld + lr) * sizeof(float);
+            const size_t bytes = ((size_t)round_up(K, 16) * vld + lr) * sizeof(float);
             if (bytes <= 80 * 1024) {
                 g.fused = true; g.f_nw = nw; g.f_IBL = ibl; g.f_JPL = (K + 15) / 16; g.f_vld = vld; g.f_lr = (int)lr;
                 g.f_lds_bytes = bytes;
