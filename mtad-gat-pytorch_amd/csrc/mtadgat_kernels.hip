@@ -816,59 +816,66 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     // per loop iteration.
     {
         const int nthr = blockDim.x;
-        if (!a.vt && (a.ldv & 3) == 0 && ((D + 3) & ~3) <= a.ldv) {
-            // unit u = one float4 of a node row: row = u / v4 (exact through the float reciprocal: the
-            // fractional part of (u + 0.5) / v4 stays >= 0.5 / v4 away from an integer)
-            const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;
+        const int srows = a.vt ? D : K, scols = a.vt ? K : D;          // valid extent of the source block
+        const int prow = a.vt ? vld : Kp16, pcol = a.vt ? Kp16 : vld;   // extent incl. the padding that must be written
+        if ((a.ldv & 3) == 0 && ((scols + 3) & ~3) <= a.ldv) {
+            // unit u = one float4 of a source row: row = u / p4 (exact through the float reciprocal: the
+            // fractional part of (u + 0.5) / p4 stays >= 0.5 / p4 away from an integer).  Few, wide load
+            // instructions: the cost of this phase is per load instruction, not per byte.
+            const float* __restrict__ vsrc = a.V + win * (long)srows * a.ldv;
             constexpr int MAXU = 8;
-            const int v4 = vld >> 2, total = Kp16 * v4;
-            const float rinv = 1.0f / (float)v4;
+            const int p4 = pcol >> 2, total = prow * p4;
+            const float rinv = 1.0f / (float)p4;
+            const int c4last = ((scols - 1) >> 2) << 2;
             f32x4 v[MAXU];
-            int off[MAXU];
+            int rr[MAXU], cc[MAXU];
 #pragma unroll
             for (int n = 0; n < MAXU; ++n) {
                 const int u = tid + n * nthr;
-                const int row = (int)(((float)u + 0.5f) * rinv), c4 = (u - row * v4) * 4;
-                off[n] = u < total ? row * vld + c4 : -1;
-                v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (u < total && row < K && c4 < D) v[n] = *reinterpret_cast<const f32x4*>(vsrc + (long)row * a.ldv + c4);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) v[n][s4] = (row < K && c4 + s4 < D) ? v[n][s4] : ((row < K && c4 + s4 == D) ? 1.f : 0.f);
+                const int row = (int)(((float)u + 0.5f) * rinv), c4 = (u - row * p4) * 4;
+                rr[n] = u < total ? row : -1;
+                cc[n] = c4;
+                // unconditional load from a clamped (always valid) address, masked below: a guarded load
+                // becomes a branch with s_waitcnt vmcnt(0) at the join, i.e. one round trip per unit
+                const int rc = row < srows ? row : srows - 1, cl = c4 < scols ? c4 : c4last;
+                v[n] = *reinterpret_cast<const f32x4*>(vsrc + (long)rc * a.ldv + cl);
             }
 #pragma unroll
-            for (int n = 0; n < MAXU; ++n)
-                if (off[n] >= 0) *reinterpret_cast<f32x4*>(Vs + off[n]) = v[n];
+            for (int n = 0; n < MAXU; ++n) {
+                const int row = rr[n], c4 = cc[n];
+                if (row >= 0) {
+                    f32x4 t = v[n];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int node = a.vt ? c4 + s4 : row, col = a.vt ? row : c4 + s4;
+                        t[s4] = (node < K && col < D) ? t[s4] : ((node < K && col == D) ? 1.f : 0.f);
+                    }
+                    if (!a.vt) {
+                        *reinterpret_cast<f32x4*>(Vs + row * vld + c4) = t;
+                    } else {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) Vs[(c4 + s4) * vld + row] = t[s4];
+                    }
+                }
+            }
             for (int u = tid + MAXU * nthr; u < total; u += nthr) {     // shapes beyond the register batch
-                const int row = u / v4, c4 = (u - row * v4) * 4;
+                const int row = u / p4, c4 = (u - row * p4) * 4;
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    Vs[row * vld + c4 + s4] = (row < K && c4 + s4 < D) ? vsrc[(long)row * a.ldv + c4 + s4] : ((row < K && c4 + s4 == D) ? 1.f : 0.f);
-            }
-        } else if (a.vt) {
-            // a wave takes whole source rows (lane = node: coalesced), all its loads in flight at once
-            const float* __restrict__ vsrc = a.V + win * (long)D * a.ldv;
-            constexpr int MAXR = 36;
-            for (int nb = 0; nb < Kp16; nb += 64) {
-                const int node = nb + lane;
-                float v[MAXR];
-#pragma unroll
-                for (int n = 0; n < MAXR; ++n) {
-                    const int srow = wave + n * NW;
-                    v[n] = (srow < D && node < K) ? vsrc[(long)srow * a.ldv + node] : ((srow == D && node < K) ? 1.f : 0.f);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int node = a.vt ? c4 + s4 : row, col = a.vt ? row : c4 + s4;
+                    const float t = (node < K && col < D) ? vsrc[(long)row * a.ldv + c4 + s4] : ((node < K && col == D) ? 1.f : 0.f);
+                    Vs[node * vld + col] = t;
                 }
-#pragma unroll
-                for (int n = 0; n < MAXR; ++n) {
-                    const int srow = wave + n * NW;
-                    if (srow < vld && node < Kp16) Vs[node * vld + srow] = v[n];
-                }
-                for (int srow = wave + MAXR * NW; srow < vld; srow += NW)
-                    if (node < Kp16) Vs[node * vld + srow] = (srow < D && node < K) ? vsrc[(long)srow * a.ldv + node] : ((srow == D && node < K) ? 1.f : 0.f);
             }
         } else {
-            const float* __restrict__ vsrc = a.V + win * (long)K * a.ldv;     // unaligned caller tensor (stage entry point)
-            for (int row = wave; row < Kp16; row += NW)
-                for (int col = lane; col < vld; col += 64)
-                    Vs[row * vld + col] = (col < D && row < K) ? vsrc[(long)row * a.ldv + col] : ((col == D && row < K) ? 1.f : 0.f);
+            // unaligned caller tensor (stage entry point mtadgat_gat)
+            const float* __restrict__ vsrc = a.V + win * (long)srows * a.ldv;
+            for (int u = tid; u < Kp16 * vld; u += nthr) {
+                const int node = u / vld, col = u - node * vld;
+                float t = 0.f;
+                if (node < K && col < D) t = a.vt ? vsrc[(long)col * a.ldv + node] : vsrc[(long)node * a.ldv + col];
+                Vs[u] = (node < K && col == D) ? 1.f : t;
+            }
         }
     }
     prefetch(0);
