@@ -276,29 +276,73 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
 // takes every MFMA B operand from there -- the straight-from-global version above re-reads each
 // input row `taps` times with 4-byte gathers (PMC: 5-9x FETCH amplification, TA-bound).
 template <int NTB>
-__global__ __launch_bounds__(64) void k_conv_lds(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
+    // blockDim.x / 64 independent waves per workgroup, each with its own 32 output rows and LDS slice:
+    // one-wave workgroups are launched too slowly to keep the matrix pipes fed at ~50 us per wave
+    extern __shared__ __attribute__((aligned(16))) float xs_all[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
+    float* __restrict__ xs = xs_all + wv * ((32 + a.taps - 1) * (a.Fp + 4));
     const int i = lane & 31, g = lane >> 5;
     const long R = a.B * a.W;
-    const long r0 = (long)blockIdx.x * 32;
+    const long r0 = ((long)blockIdx.x * nwv + wv) * 32;
     const long row = r0 + i;
     const long rowc = row < R ? row : R - 1;
     const long win = rowc / a.W;
     const int t = (int)(rowc - win * a.W);
     const int Fld = a.Fp + 4;
     const int nrow = 32 + a.taps - 1;
-    for (int rr = 0; rr < nrow; ++rr) {
+    // source row of LDS row rr: flat row r0 - pad + rr of the (B*W, F) batch; in gather mode the windows
+    // are views of the device-resident series (no (b, W, F) copy exists) and (window, t) advance together
+    long gw = 0; int gt = 0;                          // window / position of the current flat row (gather mode)
+    if (a.gather) {
+        const long f0 = r0 - a.pad < 0 ? 0 : r0 - a.pad;
+        gw = f0 / a.W;
+        gt = (int)(f0 - gw * a.W);
+    }
+    auto src_row = [&](int rr, bool& ok) -> const float* {
         const long flat = r0 - a.pad + rr;
-        const bool ok = flat >= 0 && flat < R;
+        ok = flat >= 0 && flat < R;
         long srow = ok ? flat : 0;
-        if (a.gather) {          // windows are views of the device-resident series: no (b, W, F) copy exists
-            const long w = srow / a.W;
-            const long s0 = a.starts ? a.starts[w] : a.start0 + w * a.stride;
-            srow = s0 + (srow - w * a.W);
+        if (a.gather) {
+            const long wc = gw < a.B ? gw : a.B - 1;
+            const long s0 = a.starts ? a.starts[wc] : a.start0 + wc * a.stride;
+            srow = s0 + gt;
+            if (flat >= 0 && ++gt == a.W) { gt = 0; ++gw; }      // rows are visited in increasing order, once each
         }
-        const float* __restrict__ src = a.X + srow * a.F;
-        for (int col = lane; col < Fld; col += 64) xs[rr * Fld + col] = (ok && col < a.F) ? src[col] : 0.f;
+        return a.X + srow * a.F;
+    };
+    if (Fld <= 64) {
+        // one element per lane and row; every load is unconditional (clamped column, a valid row for rows
+        // outside the batch) and all of them are issued before the first LDS store: one memory round trip
+        // per wave instead of one per row (a guarded load compiles to a branch + s_waitcnt vmcnt(0))
+        constexpr int MAXR = 40;
+        float v[MAXR];
+        const int colc = lane < a.F ? lane : a.F - 1;
+#pragma unroll
+        for (int rr = 0; rr < MAXR; ++rr) {
+            v[rr] = 0.f;
+            if (rr < nrow) {                              // wave-uniform
+                bool ok;
+                const float* __restrict__ src = src_row(rr, ok);
+                const float t = src[colc];
+                v[rr] = (ok && lane < a.F) ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < MAXR; ++rr)
+            if (rr < nrow && lane < Fld) xs[rr * Fld + lane] = v[rr];
+        for (int rr = MAXR; rr < nrow; ++rr) {
+            bool ok;
+            const float* __restrict__ src = src_row(rr, ok);
+            if (lane < Fld) xs[rr * Fld + lane] = (ok && lane < a.F) ? src[lane] : 0.f;
+        }
+    } else {
+        for (int rr = 0; rr < nrow; ++rr) {
+            bool ok;
+            const float* __restrict__ src = src_row(rr, ok);
+            for (int col = lane; col < Fld; col += 64) xs[rr * Fld + col] = (ok && col < a.F) ? src[col] : 0.f;
+        }
     }
     __syncthreads();
     const int QF = a.Fp >> 3;
@@ -306,11 +350,12 @@ __global__ __launch_bounds__(64) void k_conv_lds(const ConvArgs a) {
     const f32x4* __restrict__ Wp = a.Wp;
     if (a.HCAT && row < R && g == 0)      // zero the alignment padding of the h_cat row (the GRU reads it unguarded)
         for (int c = 3 * a.F; c < a.Dp; ++c) a.HCAT[row * a.Dp + c] = 0.f;
-    auto loadx = [&](int q) -> f32x4 {
-        const int tap = q / QF;
-        const int cb = q - tap * QF;
-        const int tt = t + tap - a.pad;                     // zero padding is per window (modules.py:14,20)
-        f32x4 v = *reinterpret_cast<const f32x4*>(xs + (i + tap) * Fld + 8 * cb + 4 * g);
+    // B operand of chunk (tap, cb): input row i + tap of the staged block, columns 8 cb + 4 g .. +3; rows
+    // of the neighbouring window count as zero padding (per window, modules.py:14,20)
+    const float* __restrict__ xrow = static_cast<const float*>(__builtin_assume_aligned(xs, 16)) + i * Fld + 4 * g;
+    auto loadx = [&](int tap, int cb) -> f32x4 {
+        const int tt = t + tap - a.pad;
+        f32x4 v = *reinterpret_cast<const f32x4*>(xrow + tap * Fld + 8 * cb);
         const bool ok = tt >= 0 && tt < a.W;
         v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f;
         return v;
@@ -321,26 +366,39 @@ __global__ __launch_bounds__(64) void k_conv_lds(const ConvArgs a) {
         for (int nb = 0; nb < NTB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        f32x4 w[NTB];
+        const f32x4* wq[NTB];
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
             const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
-            w[nb] = Wp[((long)n * Q) * 64 + lane];
+            wq[nb] = Wp + ((long)n * Q) * 64 + lane;
         }
-        for (int q = 0; q < Q; ++q) {
-            const int qn = (q + 1 < Q) ? q + 1 : q;
-            f32x4 wn[NTB];
+        // two register sets in turn (no copies): the weights of chunk q + 1 are in flight during the MFMAs
+        // of chunk q
+        f32x4 w0[NTB], w1[NTB];
 #pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) {
-                const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
-                wn[nb] = Wp[((long)n * Q + qn) * 64 + lane];
-            }
-            const f32x4 xv = loadx(q);
+        for (int nb = 0; nb < NTB; ++nb) w0[nb] = wq[nb][0];
+        int tap = 0, cb = 0;
+        for (int q = 0; q < Q; q += 2) {
+            const int q1 = q + 1 < Q ? q + 1 : q;
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) w1[nb] = wq[nb][(long)q1 * 64];
+            const f32x4 xv0 = loadx(tap, cb);
+            if (++cb == QF) { cb = 0; ++tap; }
             __builtin_amdgcn_sched_barrier(0);      // keep the next chunk's weight loads ahead of these MFMAs
 #pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w[nb], xv, acc[nb]);
+            for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w0[nb], xv0, acc[nb]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int q2 = q + 2 < Q ? q + 2 : Q - 1;
 #pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) w[nb] = wn[nb];
+            for (int nb = 0; nb < NTB; ++nb) w0[nb] = wq[nb][(long)q2 * 64];
+            if (q + 1 < Q) {
+                const f32x4 xv1 = loadx(tap, cb);
+                if (++cb == QF) { cb = 0; ++tap; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w1[nb], xv1, acc[nb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
@@ -1363,10 +1421,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)((R + 31) / 32);
     const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fp + 4) * sizeof(float);
     if (lds <= 20 * 1024) {       // >= 8 waves per CU keep their tile in LDS
+        const unsigned wpb = (grid >= 4096 && 4 * lds <= 64 * 1024) ? 4 : 1;     // waves per workgroup
+        const unsigned g4 = (grid + wpb - 1) / wpb;
         if (a.NT >= 2)
-            hipLaunchKernelGGL(k_conv_lds<2>, dim3(grid), dim3(64), lds, s, a);
+            hipLaunchKernelGGL(k_conv_lds<2>, dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
         else
-            hipLaunchKernelGGL(k_conv_lds<1>, dim3(grid), dim3(64), lds, s, a);
+            hipLaunchKernelGGL(k_conv_lds<1>, dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
     } else if (a.NT >= 2)
         hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(64), 0, s, a);
     else
