@@ -189,13 +189,26 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     const size_t N = (size_t)n;
     // un-fused path intermediates (also used by the stage entry point mtadgat_gat, which copies its input
     // into xc / xcT): the projected L'/R'^T only exist when a layer's tiles do not fit in LDS
-    ws.xc = take(N * m.W * m.Fp);
-    ws.xct = take(N * m.F * m.Wp);
+    const bool both_fused = m.temp.fused && m.feat.fused;
+    const size_t xc_n = N * m.W * m.Fp, xct_n = N * m.F * m.Wp;
+    if (!both_fused) {
+        ws.xc = take(xc_n);
+        ws.xct = take(xct_n);
+    }
     ws.lct = take(m.temp.fused ? 0 : N * m.W * m.temp.ldl);
     ws.rtt = take(m.temp.fused ? 0 : N * m.temp.rt_rows * m.temp.Kp);
     ws.lcf = take(m.feat.fused ? 0 : N * m.F * m.feat.ldl);
     ws.rtf = take(m.feat.fused ? 0 : N * m.feat.rt_rows * m.feat.Kp);
-    ws.hcat = take(N * m.W * m.Dp);
+    if (both_fused) {
+        // forward() never materialises xc / xc^T then; the stage entry point mtadgat_gat stages its input
+        // there, and does not use h_cat: the two share the space
+        const size_t hc = N * m.W * m.Dp;
+        ws.hcat = take(std::max(hc, align64(xc_n) + xct_n));
+        ws.xc = ws.hcat;
+        ws.xct = ws.hcat + align64(xc_n);
+    } else {
+        ws.hcat = take(N * m.W * m.Dp);
+    }
     ws.hend = take(N * m.gru.back().Hp);
     const bool gseq = m.gru.size() > 1;
     ws.seq0 = take(gseq ? N * m.W * m.gru[0].Hp : 0);
