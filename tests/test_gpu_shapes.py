@@ -18,6 +18,10 @@ SHAPES = [
          gru_hid_dim=97, recon_hid_dim=129, recon_n_layers=3, gru_n_layers=3),
     dict(n_features=20, window_size=128, out_dim=20, kernel_size=7, gru_hid_dim=256, recon_hid_dim=200, alpha=0.7),
     dict(n_features=129, window_size=40, out_dim=3, kernel_size=3, gru_hid_dim=40, recon_hid_dim=40),   # un-fused path (K > 128)
+    # temporal layer fused with 6 keys per lane and a staging batch beyond the register budget, feature layer un-fused
+    dict(n_features=128, window_size=96, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24),
+    dict(n_features=10, window_size=100, out_dim=1, kernel_size=7, use_gatv2=False, gru_hid_dim=30, recon_hid_dim=30),
+    dict(n_features=90, window_size=17, out_dim=4, kernel_size=5, gru_hid_dim=20, recon_hid_dim=20, feat_gat_embed_dim=7),
 ]
 
 
