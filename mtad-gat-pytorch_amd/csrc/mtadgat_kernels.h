@@ -95,6 +95,7 @@ struct GruArgs {
     const f32x4* Wx;     // [c][Qxp][3][64]  (decoder input: [t][c][Qxp][3][64])
     const f32x4* Wh;     // [c][4*NCG][3][64]
     const float* bias;   // [4][Hp]: b_ir+b_hr | b_iz+b_hz | b_in | b_hn
+    const f32x4* Wzero;  // one all-zero weight chunk [3][64] (k_gru_split: pads the chunk count per step to even)
     int Hp, H, T;
     long B;
     float* Hend;         // (B, ldhe) or null

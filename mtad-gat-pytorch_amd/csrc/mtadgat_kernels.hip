@@ -1369,6 +1369,191 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// GRU, hidden-tile split: a workgroup owns 32 windows, wave c the 32 hidden units of tile c (all three
+// gates).  Same packed weights, gate algebra and outputs as k_gru; what changes is where h lives: each
+// wave keeps only its own tile in registers and publishes it in LDS once per step (F-layout, so a chunk of
+// h_{t-1} is one 16-byte LDS read per lane), which frees ~80 VGPRs -> 3 waves per SIMD instead of 2, and
+// lets a small batch spread over NCG times as many SIMDs (a 256-window batch occupies 8 waves in k_gru).
+//   per step:  [MFMA: x chunks, then h chunks read from hs]  barrier B
+//              [gates; own tile -> hs; per-step Linear partial -> ps]  barrier A
+//              [wave t % NCG: reduce the Linear partials, store y_t]
+// Two barriers per step keep hs / ps single-buffered: nobody overwrites h_{t-1} before all waves have
+// consumed it (B), nobody reads h_t / the partials before they are complete (A).
+// Weights and B operands of chunk s + 2 are requested right after the MFMAs of chunk s have been issued
+// (two register sets, even / odd chunks); a zero-weight dummy chunk makes the chunk count per step even.
+// ---------------------------------------------------------------------------
+template <int XMODE, bool FC>
+__global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int lane = threadIdx.x & 63;
+    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NCG = blockDim.x >> 6;
+    const int i = lane & 31, g = lane >> 5;
+    const long win = (long)blockIdx.x * 32 + i;
+    const long winc = win < a.B ? win : a.B - 1;
+    const int T = a.T, Qx = a.Qx;
+    const int Qxp = (XMODE == 1) ? 1 : a.Qxp;
+    const int Qh = 4 * NCG;                        // recurrent chunks as packed
+    const int Qhe = (a.H + 7) >> 3;                // ... and as used
+    const int S = Qxp + Qhe;
+    const int Se = S + (S & 1);                    // incl. the zero-weight dummy chunk
+    f32x4* __restrict__ hs = reinterpret_cast<f32x4*>(gsm);                // [NCG][4][64] float4: h_{t-1}, F-layout
+    float* __restrict__ ps = gsm + NCG * 1024;                              // [NCG][out_dim][32] Linear partials
+
+    const f32x4* __restrict__ whc = a.Wh + (long)c * Qh * 192 + lane;      // this tile's recurrent stream
+    const float* __restrict__ xbase = (XMODE == 0) ? a.X + winc * T * a.ldx + 4 * g : a.X + winc * a.ldx;
+    auto loadx_t = [&](int t, int q) -> f32x4 {
+        const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
+        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase + (long)t * a.ldx + 8 * qq);
+        const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
+        f32x4 v;
+        v[0] = xbase[min(k0, kmax)]; v[1] = xbase[min(k0 + 1, kmax)];
+        v[2] = xbase[min(k0 + 2, kmax)]; v[3] = xbase[min(k0 + 3, kmax)];
+        return v;
+    };
+    // weights of chunk s of step t (input part: per step for the decoder, shared by all steps otherwise)
+    auto fetch_w = [&](int t, int s, f32x4 (&w)[3]) {
+        const f32x4* __restrict__ p;
+        if (s < Qxp)
+            p = a.Wx + ((long)((XMODE == 0 ? 0 : t) * NCG + c) * Qxp + s) * 192 + lane;
+        else if (s < S)
+            p = whc + (long)(s - Qxp) * 192;
+        else
+            p = a.Wzero + lane;
+        w[0] = p[0]; w[1] = p[64]; w[2] = p[128];
+    };
+    // B operand of chunk s: x_t chunk, or chunk (s - Qxp) of h_{t-1} from LDS (valid after barrier A of step t-1)
+    auto fetch_b = [&](int t, int s) -> f32x4 {
+        if (s < Qxp) return loadx_t(t, s);
+        const int q = s < S ? s - Qxp : Qhe - 1;
+        return hs[q * 64 + lane];
+    };
+
+    f32x16 hown;                                   // this wave's tile of h
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hown[r] = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 wA[3], wB[3], bA, bB;
+    fetch_w(0, 0, wA);
+    fetch_w(0, 1, wB);
+    __syncthreads();
+    bA = fetch_b(0, 0);
+    bB = fetch_b(0, 1);
+
+    for (int t = 0; t < T; ++t) {
+        f32x16 ar, az, anx, anh;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int col = 32 * c + 8 * m + 4 * g;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + a.Hp + col);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias + 2 * a.Hp + col);
+            const f32x4 b3 = *reinterpret_cast<const f32x4*>(a.bias + 3 * a.Hp + col);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                ar[4 * m + s4] = b0[s4];
+                az[4 * m + s4] = b1[s4];
+                anx[4 * m + s4] = b2[s4];
+                anh[4 * m + s4] = b3[s4];
+            }
+        }
+        const int tn = t + 1 < T ? t + 1 : t;
+        for (int s = 0; s < Se; s += 2) {
+            // even chunk (set A), then its refill with chunk s + 2 (of the next step past the end: weights
+            // always, the B operand only if it is an x chunk -- h_t does not exist yet)
+            if (s < Qxp) mfma4x3(wA, bA, ar, az, anx); else mfma4x3(wA, bA, ar, az, anh);
+            {
+                const bool wrap = s + 2 >= Se;
+                const int s2 = wrap ? s + 2 - Se : s + 2, t2 = wrap ? tn : t;
+                fetch_w(t2, s2, wA);
+                if (!wrap || s2 < Qxp) bA = fetch_b(t2, s2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < Qxp) mfma4x3(wB, bB, ar, az, anx); else mfma4x3(wB, bB, ar, az, anh);
+            {
+                const bool wrap = s + 3 >= Se;
+                const int s3 = wrap ? s + 3 - Se : s + 3, t3 = wrap ? tn : t;
+                fetch_w(t3, s3, wB);
+                if (!wrap || s3 < Qxp) bB = fetch_b(t3, s3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- gates (reference GRULayer / RNNDecoder: torch.nn.GRU equations, r|z|n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float rg = gate_sigmoid(ar[r]);
+            const float zg = gate_sigmoid(az[r]);
+            const float ng = gate_tanh(anx[r] + rg * anh[r]);
+            hown[r] = (1.0f - zg) * ng + zg * hown[r];
+        }
+        f32x4 hv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            hv[m][0] = hown[4 * m + 0]; hv[m][1] = hown[4 * m + 1]; hv[m][2] = hown[4 * m + 2]; hv[m][3] = hown[4 * m + 3];
+        }
+        __syncthreads();                           // B: every wave is done reading h_{t-1}
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = hv[m];
+        if (a.Seq && win < a.B) {
+            float* sp = a.Seq + (win * T + t) * a.ldseq + 32 * c + 4 * g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(sp + 8 * m) = hv[m];
+        }
+        const bool fc_now = FC && (a.Yfc != nullptr || t == T - 1);
+        if (fc_now) {
+            // this tile's share of y_t = W_fc h_t (+ b): the 4 chunks of h_t held in registers
+            for (int n = 0; n < a.NTfc; ++n) {
+                f32x16 y;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[r] = 0.f;
+                const f32x4* __restrict__ wp = a.Wfc + ((long)n * Qh + 4 * c) * 64 + lane;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) y = mfma4(wp[m * 64], hv[m], y);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * g;
+                    if (o < a.out_dim) ps[(c * a.out_dim + o) * 32 + i] = y[r];
+                }
+            }
+        }
+        __syncthreads();                           // A: h_t and the partials are complete
+        // B operands of the first two chunks of step t + 1 if they are h chunks (not prefetchable before A)
+        if (t + 1 < T) {
+            if (0 >= Qxp) bA = fetch_b(t + 1, 0);
+            if (1 >= Qxp) bB = fetch_b(t + 1, 1);
+        }
+        if (fc_now && c == t % NCG && win < a.B) {
+            float* yp = a.Yfc ? a.Yfc + (win * T + t) * (long)a.out_dim : nullptr;
+            float* yl = (a.Ylast && t == T - 1) ? a.Ylast + win * (long)a.out_dim : nullptr;
+            for (int o = g; o < a.out_dim; o += 2) {
+                float y = a.bfc[o];
+                for (int cc = 0; cc < NCG; ++cc) y += ps[(cc * a.out_dim + o) * 32 + i];
+                if (yp) yp[o] = y;
+                if (yl) yl[o] = y;
+            }
+        }
+    }
+    if (a.Hend && win < a.B) {
+        float* hp = a.Hend + win * a.ldhe;
+        if (a.ldhe >= a.Hp) {        // internal buffer: all Hp columns (the padding lanes of h are exact zeros)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 v;
+                v[0] = hown[4 * m + 0]; v[1] = hown[4 * m + 1]; v[2] = hown[4 * m + 2]; v[3] = hown[4 * m + 3];
+                *reinterpret_cast<f32x4*>(hp + 32 * c + 8 * m + 4 * g) = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (j < a.H) hp[j] = hown[r];
+            }
+        }
+    }
+}
+
 // small helper: copy a (R, ncols) row-major matrix into a padded (R, ld) one, or back.
 __global__ void k_copy2d(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long R, int ncols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1528,10 +1713,36 @@ static int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, hipStream_t s) {
     return launch_gru_mode<NCG, 2>(a, fc, drop, s);
 }
 
+static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.B + 31) / 32);
+    const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
+    if (lds > 64 * 1024) return -2;
+    const int xm = xmode == 0 ? 0 : (a.Qxp == 1 ? 1 : 2);
+#define SPLIT_CASE(XM, F) if (xm == XM && fc == F) hipLaunchKernelGGL((k_gru_split<XM, F>), dim3(grid), dim3(64 * ncg), lds, s, a);
+    SPLIT_CASE(0, false) SPLIT_CASE(0, true) SPLIT_CASE(1, false) SPLIT_CASE(1, true) SPLIT_CASE(2, false) SPLIT_CASE(2, true)
+#undef SPLIT_CASE
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     if (a.B <= 0) return 0;
     if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
     if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
+    // Small batches: spread the 32-window groups over ncg waves each (k_gru_split) -- k_gru needs ~2 groups
+    // per SIMD to fill the machine and leaves it mostly idle below that.  Measured crossover on MI355X
+    // (W=100, F=55, H=150): equal at 32 k windows, split 2x faster at <= 16 k.
+    {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+        }
+        const long groups = (a.B + 31) / 32;
+        const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
+        if (ncg >= 2 && groups <= 2L * n_cu && lds <= 64 * 1024) return launch_gru_split(a, ncg, xmode, fc, s);
+    }
     switch (ncg) {
         case 1: return launch_gru_ncg<1>(a, xmode, fc, s);
         case 2: return launch_gru_ncg<2>(a, xmode, fc, s);

@@ -71,6 +71,7 @@ std::string validate_and_plan(Model& m) {
         m.conv_w_off = take((size_t)m.convNT * Q * 256);
         m.conv_b_off = take((size_t)m.convNT * 32);
     }
+    m.zero_off = take(3 * 256);      // stays zero (pack_weights clears the buffer)
     // GAT layers
     auto plan_gat = [&](GatPlan& g, int K, int D, int E) {
         g.K = K; g.D = D; g.E = E;

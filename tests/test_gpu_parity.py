@@ -84,6 +84,28 @@ def test_ragged_batches_and_chunking(name, gpu_device):
     assert model(x[:0])[0].shape == (0, case.kwargs["out_dim"])
 
 
+@pytest.mark.parametrize("name", ["msl", "syn_v2_embed"])
+def test_large_batch_kernels_match_small_batch_kernels(name, gpu_device):
+    """Batches above 16 k windows run the register-resident GRU (k_gru), smaller ones the hidden-tile-split
+    one (k_gru_split); the fixture windows embedded in a 20 000-window batch must still match the reference,
+    and the large batch must agree with the same windows run as a small batch."""
+    case = Case(name)
+    model = case.build_model().to(gpu_device)
+    g = torch.Generator().manual_seed(11)
+    W, F = case.kwargs["window_size"], case.kwargs["n_features"]
+    x = torch.rand(20000, W, F, generator=g)
+    x[:case.x.shape[0]] = case.x
+    x = x.to(gpu_device)
+    with torch.no_grad():
+        p_big, r_big = model(x)
+        p_small, r_small = model(x[19000:19300].contiguous())
+    n = case.x.shape[0]
+    gate(p_big[:n], case.preds, case.preds64, what="preds in a 20000-window batch")
+    gate(r_big[:n], case.recons, case.recons64, what="recons in a 20000-window batch")
+    assert (p_big[19000:19300] - p_small).abs().max().item() <= 2e-6
+    assert (r_big[19000:19300] - r_small).abs().max().item() <= 2e-6
+
+
 def test_weight_update_is_seen(gpu_device):
     """Parameters changed in place (optimizer.step, load_state_dict) must reach the kernels."""
     a = Case("smap")
