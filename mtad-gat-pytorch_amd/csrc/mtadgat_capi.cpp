@@ -162,7 +162,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx_off);
     a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
     a.bias = m.packed_dev + g.b_off;
-    a.Wzero = reinterpret_cast<const f32x4*>(m.packed_dev + m.zero_off);
+    a.whs = 4 * g.NCG + 2;
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
     a.Hend = hend; a.ldhe = ldhe;
     a.Seq = seq; a.ldseq = g.Hp;

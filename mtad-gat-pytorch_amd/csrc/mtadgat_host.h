@@ -49,7 +49,6 @@ struct Model {
     // conv
     int convNT = 0;
     size_t conv_w_off = 0, conv_b_off = 0;
-    size_t zero_off = 0;               // one all-zero GRU weight chunk (3 x 64 float4)
     GatPlan feat, temp;
     std::vector<GruPlan> gru, rec;
     std::vector<LinPlan> fc;

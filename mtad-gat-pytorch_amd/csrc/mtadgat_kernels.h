@@ -93,9 +93,9 @@ struct GruArgs {
     int Qxp;             // packed input chunks per step (1, or Qx rounded up to a multiple of 3 with zero chunks)
     const int* m0;       // XMODE 1: first hin index used at step t
     const f32x4* Wx;     // [c][Qxp][3][64]  (decoder input: [t][c][Qxp][3][64])
-    const f32x4* Wh;     // [c][4*NCG][3][64]
+    const f32x4* Wh;     // [c][whs][3][64]
     const float* bias;   // [4][Hp]: b_ir+b_hr | b_iz+b_hz | b_in | b_hn
-    const f32x4* Wzero;  // one all-zero weight chunk [3][64] (k_gru_split: pads the chunk count per step to even)
+    int whs;             // chunks per tile in Wh: 4*NCG + 2 (the last two all zero: ring padding of k_gru_split)
     int Hp, H, T;
     long B;
     float* Hend;         // (B, ldhe) or null

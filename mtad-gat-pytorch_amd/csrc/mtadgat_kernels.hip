@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
         pwh += isx ? 0 : 192;
         const bool ws = (ps + 1 == S);             // end of this tile's chunk sequence
         ps = ws ? 0 : ps + 1;
-        pwh += ws ? (Qh - Qhe) * 192 : 0;          // skip the dropped all-padding chunks of the tile
+        pwh += ws ? (a.whs - Qhe) * 192 : 0;       // skip the unused all-padding chunks of the tile
         const bool wc = ws && (pc + 1 == NCG);     // end of the step
         pc = ws ? (wc ? 0 : pc + 1) : pc;
         pt = wc ? pt + 1 : pt;
@@ -1373,15 +1373,16 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
 // GRU, hidden-tile split: a workgroup owns 32 windows, wave c the 32 hidden units of tile c (all three
 // gates).  Same packed weights, gate algebra and outputs as k_gru; what changes is where h lives: each
 // wave keeps only its own tile in registers and publishes it in LDS once per step (F-layout, so a chunk of
-// h_{t-1} is one 16-byte LDS read per lane), which frees ~80 VGPRs -> 3 waves per SIMD instead of 2, and
-// lets a small batch spread over NCG times as many SIMDs (a 256-window batch occupies 8 waves in k_gru).
+// h_{t-1} is one 16-byte LDS read per lane).  A small batch then spreads over NCG times as many SIMDs (a
+// 256-window batch occupies 8 waves in k_gru).
 //   per step:  [MFMA: x chunks, then h chunks read from hs]  barrier B
 //              [gates; own tile -> hs; per-step Linear partial -> ps]  barrier A
 //              [wave t % NCG: reduce the Linear partials, store y_t]
 // Two barriers per step keep hs / ps single-buffered: nobody overwrites h_{t-1} before all waves have
 // consumed it (B), nobody reads h_t / the partials before they are complete (A).
-// Weights and B operands of chunk s + 2 are requested right after the MFMAs of chunk s have been issued
-// (two register sets, even / odd chunks); a zero-weight dummy chunk makes the chunk count per step even.
+// The chunk loops have the static shape of k_gru's (3-stage weight ring, unconditional loads,
+// sched_barrier after each refill): the h part is padded with zero-weight chunks so that a step is a
+// whole number of ring turns for any hidden size, which keeps NCG and H run-time values.
 // ---------------------------------------------------------------------------
 template <int XMODE, bool FC>
 __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
@@ -1393,15 +1394,37 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
     const long win = (long)blockIdx.x * 32 + i;
     const long winc = win < a.B ? win : a.B - 1;
     const int T = a.T, Qx = a.Qx;
-    const int Qxp = (XMODE == 1) ? 1 : a.Qxp;
-    const int Qh = 4 * NCG;                        // recurrent chunks as packed
-    const int Qhe = (a.H + 7) >> 3;                // ... and as used
-    const int S = Qxp + Qhe;
-    const int Se = S + (S & 1);                    // incl. the zero-weight dummy chunk
+    const int Qxp = (XMODE == 1) ? 1 : a.Qxp;      // XMODE 0/2: a multiple of 3
+    const int Qh = 4 * NCG;                        // recurrent chunks of a tile that can be non-zero
+    const int Qhe = (a.H + 7) >> 3;                // ... as needed
+    const int S3 = (Qxp + Qhe + 2) / 3 * 3;        // chunks per step: whole ring turns
+    const int NH = S3 - Qxp;                       // h chunks per step incl. zero-weight padding
     f32x4* __restrict__ hs = reinterpret_cast<f32x4*>(gsm);                // [NCG][4][64] float4: h_{t-1}, F-layout
     float* __restrict__ ps = gsm + NCG * 1024;                              // [NCG][out_dim][32] Linear partials
 
-    const f32x4* __restrict__ whc = a.Wh + (long)c * Qh * 192 + lane;      // this tile's recurrent stream
+    // ---- weight stream of this tile: [x chunks 0..Qxp) [h chunks 0..NH)] per step through a 3-stage ring
+    // Running wave-uniform pointers, advanced by adds and scalar selects only (a branch inside the chunk
+    // loops makes the compiler drain the ring with s_waitcnt vmcnt(0)); the h stream of a tile ends in
+    // two all-zero chunks, so the padded chunks need no special case.
+    const f32x4* __restrict__ whc = a.Wh + (long)c * a.whs * 192;
+    const f32x4* __restrict__ wx0 = a.Wx + (long)c * Qxp * 192;
+    const long wxskip = (XMODE == 0) ? 0 : (long)(NCG - 1) * Qxp * 192;    // decoder input weights are [t][c][Qxp]
+    int ps_ = 0, pt = 0;
+    const f32x4* __restrict__ pwx = wx0;
+    const f32x4* __restrict__ pwh = whc;
+    auto wload = [&](f32x4 (&dst)[3]) {
+        const bool isx = ps_ < Qxp;
+        const f32x4* __restrict__ p = (isx ? pwx : pwh) + lane;
+        dst[0] = p[0]; dst[1] = p[64]; dst[2] = p[128];
+        pwx += isx ? 192 : 0;
+        pwh += isx ? 0 : 192;
+        const bool ws = ps_ + 1 == S3;             // end of the step
+        ps_ = ws ? 0 : ps_ + 1;
+        pt = ws ? pt + 1 : pt;
+        pwh = ws ? whc : pwh;
+        const f32x4* __restrict__ nx = (XMODE == 0 || pt >= T) ? wx0 : pwx + wxskip;
+        pwx = ws ? nx : pwx;
+    };
     const float* __restrict__ xbase = (XMODE == 0) ? a.X + winc * T * a.ldx + 4 * g : a.X + winc * a.ldx;
     auto loadx_t = [&](int t, int q) -> f32x4 {
         const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
@@ -1412,35 +1435,18 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
         v[2] = xbase[min(k0 + 2, kmax)]; v[3] = xbase[min(k0 + 3, kmax)];
         return v;
     };
-    // weights of chunk s of step t (input part: per step for the decoder, shared by all steps otherwise)
-    auto fetch_w = [&](int t, int s, f32x4 (&w)[3]) {
-        const f32x4* __restrict__ p;
-        if (s < Qxp)
-            p = a.Wx + ((long)((XMODE == 0 ? 0 : t) * NCG + c) * Qxp + s) * 192 + lane;
-        else if (s < S)
-            p = whc + (long)(s - Qxp) * 192;
-        else
-            p = a.Wzero + lane;
-        w[0] = p[0]; w[1] = p[64]; w[2] = p[128];
-    };
-    // B operand of chunk s: x_t chunk, or chunk (s - Qxp) of h_{t-1} from LDS (valid after barrier A of step t-1)
-    auto fetch_b = [&](int t, int s) -> f32x4 {
-        if (s < Qxp) return loadx_t(t, s);
-        const int q = s < S ? s - Qxp : Qhe - 1;
-        return hs[q * 64 + lane];
-    };
+    auto hread = [&](int q) -> f32x4 { return hs[(q < Qhe ? q : Qhe - 1) * 64 + lane]; };   // padding: any finite chunk
 
     f32x16 hown;                                   // this wave's tile of h
 #pragma unroll
     for (int r = 0; r < 16; ++r) hown[r] = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 wA[3], wB[3], bA, bB;
-    fetch_w(0, 0, wA);
-    fetch_w(0, 1, wB);
+    f32x4 wr[3][3], xr[3];
+    wload(wr[0]); wload(wr[1]); wload(wr[2]);
+#pragma unroll
+    for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st);
     __syncthreads();
-    bA = fetch_b(0, 0);
-    bB = fetch_b(0, 1);
 
     for (int t = 0; t < T; ++t) {
         f32x16 ar, az, anx, anh;
@@ -1459,26 +1465,54 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
                 anh[4 * m + s4] = b3[s4];
             }
         }
-        const int tn = t + 1 < T ? t + 1 : t;
-        for (int s = 0; s < Se; s += 2) {
-            // even chunk (set A), then its refill with chunk s + 2 (of the next step past the end: weights
-            // always, the B operand only if it is an x chunk -- h_t does not exist yet)
-            if (s < Qxp) mfma4x3(wA, bA, ar, az, anx); else mfma4x3(wA, bA, ar, az, anh);
-            {
-                const bool wrap = s + 2 >= Se;
-                const int s2 = wrap ? s + 2 - Se : s + 2, t2 = wrap ? tn : t;
-                fetch_w(t2, s2, wA);
-                if (!wrap || s2 < Qxp) bA = fetch_b(t2, s2);
-            }
+        // chunk q of h_{t-1} is requested one chunk ahead of its MFMAs (LDS latency under the previous group)
+        f32x4 hv = hread(0);
+        int qh = 0;                                // next h chunk to consume
+        if (XMODE == 1) {
+            // first ring turn: the single x chunk, then h chunks 0 and 1
+            mfma4x3(wr[0], xr[0], ar, az, anx);
+            wload(wr[0]);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < Qxp) mfma4x3(wB, bB, ar, az, anx); else mfma4x3(wB, bB, ar, az, anh);
-            {
-                const bool wrap = s + 3 >= Se;
-                const int s3 = wrap ? s + 3 - Se : s + 3, t3 = wrap ? tn : t;
-                fetch_w(t3, s3, wB);
-                if (!wrap || s3 < Qxp) bB = fetch_b(t3, s3);
+#pragma unroll
+            for (int st = 1; st < 3; ++st) {
+                const f32x4 hn = hread(qh + 1);
+                mfma4x3(wr[st], hv, ar, az, anh);
+                wload(wr[st]);
+                __builtin_amdgcn_sched_barrier(0);
+                hv = hn; ++qh;
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            for (int q0 = 0; q0 < Qxp; q0 += 3) {
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+                    mfma4x3(wr[st], xr[st], ar, az, anx);
+                    wload(wr[st]);
+                    xr[st] = loadx_t(t, q0 + st + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        auto hturn = [&]() {                       // one ring turn of h chunks qh .. qh + 2
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const f32x4 hn = hread(qh + st + 1);
+                mfma4x3(wr[st], hv, ar, az, anh);
+                wload(wr[st]);
+                __builtin_amdgcn_sched_barrier(0);
+                hv = hn;
+            }
+            qh += 3;
+        };
+        // The first turn is peeled so that the loop header is only reached from code with the same
+        // outstanding-load pattern (9 weight loads in ring order): otherwise the wait counts at the header
+        // are the conservative join with the x loop's and the ring is drained every turn.
+        if (XMODE != 1) hturn();                   // NH >= 3 there
+        while (qh < NH) hturn();
+        // x chunks 0..2 of the next step: their latency hides under the gate math
+        {
+            const int tn = t + 1 < T ? t + 1 : t;
+#pragma unroll
+            for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st);
         }
         // ---- gates (reference GRULayer / RNNDecoder: torch.nn.GRU equations, r|z|n)
 #pragma unroll
@@ -1488,18 +1522,18 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
             const float ng = gate_tanh(anx[r] + rg * anh[r]);
             hown[r] = (1.0f - zg) * ng + zg * hown[r];
         }
-        f32x4 hv[4];
+        f32x4 hvv[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            hv[m][0] = hown[4 * m + 0]; hv[m][1] = hown[4 * m + 1]; hv[m][2] = hown[4 * m + 2]; hv[m][3] = hown[4 * m + 3];
+            hvv[m][0] = hown[4 * m + 0]; hvv[m][1] = hown[4 * m + 1]; hvv[m][2] = hown[4 * m + 2]; hvv[m][3] = hown[4 * m + 3];
         }
         __syncthreads();                           // B: every wave is done reading h_{t-1}
 #pragma unroll
-        for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = hv[m];
+        for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = hvv[m];
         if (a.Seq && win < a.B) {
             float* sp = a.Seq + (win * T + t) * a.ldseq + 32 * c + 4 * g;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(sp + 8 * m) = hv[m];
+            for (int m = 0; m < 4; ++m) *reinterpret_cast<f32x4*>(sp + 8 * m) = hvv[m];
         }
         const bool fc_now = FC && (a.Yfc != nullptr || t == T - 1);
         if (fc_now) {
@@ -1510,7 +1544,7 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
                 for (int r = 0; r < 16; ++r) y[r] = 0.f;
                 const f32x4* __restrict__ wp = a.Wfc + ((long)n * Qh + 4 * c) * 64 + lane;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) y = mfma4(wp[m * 64], hv[m], y);
+                for (int m = 0; m < 4; ++m) y = mfma4(wp[m * 64], hvv[m], y);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -1519,11 +1553,6 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
             }
         }
         __syncthreads();                           // A: h_t and the partials are complete
-        // B operands of the first two chunks of step t + 1 if they are h chunks (not prefetchable before A)
-        if (t + 1 < T) {
-            if (0 >= Qxp) bA = fetch_b(t + 1, 0);
-            if (1 >= Qxp) bB = fetch_b(t + 1, 1);
-        }
         if (fc_now && c == t % NCG && win < a.B) {
             float* yp = a.Yfc ? a.Yfc + (win * T + t) * (long)a.out_dim : nullptr;
             float* yl = (a.Ylast && t == T - 1) ? a.Ylast + win * (long)a.out_dim : nullptr;

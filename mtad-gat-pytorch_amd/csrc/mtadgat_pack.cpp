@@ -71,7 +71,6 @@ std::string validate_and_plan(Model& m) {
         m.conv_w_off = take((size_t)m.convNT * Q * 256);
         m.conv_b_off = take((size_t)m.convNT * 32);
     }
-    m.zero_off = take(3 * 256);      // stays zero (pack_weights clears the buffer)
     // GAT layers
     auto plan_gat = [&](GatPlan& g, int K, int D, int E) {
         g.K = K; g.D = D; g.E = E;
@@ -122,7 +121,7 @@ std::string validate_and_plan(Model& m) {
         g.Qxp = round_up(g.Qx, 3);
         g.xmode = 0;
         g.wx_off = take((size_t)g.NCG * g.Qxp * 3 * 256);
-        g.wh_off = take((size_t)g.NCG * 4 * g.NCG * 3 * 256);
+        g.wh_off = take((size_t)g.NCG * (4 * g.NCG + 2) * 3 * 256);   // 2 zero chunks per tile: k_gru_split's ring padding
         g.b_off = take((size_t)4 * g.Hp);
     }
     // forecasting head
@@ -164,7 +163,7 @@ std::string validate_and_plan(Model& m) {
             g.Qxp = round_up(g.Qx, 3);
             g.wx_off = take((size_t)g.NCG * g.Qxp * 3 * 256);
         }
-        g.wh_off = take((size_t)g.NCG * 4 * g.NCG * 3 * 256);
+        g.wh_off = take((size_t)g.NCG * (4 * g.NCG + 2) * 3 * 256);   // 2 zero chunks per tile: k_gru_split's ring padding
         g.b_off = take((size_t)4 * g.Hp);
     }
     {
@@ -290,7 +289,7 @@ static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_h
             return (r < H && k < in) ? w_ih[((size_t)st * H + r) * in + k] : 0.f;
         });
     }
-    pack_gru_tiles(out.data() + g.wh_off, g.NCG, 4 * g.NCG, [&](int st, int r, int k) -> float {
+    pack_gru_tiles(out.data() + g.wh_off, g.NCG, 4 * g.NCG + 2, [&](int st, int r, int k) -> float {
         return (r < H && k < H) ? w_hh[((size_t)st * H + r) * H + k] : 0.f;
     });
     float* b = out.data() + g.b_off;
