@@ -1759,8 +1759,9 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
     if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
     // Small batches: spread the 32-window groups over ncg waves each (k_gru_split) -- k_gru needs ~2 groups
-    // per SIMD to fill the machine and leaves it mostly idle below that.  Measured crossover on MI355X
-    // (W=100, F=55, H=150): equal at 32 k windows, split 2x faster at <= 16 k.
+    // per SIMD to fill the machine and leaves it mostly idle below that.  Measured on MI355X (W=100, F=55,
+    // H=150, GRU + decoder): 256 windows 12.0 -> 4.9 ms, 16 k windows 12.2 -> 9.9 ms, 32 k windows 12.2 vs 19.6
+    // (the 5 waves of a group land 2/1/1/1 on the SIMDs, so the split form loses once the machine is full).
     {
         static int n_cu = 0;
         if (!n_cu) {
