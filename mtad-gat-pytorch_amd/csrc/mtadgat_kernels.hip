@@ -1313,7 +1313,29 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                     *reinterpret_cast<f32x4*>(sp + 32 * c + 8 * m + 4 * g) = v;
                 }
         }
-        if (FC && (a.Yfc != nullptr || t == T - 1)) {
+        if (FC && (a.Yfc != nullptr || t == T - 1) && a.out_dim <= 4) {
+            // few outputs (target dims of MSL / SMAP: 1): a 32-output MFMA tile per step would cost 4*Qhe
+            // matrix instructions for one useful column.  Dot products on the VALU instead: lane (i, g)
+            // covers its 16 features of every tile, the two halves meet through one cross-lane add.
+            const f32x4* __restrict__ wf = a.Wfc;         // tile 0: [Qh][64 lanes][4], lane (o, g) = W[o][8q + 4g + s]
+            float* yp = (a.Yfc && win < a.B) ? a.Yfc + (win * T + t) * (long)a.out_dim : nullptr;
+            float* yl = (a.Ylast && t == T - 1 && win < a.B) ? a.Ylast + win * (long)a.out_dim : nullptr;
+            for (int o = 0; o < a.out_dim; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < Qhe; ++q) {
+                    const int cq = q >> 2, m = q & 3;
+                    const f32x4 w = wf[q * 64 + o + 32 * g];
+                    acc += w[0] * h[cq][4 * m + 0] + w[1] * h[cq][4 * m + 1] + w[2] * h[cq][4 * m + 2] + w[3] * h[cq][4 * m + 3];
+                }
+                acc += __shfl_xor(acc, 32);
+                const float y = acc + a.bfc[o];
+                if (g == 0) {
+                    if (yp) yp[o] = y;
+                    if (yl) yl[o] = y;
+                }
+            }
+        } else if (FC && (a.Yfc != nullptr || t == T - 1)) {
             for (int n = 0; n < a.NTfc; ++n) {
                 f32x16 y;
 #pragma unroll
