@@ -731,13 +731,16 @@ __global__ __launch_bounds__(64, (JPL <= 2 ? 3 : 2)) void k_attend(const AttendA
 // pairwise scores, softmax, aggregation, sigmoid -- with the node features V, the projected L' and
 // R' never leaving the CU.  Same algebra and packed weights as k_rowgemm + k_attend (which remain
 // the path for node counts / dims whose tiles do not fit in LDS).
-//   LDS:  Vs [Kp8][vld]          node feature rows of this window (zero padded rows and columns)
-//         Ls [NW*4*IBL][36]      L' columns of the current part, row-major (+ c when it is in the part)
-//         Rs [16*JPL][36]        R' columns of the current part, row-major (+ d)
-//         att[NW][4*IBL][68]     softmax rows restaged for the aggregation MFMA (aliases Ls/Rs)
-// The embedding is processed in parts of one 32-column tile per side: MFMA phase (projection of the
-// part into Ls/Rs) -> barrier -> VALU phase -> barrier.  Several workgroups per CU are in different
-// phases, so the matrix and vector pipes overlap across workgroups.
+//   LDS:  Ls [NWA*4*IBL][34]     L' columns of the current part, row-major (+ c when it is in the part)
+//         Rs [K][34]             R' columns of the current part, row-major (+ d)
+//         att[NWA][4*IBL][68]    softmax rows restaged for the aggregation MFMA (aliases Ls/Rs)
+//         Vs [Kp16][vld]         node feature rows of this window, zero padded rows / columns, column D = 1
+//                                (the projection bias is weight row D)
+// NWA = ceil(K / (4*IBL)) waves own query rows; a workgroup may have more waves than that (they only take
+// projection tiles).  The embedding is processed in parts of one 32-column tile per side: MFMA phase
+// (projection of the part into Ls/Rs, one 32-node tile per wave, weights requested a phase early) ->
+// barrier -> VALU phase -> barrier.  Several workgroups per CU are in different phases, so the matrix and
+// vector pipes overlap across workgroups.
 //
 // VALU phase = 2-D register blocking of the K x K pair grid.  A wave owns 4*IBL query rows; lane
 // (li = lane>>4, lj = lane&15) accumulates the IBL x JPL pairs {rows li + 4 ii} x {keys lj + 16 jj}.
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(64, (JPL <= 2 ? 3 : 2)) void k_attend(const AttendA
 // ~0.17 floats per VALU op (lane-per-key with wave-uniform broadcast rows needed 0.28-0.53 and was
 // LDS-return bound), no lane is spent on padding beyond 16*JPL keys, and all addresses are
 // base + immediate.  The two register sets A/B alternate: the loads of the next column pair are in
-// flight while the current pair is consumed.  Row strides of 36 floats keep every ds_read_b64 wave
+// flight while the current pair is consumed.  Row strides of 34 floats keep every ds_read_b64 wave
 // access conflict-free (16 distinct keys x 2 banks each cover 32 bank pairs).
 // ---------------------------------------------------------------------------
 typedef const __attribute__((address_space(3))) float* lds_cptr;      // explicit LDS pointer (32-bit)
