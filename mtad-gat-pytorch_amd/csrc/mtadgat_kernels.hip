@@ -1131,10 +1131,18 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 #pragma unroll
         for (int dt = 0; dt < DTMAX; ++dt)
             if (dt < DT) {
+                const int d0 = 16 * dt + 4 * kb;
+                f32x4 y;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = 16 * dt + 4 * kb + r;
-                    if (row < K && d < D) orow[(long)d * a.so_d] = gate_sigmoid(o[dt][r]);
+                for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[dt][r]);
+                if (a.so_d == 1 && row < K && d0 + 3 < D) {
+                    // 4 consecutive features of one row: one 16-byte store (dword aligned is enough for global memory)
+                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row < K && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
                 }
             }
     }
