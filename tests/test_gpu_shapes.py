@@ -44,6 +44,32 @@ def test_shape_against_oracle(kw, gpu_device):
         gate(r, r_ref, what=f"recons b={b}")
 
 
+@pytest.mark.parametrize("kw", [
+    # decoder input spread over more than 8 h_end entries per step (3-chunk folded input), stacked layers
+    dict(n_features=4, window_size=5, out_dim=2, kernel_size=3, gru_hid_dim=96, recon_hid_dim=40, gru_n_layers=2, recon_n_layers=2),
+    dict(n_features=7, window_size=12, out_dim=7, kernel_size=5, gru_hid_dim=33, recon_hid_dim=65, use_gatv2=False),
+], ids=["F4W5", "F7W12"])
+def test_large_and_small_batch_kernels_on_odd_shapes(kw, gpu_device):
+    """20 000 windows go through the register-resident GRU kernels, 40 through the hidden-tile-split ones;
+    both must match the oracle."""
+    from mtad_gat import MTAD_GAT
+    torch.manual_seed(23)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+    x = torch.rand(20000, kw["window_size"], kw["n_features"])
+    with torch.no_grad():
+        p_ref, r_ref = oracle.forward(x[:40], model.state_dict(), alpha=kw.get("alpha", 0.2))
+        m = model.to(gpu_device)
+        p_big, r_big = m(x.to(gpu_device))
+        p_small, r_small = m(x[:40].to(gpu_device))
+    gate(p_big[:40], p_ref, what="preds, large batch")
+    gate(r_big[:40], r_ref, what="recons, large batch")
+    gate(p_small, p_ref, what="preds, small batch")
+    gate(r_small, r_ref, what="recons, small batch")
+
+
 def test_unsupported_shapes_fail_loudly(gpu_device):
     from mtad_gat import MTAD_GAT
     model = MTAD_GAT(n_features=4, window_size=600, out_dim=1).eval().to(gpu_device)
