@@ -152,12 +152,11 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 }
 
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
-int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, bool xfast, int64_t n, float* hend,
+int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
                   long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s) {
     Scope sc(m, slot, s);
     GruArgs a{};
     a.X = x; a.ldx = ldx; a.Kx = kx; a.Qx = g.Qx; a.Qxp = g.Qxp;
-    (void)xfast;
     a.m0 = g.xmode == 1 ? reinterpret_cast<const int*>(m.packed_dev + g.m0_off) : nullptr;
     a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx_off);
     a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
@@ -178,27 +177,25 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     return 0;
 }
 
-// padded == true: hcat is the internal (n*W, Dp) buffer whose pad columns are zero
-int run_gru_stack(Model& m, const float* hcat, long ldx, bool padded, int64_t n, float* hend, long ldhe, float* ws,
+// hcat is the internal (n*W, Dp) buffer: 16-byte aligned rows whose pad columns are zero (the kernels read them unguarded)
+int run_gru_stack(Model& m, const float* hcat, long ldx, int64_t n, float* hend, long ldhe, float* ws,
                   const Workspace& o, hipStream_t s) {
     const int L = (int)m.gru.size();
     const float* x = hcat;
     long ld = ldx;
     int kx = 3 * m.F;
-    bool fast = padded && (ldx % 4 == 0) && (8 * m.gru[0].Qx <= ldx);
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         float* seq = last ? nullptr : ws + ((l & 1) ? o.seq1 : o.seq0);
-        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, fast, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s);
+        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s);
         if (rc) return rc;
-        x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;
-        fast = true;      // sequence buffers hold all Hp columns, padding lanes are exact zeros
+        x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;      // sequence buffers hold all Hp columns, padding lanes are exact zeros
     }
     return 0;
 }
 
-// padded == true: hend is the internal (n, Hp) buffer with zero pad columns
-int run_heads(Model& m, const float* hend, long ldh, bool padded, int64_t n, float* preds, float* recons, float* recons_last,
+// hend is the internal (n, Hp) buffer with zero pad columns
+int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, float* recons, float* recons_last,
               float* ws, const Workspace& o, hipStream_t s) {
     if (preds) {
         Scope sc(m, S_FC, s);
@@ -230,16 +227,14 @@ int run_heads(Model& m, const float* hend, long ldh, bool padded, int64_t n, flo
         const float* x = hend;
         long ld = ldh;
         int kx = m.cfg.gru_hid_dim;
-        // decoder layer 0 reads hend[m0(t) .. m0(t) + 8*Qx): inside the padded row?
-        bool fast = padded && ((long)((long)(m.W - 1) * m.cfg.gru_hid_dim / m.W) + 8 * m.rec[0].Qx <= ldh);
+        // decoder layer 0 reads hend[m0(t) .. m0(t) + 8*Qx), clamped to the (zero padded) row inside the kernel
         for (int l = 0; l < L; ++l) {
             const bool last = (l == L - 1);
             float* seq = last ? nullptr : ws + ((l & 1) ? o.rseq1 : o.rseq0);
-            int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, fast, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr,
+            int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr,
                                    last ? recons : nullptr, last ? recons_last : nullptr, s);
             if (rc) return rc;
             x = seq; ld = m.rec[l].Hp; kx = m.rec[l].H;
-            fast = true;
         }
     }
     return 0;
@@ -351,12 +346,12 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
         }
         float* hend = ws + o.hend;
         const long ldh = m.gru.back().Hp;
-        if ((rc = run_gru_stack(m, hcat, m.Dp, true, n, hend, ldh, ws, o, s))) return rc;
+        if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s))) return rc;
         if (hend_out)
             K_TRY(launch_copy2d(hend, ldh, hend_out + c0 * m.cfg.gru_hid_dim, m.cfg.gru_hid_dim, n, m.cfg.gru_hid_dim, s),
                   "h_end copy");
         if (preds || recons || recons_last) {
-            if ((rc = run_heads(m, hend, ldh, true, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
+            if ((rc = run_heads(m, hend, ldh, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
                                 recons ? recons + c0 * (int64_t)W * m.cfg.out_dim : nullptr,
                                 recons_last ? recons_last + c0 * m.cfg.out_dim : nullptr, ws, o, s)))
                 return rc;
@@ -440,7 +435,7 @@ int mtadgat_gru(mtadgat_handle h, const float* hcat, int64_t batch, float* hend,
         hipStream_t s = (hipStream_t)stream;
         HIP_TRY(hipMemsetAsync(ws + o.hcat, 0, (size_t)n * m.W * m.Dp * sizeof(float), s));
         K_TRY(launch_copy2d(hcat + c0 * (int64_t)m.W * D, D, ws + o.hcat, m.Dp, n * m.W, D, s), "h_cat pad copy");
-        if ((rc = run_gru_stack(m, ws + o.hcat, m.Dp, true, n, hend + c0 * H, H, ws, o, s))) return rc;
+        if ((rc = run_gru_stack(m, ws + o.hcat, m.Dp, n, hend + c0 * H, H, ws, o, s))) return rc;
     }
     return 0;
 }
@@ -462,7 +457,7 @@ int mtadgat_heads(mtadgat_handle h, const float* hend, int64_t batch, float* pre
         const long ldh = m.gru.back().Hp;
         HIP_TRY(hipMemsetAsync(ws + o.hend, 0, (size_t)n * ldh * sizeof(float), s));
         K_TRY(launch_copy2d(hend + c0 * H, H, ws + o.hend, ldh, n, H, s), "h_end pad copy");
-        if ((rc = run_heads(m, ws + o.hend, ldh, true, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
+        if ((rc = run_heads(m, ws + o.hend, ldh, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
                             recons ? recons + c0 * (int64_t)m.W * m.cfg.out_dim : nullptr, nullptr, ws, o, s)))
             return rc;
     }
