@@ -1169,25 +1169,34 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 // can count the outstanding loads exactly and waits with vmcnt(N > 0): the weight ring stays full.
 // (With guarded loads it fell back to vmcnt(0..2) before every MFMA group: 79k instead of 31k cycles
 // per hidden tile and step.)
-template <int NCG, int XMODE, bool FC, int DROP>
-__global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a) {
-    __shared__ float hn_s[NCG][16][64];
+// MW = 32-window groups per wave.  MW = 2 with one wave per SIMD beats two MW = 1 waves per SIMD (matrix
+// pipe 87 % vs 82 % busy on the GRU layer): the MFMAs of one wave issue back to back, interleaving two
+// waves leaves bubbles; each weight chunk is also fetched once for 64 windows.
+template <int NCG, int XMODE, bool FC, int DROP, int MW>
+__global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
+    __shared__ float hn_s[MW][NCG][16][64];
     const int lane = threadIdx.x;
     const int i = lane & 31, g = lane >> 5;
-    const long win = (long)blockIdx.x * 32 + i;
-    const long winc = win < a.B ? win : a.B - 1;
+    long win[MW], winc[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) {
+        win[w] = ((long)blockIdx.x * MW + w) * 32 + i;
+        winc[w] = win[w] < a.B ? win[w] : a.B - 1;
+    }
     const int T = a.T, Qx = a.Qx;
     const int Qxp = (XMODE == 1) ? 1 : a.Qxp;
-    constexpr int Qh = 4 * NCG;                   // recurrent chunks as packed
+    constexpr int Qh = 4 * NCG;                   // recurrent chunks that can be non-zero
     constexpr int Qhe = Qh - DROP;                // ... and as used
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % 3 : Qhe % 3;   // ring phase advance per hidden tile
     const int S = Qxp + Qhe;
 
-    f32x16 h[NCG];
+    f32x16 h[MW][NCG];
 #pragma unroll
-    for (int c = 0; c < NCG; ++c)
+    for (int w = 0; w < MW; ++w)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[c][r] = 0.f;
+        for (int c = 0; c < NCG; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[w][c][r] = 0.f;
 
     // ---- weight stream: one continuous sequence of chunks [tile c][x chunks 0..Qxp) [h chunks 0..Qhe)
     // per step, fetched through a 3-stage register ring that never drains: the cursor runs 3 chunks
@@ -1215,25 +1224,29 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
         // input-part weights: per step for the decoder ([t][c][Qxp], contiguous), shared by all steps otherwise
         pwx = wc ? ((XMODE == 0 || pt >= T) ? a.Wx : pwx) : pwx;
     };
-    const float* __restrict__ xbase = (XMODE == 0) ? a.X + winc * T * a.ldx + 4 * g : a.X + winc * a.ldx;
-    auto loadx_t = [&](int t, int q) -> f32x4 {
+    const float* xbase[MW];
+#pragma unroll
+    for (int w = 0; w < MW; ++w) xbase[w] = (XMODE == 0) ? a.X + winc[w] * T * a.ldx + 4 * g : a.X + winc[w] * a.ldx;
+    auto loadx_t = [&](int w, int t, int q) -> f32x4 {
         const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
-        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase + (long)t * a.ldx + 8 * qq);
+        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase[w] + (long)t * a.ldx + 8 * qq);
         const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
         f32x4 v;
-        v[0] = xbase[min(k0, kmax)]; v[1] = xbase[min(k0 + 1, kmax)];
-        v[2] = xbase[min(k0 + 2, kmax)]; v[3] = xbase[min(k0 + 3, kmax)];
+        v[0] = xbase[w][min(k0, kmax)]; v[1] = xbase[w][min(k0 + 1, kmax)];
+        v[2] = xbase[w][min(k0 + 2, kmax)]; v[3] = xbase[w][min(k0 + 3, kmax)];
         return v;
     };
 
-    f32x4 wr[3][3], xr[3];
+    f32x4 wr[3][3], xr[3][MW];
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
 #pragma unroll
-    for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st);
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+        for (int w = 0; w < MW; ++w) xr[st][w] = loadx_t(w, 0, st);
 
     for (int t = 0; t < T; ++t) {
         for (int c = 0; c < NCG; ++c) {
-            f32x16 ar, az, anx, anh;
+            f32x16 ar[MW], az[MW], anx[MW], anh[MW];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int col = 32 * c + 8 * m + 4 * g;
@@ -1242,27 +1255,32 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
                 const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias + 2 * a.Hp + col);
                 const f32x4 b3 = *reinterpret_cast<const f32x4*>(a.bias + 3 * a.Hp + col);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    ar[4 * m + s4] = b0[s4];
-                    az[4 * m + s4] = b1[s4];
-                    anx[4 * m + s4] = b2[s4];
-                    anh[4 * m + s4] = b3[s4];
-                }
+                for (int w = 0; w < MW; ++w)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        ar[w][4 * m + s4] = b0[s4];
+                        az[w][4 * m + s4] = b1[s4];
+                        anx[w][4 * m + s4] = b2[s4];
+                        anh[w][4 * m + s4] = b3[s4];
+                    }
             }
             // ---- input part: W_i{r,z,n} x_t.  sched_barrier pins "MFMAs of chunk j, then the loads that
             // refill its ring stage": left alone the scheduler sinks all loads of an iteration below its
             // MFMAs and the next iteration waits for them.
             if (XMODE == 1) {
-                mfma4x3(wr[0], xr[0], ar, az, anx);
+#pragma unroll
+                for (int w = 0; w < MW; ++w) mfma4x3(wr[0], xr[0][w], ar[w], az[w], anx[w]);
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
                 for (int q0 = 0; q0 < Qxp; q0 += 3) {
 #pragma unroll
                     for (int st = 0; st < 3; ++st) {
-                        mfma4x3(wr[st], xr[st], ar, az, anx);
+#pragma unroll
+                        for (int w = 0; w < MW; ++w) mfma4x3(wr[st], xr[st][w], ar[w], az[w], anx[w]);
                         wload(wr[st]);
-                        xr[st] = loadx_t(t, q0 + st + 3);
+#pragma unroll
+                        for (int w = 0; w < MW; ++w) xr[st][w] = loadx_t(w, t, q0 + st + 3);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -1273,10 +1291,13 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
             for (int q = 0; q < Qhe; ++q) {
                 constexpr int X0 = (XMODE == 1) ? 1 : 0;
                 const int cq = q >> 2, m = q & 3, st = (X0 + q) % 3;
-                f32x4 hv;
-                hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
-                hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
-                mfma4x3(wr[st], hv, ar, az, anh);
+#pragma unroll
+                for (int w = 0; w < MW; ++w) {
+                    f32x4 hv;
+                    hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
+                    hv[2] = h[w][cq][4 * m + 2]; hv[3] = h[w][cq][4 * m + 3];
+                    mfma4x3(wr[st], hv, ar[w], az[w], anh[w]);
+                }
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1292,112 +1313,125 @@ __global__ __launch_bounds__(64, (NCG <= 6 ? 2 : 1)) void k_gru(const GruArgs a)
             {
                 const int tn = (c == NCG - 1) ? (t + 1 < T ? t + 1 : t) : t;
 #pragma unroll
-                for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st);
-            }
-            // ---- gates.  h_old for this tile comes back from LDS (written at the end of step t-1)
+                for (int st = 0; st < 3; ++st)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float hold = (t > 0) ? hn_s[c][r][lane] : 0.f;
-                const float rg = gate_sigmoid(ar[r]);
-                const float zg = gate_sigmoid(az[r]);
-                const float ng = gate_tanh(anx[r] + rg * anh[r]);
-                ar[r] = (1.0f - zg) * ng + zg * hold;
+                    for (int w = 0; w < MW; ++w) xr[st][w] = loadx_t(w, tn, st);
             }
+            // ---- gates.  h_old for this tile comes back from LDS (written at the end of step t-1);
             // every lane reads and writes only its own slots -> no cross-lane hazard
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hn_s[c][r][lane] = ar[r];
+            for (int w = 0; w < MW; ++w) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hold = (t > 0) ? hn_s[w][c][r][lane] : 0.f;
+                    const float rg = gate_sigmoid(ar[w][r]);
+                    const float zg = gate_sigmoid(az[w][r]);
+                    const float ng = gate_tanh(anx[w][r] + rg * anh[w][r]);
+                    ar[w][r] = (1.0f - zg) * ng + zg * hold;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hn_s[w][c][r][lane] = ar[w][r];
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < NCG; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[c][r] = hn_s[c][r][lane];
-
-        if (a.Seq && win < a.B) {
-            float* sp = a.Seq + (win * T + t) * a.ldseq;
+        for (int w = 0; w < MW; ++w)
 #pragma unroll
             for (int c = 0; c < NCG; ++c)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    f32x4 v;
-                    v[0] = h[c][4 * m + 0]; v[1] = h[c][4 * m + 1]; v[2] = h[c][4 * m + 2]; v[3] = h[c][4 * m + 3];
-                    *reinterpret_cast<f32x4*>(sp + 32 * c + 8 * m + 4 * g) = v;
-                }
-        }
-        if (FC && (a.Yfc != nullptr || t == T - 1) && a.out_dim <= 4) {
-            // few outputs (target dims of MSL / SMAP: 1): a 32-output MFMA tile per step would cost 4*Qhe
-            // matrix instructions for one useful column.  Dot products on the VALU instead: lane (i, g)
-            // covers its 16 features of every tile, the two halves meet through one cross-lane add.
-            const f32x4* __restrict__ wf = a.Wfc;         // tile 0: [Qh][64 lanes][4], lane (o, g) = W[o][8q + 4g + s]
-            float* yp = (a.Yfc && win < a.B) ? a.Yfc + (win * T + t) * (long)a.out_dim : nullptr;
-            float* yl = (a.Ylast && t == T - 1 && win < a.B) ? a.Ylast + win * (long)a.out_dim : nullptr;
-            for (int o = 0; o < a.out_dim; ++o) {
-                float acc = 0.f;
+                for (int r = 0; r < 16; ++r) h[w][c][r] = hn_s[w][c][r][lane];
+
 #pragma unroll
-                for (int q = 0; q < Qhe; ++q) {
-                    const int cq = q >> 2, m = q & 3;
-                    const f32x4 w = wf[q * 64 + o + 32 * g];
-                    acc += w[0] * h[cq][4 * m + 0] + w[1] * h[cq][4 * m + 1] + w[2] * h[cq][4 * m + 2] + w[3] * h[cq][4 * m + 3];
-                }
-                acc += __shfl_xor(acc, 32);
-                const float y = acc + a.bfc[o];
-                if (g == 0) {
-                    if (yp) yp[o] = y;
-                    if (yl) yl[o] = y;
-                }
+        for (int w = 0; w < MW; ++w) {
+            if (a.Seq && win[w] < a.B) {
+                float* sp = a.Seq + (win[w] * T + t) * a.ldseq;
+#pragma unroll
+                for (int c = 0; c < NCG; ++c)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 v;
+                        v[0] = h[w][c][4 * m + 0]; v[1] = h[w][c][4 * m + 1]; v[2] = h[w][c][4 * m + 2]; v[3] = h[w][c][4 * m + 3];
+                        *reinterpret_cast<f32x4*>(sp + 32 * c + 8 * m + 4 * g) = v;
+                    }
             }
-        } else if (FC && (a.Yfc != nullptr || t == T - 1)) {
-            for (int n = 0; n < a.NTfc; ++n) {
-                f32x16 y;
+            if (FC && (a.Yfc != nullptr || t == T - 1) && a.out_dim <= 4) {
+                // few outputs (target dims of MSL / SMAP: 1): a 32-output MFMA tile per step would cost 4*Qhe
+                // matrix instructions for one useful column.  Dot products on the VALU instead: lane (i, g)
+                // covers its 16 features of every tile, the two halves meet through one cross-lane add.
+                const f32x4* __restrict__ wf = a.Wfc;         // tile 0: [Qh][64 lanes][4], lane (o, g) = W[o][8q + 4g + s]
+                float* yp = (a.Yfc && win[w] < a.B) ? a.Yfc + (win[w] * T + t) * (long)a.out_dim : nullptr;
+                float* yl = (a.Ylast && t == T - 1 && win[w] < a.B) ? a.Ylast + win[w] * (long)a.out_dim : nullptr;
+                for (int o = 0; o < a.out_dim; ++o) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bfc + 32 * n + 8 * m + 4 * g);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) y[4 * m + s4] = bv[s4];
+                    for (int q = 0; q < Qhe; ++q) {
+                        const int cq = q >> 2, m = q & 3;
+                        const f32x4 wv = wf[q * 64 + o + 32 * g];
+                        acc += wv[0] * h[w][cq][4 * m + 0] + wv[1] * h[w][cq][4 * m + 1] + wv[2] * h[w][cq][4 * m + 2] + wv[3] * h[w][cq][4 * m + 3];
+                    }
+                    acc += __shfl_xor(acc, 32);
+                    const float y = acc + a.bfc[o];
+                    if (g == 0) {
+                        if (yp) yp[o] = y;
+                        if (yl) yl[o] = y;
+                    }
                 }
-                const f32x4* __restrict__ wp = a.Wfc + ((long)n * Qh) * 64 + lane;
+            } else if (FC && (a.Yfc != nullptr || t == T - 1)) {
+                for (int n = 0; n < a.NTfc; ++n) {
+                    f32x16 y;
 #pragma unroll
-                for (int q = 0; q < Qhe; ++q) {
-                    const int cq = q >> 2, m = q & 3;
-                    f32x4 hv;
-                    hv[0] = h[cq][4 * m + 0]; hv[1] = h[cq][4 * m + 1];
-                    hv[2] = h[cq][4 * m + 2]; hv[3] = h[cq][4 * m + 3];
-                    y = mfma4(wp[q * 64], hv, y);
-                }
-                if (win < a.B) {
-                    float* yp = a.Yfc ? a.Yfc + (win * T + t) * (long)a.out_dim : nullptr;
-                    float* yl = (a.Ylast && t == T - 1) ? a.Ylast + win * (long)a.out_dim : nullptr;
+                    for (int m = 0; m < 4; ++m) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bfc + 32 * n + 8 * m + 4 * g);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int o = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        if (o < a.out_dim) {
-                            if (yp) yp[o] = y[r];
-                            if (yl) yl[o] = y[r];
+                        for (int s4 = 0; s4 < 4; ++s4) y[4 * m + s4] = bv[s4];
+                    }
+                    const f32x4* __restrict__ wp = a.Wfc + ((long)n * Qh) * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < Qhe; ++q) {
+                        const int cq = q >> 2, m = q & 3;
+                        f32x4 hv;
+                        hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
+                        hv[2] = h[w][cq][4 * m + 2]; hv[3] = h[w][cq][4 * m + 3];
+                        y = mfma4(wp[q * 64], hv, y);
+                    }
+                    if (win[w] < a.B) {
+                        float* yp = a.Yfc ? a.Yfc + (win[w] * T + t) * (long)a.out_dim : nullptr;
+                        float* yl = (a.Ylast && t == T - 1) ? a.Ylast + win[w] * (long)a.out_dim : nullptr;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int o = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * g;
+                            if (o < a.out_dim) {
+                                if (yp) yp[o] = y[r];
+                                if (yl) yl[o] = y[r];
+                            }
                         }
                     }
                 }
             }
         }
     }
-    if (a.Hend && win < a.B) {
-        float* hp = a.Hend + win * a.ldhe;
-        if (a.ldhe >= a.Hp) {        // internal buffer: all Hp columns (the padding lanes of h are exact zeros)
 #pragma unroll
-            for (int c = 0; c < NCG; ++c)
+    for (int w = 0; w < MW; ++w) {
+        if (a.Hend && win[w] < a.B) {
+            float* hp = a.Hend + win[w] * a.ldhe;
+            if (a.ldhe >= a.Hp) {        // internal buffer: all Hp columns (the padding lanes of h are exact zeros)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    f32x4 v;
-                    v[0] = h[c][4 * m + 0]; v[1] = h[c][4 * m + 1]; v[2] = h[c][4 * m + 2]; v[3] = h[c][4 * m + 3];
-                    *reinterpret_cast<f32x4*>(hp + 32 * c + 8 * m + 4 * g) = v;
-                }
-        } else {
+                for (int c = 0; c < NCG; ++c)
 #pragma unroll
-            for (int c = 0; c < NCG; ++c)
+                    for (int m = 0; m < 4; ++m) {
+                        f32x4 v;
+                        v[0] = h[w][c][4 * m + 0]; v[1] = h[w][c][4 * m + 1]; v[2] = h[w][c][4 * m + 2]; v[3] = h[w][c][4 * m + 3];
+                        *reinterpret_cast<f32x4*>(hp + 32 * c + 8 * m + 4 * g) = v;
+                    }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (j < a.H) hp[j] = h[c][r];
-                }
+                for (int c = 0; c < NCG; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        if (j < a.H) hp[j] = h[w][c][r];
+                    }
+            }
         }
     }
 }
@@ -1751,28 +1785,35 @@ int launch_gat(const GatArgs& a, int IBL, int JPL, int nw, size_t lds_bytes, hip
     return 0;
 }
 
-template <int NCG, int XMODE>
+template <int NCG, int XMODE, int MW>
 static int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.B + 31) / 32);
+    const unsigned grid = (unsigned)((a.B + 32 * MW - 1) / (32 * MW));
     if (!fc && drop == 0)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 0>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 0, MW>), dim3(grid), dim3(64), 0, s, a);
     else if (!fc)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 1>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 1, MW>), dim3(grid), dim3(64), 0, s, a);
     else if (drop == 0)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 0>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 0, MW>), dim3(grid), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 1>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 1, MW>), dim3(grid), dim3(64), 0, s, a);
     LAUNCH_CHECK();
     return 0;
 }
 
 template <int NCG>
-static int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, hipStream_t s) {
+static int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, bool two, hipStream_t s) {
     // trailing recurrent chunks that are pure padding: skip one when H <= 8*(4*NCG - 1)
     const int drop = (a.H <= 8 * (4 * NCG - 1)) ? 1 : 0;
-    if (xmode == 0) return launch_gru_mode<NCG, 0>(a, fc, drop, s);
-    if (a.Qxp == 1) return launch_gru_mode<NCG, 1>(a, fc, drop, s);
-    return launch_gru_mode<NCG, 2>(a, fc, drop, s);
+    if constexpr (NCG <= 5) {           // two 32-window groups per wave: 8 KB of LDS per group and tile, 4 waves per CU
+        if (two) {
+            if (xmode == 0) return launch_gru_mode<NCG, 0, 2>(a, fc, drop, s);
+            if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 2>(a, fc, drop, s);
+            return launch_gru_mode<NCG, 2, 2>(a, fc, drop, s);
+        }
+    }
+    if (xmode == 0) return launch_gru_mode<NCG, 0, 1>(a, fc, drop, s);
+    if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 1>(a, fc, drop, s);
+    return launch_gru_mode<NCG, 2, 1>(a, fc, drop, s);
 }
 
 static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
@@ -1806,15 +1847,23 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
         const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
         if (ncg >= 2 && groups <= 2L * n_cu && lds <= 64 * 1024) return launch_gru_split(a, ncg, xmode, fc, s);
     }
+    // two groups per wave once that still gives every SIMD a wave
+    static int n_cu2 = 0;
+    if (!n_cu2) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu2 <= 0)
+            n_cu2 = 256;
+    }
+    const bool two = (a.B + 31) / 32 >= 8L * n_cu2;
     switch (ncg) {
-        case 1: return launch_gru_ncg<1>(a, xmode, fc, s);
-        case 2: return launch_gru_ncg<2>(a, xmode, fc, s);
-        case 3: return launch_gru_ncg<3>(a, xmode, fc, s);
-        case 4: return launch_gru_ncg<4>(a, xmode, fc, s);
-        case 5: return launch_gru_ncg<5>(a, xmode, fc, s);
-        case 6: return launch_gru_ncg<6>(a, xmode, fc, s);
-        case 7: return launch_gru_ncg<7>(a, xmode, fc, s);
-        case 8: return launch_gru_ncg<8>(a, xmode, fc, s);
+        case 1: return launch_gru_ncg<1>(a, xmode, fc, two, s);
+        case 2: return launch_gru_ncg<2>(a, xmode, fc, two, s);
+        case 3: return launch_gru_ncg<3>(a, xmode, fc, two, s);
+        case 4: return launch_gru_ncg<4>(a, xmode, fc, two, s);
+        case 5: return launch_gru_ncg<5>(a, xmode, fc, two, s);
+        case 6: return launch_gru_ncg<6>(a, xmode, fc, two, s);
+        case 7: return launch_gru_ncg<7>(a, xmode, fc, two, s);
+        case 8: return launch_gru_ncg<8>(a, xmode, fc, two, s);
         default: return -2;
     }
 }

@@ -106,6 +106,28 @@ def test_large_batch_kernels_match_small_batch_kernels(name, gpu_device):
     assert (r_big[19000:19300] - r_small).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("name", ["msl", "syn_v2_embed"])
+def test_full_machine_batch_matches(name, gpu_device):
+    """From 65 536 windows on, the GRU kernels take two 32-window groups per wave (one wave per SIMD); a
+    ragged batch of that size must still carry the fixture windows and agree with a small-batch run."""
+    case = Case(name)
+    model = case.build_model().to(gpu_device)
+    g = torch.Generator().manual_seed(13)
+    W, F = case.kwargs["window_size"], case.kwargs["n_features"]
+    n_big = 65536 + 37
+    x = torch.rand(n_big, W, F, generator=g)
+    n = case.x.shape[0]
+    x[-n:] = case.x                                   # the last, partially filled wave
+    x = x.to(gpu_device)
+    with torch.no_grad():
+        p_big, r_big = model(x)
+        p_small, r_small = model(x[40000:40100].contiguous())
+    gate(p_big[-n:], case.preds, case.preds64, what="preds at the end of a 65573-window batch")
+    gate(r_big[-n:], case.recons, case.recons64, what="recons at the end of a 65573-window batch")
+    assert (p_big[40000:40100] - p_small).abs().max().item() <= 2e-6
+    assert (r_big[40000:40100] - r_small).abs().max().item() <= 2e-6
+
+
 def test_weight_update_is_seen(gpu_device):
     """Parameters changed in place (optimizer.step, load_state_dict) must reach the kernels."""
     a = Case("smap")

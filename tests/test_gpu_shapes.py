@@ -50,22 +50,26 @@ def test_shape_against_oracle(kw, gpu_device):
     dict(n_features=7, window_size=12, out_dim=7, kernel_size=5, gru_hid_dim=33, recon_hid_dim=65, use_gatv2=False),
 ], ids=["F4W5", "F7W12"])
 def test_large_and_small_batch_kernels_on_odd_shapes(kw, gpu_device):
-    """20 000 windows go through the register-resident GRU kernels, 40 through the hidden-tile-split ones;
-    both must match the oracle."""
+    """20 000 windows go through the register-resident GRU kernels (70 000: two window groups per wave), 40
+    through the hidden-tile-split ones; all must match the oracle."""
     from mtad_gat import MTAD_GAT
     torch.manual_seed(23)
     model = MTAD_GAT(**kw).eval()
     with torch.no_grad():
         model.feature_gat.bias.normal_()
         model.temporal_gat.bias.normal_()
-    x = torch.rand(20000, kw["window_size"], kw["n_features"])
+    x = torch.rand(70000, kw["window_size"], kw["n_features"])
     with torch.no_grad():
         p_ref, r_ref = oracle.forward(x[:40], model.state_dict(), alpha=kw.get("alpha", 0.2))
         m = model.to(gpu_device)
-        p_big, r_big = m(x.to(gpu_device))
+        p_big, r_big = m(x[:20000].to(gpu_device))
+        m._engine.set_chunk_windows(1 << 17)                       # keep the 70 000 windows in one launch
+        p_huge, r_huge = m(x.to(gpu_device))
         p_small, r_small = m(x[:40].to(gpu_device))
     gate(p_big[:40], p_ref, what="preds, large batch")
     gate(r_big[:40], r_ref, what="recons, large batch")
+    gate(p_huge[:40], p_ref, what="preds, full-machine batch")
+    gate(r_huge[:40], r_ref, what="recons, full-machine batch")
     gate(p_small, p_ref, what="preds, small batch")
     gate(r_small, r_ref, what="recons, small batch")
 
