@@ -6,12 +6,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["mtadgat_kernels.hip", "mtadgat_pack.cpp", "mtadgat_capi.cpp"]
-HEADERS = ["mtadgat_kernels.h", "mtadgat_host.h", os.path.join("..", "..", "include", "mtadgat.h")]
+SOURCES = ["mtadgat_kernels.hip", "mtadgat_attend.hip", "mtadgat_gat.hip", "mtadgat_gru.hip", "mtadgat_pack.cpp", "mtadgat_capi.cpp"]
+HEADERS = ["mtadgat_kernels.h", "mtadgat_device.h", "mtadgat_host.h", os.path.join("..", "..", "include", "mtadgat.h")]
 LIB = os.path.join(HERE, "libmtadgat.so")
-# -fno-slp-vectorize: keep the attention inner loop as single-issue v_add_f32 (2 VALU/element);
+OBJDIR = os.path.join(HERE, "build")          # object files (git-ignored)
+# -fno-slp-vectorize: keep the attention inner loops as single-issue v_add_f32 (2 VALU/element);
 # SLP packing into v_pk_add_f32 costs 3 VALU/element there.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
 
 
 def _stale():
@@ -23,11 +24,25 @@ def _stale():
 
 
 def build(force=False, verbose=True):
-    """Compile the HIP kernels + C ABI into libmtadgat.so; returns the library path."""
+    """Compile the HIP kernels + C ABI into libmtadgat.so; returns the library path.
+    One hipcc per translation unit, run concurrently, then one link step."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[mtadgat] " + " ".join(cmd), file=sys.stderr)
+        procs.append((src, obj, subprocess.Popen(cmd)))
+    objs = []
+    for src, obj, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print("[mtadgat] " + " ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -1,0 +1,145 @@
+// Device-side helpers shared by the kernel translation units (everything is inline).
+// MI355X (gfx950 / CDNA4) kernels for the MTAD-GAT per-window forward path.
+//
+// Everything here is written for wave64 + the f32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fmaf chain) because the
+// contract is <= 1e-5 parity with the reference's float32 forward.
+//
+// One idea carries all GEMM-shaped work -- the "F-layout".  A wave owns 32 data
+// rows (windows, or (window, t) / (window, feature) pairs).  Feature vectors of
+// those rows live in registers as 8-wide chunks: for chunk q lane (i = lane&31,
+// g = lane>>5) holds the four features 8q+4g .. 8q+4g+3 of row i as a float4.
+// With the weights as the MFMA "A" operand (rows = output features) and the
+// activations as the "B" operand (columns = data rows), the MFMA k-step s of
+// chunk q multiplies weight column 8q+4g+s by activation feature 8q+4g+s, and
+// the 32x32 result tile comes out with lane (i, half) holding output features
+// 32n + 8m + 4*half + {0..3} in accumulator registers 4m..4m+3 -- i.e. again in
+// F-layout, chunk 4n+m.  So the output of one product is directly the "B"
+// operand of the next one: the GRU's hidden state never leaves the register
+// file between time steps, and no LDS transpose or barrier is needed.
+//
+// Weights are pre-packed on the host (mtadgat_pack.cpp) in exactly the order a
+// wave consumes them, so every weight fetch is one coalesced 1 KiB
+// global_load_dwordx4 per wave, served by the L2 (all packed weights of a model
+// are ~2 MB and stay resident).
+#ifndef MTADGAT_DEVICE_H
+#define MTADGAT_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "mtadgat_kernels.h"
+
+namespace mtadgat {
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma4(const f32x4 w, const f32x4 x, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], x[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], x[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[3], acc, 0, 0, 0);
+    return acc;
+}
+
+// one chunk for three gate accumulators, k-steps interleaved across the accumulators so consecutive
+// MFMAs never depend on each other
+__device__ __forceinline__ void mfma4x3(const f32x4 (&w)[3], const f32x4 x, f32x16& a0, f32x16& a1, f32x16& a2) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0][s], x[s], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1][s], x[s], a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2][s], x[s], a2, 0, 0, 0);
+    }
+}
+
+// four features k0..k0+3 of a row; zero beyond kvalid.  vec_ok: row base and k0 are 16-byte aligned
+__device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ row, int k0, int kvalid, bool vec_ok) {
+    f32x4 v;
+    if (vec_ok && k0 + 3 < kvalid) {
+        v = *reinterpret_cast<const f32x4*>(row + k0);
+    } else {
+        v[0] = (k0 + 0 < kvalid) ? row[k0 + 0] : 0.f;
+        v[1] = (k0 + 1 < kvalid) ? row[k0 + 1] : 0.f;
+        v[2] = (k0 + 2 < kvalid) ? row[k0 + 2] : 0.f;
+        v[3] = (k0 + 3 < kvalid) ? row[k0 + 3] : 0.f;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// GRU gate non-linearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each):
+// ~8 VALU ops per gate instead of ~40 for the libm versions; the product x*log2(e) is formed in
+// two pieces so the exponent keeps float accuracy for |x| up to ~40.
+#ifndef MTADGAT_ACCURATE_GATES
+__device__ __forceinline__ float exp_fast(float x) {   // e^x, argument clamped to [-88, 88] (no inf/NaN in, none out)
+    x = __builtin_amdgcn_fmed3f(x, -88.0f, 88.0f);
+    const float c_hi = 1.4426950216293335f;             // log2(e) rounded to float
+    const float c_lo = 1.9259629911266175e-08f;          // log2(e) - c_hi
+    const float hi = x * c_hi;
+    const float lo = __builtin_fmaf(x, c_hi, -hi) + x * c_lo;
+    return __builtin_amdgcn_exp2f(hi) * (1.0f + 0.6931471805599453f * lo);
+}
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(exp_fast(2.0f * x) + 1.0f); }
+__device__ __forceinline__ float soft_exp(float x) { return exp_fast(x); }
+__device__ __forceinline__ float soft_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+__device__ __forceinline__ float gate_sigmoid(float x) { return sigmoidf_(x); }
+__device__ __forceinline__ float gate_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ float soft_exp(float x) { return expf(x); }
+__device__ __forceinline__ float soft_rcp(float x) { return 1.0f / x; }
+#endif
+
+// compile-time loop (DPP controls must be immediates)
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+// value of lane N of this lane's 16-lane row (gfx90a+ DPP row_newbcast); folds into the consuming VALU op
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
+}
+
+// wave-wide all-reduce without LDS: butterfly inside each 16-lane row with DPP (fused into the
+// v_max / v_add), then the four row results meet through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_move<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_move<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_move<0x140>(v));   // row_mirror
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+#define LAUNCH_CHECK()                          \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+}  // namespace mtadgat
+#endif  // MTADGAT_DEVICE_H

@@ -1,0 +1,451 @@
+// k_gat: fused graph-attention layer, one workgroup per window + launcher
+#include "mtadgat_device.h"
+
+namespace mtadgat {
+
+// ---------------------------------------------------------------------------
+// gat (fused): one workgroup per window does the whole graph-attention layer -- projection,
+// pairwise scores, softmax, aggregation, sigmoid -- with the node features V, the projected L' and
+// R' never leaving the CU.  Same algebra and packed weights as k_rowgemm + k_attend (which remain
+// the path for node counts / dims whose tiles do not fit in LDS).
+//   LDS:  Ls [NWA*4*IBL][34]     L' columns of the current part, row-major (+ c when it is in the part)
+//         Rs [K][34]             R' columns of the current part, row-major (+ d)
+//         att[NWA][4*IBL][68]    softmax rows restaged for the aggregation MFMA (aliases Ls/Rs)
+//         Vs [Kp16][vld]         node feature rows of this window, zero padded rows / columns, column D = 1
+//                                (the projection bias is weight row D)
+// NWA = ceil(K / (4*IBL)) waves own query rows; a workgroup may have more waves than that (they only take
+// projection tiles).  The embedding is processed in parts of one 32-column tile per side: MFMA phase
+// (projection of the part into Ls/Rs, one 32-node tile per wave, weights requested a phase early) ->
+// barrier -> VALU phase -> barrier.  Several workgroups per CU are in different phases, so the matrix and
+// vector pipes overlap across workgroups.
+//
+// VALU phase = 2-D register blocking of the K x K pair grid.  A wave owns 4*IBL query rows; lane
+// (li = lane>>4, lj = lane&15) accumulates the IBL x JPL pairs {rows li + 4 ii} x {keys lj + 16 jj}.
+// Per 2 embedding columns it reads IBL + JPL 8-byte LDS words (its rows of L', its keys of R') for
+// 4*IBL*JPL VALU instructions -- v_add_f32 t, l, r; v_add_f32 acc, acc, |t| -- so the LDS feeds
+// ~0.17 floats per VALU op (lane-per-key with wave-uniform broadcast rows needed 0.28-0.53 and was
+// LDS-return bound), no lane is spent on padding beyond 16*JPL keys, and all addresses are
+// base + immediate.  The two register sets A/B alternate: the loads of the next column pair are in
+// flight while the current pair is consumed.  Row strides of 34 floats keep every ds_read_b64 wave
+// access conflict-free (16 distinct keys x 2 banks each cover 32 bank pairs).
+// ---------------------------------------------------------------------------
+typedef const __attribute__((address_space(3))) float* lds_cptr;      // explicit LDS pointer (32-bit)
+constexpr int GAT_LLD = 34;     // 32 columns + 2: rows 8-byte aligned, 16 consecutive rows start on 16 distinct bank pairs
+constexpr int GAT_APITCH = 68;
+
+// lp[ii]: one base pointer per query row.  The pointers are made opaque to the compiler on purpose:
+// with a common base it merges row pairs into ds_read2_b64, which runs at half the LDS rate of two
+// ds_read_b64 (MI355X: 8 vs 2 x 2 LDS cycles per wave instruction).
+template <int IBL, int JPL>
+__device__ __forceinline__ void gat_load(f32x2 (&l)[IBL], f32x2 (&r)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp, int col) {
+    typedef const __attribute__((address_space(3))) f32x2* lds_c2;
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) l[ii] = *(lds_c2)(lp[ii] + col);
+#pragma unroll
+    for (int jj = 0; jj < JPL; ++jj) r[jj] = *(lds_c2)(rp + jj * 16 * GAT_LLD + col);
+}
+
+// The two instructions per pair are written as (volatile) inline asm: left to itself the compiler packs
+// the column pair into v_pk_add_f32 (no faster) and schedules all sums of a step
+// ahead of their uses, which costs > 100 VGPRs of temporaries and spills the accumulators.
+template <int IBL, int JPL, bool NEG>
+__device__ __forceinline__ void gat_step(float (&acc)[IBL][JPL], const f32x2 (&l)[IBL], const f32x2 (&r)[JPL]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            float t[JPL];
+            const float lv = l[ii][e];
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const float rv = r[jj][e];
+                asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(t[jj]) : "v"(lv), "v"(rv));
+            }
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                if (NEG)
+                    asm volatile("v_sub_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t[jj]));
+                else
+                    asm volatile("v_add_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t[jj]));
+            }
+        }
+}
+
+// one 8-column k tile; on entry set A holds columns 0,1 of the tile (loads possibly still in flight),
+// on exit it holds columns 0,1 of the next tile (pad columns past the end of a part: never consumed)
+template <int IBL, int JPL, bool NEG>
+__device__ __forceinline__ void gat_tile(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], f32x2 (&lB)[IBL],
+                                         f32x2 (&rB)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
+    gat_load<IBL, JPL>(lB, rB, lp, rp, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lA, rA);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL>(lA, rA, lp, rp, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lB, rB);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL>(lB, rB, lp, rp, 6);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lA, rA);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL>(lA, rA, lp, rp, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step<IBL, JPL, NEG>(acc, lB, rB);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// all-reduce over the 16 lanes of a DPP row
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    return fmaxf(v, dpp_move<0x140>(v));
+}
+__device__ __forceinline__ float row_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v + dpp_move<0x140>(v);
+}
+
+template <int IBL, int JPL>
+__global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int IBW = 4 * IBL;                       // query rows per wave
+    constexpr int QB = 8;                              // weight chunks held in registers per task batch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const long win = blockIdx.x;
+    const int K = a.K, D = a.D, PT = a.PT;
+    const int vld = a.vld;
+    const int Kp16 = (K + 15) & ~15;                   // rows of Vs: real nodes then zero rows
+    const int NWA = (K + IBW - 1) / IBW;               // waves that own query rows (the rest only project)
+    float* __restrict__ Ls = smem;
+    float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;     // K rows; lanes whose keys are >= K read on into Vs (never used)
+    float* __restrict__ Vs = smem + a.lr_floats;
+    const int i = lane & 31, g = lane >> 5;            // MFMA roles
+    const int lj = lane & 15, li = lane >> 4;          // pair-grid roles
+
+    const int NTn = (K + 31) >> 5;                    // node tiles
+    const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
+    const int Q = a.Q;
+    const int ptile = a.P8 >> 3, ntile = PT >> 3;
+    const int nparts = (PT >> 5) + 1;                 // the part holding column PT (c, d) is the last one with content
+
+    // The weights of this wave's first task of a part are requested one phase early -- before the barrier
+    // that ends the previous VALU phase, for part 0 before the window is staged -- so the L2 round trip is
+    // not on the critical path of the MFMA phase.  (The projection bias is row D of the packed weights,
+    // multiplied by a constant-one column of Vs: no separate bias loads.)
+    f32x4 w[QB];
+    auto prefetch = [&](int part) {
+        if (wave < ntask) {
+            const int wtile = wave >= NTn ? a.NT_L + part : part;
+            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < QB; ++u) w[u] = wp[(long)(u < Q ? u : Q - 1) * 64];
+        }
+    };
+
+    // ---- stage the window's node rows (coalesced global reads), zero the padding rows / columns, set
+    // the ones column D.  vt == 0: node rows are source rows (temporal layer: V = xc).  vt == 1: nodes
+    // are the source's columns (feature layer: V = xc^T), transposed on the way into LDS.  All global
+    // loads of a thread are issued before the first LDS store: one memory round trip per window, not one
+    // per loop iteration.
+    {
+        const int nthr = blockDim.x;
+        const int srows = a.vt ? D : K, scols = a.vt ? K : D;          // valid extent of the source block
+        const int prow = a.vt ? vld : Kp16, pcol = a.vt ? Kp16 : vld;   // extent incl. the padding that must be written
+        if ((a.ldv & 3) == 0 && ((scols + 3) & ~3) <= a.ldv) {
+            // unit u = one float4 of a source row: row = u / p4 (exact through the float reciprocal: the
+            // fractional part of (u + 0.5) / p4 stays >= 0.5 / p4 away from an integer).  Few, wide load
+            // instructions: the cost of this phase is per load instruction, not per byte.
+            const float* __restrict__ vsrc = a.V + win * (long)srows * a.ldv;
+            constexpr int MAXU = 8;
+            const int p4 = pcol >> 2, total = prow * p4;
+            const float rinv = 1.0f / (float)p4;
+            const int c4last = ((scols - 1) >> 2) << 2;
+            f32x4 v[MAXU];
+            int rr[MAXU], cc[MAXU];
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n) {
+                const int u = tid + n * nthr;
+                const int row = (int)(((float)u + 0.5f) * rinv), c4 = (u - row * p4) * 4;
+                rr[n] = u < total ? row : -1;
+                cc[n] = c4;
+                // unconditional load from a clamped (always valid) address, masked below: a guarded load
+                // becomes a branch with s_waitcnt vmcnt(0) at the join, i.e. one round trip per unit
+                const int rc = row < srows ? row : srows - 1, cl = c4 < scols ? c4 : c4last;
+                v[n] = *reinterpret_cast<const f32x4*>(vsrc + (long)rc * a.ldv + cl);
+            }
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n) {
+                const int row = rr[n], c4 = cc[n];
+                if (row >= 0) {
+                    f32x4 t = v[n];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int node = a.vt ? c4 + s4 : row, col = a.vt ? row : c4 + s4;
+                        t[s4] = (node < K && col < D) ? t[s4] : ((node < K && col == D) ? 1.f : 0.f);
+                    }
+                    if (!a.vt) {
+                        *reinterpret_cast<f32x4*>(Vs + row * vld + c4) = t;
+                    } else {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) Vs[(c4 + s4) * vld + row] = t[s4];
+                    }
+                }
+            }
+            for (int u = tid + MAXU * nthr; u < total; u += nthr) {     // shapes beyond the register batch
+                const int row = u / p4, c4 = (u - row * p4) * 4;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int node = a.vt ? c4 + s4 : row, col = a.vt ? row : c4 + s4;
+                    const float t = (node < K && col < D) ? vsrc[(long)row * a.ldv + c4 + s4] : ((node < K && col == D) ? 1.f : 0.f);
+                    Vs[node * vld + col] = t;
+                }
+            }
+        } else {
+            // unaligned caller tensor (stage entry point mtadgat_gat)
+            const float* __restrict__ vsrc = a.V + win * (long)srows * a.ldv;
+            for (int u = tid; u < Kp16 * vld; u += nthr) {
+                const int node = u / vld, col = u - node * vld;
+                float t = 0.f;
+                if (node < K && col < D) t = a.vt ? vsrc[(long)col * a.ldv + node] : vsrc[(long)node * a.ldv + col];
+                Vs[u] = (node < K && col == D) ? 1.f : t;
+            }
+        }
+    }
+    prefetch(0);
+    __syncthreads();
+
+    const bool rows_owner = wave < NWA;
+    const int i0 = (rows_owner ? wave : 0) * IBW;
+    lds_cptr lp[IBL];                                            // this lane's rows: i0 + li + 4 ii
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        lp[ii] = (lds_cptr)(Ls + (i0 + li + 4 * ii) * GAT_LLD);
+        asm volatile("" : "+v"(lp[ii]));
+    }
+    const lds_cptr rp = (lds_cptr)(Rs + lj * GAT_LLD);           // this lane's keys: lj + 16 jj
+    float acc[IBL][JPL];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = 0.f;
+
+    for (int part = 0; part < nparts; ++part) {
+        // ---- MFMA phase: project this part's 32 + 32 columns for all nodes into Ls / Rs
+        for (int task = wave; task < ntask; task += NW) {
+            const bool keyside = task >= NTn;
+            const int nt = keyside ? task - NTn : task;
+            const int wtile = keyside ? a.NT_L + part : part;
+            const int node = nt * 32 + i;
+            const float* __restrict__ vrow = Vs + (node < K ? node : K - 1) * vld;
+            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+            if (task != wave) {                    // more tiles than waves: later tasks pay their own round trip
+#pragma unroll
+                for (int u = 0; u < QB; ++u) w[u] = wp[(long)(u < Q ? u : Q - 1) * 64];
+            }
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            for (int qb = 0; qb < Q; qb += QB) {
+#pragma unroll
+                for (int u = 0; u < QB; ++u)
+                    if (qb + u < Q) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * (qb + u) + 4 * g);
+                        o = mfma4(w[u], xv, o);
+                        // the chunk QB further on replaces this one as soon as it has been issued
+                        if (qb + QB + u < Q) w[u] = wp[(long)(qb + QB + u) * 64];
+                    }
+            }
+            if (node < K) {
+                float* __restrict__ dst = (keyside ? Rs : Ls) + node * GAT_LLD + 4 * g;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x2 v0, v1;
+                    v0[0] = o[4 * m + 0]; v0[1] = o[4 * m + 1]; v1[0] = o[4 * m + 2]; v1[1] = o[4 * m + 3];
+                    *reinterpret_cast<f32x2*>(dst + 8 * m) = v0;
+                    *reinterpret_cast<f32x2*>(dst + 8 * m + 2) = v1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
+        int ntl = ntile - 4 * part;
+        ntl = ntl > 4 ? 4 : ntl;
+        if (ntl > 0 && rows_owner) {
+            f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
+            lds_cptr lq[IBL];
+#pragma unroll
+            for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
+            lds_cptr rq = rp;
+            gat_load<IBL, JPL>(lA, rA, lq, rq, 0);
+            int npos = ptile - 4 * part;
+            npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
+            int kt = 0;
+            // two back-to-back loops rather than a sign branch inside one: with the diamond the compiler
+            // keeps two register copies of the accumulators (and spills)
+#pragma unroll 1
+            for (; kt < npos; ++kt) {
+                gat_tile<IBL, JPL, false>(acc, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                rq += 8;
+            }
+#pragma unroll 1
+            for (; kt < ntl; ++kt) {
+                gat_tile<IBL, JPL, true>(acc, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                rq += 8;
+            }
+        }
+        if (part + 1 < nparts) {
+            prefetch(part + 1);
+            __syncthreads();
+        }
+    }
+    // rank-1 terms c_i (query column PT) and d_j (key column PT) sit in the last part
+    float cv[IBL], dv[JPL];
+    {
+        const int col = PT & 31;
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) cv[ii] = lp[ii][col];
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * 16 * GAT_LLD + col];
+    }
+    __syncthreads();
+    if (!rows_owner) return;                           // no barrier below this point
+
+    // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); a query row lives in
+    // the 16 lanes of one DPP row (x JPL registers), so the reductions are row-local DPP butterflies
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        const int irow = i0 + li + 4 * ii;
+        const int irc = irow < K ? irow : K - 1;
+        float e[JPL];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            const int j = lj + 16 * jj;
+            const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
+            float v = acc[ii][jj] + cv[ii] + dv[jj];
+            if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
+            v += b;
+            v = j < K ? v : -INFINITY;
+            e[jj] = v;
+            m = fmaxf(m, v);
+        }
+        m = row_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            e[jj] = (lj + 16 * jj < K) ? soft_exp(e[jj] - m) : 0.f;
+            sum += e[jj];
+        }
+        sum = row_sum(sum);
+        const float inv = soft_rcp(sum);
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = irow < K ? e[jj] * inv : 0.f;
+    }
+
+    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) on the matrix pipe, as out^T = V^T att^T with
+    // v_mfma_f32_16x16x4_f32 (M = 16 output features, N = this wave's 16 query rows, 4 keys per
+    // instruction): no padding to 32 rows, and each lane ends up with 4 consecutive features of one row.
+    // att is restaged, 64 keys at a time, through this wave's slice of the (now free) Ls/Rs region.
+    //   B operand: lane (n = lane&15, kb = lane>>4) = att[row n][key 4 kb + t]   (16-byte LDS read = 4 steps t)
+    //   A operand: lane (m = lane&15, kb)           = V[key 4 kb + t][16 dt + m]
+    //   D: register r of lane (n, mb = lane>>4)     = out[row n][16 dt + 4 mb + r]
+    static_assert(IBL == 4, "one 16-row MFMA group per wave");
+    constexpr int DTMAX = 8;                           // D <= 128 (plan)
+    float* __restrict__ att = Ls + wave * (IBW * GAT_APITCH);
+    const int DT = (D + 15) >> 4;
+    const int nr = lane & 15, kb = lane >> 4;
+    constexpr int PASSES = (JPL + 3) / 4;
+    f32x4 o[DTMAX];
+#pragma unroll
+    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int dcol[DTMAX];
+#pragma unroll
+    for (int dt = 0; dt < DTMAX; ++dt) {
+        const int d = 16 * dt + nr;
+        dcol[dt] = d < vld ? d : vld - 1;              // columns > D of Vs are zero
+    }
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass * 64 < K) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4)
+                    if (4 * pass + j4 < JPL) att[(li + 4 * ii) * GAT_APITCH + lj + 16 * j4] = acc[ii][4 * pass + j4];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int jn = min(64, K - pass * 64);
+            const int ngrp = (jn + 15) >> 4;                   // rows < Kp16 of Vs: real or zero
+            for (int grp = 0; grp < ngrp; ++grp) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 16 * grp + 4 * kb);
+                const float* __restrict__ vk = Vs + (pass * 64 + 16 * grp + 4 * kb) * vld;
+#pragma unroll
+                for (int dt = 0; dt < DTMAX; ++dt)
+                    if (dt < DT) {
+                        float av[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) av[t] = vk[t * vld + dcol[dt]];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bq[t], o[dt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    {
+        const int row = i0 + nr;
+        float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
+#pragma unroll
+        for (int dt = 0; dt < DTMAX; ++dt)
+            if (dt < DT) {
+                const int d0 = 16 * dt + 4 * kb;
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[dt][r]);
+                if (a.so_d == 1 && row < K && d0 + 3 < D) {
+                    // 4 consecutive features of one row: one 16-byte store (dword aligned is enough for global memory)
+                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row < K && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
+                }
+            }
+    }
+}
+
+#define GAT_CASE(I, J)                                                                          \
+    if (IBL == I && JPL == J) {                                                                 \
+        if (lds_bytes > 64 * 1024) {                                                            \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat<I, J>),    \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e_ != hipSuccess) return (int)e_;                                               \
+        }                                                                                       \
+        hipLaunchKernelGGL((k_gat<I, J>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);          \
+        launched = true;                                                                        \
+    }
+
+// IBL: query rows per lane (a wave owns 4*IBL rows), JPL: key nodes per lane (16*JPL >= K), nw waves
+int launch_gat(const GatArgs& a, int IBL, int JPL, int nw, size_t lds_bytes, hipStream_t s) {
+    if (a.nwin <= 0) return 0;
+    if (16 * JPL < a.K || nw * 4 * IBL < a.K || nw > 8) return -2;     // nw may exceed the row-owning waves: the rest only project
+    const unsigned grid = (unsigned)a.nwin;
+    bool launched = false;
+    GAT_CASE(4, 1) GAT_CASE(4, 2) GAT_CASE(4, 3) GAT_CASE(4, 4) GAT_CASE(4, 5) GAT_CASE(4, 6) GAT_CASE(4, 7) GAT_CASE(4, 8)
+    if (!launched) return -2;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mtadgat
