@@ -4,7 +4,7 @@
 namespace mtadgat {
 
 // ---------------------------------------------------------------------------
-// GRU: 32 windows per wave, hidden state resident in registers in F-layout for
+// GRU: 32 (MW = 1) or 64 (MW = 2) windows per wave, hidden state resident in registers in F-layout for
 // all T steps; W_ih / W_hh streamed from L2 in packed order; gates r|z|n as
 // torch.nn.GRU (reference GRULayer.forward modules.py:235-238, RNNDecoder
 // modules.py:255-257).  Optional per-step Linear on the new hidden state
@@ -25,7 +25,7 @@ namespace mtadgat {
 // (With guarded loads it fell back to vmcnt(0..2) before every MFMA group: 79k instead of 31k cycles
 // per hidden tile and step.)
 // MW = 32-window groups per wave.  MW = 2 with one wave per SIMD beats two MW = 1 waves per SIMD (matrix
-// pipe 87 % vs 82 % busy on the GRU layer): the MFMAs of one wave issue back to back, interleaving two
+// pipe 85 % vs 82 % busy on the GRU layer, 74 % vs 69 % on the decoder): the MFMAs of one wave issue back to back, interleaving two
 // waves leaves bubbles; each weight chunk is also fetched once for 64 windows.
 template <int NCG, int XMODE, bool FC, int DROP, int MW>
 __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
