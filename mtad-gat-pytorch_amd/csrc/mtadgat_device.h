@@ -75,8 +75,8 @@ __device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ row, int k
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // GRU gate non-linearities on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each):
-// ~8 VALU ops per gate instead of ~40 for the libm versions; the product x*log2(e) is formed in
-// two pieces so the exponent keeps float accuracy for |x| up to ~40.
+// a handful of VALU ops instead of ~40 for the libm versions.  exp_fast (softmax, output sigmoid) forms the
+// product x*log2(e) in two pieces so the exponent keeps float accuracy for |x| up to ~40.
 #ifndef MTADGAT_ACCURATE_GATES
 __device__ __forceinline__ float exp_fast(float x) {   // e^x, argument clamped to [-88, 88] (no inf/NaN in, none out)
     x = __builtin_amdgcn_fmed3f(x, -88.0f, 88.0f);
@@ -86,8 +86,17 @@ __device__ __forceinline__ float exp_fast(float x) {   // e^x, argument clamped 
     const float lo = __builtin_fmaf(x, c_hi, -hi) + x * c_lo;
     return __builtin_amdgcn_exp2f(hi) * (1.0f + 0.6931471805599453f * lo);
 }
-__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
-__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(exp_fast(2.0f * x) + 1.0f); }
+// Gates: the one-piece product x*log2(e) is enough.  Its rounding error (|x| * 1.44 * 2^-24 relative in e^x)
+// is multiplied by sigma(1 - sigma) resp. (1 - tanh^2), which decay faster than |x| grows: the result moves by
+// < 2e-8 (sigmoid) / < 4e-8 (tanh), below the fp32 spacing of the gate values themselves.  5-6 VALU ops per gate.
+__device__ __forceinline__ float gate_sigmoid(float x) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -60.0f, 60.0f) * -1.4426950408889634f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float gate_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(x, -30.0f, 30.0f) * 2.8853900817779268f);
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
 __device__ __forceinline__ float soft_exp(float x) { return exp_fast(x); }
 __device__ __forceinline__ float soft_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #else

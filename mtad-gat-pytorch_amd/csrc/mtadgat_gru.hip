@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
                     const float rg = gate_sigmoid(ar[w][r]);
                     const float zg = gate_sigmoid(az[w][r]);
                     const float ng = gate_tanh(anx[w][r] + rg * anh[w][r]);
-                    ar[w][r] = (1.0f - zg) * ng + zg * hold;
+                    ar[w][r] = __builtin_fmaf(zg, hold - ng, ng);          // (1 - z) n + z h
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hn_s[w][c][r][lane] = ar[w][r];
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
             const float rg = gate_sigmoid(ar[r]);
             const float zg = gate_sigmoid(az[r]);
             const float ng = gate_tanh(anx[r] + rg * anh[r]);
-            hown[r] = (1.0f - zg) * ng + zg * hown[r];
+            hown[r] = __builtin_fmaf(zg, hown[r] - ng, ng);       // (1 - z) n + z h
         }
         f32x4 hvv[4];
 #pragma unroll
