@@ -269,6 +269,19 @@ int mtadgat_create(const mtadgat_config* cfg, mtadgat_handle* out) {
         delete h;
         return fail(MTADGAT_ERR_UNSUPPORTED, err);
     }
+    // default chunk: up to 65 536 windows, fewer when a window needs a lot of scratch (wide models on the
+    // un-fused attention path: ~8 MB per window at F=512, W=256), so that the workspace stays within a
+    // quarter of the device memory (16 GB when no device can be queried)
+    {
+        Workspace o;
+        plan_workspace(h->m, 1024, o);
+        const double per_window = (double)o.total * sizeof(float) / 1024.0;
+        size_t free_b = 0, total_b = 0;
+        const double budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) ? (double)total_b / 4 : 16.0 * 1024 * 1024 * 1024;
+        int64_t c = (int64_t)(budget / per_window);
+        c = c / 2048 * 2048;
+        h->m.chunk = c < 2048 ? 2048 : (c > 65536 ? 65536 : c);
+    }
     *out = h;
     return 0;
 }
