@@ -138,7 +138,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     a.nwin = n;
     a.v1 = m.cfg.use_gatv2 ? 0 : 1;
     a.alpha = m.cfg.alpha;
-    K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_nw, g.f_lds_bytes, s), "fused gat");
+    K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.f_lds_bytes, s), "fused gat");
     return 0;
 }
 

@@ -20,7 +20,8 @@ namespace mtadgat {
 // vector pipes overlap across workgroups.
 //
 // VALU phase = 2-D register blocking of the K x K pair grid.  A wave owns 4*IBL query rows; lane
-// (li = lane>>4, lj = lane&15) accumulates the IBL x JPL pairs {rows li + 4 ii} x {keys lj + 16 jj}.
+// (li = lane / RJ, lj = lane % RJ; RJ = 16, RI = 4 in the numbers below) accumulates the IBL x JPL pairs
+// {rows li + RI ii} x {keys lj + RJ jj}.
 // Per 2 embedding columns it reads IBL + JPL 8-byte LDS words (its rows of L', its keys of R') for
 // 4*IBL*JPL VALU instructions -- v_add_f32 t, l, r; v_add_f32 acc, acc, |t| -- so the LDS feeds
 // ~0.17 floats per VALU op (lane-per-key with wave-uniform broadcast rows needed 0.28-0.53 and was
@@ -36,13 +37,13 @@ constexpr int GAT_APITCH = 68;
 // lp[ii]: one base pointer per query row.  The pointers are made opaque to the compiler on purpose:
 // with a common base it merges row pairs into ds_read2_b64, which runs at half the LDS rate of two
 // ds_read_b64 (MI355X: 8 vs 2 x 2 LDS cycles per wave instruction).
-template <int IBL, int JPL>
+template <int IBL, int JPL, int RJ>
 __device__ __forceinline__ void gat_load(f32x2 (&l)[IBL], f32x2 (&r)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp, int col) {
     typedef const __attribute__((address_space(3))) f32x2* lds_c2;
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) l[ii] = *(lds_c2)(lp[ii] + col);
 #pragma unroll
-    for (int jj = 0; jj < JPL; ++jj) r[jj] = *(lds_c2)(rp + jj * 16 * GAT_LLD + col);
+    for (int jj = 0; jj < JPL; ++jj) r[jj] = *(lds_c2)(rp + jj * RJ * GAT_LLD + col);
 }
 
 // The two instructions per pair are written as (volatile) inline asm: left to itself the compiler packs
@@ -73,45 +74,52 @@ __device__ __forceinline__ void gat_step(float (&acc)[IBL][JPL], const f32x2 (&l
 
 // one 8-column k tile; on entry set A holds columns 0,1 of the tile (loads possibly still in flight),
 // on exit it holds columns 0,1 of the next tile (pad columns past the end of a part: never consumed)
-template <int IBL, int JPL, bool NEG>
+template <int IBL, int JPL, int RJ, bool NEG>
 __device__ __forceinline__ void gat_tile(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], f32x2 (&lB)[IBL],
                                          f32x2 (&rB)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
-    gat_load<IBL, JPL>(lB, rB, lp, rp, 2);
+    gat_load<IBL, JPL, RJ>(lB, rB, lp, rp, 2);
     __builtin_amdgcn_sched_barrier(0);
     gat_step<IBL, JPL, NEG>(acc, lA, rA);
     __builtin_amdgcn_sched_barrier(0);
-    gat_load<IBL, JPL>(lA, rA, lp, rp, 4);
+    gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 4);
     __builtin_amdgcn_sched_barrier(0);
     gat_step<IBL, JPL, NEG>(acc, lB, rB);
     __builtin_amdgcn_sched_barrier(0);
-    gat_load<IBL, JPL>(lB, rB, lp, rp, 6);
+    gat_load<IBL, JPL, RJ>(lB, rB, lp, rp, 6);
     __builtin_amdgcn_sched_barrier(0);
     gat_step<IBL, JPL, NEG>(acc, lA, rA);
     __builtin_amdgcn_sched_barrier(0);
-    gat_load<IBL, JPL>(lA, rA, lp, rp, 8);
+    gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 8);
     __builtin_amdgcn_sched_barrier(0);
     gat_step<IBL, JPL, NEG>(acc, lB, rB);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// all-reduce over the 16 lanes of a DPP row
+// all-reduce over the RJ (16 or 8) adjacent lanes that hold one query row
+template <int RJ>
 __device__ __forceinline__ float row_max(float v) {
     v = fmaxf(v, dpp_move<0xB1>(v));
     v = fmaxf(v, dpp_move<0x4E>(v));
     v = fmaxf(v, dpp_move<0x141>(v));
-    return fmaxf(v, dpp_move<0x140>(v));
+    if (RJ == 16) v = fmaxf(v, dpp_move<0x140>(v));
+    return v;
 }
+template <int RJ>
 __device__ __forceinline__ float row_sum(float v) {
     v += dpp_move<0xB1>(v);
     v += dpp_move<0x4E>(v);
     v += dpp_move<0x141>(v);
-    return v + dpp_move<0x140>(v);
+    if (RJ == 16) v += dpp_move<0x140>(v);
+    return v;
 }
 
-template <int IBL, int JPL>
+// RJ = lanes along the key axis (16, or 8 when that pads K less: 55 features -> 56 instead of 64 keys);
+// RI = 64 / RJ lanes along the row axis; a wave owns RI*IBL = 16 query rows either way.
+template <int IBL, int JPL, int RJ>
 __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int IBW = 4 * IBL;                       // query rows per wave
+    constexpr int RI = 64 / RJ;
+    constexpr int IBW = RI * IBL;                      // query rows per wave
     constexpr int QB = 8;                              // weight chunks held in registers per task batch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;     // K rows; lanes whose keys are >= K read on into Vs (never used)
     float* __restrict__ Vs = smem + a.lr_floats;
     const int i = lane & 31, g = lane >> 5;            // MFMA roles
-    const int lj = lane & 15, li = lane >> 4;          // pair-grid roles
+    const int lj = lane % RJ, li = lane / RJ;          // pair-grid roles
 
     const int NTn = (K + 31) >> 5;                    // node tiles
     const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     lds_cptr lp[IBL];                                            // this lane's rows: i0 + li + 4 ii
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) {
-        lp[ii] = (lds_cptr)(Ls + (i0 + li + 4 * ii) * GAT_LLD);
+        lp[ii] = (lds_cptr)(Ls + (i0 + li + RI * ii) * GAT_LLD);
         asm volatile("" : "+v"(lp[ii]));
     }
     const lds_cptr rp = (lds_cptr)(Rs + lj * GAT_LLD);           // this lane's keys: lj + 16 jj
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 #pragma unroll
             for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
             lds_cptr rq = rp;
-            gat_load<IBL, JPL>(lA, rA, lq, rq, 0);
+            gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
             int npos = ptile - 4 * part;
             npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
             int kt = 0;
@@ -289,14 +297,14 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
             // keeps two register copies of the accumulators (and spills)
 #pragma unroll 1
             for (; kt < npos; ++kt) {
-                gat_tile<IBL, JPL, false>(acc, lA, rA, lB, rB, lq, rq);
+                gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                 rq += 8;
             }
 #pragma unroll 1
             for (; kt < ntl; ++kt) {
-                gat_tile<IBL, JPL, true>(acc, lA, rA, lB, rB, lq, rq);
+                gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                 rq += 8;
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 #pragma unroll
         for (int ii = 0; ii < IBL; ++ii) cv[ii] = lp[ii][col];
 #pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * 16 * GAT_LLD + col];
+        for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * RJ * GAT_LLD + col];
     }
     __syncthreads();
     if (!rows_owner) return;                           // no barrier below this point
@@ -323,13 +331,13 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     // the 16 lanes of one DPP row (x JPL registers), so the reductions are row-local DPP butterflies
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) {
-        const int irow = i0 + li + 4 * ii;
+        const int irow = i0 + li + RI * ii;
         const int irc = irow < K ? irow : K - 1;
         float e[JPL];
         float m = -INFINITY;
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
-            const int j = lj + 16 * jj;
+            const int j = lj + RJ * jj;
             const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
             float v = acc[ii][jj] + cv[ii] + dv[jj];
             if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
@@ -338,14 +346,14 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
             e[jj] = v;
             m = fmaxf(m, v);
         }
-        m = row_max(m);
+        m = row_max<RJ>(m);
         float sum = 0.f;
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
-            e[jj] = (lj + 16 * jj < K) ? soft_exp(e[jj] - m) : 0.f;
+            e[jj] = (lj + RJ * jj < K) ? soft_exp(e[jj] - m) : 0.f;
             sum += e[jj];
         }
-        sum = row_sum(sum);
+        sum = row_sum<RJ>(sum);
         const float inv = soft_rcp(sum);
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = irow < K ? e[jj] * inv : 0.f;
@@ -358,12 +366,13 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     //   B operand: lane (n = lane&15, kb = lane>>4) = att[row n][key 4 kb + t]   (16-byte LDS read = 4 steps t)
     //   A operand: lane (m = lane&15, kb)           = V[key 4 kb + t][16 dt + m]
     //   D: register r of lane (n, mb = lane>>4)     = out[row n][16 dt + 4 mb + r]
-    static_assert(IBL == 4, "one 16-row MFMA group per wave");
+    static_assert(IBW == 16, "one 16-row MFMA group per wave");
     constexpr int DTMAX = 8;                           // D <= 128 (plan)
     float* __restrict__ att = Ls + wave * (IBW * GAT_APITCH);
     const int DT = (D + 15) >> 4;
     const int nr = lane & 15, kb = lane >> 4;
-    constexpr int PASSES = (JPL + 3) / 4;
+    constexpr int JPP = 64 / RJ;                       // key registers per 64-key pass
+    constexpr int PASSES = (JPL + JPP - 1) / JPP;
     f32x4 o[DTMAX];
 #pragma unroll
     for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -381,8 +390,8 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 #pragma unroll
             for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4)
-                    if (4 * pass + j4 < JPL) att[(li + 4 * ii) * GAT_APITCH + lj + 16 * j4] = acc[ii][4 * pass + j4];
+                for (int j4 = 0; j4 < JPP; ++j4)
+                    if (JPP * pass + j4 < JPL) att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = acc[ii][JPP * pass + j4];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const int jn = min(64, K - pass * 64);
@@ -425,24 +434,26 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     }
 }
 
-#define GAT_CASE(I, J)                                                                          \
-    if (IBL == I && JPL == J) {                                                                 \
+#define GAT_CASE(I, J, RJ)                                                                      \
+    if (IBL == I && JPL == J && rj == RJ) {                                                     \
         if (lds_bytes > 64 * 1024) {                                                            \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat<I, J>),    \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat<I, J, RJ>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e_ != hipSuccess) return (int)e_;                                               \
         }                                                                                       \
-        hipLaunchKernelGGL((k_gat<I, J>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);          \
+        hipLaunchKernelGGL((k_gat<I, J, RJ>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);      \
         launched = true;                                                                        \
     }
 
-// IBL: query rows per lane (a wave owns 4*IBL rows), JPL: key nodes per lane (16*JPL >= K), nw waves
-int launch_gat(const GatArgs& a, int IBL, int JPL, int nw, size_t lds_bytes, hipStream_t s) {
+// rj lanes along the key axis (16 or 8), IBL query rows per lane (a wave owns (64/rj)*IBL = 16 rows), JPL key
+// nodes per lane (rj*JPL >= K), nw waves
+int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
     if (a.nwin <= 0) return 0;
-    if (16 * JPL < a.K || nw * 4 * IBL < a.K || nw > 8) return -2;     // nw may exceed the row-owning waves: the rest only project
+    if (rj * JPL < a.K || nw * 16 < a.K || nw > 8) return -2;     // nw may exceed the row-owning waves: the rest only project
     const unsigned grid = (unsigned)a.nwin;
     bool launched = false;
-    GAT_CASE(4, 1) GAT_CASE(4, 2) GAT_CASE(4, 3) GAT_CASE(4, 4) GAT_CASE(4, 5) GAT_CASE(4, 6) GAT_CASE(4, 7) GAT_CASE(4, 8)
+    GAT_CASE(4, 1, 16) GAT_CASE(4, 2, 16) GAT_CASE(4, 3, 16) GAT_CASE(4, 4, 16) GAT_CASE(4, 5, 16) GAT_CASE(4, 6, 16) GAT_CASE(4, 7, 16) GAT_CASE(4, 8, 16)
+    GAT_CASE(2, 1, 8) GAT_CASE(2, 3, 8) GAT_CASE(2, 5, 8) GAT_CASE(2, 7, 8)
     if (!launched) return -2;
     LAUNCH_CHECK();
     return 0;

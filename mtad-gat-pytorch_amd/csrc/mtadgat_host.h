@@ -28,7 +28,7 @@ struct GatPlan {
     int rows_per_blk = 0, nblk = 0, IB = 0;      // attend launch plan (un-fused path)
     // fused per-window kernel (k_gat) plan; fused == false -> k_rowgemm + k_attend through HBM
     bool fused = false;
-    int f_nw = 0, f_IBL = 0, f_JPL = 0, f_vld = 0, f_lr = 0;
+    int f_nw = 0, f_IBL = 0, f_JPL = 0, f_RJ = 16, f_vld = 0, f_lr = 0;
     size_t f_lds_bytes = 0;
 };
 

@@ -98,7 +98,9 @@ std::string validate_and_plan(Model& m) {
             const size_t lr = round_up((int)std::max((size_t)(rows + K) * 34, (size_t)rows * 68), 4);
             const size_t bytes = ((size_t)round_up(K, 16) * vld + lr) * sizeof(float);
             if (bytes <= 80 * 1024) {
-                g.fused = true; g.f_nw = nw; g.f_IBL = ibl; g.f_JPL = (K + 15) / 16; g.f_vld = vld; g.f_lr = (int)lr;
+                g.fused = true; g.f_nw = nw; g.f_IBL = ibl; g.f_JPL = (K + 15) / 16; g.f_RJ = 16; g.f_vld = vld; g.f_lr = (int)lr;
+                // 8 lanes along the key axis when that pads the keys less (K = 55: 56 instead of 64)
+                if (K <= 56 && ((K + 7) / 8) % 2 == 1) { g.f_RJ = 8; g.f_IBL = 2; g.f_JPL = (K + 7) / 8; }
                 g.f_lds_bytes = bytes;
                 g.Q = qf;
             }
