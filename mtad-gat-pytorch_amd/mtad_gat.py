@@ -291,3 +291,26 @@ class MTAD_GAT(nn.Module):
         with torch.no_grad():
             p, _, last = eng.forward_series(values.contiguous().float(), None, 0, 1, n + 1, want_recons=False, want_last=True)
         return p[:n], last[1:n + 1]
+
+    def anomaly_scores(self, values, target_dims=None, gamma=1.0, scale_scores=False):
+        """The per-timestamp anomaly score of `Predictor.get_score` (reference prediction.py:65-91) for a
+        whole series (N, F), computed on the device from `score_series`:
+            a_i[d] = |y_hat_i[d] - x_{i+W}[d]| + gamma * |recon_i[d] - x_{i+W}[d]|
+        (the reference writes sqrt((.)**2)), optionally (a - median) / (1 + IQR) per dimension
+        (`scale_scores`), then the mean over the target dimensions.  target_dims as in the reference
+        (`utils.get_target_dims`): None = all features, an int or a list of column indices.
+        Returns (scores (N-W,), per-dimension scores (N-W, out_dim)), both on the device.
+        Thresholding (epsilon / POT / brute force, eval_methods.py) stays the reference's numpy code: it is
+        O(N) on a 1-D array."""
+        preds, recons = self.score_series(values)
+        actual = values[self.window_size:].float()
+        if target_dims is not None:
+            dims = [target_dims] if isinstance(target_dims, int) else list(target_dims)
+            actual = actual[:, dims]
+        if actual.shape[1] != preds.shape[1]:
+            raise RuntimeError(f"target_dims select {actual.shape[1]} columns but the model has out_dim={preds.shape[1]}")
+        a = (preds - actual).abs() + gamma * (recons - actual).abs()
+        if scale_scores:
+            q = torch.quantile(a, torch.tensor([0.25, 0.5, 0.75], device=a.device, dtype=a.dtype), dim=0)
+            a = (a - q[1]) / (1.0 + (q[2] - q[0]))
+        return a.mean(dim=1), a

@@ -71,3 +71,27 @@ def test_score_series_equals_predictor_double_forward(setup, gpu_device):
         _, r_o = oracle.forward(torch.cat((x[:, 1:, :], y), dim=1), case.state_dict(), alpha=case.kwargs["alpha"])
     gate(preds[:12], p_o, what="score_series forecasts")
     gate(last[:12], r_o[:, -1, :], what="score_series reconstructions")
+
+
+def test_anomaly_scores_follow_get_score(setup, gpu_device):
+    """anomaly_scores() against the arithmetic of Predictor.get_score (reference prediction.py:65-91), restated
+    here in numpy on the outputs of score_series()."""
+    import numpy as np
+    case, model, series = setup
+    w = case.kwargs["window_size"]
+    sd = series.to(gpu_device)
+    with torch.no_grad():
+        preds, recons = model.score_series(sd)
+        for scale in (False, True):
+            scores, per_dim = model.anomaly_scores(sd, target_dims=0, gamma=0.8, scale_scores=scale)
+            p, r = preds.cpu().numpy(), recons.cpu().numpy()
+            actual = series.numpy()[w:][:, [0]]
+            ref = np.zeros_like(actual)
+            for i in range(p.shape[1]):
+                a = np.sqrt((p[:, i] - actual[:, i]) ** 2) + 0.8 * np.sqrt((r[:, i] - actual[:, i]) ** 2)
+                if scale:
+                    q75, q25 = np.percentile(a, [75, 25])
+                    a = (a - np.median(a)) / (1 + (q75 - q25))
+                ref[:, i] = a
+            assert np.abs(per_dim.cpu().numpy() - ref).max() <= 1e-6
+            assert np.abs(scores.cpu().numpy() - ref.mean(1)).max() <= 1e-6
