@@ -105,11 +105,15 @@ def _dev_ptr(t, name, shape=None):
 class Engine:
     """One model instance on the native side: packed weights + launch plans."""
 
-    def __init__(self, cfg: dict):
+    def __init__(self, cfg: dict, device):
         self.lib = load_library()
         self.cfg = Config(**cfg)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"the MI355X HIP engine lives on a GPU, not on '{device}'")
         self.handle = ctypes.c_void_p()
-        _check(self.lib.mtadgat_create(ctypes.byref(self.cfg), ctypes.byref(self.handle)), "create")
+        with torch.cuda.device(self.device):      # the library sizes its chunks from this device's memory
+            _check(self.lib.mtadgat_create(ctypes.byref(self.cfg), ctypes.byref(self.handle)), "create")
         self._ws = None
         self._keep = None
 
@@ -120,6 +124,10 @@ class Engine:
                 self.handle = ctypes.c_void_p()
         except Exception:
             pass
+
+    def backward_supported(self):
+        """True when the library has a HIP backward for this configuration."""
+        return False
 
     # -- weights ------------------------------------------------------------------------------
     def load_weights(self, sd, device):

@@ -288,6 +288,10 @@ int mtadgat_create(const mtadgat_config* cfg, mtadgat_handle* out) {
 
 int mtadgat_destroy(mtadgat_handle h) {
     if (!h) return 0;
+    if (h->m.upload_ev) {
+        (void)hipEventSynchronize(h->m.upload_ev);
+        (void)hipEventDestroy(h->m.upload_ev);
+    }
     if (h->m.packed_dev) (void)hipFree(h->m.packed_dev);
     for (auto& v : h->m.ev)
         for (auto& p : v) {
@@ -304,11 +308,31 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream
     std::vector<float> host;
     std::string err = pack_weights(m, *p, host);
     if (!err.empty()) return fail(MTADGAT_ERR_INVALID, err);
-    if (!m.packed_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.packed_dev), m.packed_floats * sizeof(float)));
+    // the packed weights live on the device that is current now (the caller's); a handle that moves to
+    // another GPU gets a fresh allocation there
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (m.packed_dev && m.packed_device != dev) {
+        int cur = dev;
+        (void)hipSetDevice(m.packed_device);
+        (void)hipFree(m.packed_dev);
+        (void)hipSetDevice(cur);
+        m.packed_dev = nullptr;
+        m.have_weights = false;
+    }
+    if (!m.packed_dev) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m.packed_dev), m.packed_floats * sizeof(float)));
+        m.packed_device = dev;
+    }
     hipStream_t s = (hipStream_t)stream;
-    // pageable source: the copy is staged before the call returns, `host` may die afterwards
-    HIP_TRY(hipMemcpyAsync(m.packed_dev, host.data(), m.packed_floats * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // Stream-ordered upload without a device synchronisation: the packed image is handed to the handle's
+    // staging buffer, which outlives the copy (it is only replaced by the next load_weights, after that
+    // call has waited for this copy through the upload event).
+    if (m.upload_ev) HIP_TRY(hipEventSynchronize(m.upload_ev));
+    else HIP_TRY(hipEventCreateWithFlags(&m.upload_ev, hipEventDisableTiming));
+    m.staging.swap(host);
+    HIP_TRY(hipMemcpyAsync(m.packed_dev, m.staging.data(), m.packed_floats * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(m.upload_ev, s));
     m.have_weights = true;
     return 0;
 }

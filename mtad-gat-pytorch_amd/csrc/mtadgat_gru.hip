@@ -556,25 +556,14 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     // per SIMD to fill the machine and leaves it mostly idle below that.  Measured on MI355X (W=100, F=55,
     // H=150, GRU + decoder): 256 windows 12.0 -> 4.9 ms, 16 k windows 12.2 -> 9.9 ms, 32 k windows 12.2 vs 19.6
     // (the 5 waves of a group land 2/1/1/1 on the SIMDs, so the split form loses once the machine is full).
+    const int n_cu = cu_count();
     {
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 256;
-        }
         const long groups = (a.B + 31) / 32;
         const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
         if (ncg >= 2 && groups <= 2L * n_cu && lds <= 64 * 1024) return launch_gru_split(a, ncg, xmode, fc, s);
     }
     // two groups per wave once that still gives every SIMD a wave
-    static int n_cu2 = 0;
-    if (!n_cu2) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu2, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu2 <= 0)
-            n_cu2 = 256;
-    }
-    const bool two = (a.B + 31) / 32 >= 8L * n_cu2;
+    const bool two = (a.B + 31) / 32 >= 8L * n_cu;
     switch (ncg) {
         case 1: return launch_gru_ncg<1>(a, xmode, fc, two, s);
         case 2: return launch_gru_ncg<2>(a, xmode, fc, two, s);

@@ -55,6 +55,9 @@ struct Model {
     LinPlan rec_fc;          // per-step Linear on the decoder state (tile format over Hp_r)
     size_t packed_floats = 0;
     float* packed_dev = nullptr;
+    int packed_device = -1;          // device ordinal packed_dev was allocated on
+    std::vector<float> staging;      // host image of the last upload (source of the async copy)
+    hipEvent_t upload_ev = nullptr;  // recorded after the last upload
     bool have_weights = false;
     int64_t chunk = 65536;
     // profiling

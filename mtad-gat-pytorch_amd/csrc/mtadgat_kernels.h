@@ -110,6 +110,19 @@ struct GruArgs {
     int out_dim;
 };
 
+// compute units of the current device (cached per device ordinal)
+inline int cu_count() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cache[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t s);
 int launch_conv(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);

@@ -14,11 +14,13 @@ shipped checkpoints, `.cuda()`, optimisers and seeded initialisation behave
 exactly as with the reference classes (`modules.py:5-311`).  Their `forward`
 methods call the corresponding stage entry point of the native library.
 
-Inference (`eval()`, any grad mode) always runs the HIP kernels and needs GPU
-tensors -- there is no CPU or PyTorch fallback for it.  The training step
-(`train()` with grad enabled, i.e. `Trainer.fit`) needs gradients, which the
-forward-only kernels do not provide yet: it is evaluated with differentiable
-torch ops over the same re-associated algebra (`_autograd.py`, interim).
+Device contract.  Tensors on the GPU ('cuda' = HIP on PyTorch-ROCm) always run the
+HIP kernels -- forward, and (when gradients are wanted) the HIP backward behind a
+`torch.autograd.Function` -- and raise if `libmtadgat.so` is missing: there is no
+fallback for GPU tensors.  A model and input left on the CPU (the reference's
+`--use_cuda False` / no-GPU branch, predict.py:122, training.py:60; BASELINE config 1)
+are evaluated by the package's own torch-op algebra (`_torchpath.py`), chosen by the
+caller through the tensors' device.
 """
 import torch
 import torch.nn as nn
@@ -26,7 +28,24 @@ import torch.nn as nn
 import _native
 
 
-class ConvLayer(nn.Module):
+class _Stage(nn.Module):
+    """Base of the parameter-holding sub-modules.  `_owner` (a weak reference to the MTAD_GAT that
+    runs the stage) is not part of the pickled / deep-copied state; MTAD_GAT re-binds it."""
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop("_owner", None)
+        return d
+
+    def _run(self, name, x):
+        owner = self.__dict__.get("_owner")
+        owner = owner() if owner is not None else None
+        if owner is None:
+            raise RuntimeError(f"{type(self).__name__} is a stage of MTAD_GAT and cannot run detached from its model")
+        return owner._stage(name, x)
+
+
+class ConvLayer(_Stage):
     """Parameters of reference `ConvLayer` (`modules.py:12-16`): `conv.weight (F,F,k)`, `conv.bias (F)`."""
 
     def __init__(self, n_features, kernel_size=7):
@@ -35,10 +54,10 @@ class ConvLayer(nn.Module):
         self.conv = nn.Conv1d(in_channels=n_features, out_channels=n_features, kernel_size=kernel_size)
 
     def forward(self, x):
-        return self._owner()._stage("conv", x)
+        return self._run("conv", x)
 
 
-class _AttentionParams(nn.Module):
+class _AttentionParams(_Stage):
     """Parameters shared by the two graph-attention layers (`modules.py:36-63`, `:137-164`)."""
 
     def __init__(self, num_nodes, node_dim, default_embed, dropout, alpha, embed_dim, use_gatv2, use_bias):
@@ -69,7 +88,7 @@ class FeatureAttentionLayer(_AttentionParams):
         self.n_features, self.window_size = n_features, window_size
 
     def forward(self, x):
-        return self._owner()._stage("feature_gat", x)
+        return self._run("feature_gat", x)
 
 
 class TemporalAttentionLayer(_AttentionParams):
@@ -80,10 +99,10 @@ class TemporalAttentionLayer(_AttentionParams):
         self.n_features, self.window_size = n_features, window_size
 
     def forward(self, x):
-        return self._owner()._stage("temporal_gat", x)
+        return self._run("temporal_gat", x)
 
 
-class GRULayer(nn.Module):
+class GRULayer(_Stage):
     """Parameters of reference `GRULayer` (`modules.py:228-233`); forward returns (None, h_end)."""
 
     def __init__(self, in_dim, hid_dim, n_layers, dropout):
@@ -95,7 +114,7 @@ class GRULayer(nn.Module):
     def forward(self, x):
         # the reference also returns out[-1] (the last batch element's sequence, a batch_first
         # quirk, modules.py:237) which MTAD_GAT.forward discards (mtad_gat.py:73): not produced.
-        return None, self._owner()._stage("gru", x)
+        return None, self._run("gru", x)
 
 
 class RNNDecoder(nn.Module):
@@ -108,7 +127,7 @@ class RNNDecoder(nn.Module):
         self.rnn = nn.GRU(in_dim, hid_dim, n_layers, batch_first=True, dropout=self.dropout)
 
 
-class ReconstructionModel(nn.Module):
+class ReconstructionModel(_Stage):
     """Parameters of reference `ReconstructionModel` (`modules.py:260-262`)."""
 
     def __init__(self, window_size, in_dim, hid_dim, out_dim, n_layers, dropout):
@@ -118,10 +137,10 @@ class ReconstructionModel(nn.Module):
         self.fc = nn.Linear(hid_dim, out_dim)
 
     def forward(self, x):
-        return self._owner()._stage("recon", x)
+        return self._run("recon", x)
 
 
-class Forecasting_Model(nn.Module):
+class Forecasting_Model(_Stage):
     """Parameters of reference `Forecasting_Model` (`modules.py:295-305`): n_layers + 1 Linear."""
 
     def __init__(self, in_dim, hid_dim, out_dim, n_layers, dropout):
@@ -134,7 +153,7 @@ class Forecasting_Model(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        return self._owner()._stage("forecast", x)
+        return self._run("forecast", x)
 
 
 class MTAD_GAT(nn.Module):
@@ -189,43 +208,93 @@ class MTAD_GAT(nn.Module):
             time_embed=self.temporal_gat.embed_dim, gru_n_layers=gru_n_layers, gru_hid_dim=gru_hid_dim,
             forecast_n_linear=forecast_n_layers + 1, forecast_hid_dim=forecast_hid_dim,
             recon_n_layers=recon_n_layers, recon_hid_dim=recon_hid_dim, alpha=float(alpha))
-        # sub-modules reach the engine through a weak back-reference (not a registered child)
+        self._bind()
+
+    # -- instance plumbing: weak back-references, copy / pickle ----------------------------------------
+    def _bind(self):
+        """(Re-)attach the sub-modules to this instance and drop any native state (engine, packed-weight
+        cache): used by __init__ and after unpickling / deepcopy, where the state belongs to the new object."""
         import weakref
         ref = weakref.ref(self)
         for mod in (self.conv, self.feature_gat, self.temporal_gat, self.gru, self.forecasting_model, self.recon_model):
             object.__setattr__(mod, "_owner", ref)
         object.__setattr__(self, "_engine", None)
         object.__setattr__(self, "_weights_key", None)
+        object.__setattr__(self, "_fp_vec", None)
+        if "check_weight_contents" not in self.__dict__:
+            # True: every GPU call fingerprints the parameter *contents* (one small reduction + a host
+            # sync), so in-place edits that bypass autograd's version counter (`p.data.mul_()`,
+            # `nn.init.*_(p.data)`) are seen.  False: trust (data_ptr, _version) only -- no sync per call;
+            # call refresh_weights() after such edits.
+            object.__setattr__(self, "check_weight_contents", True)
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in ("_engine", "_weights_key", "_fp_vec"):
+            d.pop(k, None)
+        return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._bind()
 
     # -- native engine ----------------------------------------------------------------------------
+    def _fingerprint(self, params):
+        """Exact bit-level checksum of all parameters: sum over (int32 bits * fixed odd multipliers) mod 2^64."""
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).view(torch.int32).to(torch.int64)
+        vec = self._fp_vec
+        if vec is None or vec.device != flat.device or vec.numel() != flat.numel():
+            g = torch.Generator().manual_seed(0x5EED)
+            vec = (torch.randint(0, 2 ** 31, (flat.numel(),), generator=g, dtype=torch.int64) * 2 + 1).to(flat.device)
+            object.__setattr__(self, "_fp_vec", vec)
+        return int((flat * vec).sum())
+
+    def refresh_weights(self):
+        """Force the packed kernel weights to be rebuilt from the current parameters at the next GPU call.
+        Only needed with `check_weight_contents = False` after edits autograd's version counter does not see."""
+        object.__setattr__(self, "_weights_key", None)
+
     def _sync_engine(self, device):
-        """Engine whose packed weights match the current parameters (repacked when any changed)."""
-        if self._engine is None:
-            object.__setattr__(self, "_engine", _native.Engine(self._native_cfg))
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """Engine (on `device`) whose packed weights match the current parameters (repacked when any changed)."""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        params = list(self.parameters())
+        for p in params:
+            if p.device != device:
+                raise RuntimeError(f"MTAD_GAT parameters are on '{p.device}' but the input is on '{device}': "
+                                   "move the model with .to(device) / .cuda()")
+        if self._engine is None or self._engine.device != device:
+            object.__setattr__(self, "_engine", _native.Engine(self._native_cfg, device))
+            object.__setattr__(self, "_weights_key", None)
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if self.check_weight_contents:
+            key = key + (self._fingerprint(params),)
         if key != self._weights_key:
             self._engine.load_weights(self.state_dict(), device)
             object.__setattr__(self, "_weights_key", key)
         return self._engine
 
-    def _needs_autograd(self):
-        """True when the caller will differentiate through the result (the training step)."""
-        return torch.is_grad_enabled() and self.training
-
-    def _check_mode(self, x):
-        if x.device.type != "cuda":
-            raise RuntimeError(
-                f"MTAD_GAT (MI355X HIP path) got a tensor on '{x.device}': move the model and the input to the GPU "
-                "(.cuda() / .to('cuda')); there is no CPU implementation of the inference path in this package")
-        if self.training:
-            raise NotImplementedError(
-                "MTAD_GAT HIP kernels implement the eval-mode forward; train-mode calls are only supported through "
-                "forward() with grad enabled (autograd path) -- call model.eval() for inference")
+    def _wants_grad(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
 
     def _stage(self, name, x):
-        self._check_mode(x)
+        """One sub-module call (`model.conv(x)`, ...): eval-mode stage of the HIP library on the GPU,
+        the torch-op stage on the CPU."""
+        import _torchpath as tp
+        if x.device.type != "cuda":
+            x = x.float()
+            fn = {"conv": tp.conv_stage, "feature_gat": tp.feature_gat_stage, "temporal_gat": tp.temporal_gat_stage,
+                  "gru": tp.gru_stage, "forecast": tp.forecast_stage, "recon": tp.recon_stage}[name]
+            if name in ("feature_gat", "temporal_gat", "forecast"):
+                return fn(self, x, self.training)
+            return fn(self, x)
+        if self.training:
+            raise NotImplementedError(
+                "stage calls run the eval-mode HIP kernels; train-mode (dropout / gradients) is supported through "
+                "MTAD_GAT.forward() -- call model.eval() for per-stage inference")
         eng = self._sync_engine(x.device)
-        x = x.contiguous().float()
+        x = x.detach().contiguous().float()
         if name == "conv":
             return eng.conv(x)
         if name == "feature_gat":
@@ -240,24 +309,36 @@ class MTAD_GAT(nn.Module):
             return eng.heads(x, False, True)[1]
         raise KeyError(name)
 
+    def _require_gpu(self, t, what):
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                f"MTAD_GAT.{what} is a GPU-side data path (MI355X HIP kernels) and got a tensor on '{t.device}': "
+                "move the model and the series to the GPU (.cuda() / .to('cuda'))")
+        if self.training:
+            raise NotImplementedError(f"MTAD_GAT.{what} is an inference entry point: call model.eval() first")
+
     def forward(self, x):
-        """x (b, window_size, n_features) float32 on the GPU -> (predictions (b, out_dim),
-        recons (b, window_size, out_dim)); reference `mtad_gat.py:64-79`.  x is not modified."""
+        """x (b, window_size, n_features) -> (predictions (b, out_dim), recons (b, window_size, out_dim));
+        reference `mtad_gat.py:64-79`.  x is not modified.  float32 (bf16 / fp16 inputs are answered in
+        their own dtype)."""
         if x.dim() != 3 or x.shape[1] != self.window_size or x.shape[2] != self.n_features:
             raise RuntimeError(f"expected input of shape (b, {self.window_size}, {self.n_features}), got {tuple(x.shape)}")
-        if self._needs_autograd():
-            # training step (Trainer.fit, training.py:100-130): differentiable torch ops over the same
-            # algebra (interim -- the HIP kernels are forward-only), dropout as in the reference
-            from _autograd import differentiable_forward
-            return differentiable_forward(self, x.float())
-        self._check_mode(x)
+        if x.device.type != "cuda":
+            # the caller keeps model and data on the CPU (reference: `--use_cuda False` / no GPU)
+            import _torchpath
+            preds, recons = _torchpath.forward(self, x.float())
+            return (preds.to(x.dtype), recons.to(x.dtype)) if x.dtype != torch.float32 else (preds, recons)
         eng = self._sync_engine(x.device)
-        with torch.no_grad():
-            preds, recons = eng.forward(x.contiguous().float())
+        if self.training or self._wants_grad(x):
+            # training step (Trainer.fit, training.py:100-130) or any call that will be differentiated:
+            # HIP forward that keeps what the HIP backward needs, dropout in the kernels
+            import _hipgrad
+            preds, recons = _hipgrad.forward(self, eng, x)
+        else:
+            with torch.no_grad():
+                preds, recons = eng.forward(x.contiguous().float())
         if x.dtype in (torch.bfloat16, torch.float16):
-            # reduced-precision I/O (BASELINE config "bf16 inference"): the kernels compute in fp32 -- the
-            # path is compute-bound, nothing is gained by narrower arithmetic at the 1e-5 parity target --
-            # and the results are handed back in the caller's dtype
+            # reduced-precision I/O (BASELINE config "bf16 inference"): results in the caller's dtype
             return preds.to(x.dtype), recons.to(x.dtype)
         return preds, recons
 
@@ -268,7 +349,7 @@ class MTAD_GAT(nn.Module):
         `SlidingWindowDataset` + default collate + `model(x)` (reference utils.py:107-120,
         prediction.py:43-55); consecutive windows share W-1 rows, so ~W times fewer input bytes are read.
         Returns (predictions (b, out_dim), recons (b, W, out_dim))."""
-        self._check_mode(series)
+        self._require_gpu(series, "forward_series")
         eng = self._sync_engine(series.device)
         with torch.no_grad():
             p, r, _ = eng.forward_series(series.contiguous().float(), starts, start, stride, count)
@@ -283,7 +364,7 @@ class MTAD_GAT(nn.Module):
         window j are the forecast for i = j and the reconstruction for i = j-1, so ONE forward per window
         over windows 0..N-W is enough, and only the last reconstruction step is ever written.
         Returns (preds (N-W, out_dim), recons_last (N-W, out_dim))."""
-        self._check_mode(values)
+        self._require_gpu(values, "score_series")
         n = values.shape[0] - self.window_size
         if n <= 0:
             raise RuntimeError("series shorter than window_size + 1")
@@ -299,9 +380,7 @@ class MTAD_GAT(nn.Module):
         (the reference writes sqrt((.)**2)), optionally (a - median) / (1 + IQR) per dimension
         (`scale_scores`), then the mean over the target dimensions.  target_dims as in the reference
         (`utils.get_target_dims`): None = all features, an int or a list of column indices.
-        Returns (scores (N-W,), per-dimension scores (N-W, out_dim)), both on the device.
-        Thresholding (epsilon / POT / brute force, eval_methods.py) stays the reference's numpy code: it is
-        O(N) on a 1-D array."""
+        Returns (scores (N-W,), per-dimension scores (N-W, out_dim)), both on the device."""
         preds, recons = self.score_series(values)
         actual = values[self.window_size:].float()
         if target_dims is not None:
@@ -311,6 +390,22 @@ class MTAD_GAT(nn.Module):
             raise RuntimeError(f"target_dims select {actual.shape[1]} columns but the model has out_dim={preds.shape[1]}")
         a = (preds - actual).abs() + gamma * (recons - actual).abs()
         if scale_scores:
-            q = torch.quantile(a, torch.tensor([0.25, 0.5, 0.75], device=a.device, dtype=a.dtype), dim=0)
+            # np.percentile's default (linear) interpolation per column; torch.quantile refuses inputs of more
+            # than 16 M elements, so the columns go through it one at a time
+            qs = torch.tensor([0.25, 0.5, 0.75], device=a.device, dtype=a.dtype)
+            q = torch.stack([_column_quantiles(a[:, d], qs) for d in range(a.shape[1])], dim=1)
             a = (a - q[1]) / (1.0 + (q[2] - q[0]))
         return a.mean(dim=1), a
+
+
+def _column_quantiles(col, qs):
+    """Linear-interpolation quantiles of a 1-D tensor of any length (sort based: no 16 M element limit)."""
+    n = col.numel()
+    if n <= (1 << 24):
+        return torch.quantile(col, qs)
+    s, _ = torch.sort(col)
+    pos = qs.double() * (n - 1)
+    lo = pos.floor().long()
+    hi = torch.clamp(lo + 1, max=n - 1)
+    frac = (pos - lo.double()).to(col.dtype)
+    return s[lo] + (s[hi] - s[lo]) * frac

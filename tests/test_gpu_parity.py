@@ -170,11 +170,10 @@ def test_weight_update_is_seen(gpu_device):
 def test_errors_are_loud(gpu_device):
     case = Case("syn_v2_embed")
     model = case.build_model()
-    with pytest.raises(RuntimeError, match="no CPU implementation"):
-        model(case.x)                       # CPU tensors: no fallback
+    with pytest.raises(RuntimeError, match="parameters are on"):
+        model(case.x.to(gpu_device))         # model left on the CPU, input on the GPU: no silent host round trip
     model = model.to(gpu_device)
     with pytest.raises(RuntimeError, match="expected input of shape"):
         model(case.x[:, :-1].to(gpu_device))
-    model.train()
-    with torch.no_grad(), pytest.raises(NotImplementedError):
-        model(case.x.to(gpu_device))          # train-mode (dropout) inference is not a HIP path
+    with pytest.raises(RuntimeError, match="GPU-side data path"):
+        model.forward_series(torch.rand(300, case.kwargs["n_features"]))

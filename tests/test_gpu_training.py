@@ -33,7 +33,7 @@ def test_train_steps_then_hip_inference(gpu_device):
     with torch.no_grad():
         p1, r1 = model(x)
     assert not torch.equal(p1, p0)
-    from _autograd import differentiable_forward
+    from _torchpath import forward as differentiable_forward
     with torch.no_grad():
         p2, r2 = differentiable_forward(model, x)
     assert (p1 - p2).abs().max().item() <= 1e-5 and (r1 - r2).abs().max().item() <= 1e-5

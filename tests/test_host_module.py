@@ -55,13 +55,51 @@ def test_embed_dim_doubling_and_v1_shapes():
         MTAD_GAT(9, 16, 3, kernel_size=4)
 
 
-def test_cpu_tensors_fail_loudly():
+def test_cpu_tensors_take_the_packages_torch_path():
+    """A model and input kept on the CPU (the reference's `--use_cuda False` branch, predict.py:122) are
+    evaluated by _torchpath.py -- the package's own algebra, not the oracle -- and match the reference."""
+    for name in ("syn_v2_embed", "syn_v1_small"):
+        case = Case(name)
+        model = case.build_model()
+        with torch.no_grad():
+            p, r = model(case.x)
+            assert (p - case.preds).abs().max().item() <= 1e-5 and (r - case.recons).abs().max().item() <= 1e-5
+            xc = model.conv(case.x)
+            assert (xc - case.stages["xc"]).abs().max().item() <= 1e-5
+            assert (model.feature_gat(xc) - case.stages["h_feat"]).abs().max().item() <= 1e-5
+            assert (model.temporal_gat(xc) - case.stages["h_temp"]).abs().max().item() <= 1e-5
+    # the GPU-side data-path entry points have no CPU form
+    with pytest.raises(RuntimeError, match="GPU-side data path"):
+        model.score_series(torch.rand(200, case.kwargs["n_features"]))
+
+
+def test_gpu_tensors_never_fall_back(monkeypatch):
+    """GPU tensors must reach the HIP library or raise: with the library 'missing' the engine refuses to
+    exist (no torch-op fallback for device tensors)."""
+    import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_LIB_PATH", "/nonexistent/libmtadgat.so")
+    with pytest.raises(RuntimeError, match="has not been built"):
+        _native.Engine(Case("syn_v2_embed").build_model()._native_cfg, "cuda:0")
+
+
+def test_deepcopy_and_pickle_rebind_the_stages():
+    import copy
+    import io
     case = Case("syn_v2_embed")
-    model = case.build_model()
-    with pytest.raises(RuntimeError, match="no CPU implementation"):
-        model(case.x)
-    with pytest.raises(RuntimeError, match="no CPU implementation"):
-        model.conv(case.x)
+    m = case.build_model()
+    m2 = copy.deepcopy(m)
+    assert m2.conv._owner() is m2 and m.conv._owner() is m and m2._engine is None
+    with torch.no_grad():
+        m2.conv.conv.bias.add_(1.0)                     # the copy owns its parameters
+        assert not torch.equal(m2.conv(case.x), m.conv(case.x))
+    buf = io.BytesIO()
+    torch.save(m, buf)                                  # whole-module pickle, as the reference supports
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3.gru._owner() is m3
+    with torch.no_grad():
+        assert torch.equal(m3(case.x)[0], m(case.x)[0])
 
 
 def test_product_path_does_not_import_the_oracle():

@@ -1,0 +1,126 @@
+"""north_star: "train.py and predict.py call it unchanged".
+
+The reference's own `predict.py` and `train.py` are run UNCHANGED (SURVEY.md section 8c launcher recipe,
+tests/plumbing/run_reference_script.py) twice -- once with `import mtad_gat` resolved to this
+package's drop-in module, once with the reference's module as the control -- on the same synthetic
+SMD-shaped data (machine-1-1: 38 features; the real files are not in the reference tree), and the
+`summary.txt` / losses they write are compared.
+
+These tests need the reference tree and therefore run HERE (no GPU: the scripts take the reference's
+own `device = "cpu"` branch, predict.py:122 / training.py:60, i.e. this package's CPU tensor path).
+The GPU box has no /root/reference (tests/test_gpu_plumbing.py drives the same call sequence there
+through a caller written for the test); when the tree is absent these tests SKIP and say so.
+"""
+import json
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REF = os.environ.get("MTADGAT_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+LAUNCH = os.path.join(HERE, "plumbing", "run_reference_script.py")
+
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "predict.py")),
+                                reason=f"reference tree not present at {REF}: the unchanged-script plumbing runs only where it is")
+
+
+def _make_smd(root, n_train, n_test, seed=0):
+    """Synthetic machine-1-1: smooth + noisy columns in arbitrary units (the scripts MinMax-normalise),
+    a labelled anomalous stretch in the test split."""
+    rng = np.random.default_rng(seed)
+    d = os.path.join(root, "datasets", "ServerMachineDataset", "processed")
+    os.makedirs(d, exist_ok=True)
+
+    def series(n):
+        t = np.arange(n)[:, None]
+        per = rng.uniform(20, 90, size=(1, 38))
+        x = 0.5 + 0.4 * np.sin(2 * np.pi * t / per) + 0.05 * rng.standard_normal((n, 38))
+        x[:, 30:] = (rng.random((n, 8)) < 0.05).astype(np.float64)      # on/off columns
+        return x.astype(np.float32)
+
+    train, test = series(n_train), series(n_test)
+    label = np.zeros(n_test, dtype=np.float32)
+    lo = n_test // 2
+    test[lo:lo + 25, :10] += 1.5
+    label[lo:lo + 25] = 1
+    for name, arr in (("train", train), ("test", test), ("test_label", label)):
+        with open(os.path.join(d, f"machine-1-1_{name}.pkl"), "wb") as f:
+            pickle.dump(arr, f)
+
+
+def _run(which, cwd, script, *args, seed=None):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="4", MKL_NUM_THREADS="4")
+    env.pop("PYTHONPATH", None)
+    if seed is not None:
+        env["PLUMBING_SEED"] = str(seed)
+    r = subprocess.run([sys.executable, "-B", LAUNCH, which, REF, script, *args], cwd=cwd, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, f"{script} ({which}) failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    mod = [l for l in r.stdout.splitlines() if l.startswith("MTAD_GAT_MODULE")][-1].split(" ", 1)[1]
+    return r.stdout, mod
+
+
+def _close(a, b, tol, path=""):
+    if isinstance(a, dict):
+        assert a.keys() == b.keys(), path
+        for k in a:
+            _close(a[k], b[k], tol, f"{path}/{k}")
+    elif isinstance(a, (int, float)):
+        assert abs(a - b) <= tol * max(1.0, abs(a), abs(b)), f"{path}: {a} vs {b}"
+    else:
+        assert a == b, path
+
+
+def test_predict_py_unchanged_on_shipped_smd_checkpoint(tmp_path):
+    """predict.py --dataset SMD --group 1-1 with the shipped checkpoint (strict load_state_dict of
+    output/SMD/1-1/27062021_114402/model.pt, config.txt parsing, Predictor.get_score's double forward,
+    epsilon / POT / brute-force thresholding, summary file): identical summary with either module."""
+    summaries = {}
+    for which in ("ours", "reference"):
+        cwd = tmp_path / which
+        _make_smd(str(cwd), n_train=420, n_test=520)
+        dst = cwd / "output" / "SMD" / "1-1" / "27062021_114402"
+        os.makedirs(dst)
+        for fn in ("model.pt", "config.txt"):
+            shutil.copy(os.path.join(REF, "output", "SMD", "1-1", "27062021_114402", fn), dst / fn)
+        out, mod = _run(which, str(cwd), "predict.py", "--dataset", "SMD", "--group", "1-1", "--use_cuda", "False", "--level", "0.85")
+        assert ("mtad-gat-pytorch_amd" in mod) == (which == "ours"), mod
+        summaries[which] = json.load(open(dst / "summary.txt"))
+    s = summaries["ours"]
+    assert set(s) == {"epsilon_result", "pot_result", "bf_result"}
+    # thresholds / F1 are functions of the anomaly scores; scores agree to ~1e-6, the summaries to 1e-4
+    _close(s, summaries["reference"], 1e-4)
+
+
+def test_train_py_unchanged_one_epoch(tmp_path):
+    """train.py for one epoch on a small configuration: Adam built before .cuda()/.to(), train() +
+    loss.backward() + optimizer.step() populate and consume every gradient, evaluate(), save / reload
+    of model.pt, then the Predictor.  Seeded identically, both modules draw the same initial weights,
+    shuffles and dropout masks (CPU generator), so the logged losses agree to float noise."""
+    args = ["--dataset", "SMD", "--group", "1-1", "--lookback", "24", "--epochs", "1", "--bs", "64",
+            "--gru_hid_dim", "32", "--fc_hid_dim", "24", "--recon_hid_dim", "28", "--fc_n_layers", "2",
+            "--use_cuda", "False", "--log_tensorboard", "False", "--dropout", "0.3", "--level", "0.85"]
+    logs, summaries = {}, {}
+    for which in ("ours", "reference"):
+        cwd = tmp_path / which
+        _make_smd(str(cwd), n_train=360, n_test=300)
+        out, mod = _run(which, str(cwd), "train.py", *args, seed=7)
+        assert ("mtad-gat-pytorch_amd" in mod) == (which == "ours"), mod
+        logs[which] = [l for l in out.splitlines() if l.startswith(("Init total", "[Epoch", "Test "))]
+        run_dir = [d for d in os.listdir(cwd / "output" / "SMD" / "1-1") if d != "logs"][0]
+        base = cwd / "output" / "SMD" / "1-1" / run_dir
+        assert os.path.isfile(base / "model.pt") and os.path.isfile(base / "config.txt")
+        summaries[which] = json.load(open(base / "summary.txt"))
+    assert len(logs["ours"]) >= 5 and len(logs["ours"]) == len(logs["reference"])
+    import re
+    num = re.compile(r"-?\d+\.\d+")
+    for a, b in zip(logs["ours"], logs["reference"]):
+        va, vb = [float(v) for v in num.findall(a)], [float(v) for v in num.findall(b)]
+        va, vb = va[:-1] if a.startswith("[Epoch") else va, vb[:-1] if b.startswith("[Epoch") else vb   # drop the wall time
+        assert len(va) == len(vb) and all(abs(x - y) <= 2e-4 for x, y in zip(va, vb)), (a, b)
+    _close(summaries["ours"], summaries["reference"], 5e-3)

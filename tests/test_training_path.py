@@ -1,4 +1,4 @@
-"""The training step (interim autograd path, _autograd.py): gradients equal to autograd through the
+"""The training step on CPU tensors (the package's torch-op path, _torchpath.py): gradients equal to autograd through the
 oracle, every parameter gets a gradient, and the data-parallel step reproduces the single-process
 global-batch gradient (gloo, world_size 2).  CPU only; the GPU variant is in test_gpu_training.py."""
 import os
