@@ -3,7 +3,8 @@
 
 Run in the build container (where /root/reference exists):
 
-    python -B tests/golden/make_golden.py
+    python -B tests/golden/make_golden.py            # the small per-stage fixtures
+    python -B tests/golden/make_golden.py --wide     # >= 256-window fixtures (outputs only) + C1 statistics
 
 It imports the *unmodified* reference modules (`/root/reference/mtad_gat.py`,
 `modules.py`), runs `MTAD_GAT.forward` on CPU in eval mode on seeded inputs and
@@ -115,6 +116,63 @@ def run_case(name, model, kwargs, batch, store_sd, meta_extra):
           f"-> {os.path.getsize(path)/1e6:.2f} MB")
 
 
+WIDE_BATCH = 300      # >= 256 with a ragged tail (256 + 44): SURVEY.md section 8d's parity gate
+WIDE_X_SEED = 4321
+
+
+def c1_series(n_rows, n_features, seed=0):
+    """BASELINE config 1 / SURVEY 8d input statistics: column 0 = 0.5 sin(2 pi t / 97) + 0.05 N(0,1)
+    (negative values: outside the [0,1] a MinMax-scaled training split would give), the other
+    columns Bernoulli(0.05) on/off telemetry."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_rows)
+    s = np.zeros((n_rows, n_features), dtype=np.float32)
+    s[:, 0] = 0.5 * np.sin(2 * np.pi * t / 97.0) + 0.05 * rng.standard_normal(n_rows)
+    s[:, 1:] = (rng.random((n_rows, n_features - 1)) < 0.05).astype(np.float32)
+    s[17, 3] = 1.7          # a few out-of-range values in the binary columns as well
+    s[201, 9] = -0.4
+    return s
+
+
+def run_wide(name, model, kwargs, x, extra):
+    """Outputs only (x is regenerated from the seed / stored series by the tests); the float64 reference
+    is stored rounded to float32 -- 6e-8 relative, far below the 1e-5 gate it serves."""
+    model.eval()
+    with torch.no_grad():
+        preds, recons = model(x)
+        st = stages(model, x)
+        m64 = RefMTAD(**kwargs).double()
+        m64.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+        m64.eval()
+        p64, r64 = m64(x.double())
+    out = dict(preds=preds.numpy(), recons=recons.numpy(), preds64_f32=p64.float().numpy(),
+               recons64_f32=r64.float().numpy(), stage_h_end=st["h_end"].numpy(), **extra)
+    meta = dict(name=name, kwargs=kwargs, batch=int(x.shape[0]), x_sha256=hashlib.sha256(x.numpy().tobytes()).hexdigest(),
+                sd_sha256=sd_digest(model.state_dict()), torch=torch.__version__)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: b={x.shape[0]} |p32-p64|={float((preds.double()-p64).abs().max()):.2e} "
+          f"|r32-r64|={float((recons.double()-r64).abs().max()):.2e} -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
+def main_wide():
+    """>= 256-window fixtures for the three shipped checkpoints (weights come from <case>.npz at test time)
+    and the C1-statistics series through the MSL checkpoint."""
+    torch.set_num_threads(os.cpu_count())
+    for name, (rel, dims) in SHIPPED.items():
+        kwargs = dict(SHIPPED_KW, **dims)
+        model = RefMTAD(**kwargs)
+        model.load_state_dict(torch.load(os.path.join(REF, rel), map_location="cpu"))
+        g = torch.Generator().manual_seed(WIDE_X_SEED)
+        x = torch.rand(WIDE_BATCH, kwargs["window_size"], kwargs["n_features"], generator=g)
+        run_wide(name + "_wide", model, kwargs, x, {})
+        if name == "msl":
+            series = c1_series(100 + 320, 55)
+            xs = torch.from_numpy(np.stack([series[i:i + 100] for i in range(320)]))
+            run_wide("msl_c1", model, kwargs, xs, dict(series=series))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     for name, (rel, dims) in SHIPPED.items():
@@ -137,4 +195,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--wide" in sys.argv:
+        main_wide()
+    else:
+        main()

@@ -70,3 +70,40 @@ def gate(ours, ref32, ref64=None, tol=FP32_TOL, what=""):
         assert d64 <= noise + tol, f"{what}: |ours-ref32|={d32:.3e}, |ours-ref64|={d64:.3e} > ref noise {noise:.3e} + {tol}"
         return d32
     raise AssertionError(f"{what}: max abs diff {d32:.3e} > {tol}")
+
+
+WIDE_CASES = ["msl_wide", "smap_wide", "smd_1_1_wide", "msl_c1"]
+
+
+class WideCase:
+    """>= 256-window fixture of a shipped checkpoint (tests/golden/make_golden.py --wide): reference
+    outputs only; the input is regenerated from the recorded seed (or the stored C1 series) and
+    checked against the recorded sha-256, the weights come from the small fixture of the same checkpoint."""
+
+    def __init__(self, name):
+        import hashlib
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.kwargs = self.meta["kwargs"]
+        self.base = Case({"msl_wide": "msl", "smap_wide": "smap", "smd_1_1_wide": "smd_1_1", "msl_c1": "msl"}[name])
+        self.preds = torch.from_numpy(z["preds"])
+        self.recons = torch.from_numpy(z["recons"])
+        self.preds64 = torch.from_numpy(z["preds64_f32"])
+        self.recons64 = torch.from_numpy(z["recons64_f32"])
+        self.h_end = torch.from_numpy(z["stage_h_end"])
+        if "series" in z.files:
+            self.series = torch.from_numpy(z["series"])
+            w = self.kwargs["window_size"]
+            self.x = torch.stack([self.series[i:i + w] for i in range(self.meta["batch"])])
+        else:
+            self.series = None
+            g = torch.Generator().manual_seed(4321)
+            self.x = torch.rand(self.meta["batch"], self.kwargs["window_size"], self.kwargs["n_features"], generator=g)
+        assert hashlib.sha256(self.x.numpy().tobytes()).hexdigest() == self.meta["x_sha256"], "regenerated input differs"
+
+    def build_model(self):
+        return self.base.build_model()
+
+    def state_dict(self):
+        return self.base.state_dict()

@@ -47,6 +47,32 @@ def test_stages_match_reference(case_model, gpu_device):
         gate(r, case.recons, case.recons64, what=f"{case.name} reconstruction head")
 
 
+@pytest.mark.parametrize("name", ["msl_wide", "smap_wide", "smd_1_1_wide", "msl_c1"])
+def test_wide_fixtures_match_reference(name, gpu_device):
+    """300 / 320 windows of each shipped checkpoint (a full 256-window Predictor batch + a ragged tail),
+    every window compared with the reference's output; `msl_c1` has the C1 input statistics (sine +
+    Bernoulli(0.05) columns, values outside [0,1]) and is also fed through the GPU-side window gather."""
+    from helpers import WideCase
+    case = WideCase(name)
+    model = case.build_model().to(gpu_device)
+    x = case.x.to(gpu_device)
+    with torch.no_grad():
+        outs = []
+        for lo in range(0, x.shape[0], 256):                      # the reference Predictor's batching
+            outs.append(model(x[lo:lo + 256].contiguous()))
+        preds = torch.cat([o[0] for o in outs])
+        recons = torch.cat([o[1] for o in outs])
+        p1, r1 = model(x)
+    assert torch.equal(p1, preds) and torch.equal(r1, recons)
+    dp = gate(preds, case.preds, case.preds64, what=f"{name} predictions")
+    dr = gate(recons, case.recons, case.recons64, what=f"{name} recons")
+    print(f"{name}: |preds-ref|={dp:.2e} |recons-ref|={dr:.2e}")
+    if case.series is not None:
+        with torch.no_grad():
+            ps, rs = model.forward_series(case.series.to(gpu_device), count=x.shape[0])
+        assert torch.equal(ps, preds) and torch.equal(rs, recons)
+
+
 def test_input_not_modified(case_model, gpu_device):
     case, model = case_model
     x = case.x.to(gpu_device)
@@ -165,6 +191,19 @@ def test_weight_update_is_seen(gpu_device):
         model.load_state_dict(a.state_dict())
         p2, _ = model(x)
         assert torch.equal(p2, p0)
+        # edits through .data do not bump autograd's version counter: the content fingerprint sees them
+        v = model.forecasting_model.layers[3].bias._version
+        model.forecasting_model.layers[3].bias.data.add_(2.0)
+        assert model.forecasting_model.layers[3].bias._version == v
+        p3, _ = model(x)
+        assert torch.allclose(p3, p0 + 2.0, atol=1e-6)
+        # ... unless the caller opts out of the per-call check; then refresh_weights() is the contract
+        model.check_weight_contents = False
+        model(x)
+        model.forecasting_model.layers[3].bias.data.sub_(2.0)
+        assert torch.equal(model(x)[0], p3)
+        model.refresh_weights()
+        assert torch.equal(model(x)[0], p0)
 
 
 def test_errors_are_loud(gpu_device):

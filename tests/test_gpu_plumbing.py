@@ -1,0 +1,200 @@
+"""The reference's callers' call sequences on the GPU.
+
+The reference tree does not exist on the GPU box, so its scripts cannot be launched there (they are run
+unchanged, on the CPU tensor path, by tests/test_plumbing_reference_scripts.py where the tree exists).
+Here the same *call sequences* -- `Predictor.get_score` (prediction.py:43-63) and `Trainer.fit` /
+`Trainer.evaluate` (training.py:76-77, 100-130, 188-228), re-written for this test -- drive the module
+on the device, and the results are checked against the package's CPU tensor path (itself pinned to the
+reference by the CPU tests) and against the fused series entry points.
+Also: the distributed plumbing on the hardware at hand -- RCCL initialised with world_size 1, and two
+processes sharing the one GPU, each running the HIP forward on its shard.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from helpers import Case, WideCase, gate
+
+pytestmark = pytest.mark.gpu
+
+
+class _Windows(torch.utils.data.Dataset):
+    def __init__(self, data, window):
+        self.data, self.window = data, window
+
+    def __getitem__(self, i):
+        return self.data[i:i + self.window], self.data[i + self.window:i + self.window + 1]
+
+    def __len__(self):
+        return len(self.data) - self.window
+
+
+def test_predictor_call_sequence_batch_256(gpu_device):
+    """batch 256, default collate, two forwards per batch (x, then x shifted by the observed row),
+    `.detach().cpu().numpy()` on the outputs -- prediction.py:43-63."""
+    case = WideCase("msl_c1")
+    model = case.build_model().to(gpu_device)
+    series = case.series                                        # (420, 55) on the host, as the reference holds it
+    W = case.kwargs["window_size"]
+    loader = torch.utils.data.DataLoader(_Windows(series, W), batch_size=256, shuffle=False)
+    model.eval()
+    preds, recons = [], []
+    with torch.no_grad():
+        for x, y in loader:
+            x, y = x.to(gpu_device), y.to(gpu_device)
+            y_hat, _ = model(x)
+            recon_x = torch.cat((x[:, 1:, :], y), dim=1)
+            _, window_recon = model(recon_x)
+            preds.append(y_hat.detach().cpu().numpy())
+            recons.append(window_recon[:, -1, :].detach().cpu().numpy())
+    import numpy as np
+    preds, recons = np.concatenate(preds), np.concatenate(recons)
+    assert preds.shape == (320, 1) and recons.shape == (320, 1)
+    # window i's forecast is the fixture's; the shifted window's reconstruction is window i+1's last step
+    gate(torch.from_numpy(preds), case.preds, case.preds64, what="Predictor-style forecasts")
+    gate(torch.from_numpy(recons[:-1]), case.recons[1:, -1, :], case.recons64[1:, -1, :], what="Predictor-style recons")
+    # ... and equals the fused series entry point bit for bit
+    p2, r2 = model.score_series(series.to(gpu_device))
+    assert torch.equal(p2.cpu(), torch.from_numpy(preds)) and torch.equal(r2.cpu(), torch.from_numpy(recons))
+
+
+def _epoch(model, opt, batches, device, train=True):
+    f_l, r_l = [], []
+    model.train(train)
+    for x, y in batches:
+        x, y = x.to(device), y.to(device)
+        if train:
+            opt.zero_grad()
+        with torch.set_grad_enabled(train):
+            preds, recons = model(x)
+            if preds.ndim == 3:
+                preds = preds.squeeze(1)
+            y = y.squeeze(1)
+            fl = torch.sqrt(F.mse_loss(y, preds))
+            rl = torch.sqrt(F.mse_loss(x, recons))
+            if train:
+                (fl + rl).backward()
+                opt.step()
+        f_l.append(fl.item())
+        r_l.append(rl.item())
+    return f_l, r_l
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.3])
+def test_trainer_call_sequence(dropout, gpu_device):
+    """Adam built BEFORE the model moves to the GPU (train.py:92 vs training.py:76-77), model.cuda(),
+    train() epochs with a ragged last batch, evaluate(), save / load of the state_dict.  With dropout 0
+    the GPU run must track the same training run on the package's CPU tensor path step by step."""
+    from mtad_gat import MTAD_GAT
+    kw = dict(n_features=12, window_size=30, out_dim=12, kernel_size=5, gru_hid_dim=40, forecast_n_layers=2,
+              forecast_hid_dim=36, recon_hid_dim=44, dropout=dropout, alpha=0.2)
+    g = torch.Generator().manual_seed(3)
+    series = torch.rand(30 + 150, 12, generator=g)
+    ds = _Windows(series, 30)
+    batches = [torch.utils.data.default_collate([ds[i] for i in range(lo, min(lo + 64, len(ds)))]) for lo in range(0, len(ds), 64)]
+    assert len(batches) == 3 and batches[-1][0].shape[0] == 22          # ragged tail
+
+    def run(device):
+        torch.manual_seed(0)
+        model = MTAD_GAT(**kw)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        if device.type == "cuda":
+            model.cuda()                                                # parameters move in place; Adam keeps them
+        init = _epoch(model, opt, batches, device, train=False)
+        torch.manual_seed(1)
+        hist = [_epoch(model, opt, batches, device, train=True) for _ in range(3)]
+        final = _epoch(model, opt, batches, device, train=False)
+        return model, init, hist, final
+
+    m_gpu, init_g, hist_g, final_g = run(gpu_device)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m_gpu.parameters())
+    assert sum(final_g[0]) + sum(final_g[1]) < sum(init_g[0]) + sum(init_g[1])     # it learns
+    sd = {k: v.detach().cpu().clone() for k, v in m_gpu.state_dict().items()}
+    m2 = MTAD_GAT(**kw)
+    m2.load_state_dict(sd)                                                          # Trainer.load
+    m2 = m2.to(gpu_device).eval()
+    with torch.no_grad():
+        xa = batches[0][0].to(gpu_device)
+        assert torch.equal(m2(xa)[0], m_gpu.eval()(xa)[0])
+    if dropout == 0.0:
+        m_cpu, init_c, hist_c, final_c = run(torch.device("cpu"))
+        flat = lambda h: [v for ep in h for part in ep for v in part]   # noqa: E731
+        for a, b in zip(flat([init_g] + hist_g + [final_g]), flat([init_c] + hist_c + [final_c])):
+            assert abs(a - b) <= 2e-4, (a, b)
+        for (n, p), q in zip(m_gpu.named_parameters(), m_cpu.parameters()):
+            assert (p.detach().cpu() - q.detach()).abs().max().item() <= 2e-3, n    # 9 Adam steps of lr 1e-3
+
+
+def test_rccl_world_size_1_runs_the_n_rank_code(gpu_device):
+    """`init_process_group("nccl")` = RCCL: the collective calls of the data-parallel training step and of
+    bench.py's timing (barrier, max over ranks, gather) execute on this GPU with a world of one."""
+    from sharding import dp_training_step, gather_windows, max_over_ranks
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        t = torch.ones(4, device=gpu_device)
+        dist.all_reduce(t)                                     # goes through RCCL even for one rank
+        dist.barrier()
+        assert torch.equal(t.cpu(), torch.ones(4))
+        assert max_over_ranks(1.25, gpu_device) == 1.25
+        case = Case("syn_v2_embed")
+        model = case.build_model().to(gpu_device).train()
+        x = case.x.to(gpu_device)
+        y = torch.rand(x.shape[0], 1, case.kwargs["n_features"], device=gpu_device)
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        torch.manual_seed(5)
+        rm = dp_training_step(model, x, y, opt, target_dims=list(range(case.kwargs["out_dim"])))
+        assert all(p.grad is not None for p in model.parameters()) and rm[0] > 0 and rm[1] > 0
+        with torch.no_grad():
+            p, _ = model.eval()(x)
+        assert torch.equal(gather_windows(p, x.shape[0]), p)
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_path):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "mtad-gat-pytorch_amd"), root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import Case
+    from sharding import gather_windows, max_over_ranks, shard_range
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)                              # both ranks share the box's one GPU
+    case = Case("syn_v2_embed")                                # 37 windows: 19 + 18
+    model = case.build_model().to(dev)
+    lo, hi = shard_range(case.x.shape[0], rank, world)
+    with torch.no_grad():
+        p, r = model(case.x[lo:hi].to(dev))                    # the HIP forward of this rank's shard
+    torch.cuda.synchronize(dev)
+    p_all = gather_windows(p.cpu(), case.x.shape[0])
+    r_all = gather_windows(r.cpu(), case.x.shape[0])
+    t = max_over_ranks(1.0 + rank)
+    dist.barrier()
+    if rank == 0:
+        import _native
+        torch.save(dict(p=p_all, r=r_all, t=t, lib=_native.library_path()), out_path)
+    dist.destroy_process_group()
+
+
+def test_two_processes_share_the_gpu_and_run_the_hip_forward(tmp_path, gpu_device):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "out.pt")
+    mp.spawn(_two_rank_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    case = Case("syn_v2_embed")
+    assert res["t"] == 2.0 and res["lib"].endswith("libmtadgat.so")
+    gate(res["p"], case.preds, case.preds64, what="2-rank preds")
+    gate(res["r"], case.recons, case.recons64, what="2-rank recons")

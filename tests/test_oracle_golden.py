@@ -60,3 +60,15 @@ def test_reconstruction_input_quirk():
     for t in range(W):
         for j in range(H):
             assert rep[0, t, j].item() == (t * H + j) // W
+
+
+@pytest.mark.parametrize("name", ["smap_wide", "msl_c1"])
+def test_oracle_matches_reference_on_wide_fixtures(name):
+    """>= 256 windows incl. a ragged tail (SURVEY.md section 8d's gate), and the C1 input statistics
+    (sine + Bernoulli columns, values outside [0,1]) through the MSL checkpoint with its 1.8e23 biases."""
+    from helpers import WideCase
+    case = WideCase(name)
+    with torch.no_grad():
+        p, r = oracle.forward(case.x, case.state_dict(), alpha=case.kwargs["alpha"], aten_gru=True)
+    assert (p - case.preds).abs().max().item() <= 2e-6
+    assert (r - case.recons).abs().max().item() <= 5e-6

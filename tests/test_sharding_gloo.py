@@ -1,6 +1,6 @@
 """The N>1 path on CPU: window sharding + max-over-ranks timing + gather, world_size 2 over gloo.
-The per-rank forward is stood in by the oracle (this test is about the distributed plumbing that
-bench.py and a multi-GPU caller use; the HIP forward itself is covered by the -m gpu tests)."""
+Every rank runs the drop-in module on its shard (CPU tensors -> the package's torch-op path; the same
+test with the HIP forward per rank is tests/test_gpu_plumbing.py::test_two_processes_share_the_gpu...)."""
 import os
 import socket
 
@@ -30,7 +30,6 @@ def _worker(rank, world, port, out_path):
     for p in (os.path.join(root, "mtad-gat-pytorch_amd"), root, os.path.join(root, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    from oracle import mtad_gat_oracle as oracle
     from sharding import gather_windows, max_over_ranks, shard_range
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,8 +37,9 @@ def _worker(rank, world, port, out_path):
     torch.set_num_threads(2)
     case = Case("syn_v2_embed")            # 37 windows: ragged split 19 + 18
     lo, hi = shard_range(case.x.shape[0], rank, world)
+    model = case.build_model()
     with torch.no_grad():
-        p, r = oracle.forward(case.x[lo:hi], case.state_dict(), alpha=case.kwargs["alpha"])
+        p, r = model(case.x[lo:hi])
     p_all = gather_windows(p, case.x.shape[0])
     r_all = gather_windows(r, case.x.shape[0])
     t = max_over_ranks(1.0 + rank)          # slowest rank wins
