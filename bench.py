@@ -18,8 +18,13 @@ Also in the line:
                    algorithmic FLOPs per launch / average duration vs the fp32 MFMA peak;
                    plus `hbm` with the algorithmic-bytes rate vs 8 TB/s that BASELINE.json
                    asks for (this path is compute-bound by ~100x).
-  cpu_baseline  -- the oracle (the reference's formulation on CPU PyTorch, oracle/) timed on
-                   this host's cores on a bounded sample, N=1 / rank 0 only.
+  cpu_baseline  -- the unmodified reference module (imported from $MTADGAT_REFERENCE or /root/reference,
+                   kind "reference") when that tree exists on this host, else the oracle port of it
+                   (oracle/, kind "port"), timed on this host's cores on a bounded sample, N=1 / rank 0 only.
+  sub           -- outside the timed region, N=1 only: `batch256` (the reference Predictor's fixed batch,
+                   prediction.py:31: latency of one forward), `train_step` (BASELINE config 3 shape: SMD
+                   F=38, out=38, batch 256 -- forward + loss + backward + Adam, training.py:106-127) and
+                   `smap_bf16_b4096` (config 2); each names the code path that ran.
 """
 import argparse
 import json
@@ -37,6 +42,7 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T fp32 lane-ops/s
 
 
 def load_msl_state_dict():
@@ -57,8 +63,8 @@ def algorithmic_flops(kw):
     return {
         "conv": 2 * W * F * F * k,
         "proj": 2 * F * (2 * W) * Ef + 2 * W * (2 * F) * Et,
-        # pairwise |L+R| terms (2 VALU ops each) + aggregation GEMMs
-        "attend": 2 * (F * F * Ef + W * W * Et) + 2 * F * F * W + 2 * W * W * F,
+        # aggregation GEMMs att (K x K) . V (K x D); the pairwise |L+R| term is VALU work (valu_lane_ops)
+        "attend": 2 * F * F * W + 2 * W * W * F,
         "gru": 2 * (3 * H * 3 * F + 3 * H * H) * W,
         "fc": fc,
         # decoder: recurrent GEMM + per-step Linear (+ the folded input term, <= 3 columns)
@@ -66,40 +72,131 @@ def algorithmic_flops(kw):
     }
 
 
+def _reference_module():
+    """The unmodified reference MTAD_GAT class, if its tree is on this host (never on the GPU box)."""
+    ref = os.environ.get("MTADGAT_REFERENCE", "/root/reference")
+    if not os.path.isfile(os.path.join(ref, "mtad_gat.py")):
+        return None
+    import importlib.util
+    sys.path.append(ref)                      # its `from modules import ...`; appended: never shadows this package
+    try:
+        spec = importlib.util.spec_from_file_location("_reference_mtad_gat", os.path.join(ref, "mtad_gat.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.MTAD_GAT
+    except Exception:
+        return None
+    finally:
+        sys.path.remove(ref)
+
+
+def valu_lane_ops(kw):
+    """Per-window VALU lane-operations of the pairwise term: 2 per (i, j, k) element (add, |.|-accumulate)."""
+    F, W = kw["n_features"], kw["window_size"]
+    return {"attend": 2 * (F * F * 2 * W + W * W * 2 * F)}
+
+
 def cpu_baseline(sd, kw, budget_s=10.0):
-    """Reference CPU path (oracle = the reference's formulation on CPU PyTorch) on this host's cores.
+    """Reference CPU path on this host's cores: the reference module itself when its tree is present
+    (kind "reference"), otherwise the oracle = the reference's formulation restated on CPU PyTorch
+    (kind "port"; the two agree to 2e-6, tests/test_oracle_vs_reference.py).
 
     The reference formulation is memory-bound (it materialises the (b,K,K,2D) pairwise tensors), so
     more threads is not faster on a many-core host: a one-iteration sweep picks the thread count,
     then that setting is timed for ~budget_s seconds."""
-    from oracle import mtad_gat_oracle as oracle
     ncores = os.cpu_count() or 1
     b = 256   # the reference's own batch (args.py:47, prediction.py:31)
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g)
+    Ref = _reference_module()
+    if Ref is not None:
+        ref = Ref(**kw)
+        ref.load_state_dict(sd)
+        ref.eval()
+        run, kind, what = (lambda xx: ref(xx)), "reference", "unmodified reference MTAD_GAT.forward (torch CPU fp32)"
+    else:
+        from oracle import mtad_gat_oracle as oracle
+        run, kind = (lambda xx: oracle.forward(xx, sd, kw["alpha"], aten_gru=True)), "port"
+        what = "oracle/mtad_gat_oracle.py forward (reference formulation, torch CPU fp32, aten::gru); reference tree absent on this host"
     cands = sorted({min(n, ncores) for n in (8, 32, 128)})
     sweep = {}
     with torch.no_grad():
         for nt in cands:
             torch.set_num_threads(nt)
-            oracle.forward(x[:32], sd, kw["alpha"], aten_gru=True)      # warm-up
+            run(x[:32])      # warm-up
             t0 = time.perf_counter()
-            oracle.forward(x, sd, kw["alpha"], aten_gru=True)
+            run(x)
             sweep[nt] = b / (time.perf_counter() - t0)
         best = max(sweep, key=sweep.get)
         torch.set_num_threads(best)
         iters, t0 = 0, time.perf_counter()
         while True:
-            oracle.forward(x, sd, kw["alpha"], aten_gru=True)
+            run(x)
             iters += 1
             el = time.perf_counter() - t0
             if el >= budget_s or iters >= 50:
                 break
-    return {"value": round(b * iters / el, 2), "unit": "windows/s", "cores": best, "kind": "port",
-            "sample": f"{iters} x {b}-window batches (W={kw['window_size']},F={kw['n_features']}) in {el:.1f} s; "
-                      f"oracle/mtad_gat_oracle.py forward (reference formulation, torch CPU fp32, aten::gru); "
+    return {"value": round(b * iters / el, 2), "unit": "windows/s", "cores": best, "kind": kind,
+            "sample": f"{iters} x {b}-window batches (W={kw['window_size']},F={kw['n_features']}) in {el:.1f} s; {what}; "
                       f"threads picked by a 1-iteration sweep {{{', '.join(f'{k}: {v:.0f} w/s' for k, v in sweep.items())}}} "
                       f"on a host with {ncores} logical cores"}
+
+
+def _timed(fn, dev, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / iters
+
+
+def sub_records(model, kw, dev):
+    """Measurements of the other BASELINE configurations, outside the timed region (N=1 only)."""
+    import torch.nn.functional as F
+    from mtad_gat import MTAD_GAT
+    out = {}
+    g = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        x256 = torch.rand(256, kw["window_size"], kw["n_features"], generator=g).to(dev)
+        model.check_weight_contents = False
+        t = _timed(lambda: model(x256), dev, 20)
+        out["batch256"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1),
+                           "what": "one eval forward of the reference Predictor's fixed 256-window batch (prediction.py:31), MSL shape"}
+    # BASELINE config 3 shape: SMD machine-1-1, F=38 -> out 38, batch 256 (args.py:47), dropout 0.3
+    kw3 = dict(kw, n_features=38, out_dim=38, dropout=0.3)
+    torch.manual_seed(0)
+    m3 = MTAD_GAT(**kw3).to(dev).train()
+    m3.check_weight_contents = False
+    opt = torch.optim.Adam(m3.parameters(), lr=1e-3)
+    x3 = torch.rand(256, kw3["window_size"], 38, generator=g).to(dev)
+    y3 = torch.rand(256, 38, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad()
+        p, r = m3(x3)
+        loss = torch.sqrt(F.mse_loss(y3, p)) + torch.sqrt(F.mse_loss(x3, r))
+        loss.backward()
+        opt.step()
+
+    t = _timed(step, dev, 10)
+    out["train_step"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1),
+                         "grad_path": getattr(m3, "grad_path", "hip"),
+                         "what": "SMD shape (F=38, W=100, out=38), batch 256, dropout 0.3: forward + RMSE losses + backward + Adam "
+                                 "(training.py:106-127), fp32"}
+    # BASELINE config 2: SMAP shape F=25, batch 4096, bf16 I/O
+    kw2 = dict(kw, n_features=25, out_dim=1)
+    torch.manual_seed(0)
+    m2 = MTAD_GAT(**kw2).to(dev).eval()
+    m2.check_weight_contents = False
+    x2 = torch.rand(4096, kw2["window_size"], 25, generator=g).to(dev).to(torch.bfloat16)
+    with torch.no_grad():
+        t = _timed(lambda: m2(x2), dev, 10)
+    out["smap_bf16_b4096"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(4096 / t, 1),
+                              "what": "SMAP shape (F=25), batch 4096, bf16 in / bf16 out, random-init weights"}
+    return out
 
 
 def main():
@@ -111,6 +208,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="windows per internal chunk (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="skip the batch256 / train_step / bf16 sub-records")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,6 +281,7 @@ def main():
         }
         if prof:
             flops = algorithmic_flops(kw)
+            valu = valu_lane_ops(kw)
             # launch families by kernel template: the GRU layer and the reconstruction decoder are two
             # launches of the same kernel (k_gru), the two attention layers two launches of k_gat
             groups = {"k_conv": ["conv"], "k_gat": ["proj", "attend"], "k_gru": ["gru", "recon"], "k_rowgemm(fc)": ["fc"]}
@@ -192,33 +291,48 @@ def main():
                 ms = sum(prof[s_][0] for s_ in slots)
                 n = sum(prof[s_][1] for s_ in slots)
                 fl = sum(flops[s_] for s_ in slots)
+                vl = sum(valu.get(s_, 0) for s_ in slots)
                 if n:
                     tot[fam] = (ms, n, fl)
+                    tf = fl * B * args.steps / (ms * 1e-3) / 1e12
                     fams[fam] = {"ms_per_step": round(ms / args.steps, 3), "launches": int(n),
-                                 "alg_gflop_per_launch": round(fl * B * args.steps / n / 1e9, 3),
-                                 "tflops": round(fl * B * args.steps / (ms * 1e-3) / 1e12, 2)}
-            fams["k_gat"]["note"] = "VALU-bound: 2 VALU ops per pairwise element counted as 2 flop"
+                                 "alg_mfma_gflop_per_launch": round(fl * B * args.steps / n / 1e9, 3),
+                                 "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+                    if vl:
+                        tl = vl * B * args.steps / (ms * 1e-3) / 1e12
+                        fams[fam]["alg_valu_glaneops_per_launch"] = round(vl * B * args.steps / n / 1e9, 3)
+                        fams[fam]["valu_tlaneops"] = round(tl, 2)
+                        fams[fam]["valu_frac"] = round(tl / VALU_PEAK_TLANEOPS, 4)
             res["kernels"] = fams
             dom = max(fams, key=lambda k: fams[k]["ms_per_step"])
             ms_dom, n_dom, fl_dom = tot[dom]
-            flops = dict(flops, **{dom: fl_dom})
             ach = fl_dom * B * args.steps / (ms_dom * 1e-3) / 1e12
-            traffic = None   # HBM bytes per launch from the committed PMC pass (profiles/), scaled to this batch
+            # HBM bytes per launch: NOT measured in this run (PMC counters need their own rocprofv3 pass,
+            # profiles/collect.sh); taken from the newest committed PMC summary and scaled to this batch
+            traffic, tsrc = None, None
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+                tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
                 if dom in tj["bytes_per_window"]:
                     traffic = int(tj["bytes_per_window"][dom] * B * args.steps / n_dom)
+                    tsrc = f"profiles/{cands[-1]} (rocprofv3 --pmc pass, {tj.get('git', 'unknown commit')}), scaled to this batch; not measured in this run"
             except Exception:
                 pass
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_source": tsrc,
                                "avg_launch_ms": round(ms_dom / n_dom, 3),
-                               "alg_flop_per_window": flops[dom],
+                               "alg_flop_per_window": fl_dom,
                                "note": "v_mfma_f32_32x32x2_f32 (exact f32) peak; algorithmic FLOPs exclude tile padding"}
         gbs = value * alg_bytes / 1e9
         res["hbm"] = {"alg_bytes_per_window": alg_bytes, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(gbs / HBM_PEAK_GBS / world, 5),
                       "note": "whole-forward algorithmic bytes rate per GPU vs HBM peak; the path is compute-bound"}
+        if world == 1 and not args.no_sub:
+            try:
+                res["sub"] = sub_records(model, kw, dev)
+            except Exception as e:
+                res["sub"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(sd, kw)

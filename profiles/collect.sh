@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the files under profiles/ on a GPU box:  bash profiles/collect.sh r01
+# Regenerates the files under profiles/ on a GPU box:  bash profiles/collect.sh r02 <git rev>
 # (rocprofv3 passes are separate: --kernel-trace --stats, then one --pmc pass per counter group).
 set -u
 TAG=${1:-r01}
@@ -8,12 +8,12 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.log"
-rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/kt_bench_line.json" 2> /dev/null
+rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-sub > "$OUT/kt_bench_line.json" 2> /dev/null
 cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$C && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python "$ROOT/bench.py" --steps 1 --warmup 1 --batch 65536 --no-cpu-baseline > /dev/null 2>&1
+  rm -rf /tmp/pmc_$C && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python "$ROOT/bench.py" --steps 1 --warmup 1 --batch 65536 --no-cpu-baseline --no-sub > /dev/null 2>&1
   cp "$(find /tmp/pmc_$C -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$C.csv"
 done
-rm -rf /tmp/pmc_sq && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rm -rf /tmp/pmc_sq && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-sub > /dev/null 2>&1
 cp "$(find /tmp/pmc_sq -name '*counter_collection.csv' | head -1)" "$OUT/pmc_SQ.csv"
-python "$ROOT/profiles/summarize.py" "$OUT" "$TAG"
+python "$ROOT/profiles/summarize.py" "$OUT" "$TAG" "${2:-unknown}"
