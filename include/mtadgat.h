@@ -164,6 +164,43 @@ int mtadgat_heads(mtadgat_handle h, const float* hend_dev, int64_t batch,
                   float* preds_dev, float* recons_dev,
                   void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* ---- training step --------------------------------------------------------------------------------
+ * Replaces what autograd does for the reference around MTAD_GAT.forward in Trainer.fit
+ * (training.py:106-127: preds, recons = model(x); loss.backward()): a forward that keeps the
+ * activations the backward needs in a caller-owned "tape" and applies dropout inside the kernels
+ * (attention matrices modules.py:90 / :189, forecasting layers modules.py:310), and the backward
+ * that turns d loss / d preds, d loss / d recons into the gradients of all parameters.
+ *
+ * Dropout is counter based: the mask of window `window0 + w` depends only on (seed, site, that global
+ * window index, element), so chunking, sharding or recomputing a batch reproduces the same masks.
+ * dropout_p = 0 gives the deterministic (eval-mode) function, e.g. for gradients in eval().
+ *
+ * Gradients are ACCUMULATED (+=) into `grads_dev`, a flat float32 buffer of mtadgat_grad_floats()
+ * entries holding the reference's parameters' gradients in their own shapes, in the field order of
+ * mtadgat_params (offsets: mtadgat_grad_offsets); zero it before the first chunk of a step.
+ * Not every configuration has a HIP backward (mtadgat_backward_supported; GATv2, single-layer GRU /
+ * decoder, <= 128 nodes and features per attention layer do).  `batch` windows are processed as one
+ * chunk: tape and workspace grow linearly with it (~0.85 + 0.75 MB per window at W=100, F=55). */
+int     mtadgat_backward_supported(mtadgat_handle h);
+size_t  mtadgat_tape_bytes(mtadgat_handle h, int64_t batch);
+size_t  mtadgat_backward_workspace_bytes(mtadgat_handle h, int64_t batch);
+int64_t mtadgat_grad_floats(mtadgat_handle h);
+/* offsets (floats) of conv w,b | feature lin w,b,a,bias | temporal lin w,b,a,bias | gru w_ih,w_hh,b_ih,b_hh |
+ * fc (w,b) x forecast_n_linear | decoder w_ih,w_hh,b_ih,b_hh | recon fc w,b; returns the count */
+int     mtadgat_grad_offsets(mtadgat_handle h, int64_t* offsets_out, int max_n);
+int mtadgat_forward_train(mtadgat_handle h, const float* x_dev, int64_t batch, int64_t window0, float dropout_p,
+                          uint64_t seed, float* preds_dev, float* recons_dev, void* tape_dev, size_t tape_bytes,
+                          void* stream);
+int mtadgat_backward(mtadgat_handle h, const float* x_dev, int64_t batch, int64_t window0, float dropout_p, uint64_t seed,
+                     const float* d_preds_dev, const float* d_recons_dev, const void* tape_dev, size_t tape_bytes,
+                     float* grads_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* Diagnostics for the tests: the keep-masks (1 / 0) the kernels apply -- mask_feat (batch, F, F), mask_temp
+ * (batch, W, W), mask_fc (forecast_n_linear - 1, batch, forecast_hid_dim), any may be NULL -- and the offsets
+ * (floats) of the tape / backward-workspace regions (order: see mtadgat_capi.cpp). */
+int mtadgat_dropout_masks(mtadgat_handle h, int64_t batch, int64_t window0, float dropout_p, uint64_t seed,
+                          float* mask_feat_dev, float* mask_temp_dev, float* mask_fc_dev, void* stream);
+int mtadgat_train_layout(mtadgat_handle h, int64_t batch, int64_t* offsets_out, int max_n);
+
 /* Per-kernel launch timing for bench.py's roofline leg: when enabled, forward()
  * brackets each kernel family with hipEvents on `stream`; mtadgat_profile_read
  * synchronises those events and returns accumulated milliseconds + launch counts

@@ -1,18 +1,93 @@
-"""Differentiable GPU forward: `torch.autograd.Function` over the HIP forward (training variant that keeps
-the activations the backward needs, dropout in the kernels) and the HIP backward (`mtadgat_backward`).
+"""Differentiable GPU forward: `torch.autograd.Function` over the HIP training forward (keeps the
+activations the backward needs in a tape, dropout inside the kernels) and the HIP backward
+(`mtadgat_forward_train` / `mtadgat_backward`, include/mtadgat.h).
 
-Configurations the HIP backward does not cover (see `Engine.backward_supported`) are evaluated by the
-package's torch-op algebra (`_torchpath.py`) with autograd -- stated in DESIGN.md, and visible to the
-caller through `MTAD_GAT.grad_path`.
+Configurations without a HIP backward (`Engine.backward_supported()` false: GAT v1, stacked GRU layers,
+attention layers beyond 128 nodes) and inputs that themselves require a gradient are evaluated by the
+package's torch-op algebra (`_torchpath.py`) with autograd; `MTAD_GAT.grad_path` says which path the last
+differentiable call took ("hip" / "torch-ops: <reason>").
 """
 import torch
 
 import _torchpath
 
+# windows per chunk of the training step: tape + workspace are ~1.6 MB per window (W=100, F=55); a batch larger
+# than this is processed chunk by chunk, re-running the chunk's forward inside backward (the counter-based
+# dropout reproduces its masks) so that memory stays bounded whatever the batch
+TRAIN_CHUNK = 8192
+
+
+def param_order(model):
+    """The model's parameters in the field order of mtadgat_params / mtadgat_grad_offsets."""
+    names = ["conv.conv.weight", "conv.conv.bias"]
+    for g in ("feature_gat", "temporal_gat"):
+        names += [f"{g}.lin.weight", f"{g}.lin.bias", f"{g}.a", f"{g}.bias"]
+    names += [f"gru.gru.{k}_l0" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    for i in range(len(model.forecasting_model.layers)):
+        names += [f"forecasting_model.layers.{i}.weight", f"forecasting_model.layers.{i}.bias"]
+    names += [f"recon_model.decoder.rnn.{k}_l0" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    names += ["recon_model.fc.weight", "recon_model.fc.bias"]
+    named = dict(model.named_parameters())
+    return [named[n] for n in names]
+
+
+class _HipStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, x, p, seed, *params):
+        b = x.shape[0]
+        chunks = [(lo, min(lo + TRAIN_CHUNK, b)) for lo in range(0, b, TRAIN_CHUNK)] or [(0, 0)]
+        tape = None
+        if len(chunks) == 1:
+            preds, recons, tape = eng.forward_train(x, p, seed, 0)
+        else:
+            outs = []
+            scratch = getattr(eng, "_train_tape", None)
+            for lo, hi in chunks:
+                pr, rc, scratch = eng.forward_train(x[lo:hi], p, seed, lo, tape=scratch)
+                outs.append((pr, rc))
+            preds = torch.cat([o[0] for o in outs])
+            recons = torch.cat([o[1] for o in outs])
+            eng._train_tape = scratch            # reused by backward's recomputation
+        ctx.eng, ctx.p, ctx.seed, ctx.chunks, ctx.tape = eng, p, seed, chunks, tape
+        ctx.save_for_backward(x)
+        ctx.shapes = [(q.shape, q.numel()) for q in params]
+        return preds, recons
+
+    @staticmethod
+    def backward(ctx, d_preds, d_recons):
+        eng = ctx.eng
+        (x,) = ctx.saved_tensors
+        offs, total = eng.grad_layout()
+        grads = torch.zeros(total, dtype=torch.float32, device=x.device)
+        d_preds = d_preds.contiguous().float()
+        d_recons = d_recons.contiguous().float()
+        if x.shape[0]:
+            if ctx.tape is not None:
+                eng.backward(x, ctx.p, ctx.seed, d_preds, d_recons, ctx.tape, grads, 0)
+            else:
+                scratch = getattr(eng, "_train_tape", None)
+                for lo, hi in ctx.chunks:
+                    xc = x[lo:hi]
+                    _, _, scratch = eng.forward_train(xc, ctx.p, ctx.seed, lo, tape=scratch)
+                    eng.backward(xc, ctx.p, ctx.seed, d_preds[lo:hi].contiguous(), d_recons[lo:hi].contiguous(), scratch, grads, lo)
+        ctx.tape = None
+        out = [grads[o:o + n].view(shape) for o, (shape, n) in zip(offs, ctx.shapes)]
+        return (None, None, None, None, *out)
+
 
 def forward(model, eng, x):
     """(preds, recons) with autograd history when grad is enabled; dropout active iff model.training."""
+    why = None
     if not eng.backward_supported():
-        object.__setattr__(model, "grad_path", "torch-ops")
+        why = eng.why_not()
+    elif x.requires_grad and torch.is_grad_enabled():
+        why = "the input requires a gradient (the HIP backward produces parameter gradients only)"
+    if why is not None:
+        object.__setattr__(model, "grad_path", "torch-ops: " + why)
         return _torchpath.forward(model, x.float())
-    raise NotImplementedError
+    object.__setattr__(model, "grad_path", "hip")
+    p = float(model.dropout_p) if model.training else 0.0
+    # one seed per call from torch's (CPU) generator: runs are reproducible under torch.manual_seed
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+    params = param_order(model)
+    return _HipStep.apply(eng, x.detach().contiguous().float(), p, seed, *params)

@@ -70,6 +70,19 @@ def load_library():
     lib.mtadgat_gat.argtypes = [vp, ctypes.c_int, vp, i64, vp, vp, sz, vp]
     lib.mtadgat_gru.argtypes = [vp, vp, i64, vp, vp, sz, vp]
     lib.mtadgat_heads.argtypes = [vp, vp, i64, vp, vp, vp, sz, vp]
+    u64, f32 = ctypes.c_uint64, ctypes.c_float
+    lib.mtadgat_backward_supported.argtypes = [vp]
+    lib.mtadgat_tape_bytes.argtypes = [vp, i64]
+    lib.mtadgat_tape_bytes.restype = sz
+    lib.mtadgat_backward_workspace_bytes.argtypes = [vp, i64]
+    lib.mtadgat_backward_workspace_bytes.restype = sz
+    lib.mtadgat_grad_floats.argtypes = [vp]
+    lib.mtadgat_grad_floats.restype = i64
+    lib.mtadgat_grad_offsets.argtypes = [vp, ctypes.POINTER(i64), ctypes.c_int]
+    lib.mtadgat_train_layout.argtypes = [vp, i64, ctypes.POINTER(i64), ctypes.c_int]
+    lib.mtadgat_forward_train.argtypes = [vp, vp, i64, i64, f32, u64, vp, vp, vp, sz, vp]
+    lib.mtadgat_backward.argtypes = [vp, vp, i64, i64, f32, u64, vp, vp, vp, sz, vp, vp, sz, vp]
+    lib.mtadgat_dropout_masks.argtypes = [vp, i64, i64, f32, u64, vp, vp, vp, vp]
     lib.mtadgat_profile_enable.argtypes = [vp, ctypes.c_int]
     lib.mtadgat_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     lib.mtadgat_profile_name.argtypes = [ctypes.c_int]
@@ -125,9 +138,85 @@ class Engine:
         except Exception:
             pass
 
+    # -- training step ------------------------------------------------------------------------------
     def backward_supported(self):
-        """True when the library has a HIP backward for this configuration."""
-        return False
+        """True when the library has a HIP backward for this configuration (else why_not() says why)."""
+        return bool(self.lib.mtadgat_backward_supported(self.handle))
+
+    def why_not(self):
+        self.lib.mtadgat_backward_supported(self.handle)
+        return self.lib.mtadgat_last_error().decode("utf-8", "replace")
+
+    def grad_layout(self):
+        """[offsets] of the flat gradient buffer in the field order of mtadgat_params, total floats."""
+        n = 14 + 2 * self.cfg.forecast_n_linear + 6
+        offs = (ctypes.c_int64 * n)()
+        got = self.lib.mtadgat_grad_offsets(self.handle, offs, n)
+        if got != n:
+            raise RuntimeError("mtadgat_grad_offsets: unexpected parameter count")
+        return list(offs), int(self.lib.mtadgat_grad_floats(self.handle))
+
+    TAPE_FIELDS = ("hcat", "xct", "att_f", "att_t", "hend", "gates_g", "seq_g", "gates_d", "seq_d", "xdec")
+    WS_FIELDS = ("da", "dhcat", "dhdec", "dhend", "dz0", "dz1", "de_f", "de_t", "dv_f", "dv_t", "dlr_f", "dlr_t",
+                 "dap_f", "dap_t", "dpre")
+
+    def train_layout(self, batch):
+        """Diagnostics: float offsets of the tape / backward-workspace regions for `batch` windows."""
+        n = len(self.TAPE_FIELDS) + len(self.WS_FIELDS)
+        offs = (ctypes.c_int64 * n)()
+        if self.lib.mtadgat_train_layout(self.handle, batch, offs, n) != n:
+            raise RuntimeError("mtadgat_train_layout failed")
+        v = list(offs)
+        return dict(zip(self.TAPE_FIELDS, v[:len(self.TAPE_FIELDS)])), dict(zip(self.WS_FIELDS, v[len(self.TAPE_FIELDS):]))
+
+    def _buf(self, name, nbytes, device):
+        cur = getattr(self, name, None)
+        if cur is None or cur.device != device or cur.numel() * 4 < nbytes:
+            setattr(self, name, None)
+            cur = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            setattr(self, name, cur)
+        return cur
+
+    def forward_train(self, x, p, seed, window0=0, tape=None):
+        """Training forward of `x` (one chunk): (preds, recons, tape).  Dropout with probability p inside the kernels."""
+        c = self.cfg
+        b = x.shape[0]
+        xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
+        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=x.device)
+        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=x.device)
+        if b == 0:
+            return preds, recons, None
+        need = self.lib.mtadgat_tape_bytes(self.handle, b)
+        if tape is None or tape.numel() * 4 < need:
+            tape = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        self._call(self.lib.mtadgat_forward_train, "forward_train", x.device, xp, b, int(window0), float(p), int(seed),
+                   _dev_ptr(preds, "preds"), _dev_ptr(recons, "recons"), _dev_ptr(tape, "tape"), need)
+        return preds, recons, tape
+
+    def backward(self, x, p, seed, d_preds, d_recons, tape, grads, window0=0):
+        """Accumulates the parameter gradients of one chunk into the flat buffer `grads`."""
+        c = self.cfg
+        b = x.shape[0]
+        if b == 0:
+            return
+        xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
+        need_t = self.lib.mtadgat_tape_bytes(self.handle, b)
+        need_w = self.lib.mtadgat_backward_workspace_bytes(self.handle, b)
+        ws = self._buf("_bws", need_w, x.device)
+        self._call(self.lib.mtadgat_backward, "backward", x.device, xp, b, int(window0), float(p), int(seed),
+                   _dev_ptr(d_preds, "d_preds", (b, c.out_dim)), _dev_ptr(d_recons, "d_recons", (b, c.window_size, c.out_dim)),
+                   _dev_ptr(tape, "tape"), need_t, _dev_ptr(grads, "grads"), _dev_ptr(ws, "workspace"), need_w)
+
+    def dropout_masks(self, batch, p, seed, device, window0=0):
+        """The keep-masks the kernels apply: {"feat": (b,F,F), "temp": (b,W,W), "fc": [(b,hid)] * hidden layers}."""
+        c = self.cfg
+        mf = torch.empty((batch, c.n_features, c.n_features), dtype=torch.float32, device=device)
+        mt = torch.empty((batch, c.window_size, c.window_size), dtype=torch.float32, device=device)
+        nh = c.forecast_n_linear - 1
+        mfc = torch.empty((max(nh, 1), batch, c.forecast_hid_dim), dtype=torch.float32, device=device)
+        self._call(self.lib.mtadgat_dropout_masks, "dropout_masks", device, batch, int(window0), float(p), int(seed),
+                   _dev_ptr(mf, "mask"), _dev_ptr(mt, "mask"), _dev_ptr(mfc, "mask"))
+        return {"feat": mf, "temp": mt, "fc": [mfc[i] for i in range(nh)]}
 
     # -- weights ------------------------------------------------------------------------------
     def load_weights(self, sd, device):

@@ -85,7 +85,7 @@ def forecast_stage(model, h_end, training=False, masks=None):
 
 def recon_stage(model, h_end):
     w = model.recon_model.window_size
-    rep = h_end.repeat_interleave(w, dim=1).view(h_end.shape[0], w, -1)     # the reference's decoder input (modules.py:279)
+    rep = h_end.repeat_interleave(w, dim=1).view(h_end.shape[0], w, h_end.shape[1])     # the reference's decoder input (modules.py:279)
     dec, _ = model.recon_model.decoder.rnn(rep)
     return model.recon_model.fc(dec)
 

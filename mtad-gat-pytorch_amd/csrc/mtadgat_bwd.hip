@@ -1,0 +1,841 @@
+// Backward kernels of the MTAD-GAT hot path (training step, reference training.py:106-127: loss.backward()
+// through MTAD_GAT.forward) + launchers.  gfx950, wave64, fp32.
+//
+//   k_wgrad / k_wgrad_reduce   every weight / bias gradient: dW = A^T B over all (window, step) rows, split over
+//                              row slabs, deterministic two-stage sum, scattered into the reference's parameter layout
+//   k_gru_bwd                  back-propagation through time of a GRU layer (GRULayer / RNNDecoder, modules.py:235-257)
+//   k_gat_bwd_att / _pair      backward of a graph-attention layer (modules.py:65-95, :166-193), per window
+//   small kernels              decoder-input adjoint (modules.py:279), conv pre-activation gradient, dropout masks
+//
+// The data gradients of the Linear layers (d X = d Y W) reuse k_rowgemm with transposed weight packs.
+#include "mtadgat_device.h"
+
+namespace mtadgat {
+
+// ---------------------------------------------------------------------------
+// wgrad: P[slab][m][n] = sum_{rows of the slab} A[row][m] * B[row][n].
+// MFMA with the data rows as the contraction index: for v_mfma_f32_32x32x2_f32 lane (c = lane & 31,
+// kk = lane >> 5) supplies A[row][m = c] and B[row][n = c] of row r + 4 kk + s for the s-th of four
+// instructions -- 8 rows per group, one dword per operand and lane, coalesced 128-byte row segments.
+// A wave owns a 2 x 2 block of 32 x 32 output tiles; every load is unconditional from a clamped address and
+// masked afterwards (a guarded load would cost one memory round trip per group).
+// ---------------------------------------------------------------------------
+template <int BMODE>
+__global__ __launch_bounds__(64) void k_wgrad(const WgradArgs a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 31, kk = lane >> 5;
+    const int Nb = (a.Np + 63) >> 6;
+    const int mb = blockIdx.x / Nb, nb = blockIdx.x - mb * Nb;
+    const int slab = blockIdx.y;
+    const long rbeg = (long)slab * a.rows_per_slab;
+    const long rend = rbeg + a.rows_per_slab < a.R ? rbeg + a.rows_per_slab : a.R;
+    const int T = a.T > 0 ? a.T : 1;
+
+    int mcol[2], ncol[2], mc[2], nc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        mcol[u] = 64 * mb + 32 * u + c;
+        ncol[u] = 64 * nb + 32 * u + c;
+        mc[u] = mcol[u] < a.M ? mcol[u] : a.M - 1;
+        nc[u] = ncol[u] < a.N ? ncol[u] : a.N - 1;
+    }
+    // conv im2col: column n = tap * F + ch
+    int tapn[2] = {0, 0}, chn[2] = {0, 0};
+    if (BMODE == 1) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            tapn[u] = nc[u] / a.F;
+            chn[u] = nc[u] - tapn[u] * a.F;
+        }
+    }
+    const bool need_t = (BMODE == 1) || a.ashift;
+    int ts[4];                                        // step index within the window of this lane's 4 rows
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ts[s] = need_t ? (int)((rbeg + 4 * kk + s) % T) : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+
+    auto load = [&](long r0, float (&av)[2][4], float (&bv)[2][4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long row = r0 + 4 * kk + s;
+            const bool rok = row < rend;
+            const long rowc = rok ? row : a.R - 1;
+            const int t = ts[s];
+            // A
+            const bool aok = rok && !(a.ashift && t == T - 1);
+            long arow = rowc + (a.ashift ? 1 : 0);
+            arow = arow < a.R ? arow : a.R - 1;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float v = a.A[arow * a.lda + mc[u]];
+                av[u][s] = (aok && mcol[u] < a.M) ? v : 0.f;
+            }
+            // B
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v;
+                bool ok = rok && ncol[u] < a.N;
+                if (BMODE == 1) {
+                    const int tt = t + tapn[u] - a.pad;
+                    const bool tin = tt >= 0 && tt < T;
+                    long xr = rowc + tapn[u] - a.pad;
+                    xr = xr < 0 ? 0 : (xr < a.R ? xr : a.R - 1);
+                    v = a.B[xr * a.F + chn[u]];
+                    ok = ok && tin;
+                } else {
+                    v = a.B[rowc * a.ldb + nc[u]];
+                }
+                v = ok ? v : 0.f;
+                bv[u][s] = (rok && ncol[u] == a.N) ? 1.f : v;            // the all-ones column: bias gradients
+            }
+        }
+    };
+    auto advance = [&]() {
+        if (need_t) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                int t = ts[s] + 8;
+                while (t >= T) t -= T;
+                ts[s] = t;
+            }
+        }
+    };
+
+    float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
+    if (rbeg < rend) {
+        load(rbeg, a0, b0);
+        for (long r = rbeg; r < rend; r += 8) {
+            advance();
+            load(r + 8, a1, b1);                      // rows past the slab come back masked to zero
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[x][s], b0[y][s], acc[x][y], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { a0[u][s] = a1[u][s]; b0[u][s] = b1[u][s]; }
+        }
+    }
+    float* __restrict__ P = a.P + (long)slab * a.Mp * a.Np;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int m0 = 64 * mb + 32 * x, n = 64 * nb + 32 * y + c;
+            if (m0 < a.Mp && n < a.Np) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+                    P[(long)m * a.Np + n] = acc[x][y][q];
+                }
+            }
+        }
+}
+
+__global__ void k_wgrad_reduce(const WgradReduceArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NN = a.N + 1;
+    if (idx >= (long)a.M * NN) return;
+    const int m = (int)(idx / NN), n = (int)(idx - (long)m * NN);
+    float v = 0.f;
+    for (int s = 0; s < a.nslab; ++s) v += a.P[((long)s * a.Mp + m) * a.Np + n];
+    if (n < a.N) {
+        const int ro = a.rowmapW[m], co = a.colmap[n];
+        if (ro >= 0 && co >= 0) a.outW[ro + co] += v;
+    } else if (a.rowmapB) {
+        const int ro = a.rowmapB[m];
+        if (ro >= 0) a.outB[ro] += v;
+    }
+}
+
+int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    if (a.R <= 0 || a.M <= 0 || a.N <= 0) return 0;
+    const dim3 grid((unsigned)(((a.Mp + 63) / 64) * ((a.Np + 63) / 64)), (unsigned)a.nslab);
+    if (a.bmode == 1)
+        hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_wgrad<0>, grid, dim3(64), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s) {
+    const long total = (long)a.M * (a.N + 1);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// column sums over many rows (d bias of the attention layers = sum over windows of d e; d a partials)
+// ---------------------------------------------------------------------------
+static inline int sum_rows_slabs(long R) { return (int)(R < 64 ? (R < 1 ? 1 : R) : 64); }
+size_t sum_rows_scratch(long R, int N) { return (size_t)sum_rows_slabs(R) * (size_t)N; }
+
+__global__ void k_sum_rows1(const float* __restrict__ src, long ld, long R, int N, long rows_per_slab, float* __restrict__ part) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const long r0 = (long)blockIdx.y * rows_per_slab;
+    const long r1 = r0 + rows_per_slab < R ? r0 + rows_per_slab : R;
+    float v = 0.f;
+    for (long r = r0; r < r1; ++r) v += src[r * ld + n];
+    part[(long)blockIdx.y * N + n] = v;
+}
+__global__ void k_sum_rows2(const float* __restrict__ part, int nslab, int N, float* __restrict__ dst) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float v = 0.f;
+    for (int s = 0; s < nslab; ++s) v += part[(long)s * N + n];
+    dst[n] += v;
+}
+int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, float* dst, hipStream_t s) {
+    if (R <= 0 || N <= 0) return 0;
+    const int S = sum_rows_slabs(R);
+    const long rps = (R + S - 1) / S;
+    hipLaunchKernelGGL(k_sum_rows1, dim3((unsigned)((N + 255) / 256), (unsigned)S), dim3(256), 0, s, src, ld, R, N, rps, scratch);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_rows2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, scratch, S, N, dst);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// GRU backward through time.  Workgroup = 32 windows, wave c = hidden tile c (as k_gru_split).  Per step,
+// from the last to the first:
+//     d n = d h (1 - z),  d a_n = d n (1 - n^2),  d a_z = d h (h_{t-1} - n) z (1 - z),
+//     d a_r = d a_n q r (1 - r),  d a_nh = d a_n r          (q = W_hn h_{t-1} + b_hn)
+//     d h_{t-1} = d h z + W_hr^T d a_r + W_hz^T d a_z + W_hn^T d a_nh   (+ the external gradient of h_{t-1})
+// The three gradient blocks are published in LDS in F-layout and every wave runs its 32-unit tile of the
+// transposed recurrent product on the MFMA (same chunk / lane mapping as the forward).  d a_* of every step
+// are written out for the weight-gradient GEMMs and the input-gradient rowgemm.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    f32x4* __restrict__ das = reinterpret_cast<f32x4*>(gsm);          // [3][NCG][4][64]
+    const int lane = threadIdx.x & 63;
+    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NCG = a.NCG;
+    const int i = lane & 31, g = lane >> 5;
+    const long win = (long)blockIdx.x * 32 + i;
+    const long winc = win < a.B ? win : a.B - 1;
+    const int T = a.T, Hp = a.Hp;
+    const int NQ = 12 * NCG;
+    const int Q4 = 4 * NCG;
+    const f32x4* __restrict__ W = a.WhT + (long)c * NQ * 64 + lane;
+    const int col0 = 32 * c + 4 * g;
+
+    f32x16 dh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+    if (a.DHend) {
+        const float* p = a.DHend + winc * a.ldde + col0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 8 * m);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) dh[4 * m + s4] = v[s4];
+        }
+    }
+    f32x4 wr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wr[u] = W[u * 64];
+
+    for (int t = T - 1; t >= 0; --t) {
+        const long row = winc * T + t;
+        const float* gp = a.Gates + row * (4L * Hp) + col0;
+        const float* hp = a.Seq + (row - (t > 0 ? 1 : 0)) * (long)Hp + col0;
+        f32x4 r4[4], z4[4], n4[4], q4[4], h4[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            r4[m] = *reinterpret_cast<const f32x4*>(gp + 8 * m);
+            z4[m] = *reinterpret_cast<const f32x4*>(gp + Hp + 8 * m);
+            n4[m] = *reinterpret_cast<const f32x4*>(gp + 2 * Hp + 8 * m);
+            q4[m] = *reinterpret_cast<const f32x4*>(gp + 3 * Hp + 8 * m);
+            h4[m] = *reinterpret_cast<const f32x4*>(hp + 8 * m);
+        }
+        if (a.DHseq) {
+            const float* dp = a.DHseq + row * a.lddh + col0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(dp + 8 * m);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) dh[4 * m + s4] += v[s4];
+            }
+        }
+        const float hmask = t > 0 ? 1.f : 0.f;         // h_{-1} = 0
+        f32x16 dhz;
+        f32x4 dan4[4], dar4[4], daz4[4], dnh4[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float dv = dh[4 * m + s4];
+                const float r = r4[m][s4], z = z4[m][s4], n = n4[m][s4], q = q4[m][s4], hprev = h4[m][s4] * hmask;
+                const float dan = dv * (1.f - z) * (1.f - n * n);
+                dan4[m][s4] = dan;
+                daz4[m][s4] = dv * (hprev - n) * z * (1.f - z);
+                dar4[m][s4] = dan * q * r * (1.f - r);
+                dnh4[m][s4] = dan * r;
+                dhz[4 * m + s4] = dv * z;
+            }
+        if (win < a.B) {
+            float* op = a.DA + row * (4L * Hp) + col0;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                *reinterpret_cast<f32x4*>(op + 8 * m) = dan4[m];
+                *reinterpret_cast<f32x4*>(op + Hp + 8 * m) = dar4[m];
+                *reinterpret_cast<f32x4*>(op + 2 * Hp + 8 * m) = daz4[m];
+                *reinterpret_cast<f32x4*>(op + 3 * Hp + 8 * m) = dnh4[m];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            das[((0 * NCG + c) * 4 + m) * 64 + lane] = dar4[m];
+            das[((1 * NCG + c) * 4 + m) * 64 + lane] = daz4[m];
+            das[((2 * NCG + c) * 4 + m) * 64 + lane] = dnh4[m];
+        }
+        __syncthreads();
+        f32x16 acc = dhz;
+        for (int q0 = 0; q0 < NQ; q0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 xv = das[(q0 + u) * 64 + lane];
+                acc = mfma4(wr[u], xv, acc);
+                int qn = q0 + u + 4;
+                qn = qn >= NQ ? qn - NQ : qn;
+                wr[u] = W[qn * 64];
+            }
+        }
+        dh = acc;
+        __syncthreads();
+    }
+    (void)Q4;
+}
+
+int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
+    if (a.B <= 0) return 0;
+    const size_t lds = (size_t)3 * a.NCG * 4 * 64 * sizeof(f32x4);
+    if (a.NCG < 1 || a.NCG > 8 || lds > 160 * 1024) return -2;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_gru_bwd, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// graph attention backward, part 1 (one workgroup per window, thread <-> (query row, key) pair grid of the
+// forward k_gat):  h = sigmoid(S), S = att' V, att' = dropout(att), att = softmax_j(e)
+//     d S = d h * h (1 - h);  d att' = d S V^T;  d att = d att' * mask / (1 - p)
+//     d e_ij = att_ij (d att_ij - sum_j att_ij d att_ij)              -> DE   (also d bias before the batch sum)
+//     d V_j (aggregation path) = sum_i att'_ij d S_i                     -> DV   (MFMA 16x16x4 + LDS float atomics)
+// ---------------------------------------------------------------------------
+constexpr int GB_APITCH = 68;
+
+size_t gat_bwd_att_lds(int K, int D, int vld, int nwa) {
+    (void)D;
+    const int Kp16 = (K + 15) & ~15;
+    return ((size_t)3 * Kp16 * vld + (size_t)nwa * 16 * GB_APITCH) * sizeof(float);
+}
+
+template <int RJ>
+__device__ __forceinline__ float bw_row_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    if (RJ == 16) v += dpp_move<0x140>(v);
+    return v;
+}
+
+template <int IBL, int JPL, int RJ>
+__global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RI = 64 / RJ;
+    constexpr int IBW = RI * IBL;
+    static_assert(IBW == 16, "a wave owns 16 query rows");
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long win = blockIdx.x;
+    const int K = a.K, D = a.D, vld = a.vld;
+    const int Kp16 = (K + 15) & ~15;
+    const int NWA = Kp16 >> 4;
+    float* __restrict__ Vs = smem;
+    float* __restrict__ dSs = Vs + Kp16 * vld;
+    float* __restrict__ dVacc = dSs + Kp16 * vld;
+    float* __restrict__ atts = dVacc + Kp16 * vld;
+    const int lj = lane % RJ, li = lane / RJ;
+
+    // ---- stage V, d S (zero padded), clear the d V accumulators
+    {
+        const float* __restrict__ vsrc = a.V + win * (long)(a.vt ? D : K) * a.ldv;
+        const int total = Kp16 * vld;
+        if (!a.vt) {
+            for (int u = tid; u < total; u += nthr) {
+                const int node = u / vld, col = u - node * vld;
+                Vs[u] = (node < K && col < D) ? vsrc[(long)node * a.ldv + col] : 0.f;
+                dVacc[u] = 0.f;
+            }
+        } else {
+            for (int u = tid; u < total; u += nthr) {            // node fastest: coalesced reads of the transposed source
+                const int col = u / Kp16, node = u - col * Kp16;
+                Vs[node * vld + col] = (node < K && col < D) ? vsrc[(long)col * a.ldv + node] : 0.f;
+                dVacc[node * vld + col] = 0.f;
+            }
+        }
+        const float* __restrict__ hsrc = a.H + win * a.so_w;
+        const float* __restrict__ dsrc = a.dH + win * a.so_w;
+        if (a.so_d == 1) {
+            for (int u = tid; u < total; u += nthr) {
+                const int node = u / vld, col = u - node * vld;
+                float v = 0.f;
+                if (node < K && col < D) {
+                    const long o = (long)node * a.so_i + col;
+                    const float h = hsrc[o];
+                    v = dsrc[o] * h * (1.f - h);
+                }
+                dSs[u] = v;
+            }
+        } else {
+            for (int u = tid; u < total; u += nthr) {
+                const int col = u / Kp16, node = u - col * Kp16;
+                float v = 0.f;
+                if (node < K && col < D) {
+                    const long o = (long)node * a.so_i + (long)col * a.so_d;
+                    const float h = hsrc[o];
+                    v = dsrc[o] * h * (1.f - h);
+                }
+                dSs[node * vld + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    const bool rows_owner = wave < NWA;
+    const int i0 = (rows_owner ? wave : 0) * IBW;
+    float acc[IBL][JPL];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = 0.f;
+
+    if (rows_owner) {
+        // ---- d att'_ij = d S_i . V_j over the D features (columns >= D are zero in dSs)
+        const float* lrow[IBL];
+        const float* rrow[JPL];
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) lrow[ii] = dSs + (i0 + li + RI * ii) * vld;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            const int j = lj + RJ * jj;
+            rrow[jj] = Vs + (j < Kp16 ? j : Kp16 - 1) * vld;
+        }
+        const int Dr = (D + 1) & ~1;
+        for (int d = 0; d < Dr; d += 2) {
+            f32x2 l[IBL], r[JPL];
+#pragma unroll
+            for (int ii = 0; ii < IBL; ++ii) l[ii] = *reinterpret_cast<const f32x2*>(lrow[ii] + d);
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) r[jj] = *reinterpret_cast<const f32x2*>(rrow[jj] + d);
+#pragma unroll
+            for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] += l[ii][0] * r[jj][0] + l[ii][1] * r[jj][1];
+        }
+        // ---- softmax backward (rows live in RJ adjacent lanes x JPL registers); acc becomes att'
+        const unsigned key = drop_window_key(a.drop, a.drop_stream, win);
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            const int irow = i0 + li + RI * ii;
+            const int irc = irow < K ? irow : K - 1;
+            const float* __restrict__ ap = a.ATT + (win * K + irc) * (long)K;
+            float attv[JPL], dat[JPL];
+            float csum = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = lj + RJ * jj;
+                const int jc = j < K ? j : K - 1;
+                const bool valid = irow < K && j < K;
+                const float av = valid ? ap[jc] : 0.f;
+                float sc = 1.f;
+                if (a.drop.thresh) sc = drop_keep(key, (unsigned)(irc * K + jc), a.drop.thresh) ? a.drop.keep_scale : 0.f;
+                const float datt = acc[ii][jj] * sc;
+                csum += av * datt;
+                attv[jj] = av;
+                dat[jj] = datt;
+                acc[ii][jj] = av * sc;
+            }
+            csum = bw_row_sum<RJ>(csum);
+            float* __restrict__ dep = a.DE + (win * K + irc) * (long)K;
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = lj + RJ * jj;
+                if (irow < K && j < K) dep[j] = attv[jj] * (dat[jj] - csum);
+            }
+        }
+        // ---- d V (aggregation path): out[key][feature] += sum over this wave's 16 rows att'[row][key] d S[row][feature]
+        //   v_mfma_f32_16x16x4_f32: A[m = key][k = row], B[k = row][n = feature]; lane (nr = lane & 15, kb = lane >> 4)
+        //   holds A[nr][kb], B[kb][nr] of rows 4 s + kb for instruction s; D register q of lane (nr, kb) = out[4 kb + q][nr]
+        float* __restrict__ att = atts + wave * (IBW * GB_APITCH);
+        const int nr = lane & 15, kb = lane >> 4;
+        constexpr int JPP = 64 / RJ;
+        constexpr int PASSES = (JPL + JPP - 1) / JPP;
+        const int DT = (D + 15) >> 4;
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+            if (pass * 64 < K) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                    for (int j4 = 0; j4 < JPP; ++j4)
+                        if (JPP * pass + j4 < JPL) att[(li + RI * ii) * GB_APITCH + lj + RJ * j4] = acc[ii][JPP * pass + j4];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const int jn = min(64, Kp16 - pass * 64);
+                for (int jt = 0; jt < (jn >> 4); ++jt) {
+                    float av[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) av[s] = att[(4 * s + kb) * GB_APITCH + 16 * jt + nr];
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const int dcol = 16 * dt + nr;
+                        const int dcc = dcol < vld ? dcol : vld - 1;
+                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const float bv = dSs[(i0 + 4 * s + kb) * vld + dcc];
+                            o = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, o, 0, 0, 0);
+                        }
+                        if (dcol < D) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) atomicAdd(&dVacc[(pass * 64 + 16 * jt + 4 * kb + q) * vld + dcol], o[q]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int u = tid; u < K * D; u += nthr) {
+        const int node = u / D, col = u - node * D;
+        a.DV[(win * K + node) * (long)a.lddv + col] = dVacc[node * vld + col];
+    }
+}
+
+#define GBA_CASE(I, J, RJ_)                                                                                   \
+    if (IBL == I && JPL == J && rj == RJ_) {                                                                  \
+        if (lds_bytes > 64 * 1024) {                                                                          \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_att<I, J, RJ_>),     \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+            if (e_ != hipSuccess) return (int)e_;                                                             \
+        }                                                                                                     \
+        hipLaunchKernelGGL((k_gat_bwd_att<I, J, RJ_>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);           \
+        launched = true;                                                                                      \
+    }
+
+int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
+    if (a.nwin <= 0) return 0;
+    if (rj * JPL < a.K || nw * 16 < a.K || nw > 8 || lds_bytes > 160 * 1024) return -2;
+    const unsigned grid = (unsigned)a.nwin;
+    bool launched = false;
+    GBA_CASE(4, 1, 16) GBA_CASE(4, 2, 16) GBA_CASE(4, 3, 16) GBA_CASE(4, 4, 16) GBA_CASE(4, 5, 16) GBA_CASE(4, 6, 16) GBA_CASE(4, 7, 16) GBA_CASE(4, 8, 16)
+    GBA_CASE(2, 1, 8) GBA_CASE(2, 3, 8) GBA_CASE(2, 5, 8) GBA_CASE(2, 7, 8)
+    if (!launched) return -2;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// graph attention backward, part 2 (GATv2 scores e_ij = sum_k a_k LeakyReLU(L_ik + R_jk), L = W_l v + b,
+// R = W_r v; modules.py:74-77 / :174-177).  With t = L_ik + R_jk and g = [t > 0]:
+//     d L_ik = a_k (1 - alpha) sum_j d e_ij g         (the alpha part vanishes: sum_j d e_ij = 0, softmax rows)
+//     d R_jk = a_k (alpha sum_i d e_ij + (1 - alpha) sum_i d e_ij g)
+//     d a_k  = sum_ij d e_ij LeakyReLU(t) = (1+alpha)/2 sum d e t + (1-alpha)/2 sum d e |t|
+// One workgroup per window.  L, R are re-projected 32 columns at a time on the MFMA (un-scaled weight tiles)
+// exactly as in the forward; in the pair phase a lane owns one embedding column k (so d L and the d a sums
+// stay in registers), a half-wave one query row at a time, and the d R partial sums of all K keys live in
+// registers (the j loop is fully unrolled) until they are merged through LDS float atomics.
+// ---------------------------------------------------------------------------
+constexpr int GP_LLD = 34;
+
+static inline int pair_nj8(int K) {
+    const int need = (K + 7) / 8;
+    const int opts[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16};
+    for (int o : opts)
+        if (o >= need) return o;
+    return -1;
+}
+
+size_t gat_bwd_pair_lds(int K, int vld, int Ep) {
+    (void)Ep;
+    const int Kp16 = (K + 15) & ~15;
+    const int nj8 = pair_nj8(K);
+    if (nj8 < 0) return (size_t)1 << 30;
+    const int KPD = 8 * nj8 + 4;
+    const int NTn = (K + 31) >> 5;
+    size_t f = (size_t)Kp16 * vld + (size_t)((K * KPD + 3) & ~3) + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)8 * nj8 * 32 + 8 * nj8 + 64;
+    return f * sizeof(float);
+}
+
+template <int NJ8>
+__global__ __launch_bounds__(512) void k_gat_bwd_pair(const GatBwdPairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KJ = 8 * NJ8;
+    constexpr int KPD = KJ + 4;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = nthr >> 6;
+    const long win = blockIdx.x;
+    const int K = a.K, D = a.D, vld = a.vld, Ep = a.Ep;
+    const int Kp16 = (K + 15) & ~15;
+    const int NTn = (K + 31) >> 5;
+    float* __restrict__ Vs = smem;
+    float* __restrict__ deS = Vs + Kp16 * vld;
+    float* __restrict__ Ls = deS + ((K * KPD + 3) & ~3);
+    float* __restrict__ Rs = Ls + NTn * 32 * GP_LLD;
+    float* __restrict__ NS = Rs + NTn * 32 * GP_LLD;
+    float* __restrict__ cs = NS + KJ * 32;
+    float* __restrict__ daS = cs + KJ;
+    const int i = lane & 31, g = lane >> 5;
+
+    // ---- stage V (+ the ones column D: the projection bias is weight row D), d e, clear the accumulators
+    {
+        const float* __restrict__ vsrc = a.V + win * (long)(a.vt ? D : K) * a.ldv;
+        const int total = Kp16 * vld;
+        if (!a.vt) {
+            for (int u = tid; u < total; u += nthr) {
+                const int node = u / vld, col = u - node * vld;
+                float v = 0.f;
+                if (node < K && col < D) v = vsrc[(long)node * a.ldv + col];
+                Vs[u] = (node < K && col == D) ? 1.f : v;
+            }
+        } else {
+            for (int u = tid; u < total; u += nthr) {
+                const int col = u / Kp16, node = u - col * Kp16;
+                float v = 0.f;
+                if (node < K && col < D) v = vsrc[(long)col * a.ldv + node];
+                Vs[node * vld + col] = (node < K && col == D) ? 1.f : v;
+            }
+        }
+        const float* __restrict__ de = a.DE + win * (long)K * K;
+        for (int u = tid; u < K * KPD; u += nthr) {
+            const int r = u / KPD, j = u - r * KPD;
+            deS[u] = j < K ? de[(long)r * K + j] : 0.f;
+        }
+        for (int u = tid; u < 2 * NTn * 32 * GP_LLD; u += nthr) Ls[u] = 0.f;      // Ls and Rs (rows >= K stay zero)
+        for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
+        if (tid < 64) daS[tid] = 0.f;
+    }
+    __syncthreads();
+    for (int j = tid; j < KJ; j += nthr) {
+        float s = 0.f;
+        for (int r = 0; r < K; ++r) s += deS[r * KPD + j];
+        cs[j] = s;
+    }
+
+    const int NTu = a.NTu, Q = a.Q;
+    const int ntask = 2 * NTn;
+    const int k = lane & 31, half = lane >> 5;
+    const int rw = 2 * wave + half, NWK = 2 * NW;
+    for (int part = 0; part < NTu; ++part) {
+        // ---- MFMA phase: L, R columns [32 part, 32 part + 32) of all nodes
+        for (int task = wave; task < ntask; task += NW) {
+            const bool keyside = task >= NTn;
+            const int nt = keyside ? task - NTn : task;
+            const int wtile = keyside ? NTu + part : part;
+            const int node = nt * 32 + i;
+            const float* __restrict__ vrow = Vs + (node < K ? node : K - 1) * vld;
+            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            f32x4 w = wp[0];
+            for (int q = 0; q < Q; ++q) {
+                const f32x4 wn = wp[(long)(q + 1 < Q ? q + 1 : q) * 64];
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * q + 4 * g);
+                o = mfma4(w, xv, o);
+                w = wn;
+            }
+            if (node < K) {
+                float* __restrict__ dst = (keyside ? Rs : Ls) + node * GP_LLD + 4 * g;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x2 v0, v1;
+                    v0[0] = o[4 * m + 0]; v0[1] = o[4 * m + 1]; v1[0] = o[4 * m + 2]; v1[1] = o[4 * m + 3];
+                    *reinterpret_cast<f32x2*>(dst + 8 * m) = v0;
+                    *reinterpret_cast<f32x2*>(dst + 8 * m + 2) = v1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- pair phase
+        {
+            const int col = 32 * part + k;
+            const float ak = a.avec[col];
+            const float cl = ak * (1.f - a.alpha);
+            float Nacc[KJ];
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) Nacc[j] = 0.f;
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = rw; r < K; r += NWK) {
+                const float L = Ls[r * GP_LLD + k];
+                const float* __restrict__ drow = deS + r * KPD;
+                float Macc = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < NJ8; ++jb) {
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(drow + 8 * jb);
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(drow + 8 * jb + 4);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = 8 * jb + u;
+                        const float dv = u < 4 ? d0[u & 3] : d1[u & 3];
+                        const float t = L + Rs[j * GP_LLD + k];
+                        const float mm = t > 0.f ? dv : 0.f;
+                        Macc += mm;
+                        Nacc[j] += mm;
+                        s1 = __builtin_fmaf(dv, t, s1);
+                        s2 = __builtin_fmaf(dv, fabsf(t), s2);
+                    }
+                }
+                a.DLR[(win * K + r) * (long)(2 * Ep) + col] = cl * Macc;
+            }
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) atomicAdd(&NS[j * 32 + k], Nacc[j]);
+            atomicAdd(&daS[k], s1);
+            atomicAdd(&daS[32 + k], s2);
+        }
+        __syncthreads();
+        for (int u = tid; u < K * 32; u += nthr) {
+            const int j = u >> 5, kk = u & 31;
+            const int col = 32 * part + kk;
+            const float ak = a.avec[col];
+            a.DLR[(win * K + j) * (long)(2 * Ep) + Ep + col] = ak * (a.alpha * cs[j] + (1.f - a.alpha) * NS[u]);
+        }
+        if (tid < 32) {
+            const int col = 32 * part + tid;
+            a.DApart[win * Ep + col] = 0.5f * (1.f + a.alpha) * daS[tid] + 0.5f * (1.f - a.alpha) * daS[32 + tid];
+        }
+        __syncthreads();
+        for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
+        if (tid < 64) daS[tid] = 0.f;
+        // (the next part's MFMA phase ends in a barrier before anybody adds to NS / daS again)
+    }
+}
+
+int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s) {
+    if (a.nwin <= 0) return 0;
+    const int nj8 = pair_nj8(a.K);
+    if (nj8 < 0 || lds_bytes > 160 * 1024) return -2;
+    const unsigned grid = (unsigned)a.nwin;
+#define GBP_CASE(N)                                                                                                    \
+    if (nj8 == N) {                                                                                                    \
+        if (lds_bytes > 64 * 1024) {                                                                                   \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_pair<N>),                     \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
+            if (e_ != hipSuccess) return (int)e_;                                                                      \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_gat_bwd_pair<N>), dim3(grid), dim3(512), lds_bytes, s, a);                               \
+    }
+    GBP_CASE(1) GBP_CASE(2) GBP_CASE(3) GBP_CASE(4) GBP_CASE(5) GBP_CASE(6) GBP_CASE(7) GBP_CASE(8) GBP_CASE(10) GBP_CASE(13) GBP_CASE(16)
+#undef GBP_CASE
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------
+__global__ void k_xdec(const float* __restrict__ hend, long ldh, int H, int T, long B, float* __restrict__ X, long ldx) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = B * T * ldx;
+    if (idx >= total) return;
+    const long row = idx / ldx;
+    const int j = (int)(idx - row * ldx);
+    const long b = row / T;
+    const int t = (int)(row - b * T);
+    X[idx] = j < H ? hend[b * ldh + ((long)t * H + j) / T] : 0.f;
+}
+int launch_xdec(const float* hend, long ldh, int H, int T, long B, float* X, long ldx, hipStream_t s) {
+    const long total = B * T * ldx;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_xdec, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hend, ldh, H, T, B, X, ldx);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_xdec_bwd(const float* __restrict__ dX, long ldx, int H, int T, long B, float* __restrict__ dhend, long ldh) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H) return;
+    const long b = idx / H;
+    const int m = (int)(idx - b * H);
+    float v = 0.f;
+    for (int k = 0; k < T; ++k) {
+        const long f = (long)m * T + k;
+        const int t = (int)(f / H), j = (int)(f - (long)t * H);
+        v += dX[(b * T + t) * ldx + j];
+    }
+    dhend[b * ldh + m] += v;
+}
+int launch_xdec_bwd(const float* dX, long ldx, int H, int T, long B, float* dhend, long ldh, hipStream_t s) {
+    const long total = B * H;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_xdec_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dX, ldx, H, T, B, dhend, ldh);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_dxc(const float* __restrict__ hcat, const float* __restrict__ dhcat, long ldh, const float* __restrict__ dvt,
+                      long ldt, const float* __restrict__ dvf, long ldf, long B, int T, int F, float* __restrict__ dpre, long ldp) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = B * T * ldp;
+    if (idx >= total) return;
+    const long row = idx / ldp;
+    const int f = (int)(idx - row * ldp);
+    float v = 0.f;
+    if (f < F) {
+        const long b = row / T;
+        const int t = (int)(row - b * T);
+        if (hcat[row * ldh + f] > 0.f) v = dhcat[row * ldh + f] + dvt[row * ldt + f] + dvf[(b * F + f) * ldf + t];
+    }
+    dpre[idx] = v;
+}
+int launch_dxc(const float* hcat, const float* dhcat, long ldh, const float* dvt, long ldt, const float* dvf, long ldf, long B,
+               int T, int F, float* dpre, long ldp, hipStream_t s) {
+    const long total = B * T * ldp;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_dxc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hcat, dhcat, ldh, dvt, ldt, dvf, ldf, B, T, F, dpre, ldp);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void k_dropmask(const DropArgs d, unsigned stream, long nwin, long n, float* __restrict__ mask) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nwin * n) return;
+    const long w = idx / n;
+    const unsigned e = (unsigned)(idx - w * n);
+    const unsigned key = drop_window_key(d, stream, w);
+    mask[idx] = (d.thresh == 0 || drop_keep(key, e, d.thresh)) ? 1.f : 0.f;
+}
+int launch_dropmask(const DropArgs& d, unsigned stream, long nwin, long n_per_win, float* mask, hipStream_t s) {
+    const long total = nwin * n_per_win;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_dropmask, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d, stream, nwin, n_per_win, mask);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mtadgat

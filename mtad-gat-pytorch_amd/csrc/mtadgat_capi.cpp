@@ -126,7 +126,7 @@ bool use_fused(const GatPlan& g) { return g.fused; }
 
 // fused layer: V rows (n*K, ldv) -> out, nothing but V read from / out written to HBM
 int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, int64_t n, float* out, long so_w, long so_i,
-                  long so_d, hipStream_t s) {
+                  long so_d, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0) {
     Scope sc(m, S_ATTEND, s);
     GatArgs a{};
     a.V = v; a.ldv = ldv; a.vt = vt; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.lr_floats = g.f_lr;
@@ -138,6 +138,9 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     a.nwin = n;
     a.v1 = m.cfg.use_gatv2 ? 0 : 1;
     a.alpha = m.cfg.alpha;
+    a.ATT = att;
+    if (drop) a.drop = *drop;
+    a.drop_stream = drop_stream;
     K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.f_lds_bytes, s), "fused gat");
     return 0;
 }
@@ -153,7 +156,7 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
 int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
-                  long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s) {
+                  long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s, float* gates = nullptr) {
     Scope sc(m, slot, s);
     GruArgs a{};
     a.X = x; a.ldx = ldx; a.Kx = kx; a.Qx = g.Qx; a.Qxp = g.Qxp;
@@ -172,6 +175,11 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.Yfc = yfc;
         a.Ylast = ylast;
         a.out_dim = fc->out_dim;
+    }
+    if (gates) {     // training forward: keep the gate activations of every step
+        a.Gates = gates;
+        K_TRY(launch_gru_train(a, g.NCG, g.xmode, fc != nullptr, s), "gru (training)");
+        return 0;
     }
     K_TRY(launch_gru(a, g.NCG, g.xmode, fc != nullptr, s), "gru");
     return 0;
@@ -528,6 +536,346 @@ int mtadgat_profile_read(mtadgat_handle h, double ms[MTADGAT_PROFILE_SLOTS], int
 
 const char* mtadgat_profile_name(int slot) {
     return (slot >= 0 && slot < MTADGAT_PROFILE_SLOTS) ? kSlotNames[slot] : "";
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// training step: forward that keeps the activations ("tape") + backward  (reference training.py:106-127)
+// =====================================================================================================
+namespace {
+
+DropArgs make_drop(float p, uint64_t seed, int64_t win0) {
+    DropArgs d{};
+    if (p > 0.f) {
+        double t = (double)p * 4294967296.0;
+        d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+        if (d.thresh == 0) d.thresh = 1;
+        d.keep_scale = 1.0f / (1.0f - p);
+    } else {
+        d.thresh = 0;
+        d.keep_scale = 1.0f;
+    }
+    d.seed_lo = (unsigned)(seed & 0xffffffffu);
+    d.seed_hi = (unsigned)(seed >> 32);
+    d.win0 = win0;
+    return d;
+}
+
+int check_train(mtadgat_handle h, int64_t batch, float p) {
+    if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");
+    if (batch < 0) return fail(MTADGAT_ERR_INVALID, "negative batch");
+    if (!h->m.have_weights) return fail(MTADGAT_ERR_NOWEIGHTS, "mtadgat_load_weights has not been called");
+    if (!h->m.bw.supported) return fail(MTADGAT_ERR_UNSUPPORTED, "no HIP backward for this configuration: " + h->m.bw.why);
+    if (!(p >= 0.f && p < 1.f)) return fail(MTADGAT_ERR_INVALID, "dropout probability must be in [0, 1)");
+    return 0;
+}
+
+// d X = d Y W through k_rowgemm with the transposed pack
+int run_rowgemm_T(Model& m, const LinTPlan& p, const float* X, long ldx, long R, float* Y, long ldy, int nvalid, bool accumulate,
+                  const float* gate, long ldg, float gate_scale, hipStream_t s) {
+    RowGemmArgs a{};
+    a.X = X; a.ldx = ldx; a.Kvalid = p.in_dim; a.Q = p.Q;
+    a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
+    a.bias = m.packed_dev + m.bw.zero_off;
+    a.Y = Y; a.ldy = ldy; a.Nvalid = nvalid;
+    a.vec_store = ((ldy & 3) == 0 && aligned16(Y)) ? 1 : 0;
+    a.R = R; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
+    a.accumulate = accumulate ? 1 : 0;
+    a.gate = gate; a.ldg = ldg; a.gate_scale = gate_scale;
+    K_TRY(launch_rowgemm(a, s), "data-gradient rowgemm");
+    return 0;
+}
+
+struct WgradIn {
+    const float* A = nullptr; long lda = 0; int ashift = 0;
+    const float* B = nullptr; long ldb = 0; int bmode = 0;
+    long R = 0; int T = 1;
+};
+int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, float* wpart, float* outW, float* outB, hipStream_t s) {
+    WgradArgs a{};
+    a.A = in.A; a.lda = in.lda; a.M = p.M; a.ashift = in.ashift;
+    a.B = in.B; a.ldb = in.ldb; a.N = p.N; a.bmode = in.bmode;
+    a.T = in.T; a.F = m.F; a.taps = m.taps; a.pad = m.pad;
+    a.R = in.R;
+    a.nslab = wgrad_slabs(in.R, p.Mp, p.Np);
+    long rps = (in.R + a.nslab - 1) / a.nslab;
+    rps = (rps + 7) / 8 * 8;
+    a.rows_per_slab = rps;
+    a.P = wpart; a.Mp = p.Mp; a.Np = p.Np;
+    K_TRY(launch_wgrad(a, s), "weight-gradient GEMM");
+    WgradReduceArgs r{};
+    r.P = wpart; r.nslab = a.nslab; r.Mp = p.Mp; r.Np = p.Np; r.M = p.M; r.N = p.N;
+    r.rowmapW = reinterpret_cast<const int*>(m.packed_dev + p.rowW_off);
+    r.colmap = reinterpret_cast<const int*>(m.packed_dev + p.col_off);
+    r.rowmapB = p.has_bias && outB ? reinterpret_cast<const int*>(m.packed_dev + p.rowB_off) : nullptr;
+    r.outW = outW; r.outB = outB;
+    K_TRY(launch_wgrad_reduce(r, s), "weight-gradient reduction");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtadgat_backward_supported(mtadgat_handle h) {
+    if (!h) return 0;
+    if (!h->m.bw.supported) g_err = "no HIP backward for this configuration: " + h->m.bw.why;
+    return h->m.bw.supported ? 1 : 0;
+}
+
+size_t mtadgat_tape_bytes(mtadgat_handle h, int64_t batch) {
+    if (!h || batch <= 0 || !h->m.bw.supported) return 0;
+    Tape t;
+    plan_tape(h->m, batch, t);
+    return t.total * sizeof(float);
+}
+
+size_t mtadgat_backward_workspace_bytes(mtadgat_handle h, int64_t batch) {
+    if (!h || batch <= 0 || !h->m.bw.supported) return 0;
+    BwdWorkspace w;
+    plan_bwd_workspace(h->m, batch, w);
+    return w.total * sizeof(float);
+}
+
+int64_t mtadgat_grad_floats(mtadgat_handle h) { return h ? h->m.bw.gl.total : 0; }
+
+int mtadgat_grad_offsets(mtadgat_handle h, int64_t* out, int max_n) {
+    if (!h || !out) return fail(MTADGAT_ERR_INVALID, "null argument");
+    const GradLayout& g = h->m.bw.gl;
+    std::vector<int64_t> v = {g.conv_w, g.conv_b, g.lin_w[0], g.lin_b[0], g.a[0], g.bias[0], g.lin_w[1], g.lin_b[1], g.a[1], g.bias[1],
+                              g.gru_wih, g.gru_whh, g.gru_bih, g.gru_bhh};
+    for (size_t i = 0; i < g.fc_w.size(); ++i) { v.push_back(g.fc_w[i]); v.push_back(g.fc_b[i]); }
+    v.insert(v.end(), {g.rec_wih, g.rec_whh, g.rec_bih, g.rec_bhh, g.rec_fc_w, g.rec_fc_b});
+    if ((int)v.size() > max_n) return fail(MTADGAT_ERR_INVALID, "offset array too small");
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+int mtadgat_train_layout(mtadgat_handle h, int64_t batch, int64_t* out, int max_n) {
+    if (!h || !out || batch <= 0 || !h->m.bw.supported) return fail(MTADGAT_ERR_INVALID, "bad argument");
+    Tape t;
+    plan_tape(h->m, batch, t);
+    BwdWorkspace w;
+    plan_bwd_workspace(h->m, batch, w);
+    std::vector<int64_t> v = {(int64_t)t.hcat, (int64_t)t.xct, (int64_t)t.att_f, (int64_t)t.att_t, (int64_t)t.hend, (int64_t)t.gates_g,
+                              (int64_t)t.seq_g, (int64_t)t.gates_d, (int64_t)t.seq_d, (int64_t)t.xdec,
+                              (int64_t)w.da, (int64_t)w.dhcat, (int64_t)w.dhdec, (int64_t)w.dhend, (int64_t)w.dz0, (int64_t)w.dz1,
+                              (int64_t)w.de_f, (int64_t)w.de_t, (int64_t)w.dv_f, (int64_t)w.dv_t, (int64_t)w.dlr_f, (int64_t)w.dlr_t,
+                              (int64_t)w.dap_f, (int64_t)w.dap_t, (int64_t)w.dpre};
+    if ((int)v.size() > max_n) return fail(MTADGAT_ERR_INVALID, "layout array too small");
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64_t window0, float dropout_p, uint64_t seed,
+                          float* preds, float* recons, void* tape_, size_t tape_bytes, void* stream) {
+    int rc = check_train(h, batch, dropout_p);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!x || !preds || !recons || !tape_) return fail(MTADGAT_ERR_INVALID, "null tensor");
+    Model& m = h->m;
+    Tape t;
+    plan_tape(m, batch, t);
+    if (!aligned16(tape_) || tape_bytes < t.total * sizeof(float)) return fail(MTADGAT_ERR_WORKSPACE, "tape too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* T = static_cast<float*>(tape_);
+    const int F = m.F, W = m.W;
+    const int64_t n = batch;
+    const DropArgs drop = make_drop(dropout_p, seed, window0);
+    float* hcat = T + t.hcat;
+    XSource src;
+    src.x = x;
+    if ((rc = run_conv(m, src, 0, n, nullptr, T + t.xct, hcat, nullptr, s))) return rc;
+    if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
+    if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
+    const GruPlan& g = m.gru[0];
+    float* hend = T + t.hend;
+    if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g))) return rc;
+    // forecasting head: ReLU + dropout on the hidden layers (modules.py:307-311), activations kept
+    {
+        Scope sc(m, S_FC, s);
+        const float* xin = hend;
+        long ld = g.Hp;
+        const int nfc = (int)m.fc.size();
+        for (int i = 0; i < nfc; ++i) {
+            const LinPlan& p = m.fc[i];
+            const bool last = (i == nfc - 1);
+            RowGemmArgs a{};
+            a.X = xin; a.ldx = ld; a.Kvalid = p.in_dim; a.Q = p.Q;
+            a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
+            a.bias = m.packed_dev + p.b_off;
+            a.R = n; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1;
+            if (last) {
+                a.Y = preds; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
+                a.vec_store = (p.out_dim % 4 == 0 && aligned16(preds)) ? 1 : 0;
+                a.relu = 0;
+            } else {
+                a.Y = T + t.fc_act[i]; a.ldy = p.NT * 32; a.Nvalid = p.NT * 32; a.vec_store = 1;
+                a.relu = 1;
+                a.drop_thresh = drop.thresh; a.seed_lo = drop.seed_lo; a.seed_hi = drop.seed_hi; a.keep_scale = drop.keep_scale;
+                a.drop_stream = DROP_FC0 + (unsigned)i; a.row0 = window0;
+            }
+            K_TRY(launch_rowgemm(a, s), "forecasting head (training)");
+            xin = a.Y; ld = a.ldy;
+        }
+    }
+    // reconstruction decoder, all steps kept
+    const GruPlan& r = m.rec[0];
+    if ((rc = run_gru_layer(m, S_RECON, r, hend, g.Hp, m.cfg.gru_hid_dim, n, nullptr, 0, T + t.seq_d, &m.rec_fc, recons, nullptr, s, T + t.gates_d)))
+        return rc;
+    K_TRY(launch_xdec(hend, g.Hp, m.cfg.gru_hid_dim, W, n, T + t.xdec, g.Hp, s), "decoder input");
+    return 0;
+}
+
+int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t window0, float dropout_p, uint64_t seed,
+                     const float* d_preds, const float* d_recons, const void* tape_, size_t tape_bytes, float* grads,
+                     void* ws_, size_t ws_bytes, void* stream) {
+    int rc = check_train(h, batch, dropout_p);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!x || !d_preds || !d_recons || !tape_ || !grads || !ws_) return fail(MTADGAT_ERR_INVALID, "null tensor");
+    Model& m = h->m;
+    const BwdPlan& b = m.bw;
+    const GradLayout& gl = b.gl;
+    Tape t;
+    plan_tape(m, batch, t);
+    BwdWorkspace w;
+    plan_bwd_workspace(m, batch, w);
+    if (tape_bytes < t.total * sizeof(float)) return fail(MTADGAT_ERR_WORKSPACE, "tape too small");
+    if (!aligned16(ws_) || ws_bytes < w.total * sizeof(float)) return fail(MTADGAT_ERR_WORKSPACE, "backward workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    const float* T = static_cast<const float*>(tape_);
+    float* ws = static_cast<float*>(ws_);
+    const int F = m.F, W = m.W, od = m.cfg.out_dim;
+    const int64_t n = batch;
+    const long RW = (long)n * W;
+    const DropArgs drop = make_drop(dropout_p, seed, window0);
+    const GruPlan& g = m.gru[0];
+    const GruPlan& r = m.rec[0];
+    const float* hcat = T + t.hcat;
+    const float* hend = T + t.hend;
+    float* wpart = ws + w.wpart;
+    float* dhend = ws + w.dhend;
+
+    // ---- 1. forecasting head (modules.py:307-311)
+    {
+        const int nfc = (int)m.fc.size();
+        const float* dy = d_preds;
+        long lddy = od;
+        for (int i = nfc - 1; i >= 0; --i) {
+            const LinPlan& p = m.fc[i];
+            const float* act = i > 0 ? T + t.fc_act[i - 1] : hend;
+            const long lda = i > 0 ? (long)m.fc[i - 1].NT * 32 : g.Hp;
+            WgradIn in;
+            in.A = dy; in.lda = lddy; in.B = act; in.ldb = lda; in.R = n; in.T = 1;
+            if ((rc = run_wgrad(m, b.fc_wg[i], in, wpart, grads + gl.fc_w[i], grads + gl.fc_b[i], s))) return rc;
+            float* y = i > 0 ? ws + ((i & 1) ? w.dz1 : w.dz0) : dhend;
+            const long ldy = i > 0 ? (long)b.fcT[i].NT * 32 : g.Hp;
+            if ((rc = run_rowgemm_T(m, b.fcT[i], dy, lddy, n, y, ldy, (int)ldy, false, i > 0 ? act : nullptr, lda, drop.keep_scale, s))) return rc;
+            dy = y; lddy = ldy;
+        }
+    }
+    // ---- 2. reconstruction model (modules.py:276-283): per-step Linear, decoder GRU, decoder input
+    float* da = ws + w.da;
+    float* dhdec = ws + w.dhdec;
+    {
+        if ((rc = run_rowgemm_T(m, b.recfcT, d_recons, od, RW, dhdec, r.Hp, r.Hp, false, nullptr, 0, 1.f, s))) return rc;
+        WgradIn in;
+        in.A = d_recons; in.lda = od; in.B = T + t.seq_d; in.ldb = r.Hp; in.R = RW; in.T = W;
+        if ((rc = run_wgrad(m, b.recfc_wg, in, wpart, grads + gl.rec_fc_w, grads + gl.rec_fc_b, s))) return rc;
+        GruBwdArgs ga{};
+        ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
+        ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.rec.whT_off);
+        ga.DA = da; ga.Hp = r.Hp; ga.H = r.H; ga.T = W; ga.NCG = r.NCG; ga.B = n;
+        K_TRY(launch_gru_bwd(ga, s), "decoder backward");
+        WgradIn hh;
+        hh.A = da + r.Hp; hh.lda = 4L * r.Hp; hh.ashift = 1; hh.B = T + t.seq_d; hh.ldb = r.Hp; hh.R = RW; hh.T = W;
+        if ((rc = run_wgrad(m, b.rec.wg_hh, hh, wpart, grads + gl.rec_whh, grads + gl.rec_bhh, s))) return rc;
+        WgradIn ih;
+        ih.A = da; ih.lda = 4L * r.Hp; ih.B = T + t.xdec; ih.ldb = g.Hp; ih.R = RW; ih.T = W;
+        if ((rc = run_wgrad(m, b.rec.wg_ih, ih, wpart, grads + gl.rec_wih, grads + gl.rec_bih, s))) return rc;
+        // d (decoder input) -> d h_end through the repeat_interleave / view of modules.py:279
+        if ((rc = run_rowgemm_T(m, b.rec.wihT, da, 4L * r.Hp, RW, dhdec, g.Hp, g.Hp, false, nullptr, 0, 1.f, s))) return rc;
+        K_TRY(launch_xdec_bwd(dhdec, g.Hp, m.cfg.gru_hid_dim, W, n, dhend, g.Hp, s), "decoder input adjoint");
+    }
+    // ---- 3. GRU layer (modules.py:235-238)
+    float* dhcat = ws + w.dhcat;
+    {
+        GruBwdArgs ga{};
+        ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
+        ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.gru.whT_off);
+        ga.DA = da; ga.Hp = g.Hp; ga.H = g.H; ga.T = W; ga.NCG = g.NCG; ga.B = n;
+        K_TRY(launch_gru_bwd(ga, s), "gru backward");
+        WgradIn hh;
+        hh.A = da + g.Hp; hh.lda = 4L * g.Hp; hh.ashift = 1; hh.B = T + t.seq_g; hh.ldb = g.Hp; hh.R = RW; hh.T = W;
+        if ((rc = run_wgrad(m, b.gru.wg_hh, hh, wpart, grads + gl.gru_whh, grads + gl.gru_bhh, s))) return rc;
+        WgradIn ih;
+        ih.A = da; ih.lda = 4L * g.Hp; ih.B = hcat; ih.ldb = m.Dp; ih.R = RW; ih.T = W;
+        if ((rc = run_wgrad(m, b.gru.wg_ih, ih, wpart, grads + gl.gru_wih, grads + gl.gru_bih, s))) return rc;
+        if ((rc = run_rowgemm_T(m, b.gru.wihT, da, 4L * g.Hp, RW, dhcat, m.Dp, m.Dp, false, nullptr, 0, 1.f, s))) return rc;
+    }
+    // ---- 4. the two graph-attention layers (modules.py:65-95, :166-193)
+    for (int which = 1; which >= 0; --which) {
+        const GatPlan& gp = which == 0 ? m.feat : m.temp;
+        const GatBwdPlan& gb = b.gat[which];
+        const int K = gp.K;
+        float* de = ws + (which == 0 ? w.de_f : w.de_t);
+        float* dv = ws + (which == 0 ? w.dv_f : w.dv_t);
+        float* dlr = ws + (which == 0 ? w.dlr_f : w.dlr_t);
+        float* dap = ws + (which == 0 ? w.dap_f : w.dap_t);
+        const int lddv = which == 0 ? m.Wp : m.Fp;
+        const int colofs = which == 0 ? F : 2 * F;
+        GatBwdAttArgs aa{};
+        aa.V = hcat; aa.ldv = m.Dp; aa.D = gp.D; aa.K = K; aa.vt = which == 0 ? 1 : 0; aa.vld = gp.f_vld;
+        aa.H = hcat + colofs; aa.dH = dhcat + colofs;
+        aa.so_w = (long)W * m.Dp; aa.so_i = which == 0 ? 1 : m.Dp; aa.so_d = which == 0 ? m.Dp : 1;
+        aa.ATT = T + (which == 0 ? t.att_f : t.att_t);
+        aa.DE = de; aa.DV = dv; aa.lddv = lddv; aa.nwin = n;
+        aa.drop = drop; aa.drop_stream = which == 0 ? DROP_FEAT : DROP_TEMP;
+        K_TRY(launch_gat_bwd_att(aa, gp.f_IBL, gp.f_JPL, gp.f_RJ, gp.f_nw, gb.att_lds, s), "attention backward (scores)");
+        GatBwdPairArgs pa{};
+        pa.V = hcat; pa.ldv = m.Dp; pa.D = gp.D; pa.K = K; pa.vt = aa.vt; pa.vld = gp.f_vld;
+        pa.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + gb.wu_off);
+        pa.NTu = gb.NTu; pa.Q = gp.Q; pa.E = gp.E; pa.Ep = gb.Ep;
+        pa.avec = m.packed_dev + gb.a_off;
+        pa.DE = de; pa.DLR = dlr; pa.DApart = dap; pa.nwin = n; pa.alpha = m.cfg.alpha;
+        K_TRY(launch_gat_bwd_pair(pa, gb.pair_lds, s), "attention backward (pairs)");
+        const long RK = (long)n * K;
+        if ((rc = run_rowgemm_T(m, gb.lrT, dlr, 2L * gb.Ep, RK, dv, lddv, gp.D, true, nullptr, 0, 1.f, s))) return rc;
+        WgradIn in;
+        in.A = dlr; in.lda = 2L * gb.Ep; in.R = RK; in.T = 1;
+        if (which == 0) { in.B = T + t.xct; in.ldb = m.Wp; } else { in.B = hcat; in.ldb = m.Dp; }
+        if ((rc = run_wgrad(m, gb.wg, in, wpart, grads + gl.lin_w[which], grads + gl.lin_b[which], s))) return rc;
+        K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
+        K_TRY(launch_sum_rows(dap, gb.Ep, n, gp.E, ws + w.sums, grads + gl.a[which], s), "attention vector gradient");
+    }
+    // ---- 5. convolution (modules.py:18-22)
+    {
+        float* dpre = ws + w.dpre;
+        K_TRY(launch_dxc(hcat, dhcat, m.Dp, ws + w.dv_t, m.Fp, ws + w.dv_f, m.Wp, n, W, F, dpre, m.Fp, s), "conv pre-activation gradient");
+        WgradIn in;
+        in.A = dpre; in.lda = m.Fp; in.B = x; in.bmode = 1; in.R = RW; in.T = W;
+        if ((rc = run_wgrad(m, b.conv_wg, in, wpart, grads + gl.conv_w, grads + gl.conv_b, s))) return rc;
+    }
+    return 0;
+}
+
+int mtadgat_dropout_masks(mtadgat_handle h, int64_t batch, int64_t window0, float dropout_p, uint64_t seed, float* mask_feat,
+                          float* mask_temp, float* mask_fc, void* stream) {
+    if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");
+    if (batch <= 0) return 0;
+    Model& m = h->m;
+    hipStream_t s = (hipStream_t)stream;
+    const DropArgs drop = make_drop(dropout_p, seed, window0);
+    if (mask_feat) K_TRY(launch_dropmask(drop, DROP_FEAT, batch, (long)m.F * m.F, mask_feat, s), "dropout mask");
+    if (mask_temp) K_TRY(launch_dropmask(drop, DROP_TEMP, batch, (long)m.W * m.W, mask_temp, s), "dropout mask");
+    if (mask_fc) {
+        const int hid = m.cfg.forecast_hid_dim;
+        for (size_t i = 0; i + 1 < m.fc.size(); ++i)
+            K_TRY(launch_dropmask(drop, DROP_FC0 + (unsigned)i, batch, hid, mask_fc + i * (size_t)batch * hid, s), "dropout mask");
+    }
+    return 0;
 }
 
 }  // extern "C"

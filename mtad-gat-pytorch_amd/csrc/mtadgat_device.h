@@ -144,6 +144,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+// ---- dropout: counter-based, stateless.  The keep decision of element `idx` of window `win` in dropout
+// stream `stream` is a pure function of (seed, stream, win, idx), so the forward, a re-computed forward and
+// the backward see the same mask whatever the chunking / sharding of the batch (reference: F.dropout on the
+// attention matrices, modules.py:90 / :189, and nn.Dropout in Forecasting_Model, modules.py:310 -- same
+// distribution, not the same random stream).
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_window_key(const DropArgs& d, unsigned stream, long win_local) {
+    const unsigned long w = (unsigned long)(d.win0 + win_local);
+    unsigned h = mix32((unsigned)w ^ d.seed_lo);
+    h = mix32(h + (unsigned)(w >> 32) * 0x9E3779B9U + d.seed_hi + stream * 0x85EBCA6BU);
+    return h;
+}
+__device__ __forceinline__ bool drop_keep(unsigned key, unsigned idx, unsigned thresh) {
+    return mix32(key ^ (idx * 0x9E3779B1U + 0x7F4A7C15U)) >= thresh;
+}
+
 #define LAUNCH_CHECK()                          \
     do {                                        \
         hipError_t e__ = hipGetLastError();     \

@@ -357,6 +357,19 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
         const float inv = soft_rcp(sum);
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = irow < K ? e[jj] * inv : 0.f;
+        if (a.ATT) {
+            // training: keep the softmax row for the backward, then drop attention entries (reference
+            // F.dropout(attention, p, training), modules.py:90 / :189) -- the aggregation below sees att * mask / (1 - p)
+            float* __restrict__ ap = a.ATT + (win * K + irc) * (long)K;
+            const unsigned key = drop_window_key(a.drop, a.drop_stream, win);
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = lj + RJ * jj;
+                if (irow < K && j < K) ap[j] = acc[ii][jj];
+                if (a.drop.thresh)
+                    acc[ii][jj] = drop_keep(key, (unsigned)(irc * K + j), a.drop.thresh) ? acc[ii][jj] * a.drop.keep_scale : 0.f;
+            }
+        }
     }
 
     // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) on the matrix pipe, as out^T = V^T att^T with

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
 // sched_barrier after each refill): the h part is padded with zero-weight chunks so that a step is a
 // whole number of ring turns for any hidden size, which keeps NCG and H run-time values.
 // ---------------------------------------------------------------------------
-template <int XMODE, bool FC>
+// SAVE (training): the gate activations r, z, n and q = W_hn h + b_hn of every step go to a.Gates for the backward.
+template <int XMODE, bool FC, bool SAVE = false>
 __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     const int lane = threadIdx.x & 63;
@@ -443,6 +444,20 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
             const float zg = gate_sigmoid(az[r]);
             const float ng = gate_tanh(anx[r] + rg * anh[r]);
             hown[r] = __builtin_fmaf(zg, hown[r] - ng, ng);       // (1 - z) n + z h
+            if (SAVE) { ar[r] = rg; az[r] = zg; anx[r] = ng; }    // anh[r] already is q
+        }
+        if (SAVE && win < a.B) {
+            float* gp = a.Gates + (win * T + t) * (4L * a.Hp) + 32 * c + 4 * g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 v0, v1, v2, v3;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { v0[s4] = ar[4 * m + s4]; v1[s4] = az[4 * m + s4]; v2[s4] = anx[4 * m + s4]; v3[s4] = anh[4 * m + s4]; }
+                *reinterpret_cast<f32x4*>(gp + 8 * m) = v0;
+                *reinterpret_cast<f32x4*>(gp + a.Hp + 8 * m) = v1;
+                *reinterpret_cast<f32x4*>(gp + 2 * a.Hp + 8 * m) = v2;
+                *reinterpret_cast<f32x4*>(gp + 3 * a.Hp + 8 * m) = v3;
+            }
         }
         f32x4 hvv[4];
 #pragma unroll
@@ -541,11 +556,25 @@ static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipSt
     const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
     if (lds > 64 * 1024) return -2;
     const int xm = xmode == 0 ? 0 : (a.Qxp == 1 ? 1 : 2);
-#define SPLIT_CASE(XM, F) if (xm == XM && fc == F) hipLaunchKernelGGL((k_gru_split<XM, F>), dim3(grid), dim3(64 * ncg), lds, s, a);
+    const bool save = a.Gates != nullptr;
+#define SPLIT_CASE(XM, F)                                                                                        \
+    if (xm == XM && fc == F) {                                                                                   \
+        if (save) hipLaunchKernelGGL((k_gru_split<XM, F, true>), dim3(grid), dim3(64 * ncg), lds, s, a);         \
+        else hipLaunchKernelGGL((k_gru_split<XM, F, false>), dim3(grid), dim3(64 * ncg), lds, s, a);             \
+    }
     SPLIT_CASE(0, false) SPLIT_CASE(0, true) SPLIT_CASE(1, false) SPLIT_CASE(1, true) SPLIT_CASE(2, false) SPLIT_CASE(2, true)
 #undef SPLIT_CASE
     LAUNCH_CHECK();
     return 0;
+}
+
+// training forward: the hidden-tile-split kernel at every batch size (it is the one that keeps the gates)
+int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
+    if (a.B <= 0) return 0;
+    if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
+    if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
+    if (ncg < 1) return -2;
+    return launch_gru_split(a, ncg, xmode, fc, s);
 }
 
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {

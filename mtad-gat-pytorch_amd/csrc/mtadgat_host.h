@@ -43,6 +43,54 @@ struct LinPlan {
     size_t w_off = 0, b_off = 0;
 };
 
+// ---- backward (training) plans -------------------------------------------------------------------------
+// transposed Linear for the data gradient d X = d Y W through k_rowgemm: rows of the pack = input features
+struct LinTPlan {
+    int in_dim = 0;      // features of d Y the product runs over (the pack's K)
+    int out_dim = 0;     // features of d X
+    int NT = 0, Q = 0;
+    size_t w_off = 0;
+};
+// one weight-gradient GEMM: shapes, index maps into the flat gradient buffer (ints stored in the packed buffer)
+struct WgradPlan {
+    int M = 0, N = 0, Mp = 0, Np = 0;
+    size_t rowW_off = 0, col_off = 0, rowB_off = 0;     // offsets (floats) of the int maps in the packed buffer
+    bool has_bias = false;
+};
+struct GatBwdPlan {
+    int Ep = 0, NTu = 0;            // E rounded up to 32, tiles per side
+    size_t wu_off = 0;              // un-scaled projection tiles [2*NTu][Q][64]
+    size_t a_off = 0;               // a (Ep floats, zero padded)
+    LinTPlan lrT;                   // d V += [dL | dR] [W_l ; W_r]
+    WgradPlan wg;                   // lin.weight / lin.bias
+    size_t att_lds = 0, pair_lds = 0;
+};
+struct GruBwdPlan {
+    size_t whT_off = 0;             // W_hh^T tiles for k_gru_bwd
+    LinTPlan wihT;                  // d x = d a W_ih
+    WgradPlan wg_ih, wg_hh;
+};
+struct GradLayout {                 // offsets (floats) into the flat gradient buffer, reference parameter shapes
+    int64_t conv_w = 0, conv_b = 0;
+    int64_t lin_w[2] = {0, 0}, lin_b[2] = {0, 0}, a[2] = {0, 0}, bias[2] = {0, 0};   // [0] feature, [1] temporal
+    int64_t gru_wih = 0, gru_whh = 0, gru_bih = 0, gru_bhh = 0;
+    std::vector<int64_t> fc_w, fc_b;
+    int64_t rec_wih = 0, rec_whh = 0, rec_bih = 0, rec_bhh = 0, rec_fc_w = 0, rec_fc_b = 0;
+    int64_t total = 0;
+};
+struct BwdPlan {
+    bool supported = false;
+    std::string why;                // reason when not supported
+    GatBwdPlan gat[2];              // [0] feature, [1] temporal
+    GruBwdPlan gru, rec;
+    std::vector<LinTPlan> fcT;
+    std::vector<WgradPlan> fc_wg;
+    LinTPlan recfcT;                // d h_t (decoder) = d recons_t W_fc
+    WgradPlan recfc_wg, conv_wg;
+    size_t zero_off = 0;            // >= 1024 zero floats (bias of the transposed rowgemms)
+    GradLayout gl;
+};
+
 struct Model {
     mtadgat_config cfg{};
     int F = 0, W = 0, Fp = 0, Wp = 0, Dp = 0, taps = 0, pad = 0;
@@ -53,6 +101,7 @@ struct Model {
     std::vector<GruPlan> gru, rec;
     std::vector<LinPlan> fc;
     LinPlan rec_fc;          // per-step Linear on the decoder state (tile format over Hp_r)
+    BwdPlan bw;
     size_t packed_floats = 0;
     float* packed_dev = nullptr;
     int packed_device = -1;          // device ordinal packed_dev was allocated on
@@ -70,8 +119,22 @@ struct Workspace {
     size_t xc, xct, lct, rtt, lcf, rtf, hcat, hend, seq0, seq1, fc0, fc1, rseq0, rseq1, total;
 };
 
+// activations kept between the training forward and the backward (caller-owned "tape"), offsets in floats
+struct Tape {
+    size_t hcat, xct, att_f, att_t, hend, gates_g, seq_g, gates_d, seq_d, xdec, total;
+    std::vector<size_t> fc_act;     // outputs of the hidden forecasting layers (after ReLU + dropout)
+};
+// scratch of the backward
+struct BwdWorkspace {
+    size_t da, dhcat, dhdec, dhend, dz0, dz1, de_f, de_t, dv_f, dv_t, dlr_f, dlr_t, dap_f, dap_t, dpre, wpart, sums, total;
+    size_t wpart_floats;
+};
+
 std::string validate_and_plan(Model& m);                       // "" on success
 void plan_workspace(const Model& m, int64_t n, Workspace& ws); // sizes for n windows
+void plan_tape(const Model& m, int64_t n, Tape& t);
+void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w);
+int wgrad_slabs(long R, int Mp, int Np);                       // row slabs of one weight-gradient GEMM
 // packs params into host buffer `out` (size m.packed_floats); returns "" on success
 std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& out);
 

@@ -27,6 +27,25 @@ struct RowGemmArgs {
     int NT_rm;           // number of leading row-major tiles (== NT when nothing is transposed)
     float* YT;
     int group, YT_rows, YT_ld;
+    // ---- training-path epilogue options (all off when zero-initialised)
+    int accumulate;      // 1: Y += result (row-major tiles only)
+    const float* gate;   // backward through ReLU (+ dropout): result = gate[row*ldg + col] > 0 ? result * gate_scale : 0
+    long ldg;
+    float gate_scale;
+    // forward dropout after the ReLU (Forecasting_Model, reference modules.py:309-310): element (row0 + row, col)
+    // of dropout stream `drop_stream` is zeroed with probability drop_thresh / 2^32, kept ones scaled by keep_scale
+    unsigned drop_thresh, seed_lo, seed_hi, drop_stream;
+    float keep_scale;
+    long row0;
+};
+
+// dropout streams (one per dropout site of the reference: modules.py:90, :189, :310)
+enum { DROP_FEAT = 1, DROP_TEMP = 2, DROP_FC0 = 16 };
+
+struct DropArgs {
+    unsigned thresh, seed_lo, seed_hi;   // P(drop) = thresh / 2^32; thresh == 0: no dropout
+    float keep_scale;                    // 1 / (1 - p)
+    long win0;                           // global index of window 0 of this launch (masks do not depend on chunking)
 };
 
 struct ConvArgs {
@@ -83,6 +102,86 @@ struct GatArgs {
     long nwin;
     int v1;
     float alpha;
+    // training mode: the softmax rows (before dropout) are kept for the backward, dropout (modules.py:90 / :189)
+    // is applied to the attention matrix inside the kernel
+    float* ATT;          // (B, K, K) or null
+    DropArgs drop;
+    unsigned drop_stream;
+};
+
+// backward of one graph-attention layer, part 1 (per window): d e_ij (the gradient of the attention scores
+// = of the layer's bias before the sum over windows) and the aggregation path's d V
+struct GatBwdAttArgs {
+    const float* V;      // node rows as in GatArgs (vt: transposed source)
+    int ldv, D, K, vt, vld;
+    const float* H;      // the layer's forward output, H[win*so_w + i*so_i + d*so_d]
+    const float* dH;     // its gradient, same indexing
+    long so_w, so_i, so_d;
+    const float* ATT;    // (B, K, K) softmax rows kept by the forward
+    float* DE;           // (B, K, K) out
+    float* DV;           // (B*K, lddv) out: sum_i att'_ij dS_i (node-major rows)
+    int lddv;
+    long nwin;
+    DropArgs drop;
+    unsigned drop_stream;
+};
+
+// part 2 (per window, GATv2): from d e_ij to the gradients of the projected L, R (written per node for the
+// weight-gradient GEMM and the d V rowgemm) and of `a` (per-window partials)
+struct GatBwdPairArgs {
+    const float* V;
+    int ldv, D, K, vt, vld;
+    const f32x4* Wp;     // un-scaled projection tiles [2*NTu][Q][64]: query-side tiles (bias = weight row D) then key-side
+    int NTu, Q, E, Ep;   // Ep = 32*NTu
+    const float* avec;   // a (E, zero padded to Ep)
+    const float* DE;     // (B, K, K)
+    float* DLR;          // (B*K, 2*Ep): [dL | dR]
+    float* DApart;       // (B, Ep): this window's share of d a
+    long nwin;
+    float alpha;
+};
+
+struct GruBwdArgs {
+    const float* Gates;  // (B*T, 4*Hp): r | z | n | q (= W_hn h + b_hn) kept by the forward
+    const float* Seq;    // (B*T, Hp): h_t
+    const float* DHseq;  // (B*T, lddh) external gradient of every h_t, or null
+    long lddh;
+    const float* DHend;  // (B, ldde) external gradient of h_T, or null
+    long ldde;
+    const f32x4* WhT;    // [NCG][12*NCG][64]: W_hh^T tiles over the [dr | dz | dnh] features
+    float* DA;           // (B*T, 4*Hp) out: dn_x | dr | dz | dn_h  (pre-activation gradients)
+    int Hp, H, T, NCG;
+    long B;
+};
+
+// dW[m][n] = sum_rows A[row][m] * B[row][n]   (+ a virtual all-ones column n == N: bias gradients)
+struct WgradArgs {
+    const float* A;      // (R, lda), M valid columns
+    long lda;
+    int M;
+    int ashift;          // rows of A are taken one step later: A[row + 1], zero when row is the last step of its window
+    const float* B;      // bmode 0: (R, ldb), N valid columns
+    long ldb;
+    int N;
+    int bmode;           // 0 plain rows; 1 conv im2col: B = x (b, T, F), column n = tap*F + ch -> x[b, t + tap - pad, ch]
+    int T;               // steps per window (ashift / bmode 1: row = win*T + t)
+    int F, taps, pad;
+    long R;
+    long rows_per_slab;
+    int nslab;
+    float* P;            // partial sums [nslab][Mp][Np],  Mp = 32*ceil(M/32), Np = 32*ceil((N+1)/32)
+    int Mp, Np;
+};
+
+// out[rowmap[m] + colmap[n]] += sum_slab P[slab][m][n];  column N (ones) -> outB[rowmapB[m]]
+struct WgradReduceArgs {
+    const float* P;
+    int nslab, Mp, Np, M, N;
+    const int* rowmapW;  // element offset of row m in outW, or -1
+    const int* colmap;   // element offset of column n, or -1
+    const int* rowmapB;  // element offset in outB, or -1  (null: no bias output)
+    float* outW;
+    float* outB;
 };
 
 struct GruArgs {
@@ -108,6 +207,7 @@ struct GruArgs {
     float* Yfc;          // (B*T, out_dim) or null (then only the last step is produced)
     float* Ylast;        // (B, out_dim): the per-step Linear at the last step only, or null
     int out_dim;
+    float* Gates;        // training: (B*T, 4*Hp) r | z | n | q kept for the backward (k_gru_split only), or null
 };
 
 // compute units of the current device (cached per device ordinal)
@@ -129,6 +229,26 @@ void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
+int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
+int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
+int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
+int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s);
+size_t gat_bwd_att_lds(int K, int D, int vld, int nwa);
+size_t gat_bwd_pair_lds(int K, int vld, int Ep);
+int launch_wgrad(const WgradArgs& a, hipStream_t s);
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s);
+// dst[n] += sum_r src[r*ld + n]  (n < N), two-stage through `scratch` (>= sum_rows_scratch(R, N) floats)
+size_t sum_rows_scratch(long R, int N);
+int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, float* dst, hipStream_t s);
+// decoder input of the reference (modules.py:279) materialised: X[(b*T + t)*ldx + j] = hend[b*ldh + (t*H + j) / T]
+int launch_xdec(const float* hend, long ldh, int H, int T, long B, float* X, long ldx, hipStream_t s);
+// and its adjoint: dhend[b*ldh + m] += sum over the flat positions f = t*H + j with f / T == m of dX[(b*T + t)*ldx + j]
+int launch_xdec_bwd(const float* dX, long ldx, int H, int T, long B, float* dhend, long ldh, hipStream_t s);
+// dpre[(b*T + t)*ldp + f] = xc > 0 ? dhcat[.., f] + dvt[(b*T + t)*ldt + f] + dvf[(b*F + f)*ldf + t] : 0   (xc = hcat[.., f])
+int launch_dxc(const float* hcat, const float* dhcat, long ldh, const float* dvt, long ldt, const float* dvf, long ldf,
+               long B, int T, int F, float* dpre, long ldp, hipStream_t s);
+// keep-mask (1 / 0) of a dropout stream: mask[w*n + idx] for windows win0 + w (test hook)
+int launch_dropmask(const DropArgs& d, unsigned stream, long nwin, long n_per_win, float* mask, hipStream_t s);
 int launch_copy2d(const float* src, long lds, float* dst, long ldd, long R, int ncols, hipStream_t s);
 int launch_transpose_win(const float* src, long lds, float* dst, long ldd, long B, int R, int C, hipStream_t s);
 

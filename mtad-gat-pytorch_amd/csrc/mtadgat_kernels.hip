@@ -66,6 +66,26 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
                     float t = acc[nb][4 * m + s] + bv[s];
                     v[s] = a.relu ? fmaxf(t, 0.f) : t;
                 }
+                if (a.drop_thresh) {      // training forward: dropout after the ReLU (modules.py:309-310)
+                    const DropArgs dd{a.drop_thresh, a.seed_lo, a.seed_hi, a.keep_scale, a.row0};
+                    const unsigned key = drop_window_key(dd, a.drop_stream, rowc);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) v[s] = drop_keep(key, (unsigned)(col + s), a.drop_thresh) ? v[s] * a.keep_scale : 0.f;
+                }
+                if (a.gate) {             // backward through ReLU (+ dropout): the kept activation tells which units were live
+                    const float* gp = a.gate + rowc * a.ldg;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float gv = (col + s < a.Nvalid) ? gp[col + s] : 0.f;
+                        v[s] = gv > 0.f ? v[s] * a.gate_scale : 0.f;
+                    }
+                }
+                if (a.accumulate && row < a.R && !transposed) {
+                    const float* yo = a.Y + row * a.ldy + col;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        if (col + s < a.Nvalid) v[s] += yo[s];
+                }
                 if (row < a.R) {
                     if (transposed) {   // lanes i <-> consecutive group members: coalesced 4-byte stores
                         float* tp = a.YT + (grp * a.YT_rows + (col - 32 * a.NT_rm)) * (long)a.YT_ld + member;

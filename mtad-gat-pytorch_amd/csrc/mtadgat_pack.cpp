@@ -177,6 +177,86 @@ std::string validate_and_plan(Model& m) {
         p.w_off = take((size_t)p.NT * p.Q * 256);
         p.b_off = take((size_t)p.NT * 32);
     }
+
+    // ---- backward (training) plans: transposed packs, un-scaled attention projections, gradient index maps
+    {
+        BwdPlan& b = m.bw;
+        b = BwdPlan();
+        auto lint = [&](LinTPlan& p, int kdim, int outdim) {
+            p.in_dim = kdim; p.out_dim = outdim;
+            p.NT = (outdim + 31) / 32; p.Q = (kdim + 7) / 8;
+            p.w_off = take((size_t)p.NT * p.Q * 256);
+        };
+        auto wg = [&](WgradPlan& p, int M, int N, bool bias) {
+            p.M = M; p.N = N; p.has_bias = bias;
+            p.Mp = round_up(M, 32); p.Np = round_up(N + 1, 32);
+            p.rowW_off = take((size_t)p.Mp);
+            p.col_off = take((size_t)p.Np);
+            p.rowB_off = take((size_t)p.Mp);
+        };
+        // flat gradient layout: the reference's parameters in the order of mtadgat_params
+        GradLayout& gl = b.gl;
+        int64_t go = 0;
+        auto gtake = [&](int64_t n) { int64_t o = go; go += n; return o; };
+        gl.conv_w = gtake((int64_t)m.F * m.F * m.taps); gl.conv_b = gtake(m.F);
+        for (int which = 0; which < 2; ++which) {       // 0 feature, 1 temporal  (mtadgat_params order)
+            const GatPlan& g = which == 0 ? m.feat : m.temp;
+            const int lin_in = c.use_gatv2 ? 2 * g.D : g.D;
+            gl.lin_w[which] = gtake((int64_t)g.E * lin_in); gl.lin_b[which] = gtake(g.E);
+            gl.a[which] = gtake(c.use_gatv2 ? g.E : 2 * g.E); gl.bias[which] = gtake((int64_t)g.K * g.K);
+        }
+        for (int l = 0; l < c.gru_n_layers; ++l) {
+            const int in = m.gru[l].in_dim, H = m.gru[l].H;
+            const int64_t a0 = gtake((int64_t)3 * H * in), a1 = gtake((int64_t)3 * H * H), a2 = gtake(3 * H), a3 = gtake(3 * H);
+            if (l == 0) { gl.gru_wih = a0; gl.gru_whh = a1; gl.gru_bih = a2; gl.gru_bhh = a3; }
+        }
+        gl.fc_w.clear(); gl.fc_b.clear();
+        for (const LinPlan& p : m.fc) { gl.fc_w.push_back(gtake((int64_t)p.out_dim * p.in_dim)); gl.fc_b.push_back(gtake(p.out_dim)); }
+        for (int l = 0; l < c.recon_n_layers; ++l) {
+            const int in = m.rec[l].in_dim, H = m.rec[l].H;
+            const int64_t a0 = gtake((int64_t)3 * H * in), a1 = gtake((int64_t)3 * H * H), a2 = gtake(3 * H), a3 = gtake(3 * H);
+            if (l == 0) { gl.rec_wih = a0; gl.rec_whh = a1; gl.rec_bih = a2; gl.rec_bhh = a3; }
+        }
+        gl.rec_fc_w = gtake((int64_t)c.out_dim * c.recon_hid_dim); gl.rec_fc_b = gtake(c.out_dim);
+        gl.total = go;
+
+        b.supported = true;
+        if (!c.use_gatv2) { b.supported = false; b.why = "GAT (v1) attention"; }
+        else if (!m.feat.fused || !m.temp.fused) { b.supported = false; b.why = "graph-attention layers beyond the fused kernel (more than 128 nodes / features)"; }
+        else if (c.gru_n_layers != 1 || c.recon_n_layers != 1) { b.supported = false; b.why = "stacked GRU / decoder layers"; }
+        if (b.supported) {
+            for (int which = 0; which < 2; ++which) {
+                const GatPlan& g = which == 0 ? m.feat : m.temp;
+                GatBwdPlan& gb = b.gat[which];
+                gb.Ep = round_up(g.E, 32); gb.NTu = gb.Ep / 32;
+                gb.wu_off = take((size_t)2 * gb.NTu * g.Q * 256);
+                gb.a_off = take((size_t)gb.Ep);
+                lint(gb.lrT, 2 * gb.Ep, g.D);
+                wg(gb.wg, 2 * gb.Ep, g.D, true);
+                gb.att_lds = gat_bwd_att_lds(g.K, g.D, g.f_vld, (g.K + 15) / 16);
+                gb.pair_lds = gat_bwd_pair_lds(g.K, g.f_vld, gb.Ep);
+                if (gb.att_lds > 160 * 1024 || gb.pair_lds > 160 * 1024) { b.supported = false; b.why = "attention backward tiles exceed the LDS"; }
+            }
+            auto gru_b = [&](GruBwdPlan& gb, const GruPlan& g) {
+                gb.whT_off = take((size_t)g.NCG * 12 * g.NCG * 256);
+                lint(gb.wihT, 3 * g.Hp, g.in_dim);
+                wg(gb.wg_ih, 3 * g.Hp, g.in_dim, true);
+                wg(gb.wg_hh, 3 * g.Hp, g.H, true);
+            };
+            gru_b(b.gru, m.gru[0]);
+            gru_b(b.rec, m.rec[0]);
+            b.fcT.assign(m.fc.size(), LinTPlan());
+            b.fc_wg.assign(m.fc.size(), WgradPlan());
+            for (size_t i = 0; i < m.fc.size(); ++i) {
+                lint(b.fcT[i], m.fc[i].out_dim, m.fc[i].in_dim);
+                wg(b.fc_wg[i], m.fc[i].out_dim, m.fc[i].in_dim, true);
+            }
+            lint(b.recfcT, c.out_dim, m.rec.back().Hp);
+            wg(b.recfc_wg, c.out_dim, c.recon_hid_dim, true);
+            wg(b.conv_wg, m.F, m.taps * m.F, true);
+            b.zero_off = take(1024);
+        }
+    }
     m.packed_floats = off;
     return "";
 }
@@ -223,6 +303,88 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     ws.rseq0 = take(rseq ? N * m.W * m.rec[0].Hp : 0);
     ws.rseq1 = take(m.rec.size() > 2 ? N * m.W * m.rec[0].Hp : 0);
     ws.total = off;
+}
+
+
+int wgrad_slabs(long R, int Mp, int Np) {
+    const long tiles = (long)((Mp + 63) / 64) * ((Np + 63) / 64);
+    long s = 2048 / (tiles > 0 ? tiles : 1);
+    const long rmax = (R + 63) / 64;
+    if (s > rmax) s = rmax;
+    if (s > 512) s = 512;
+    return (int)(s < 1 ? 1 : s);
+}
+
+void plan_tape(const Model& m, int64_t n, Tape& t) {
+    size_t off = 0;
+    auto take = [&](size_t cnt) {
+        size_t o = off;
+        off = align64(off + cnt);
+        return o;
+    };
+    const size_t N = (size_t)n;
+    const GruPlan& g = m.gru[0];
+    const GruPlan& r = m.rec[0];
+    t.hcat = take(N * m.W * m.Dp);
+    t.xct = take(N * m.F * m.Wp);
+    t.att_f = take(N * m.F * m.F);
+    t.att_t = take(N * m.W * m.W);
+    t.hend = take(N * g.Hp);
+    t.gates_g = take(N * m.W * 4 * g.Hp);
+    t.seq_g = take(N * m.W * g.Hp);
+    t.gates_d = take(N * m.W * 4 * r.Hp);
+    t.seq_d = take(N * m.W * r.Hp);
+    t.xdec = take(N * m.W * g.Hp);
+    t.fc_act.clear();
+    for (size_t i = 0; i + 1 < m.fc.size(); ++i) t.fc_act.push_back(take(N * (size_t)m.fc[i].NT * 32));
+    t.total = off;
+}
+
+void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
+    size_t off = 0;
+    auto take = [&](size_t cnt) {
+        size_t o = off;
+        off = align64(off + cnt);
+        return o;
+    };
+    const size_t N = (size_t)n;
+    const GruPlan& g = m.gru[0];
+    const GruPlan& r = m.rec[0];
+    const BwdPlan& b = m.bw;
+    const size_t hpmax = std::max(g.Hp, r.Hp);
+    w.da = take(N * m.W * 4 * hpmax);
+    w.dhcat = take(N * m.W * m.Dp);
+    w.dhdec = take(N * m.W * hpmax);
+    w.dhend = take(N * g.Hp);
+    size_t fcw = 32;
+    for (const LinPlan& p : m.fc) fcw = std::max(fcw, (size_t)std::max(p.NT * 32, round_up(p.in_dim, 32)));
+    w.dz0 = take(N * fcw);
+    w.dz1 = take(N * fcw);
+    w.de_f = take(N * m.F * m.F);
+    w.de_t = take(N * m.W * m.W);
+    w.dv_f = take(N * m.F * m.Wp);
+    w.dv_t = take(N * m.W * m.Fp);
+    w.dlr_f = take(N * m.F * 2 * b.gat[0].Ep);
+    w.dlr_t = take(N * m.W * 2 * b.gat[1].Ep);
+    w.dap_f = take(N * b.gat[0].Ep);
+    w.dap_t = take(N * b.gat[1].Ep);
+    w.dpre = take(N * m.W * m.Fp);
+    // partial sums of the weight-gradient GEMMs (one at a time)
+    size_t wp = 0;
+    auto need = [&](const WgradPlan& p, long R) { wp = std::max(wp, (size_t)wgrad_slabs(R, p.Mp, p.Np) * p.Mp * p.Np); };
+    const long RW = (long)n * m.W;
+    need(b.conv_wg, RW);
+    need(b.gat[0].wg, (long)n * m.F);
+    need(b.gat[1].wg, RW);
+    need(b.gru.wg_ih, RW); need(b.gru.wg_hh, RW);
+    need(b.rec.wg_ih, RW); need(b.rec.wg_hh, RW);
+    need(b.recfc_wg, RW);
+    for (const WgradPlan& p : b.fc_wg) need(p, (long)n);
+    w.wpart_floats = wp;
+    w.wpart = take(wp);
+    const size_t smax = std::max((size_t)m.W * m.W, std::max((size_t)m.F * m.F, (size_t)std::max(b.gat[0].Ep, b.gat[1].Ep)));
+    w.sums = take(sum_rows_scratch(n, (int)smax));
+    w.total = off;
 }
 
 static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_b, const float* a, const float* bias,
@@ -365,6 +527,78 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
             return (n < lp.out_dim && k < lp.in_dim) ? p.rec_fc_weight[(size_t)n * lp.in_dim + k] : 0.f;
         });
         for (int n = 0; n < lp.out_dim; ++n) out[lp.b_off + n] = p.rec_fc_bias[n];
+    }
+
+    // ---- backward packs (transposed weights, un-scaled attention projections, gradient index maps)
+    if (m.bw.supported) {
+        const BwdPlan& b = m.bw;
+        auto maps = [&](const WgradPlan& wp, const std::function<int(int)>& rowW, const std::function<int(int)>& col,
+                        const std::function<int(int)>& rowB) {
+            int* rw = reinterpret_cast<int*>(out.data() + wp.rowW_off);
+            int* cm = reinterpret_cast<int*>(out.data() + wp.col_off);
+            int* rb = reinterpret_cast<int*>(out.data() + wp.rowB_off);
+            for (int i = 0; i < wp.Mp; ++i) { rw[i] = i < wp.M ? rowW(i) : -1; rb[i] = i < wp.M ? rowB(i) : -1; }
+            for (int i = 0; i < wp.Np; ++i) cm[i] = i < wp.N ? col(i) : -1;
+        };
+        auto ident = [](int n) { return n; };
+        for (int which = 0; which < 2; ++which) {
+            const GatPlan& g = which == 0 ? m.feat : m.temp;
+            const GatBwdPlan& gb = b.gat[which];
+            const float* lw = which == 0 ? p.feat_lin_weight : p.temp_lin_weight;
+            const float* lb = which == 0 ? p.feat_lin_bias : p.temp_lin_bias;
+            const float* av = which == 0 ? p.feat_a : p.temp_a;
+            const int E = g.E, D = g.D, Ep = gb.Ep;
+            pack_tiles(out.data() + gb.wu_off, 2 * gb.NTu, g.Q, [&](int n, int k) -> float {
+                const int side = n / Ep, e = n % Ep;
+                if (e >= E) return 0.f;
+                if (k < D) return lw[(size_t)e * 2 * D + (size_t)side * D + k];
+                return (k == D && side == 0) ? lb[e] : 0.f;
+            });
+            for (int e = 0; e < E; ++e) out[gb.a_off + e] = av[e];
+            pack_tiles(out.data() + gb.lrT.w_off, gb.lrT.NT, gb.lrT.Q, [&](int n, int k) -> float {
+                const int side = k / Ep, e = k % Ep;
+                return (n < D && e < E && side < 2) ? lw[(size_t)e * 2 * D + (size_t)side * D + n] : 0.f;
+            });
+            maps(gb.wg, [&](int r) { const int side = r / Ep, e = r % Ep; return e < E ? e * 2 * D + side * D : -1; }, ident,
+                 [&](int r) { const int side = r / Ep, e = r % Ep; return (side == 0 && e < E) ? e : -1; });
+        }
+        auto gru_pack = [&](const GruBwdPlan& gb, const GruPlan& g, const float* w_ih, const float* w_hh) {
+            const int H = g.H, Hp = g.Hp, in = g.in_dim;
+            pack_tiles(out.data() + gb.whT_off, g.NCG, 12 * g.NCG, [&](int n, int k) -> float {      // blocks r | z | nh
+                const int blk = k / Hp, u = k % Hp;
+                return (n < H && u < H && blk < 3) ? w_hh[((size_t)blk * H + u) * H + n] : 0.f;
+            });
+            auto gate_ih = [](int blk) { return blk == 0 ? 2 : blk - 1; };                            // blocks n | r | z
+            pack_tiles(out.data() + gb.wihT.w_off, gb.wihT.NT, gb.wihT.Q, [&](int n, int k) -> float {
+                const int blk = k / Hp, u = k % Hp;
+                return (n < in && u < H && blk < 3) ? w_ih[((size_t)gate_ih(blk) * H + u) * in + n] : 0.f;
+            });
+            maps(gb.wg_ih, [&](int r) { const int blk = r / Hp, u = r % Hp; return u < H ? (gate_ih(blk) * H + u) * in : -1; }, ident,
+                 [&](int r) { const int blk = r / Hp, u = r % Hp; return u < H ? gate_ih(blk) * H + u : -1; });
+            maps(gb.wg_hh, [&](int r) { const int blk = r / Hp, u = r % Hp; return u < H ? (blk * H + u) * H : -1; }, ident,
+                 [&](int r) { const int blk = r / Hp, u = r % Hp; return u < H ? blk * H + u : -1; });
+        };
+        gru_pack(b.gru, m.gru[0], p.gru_w_ih[0], p.gru_w_hh[0]);
+        gru_pack(b.rec, m.rec[0], p.rec_w_ih[0], p.rec_w_hh[0]);
+        for (size_t i = 0; i < m.fc.size(); ++i) {
+            const LinPlan& lp = m.fc[i];
+            const float* w = p.fc_weight[i];
+            pack_tiles(out.data() + b.fcT[i].w_off, b.fcT[i].NT, b.fcT[i].Q, [&](int n, int k) -> float {
+                return (n < lp.in_dim && k < lp.out_dim) ? w[(size_t)k * lp.in_dim + n] : 0.f;
+            });
+            maps(b.fc_wg[i], [&](int r) { return r * lp.in_dim; }, ident, ident);
+        }
+        {
+            const int Hr = c.recon_hid_dim, od = c.out_dim;
+            pack_tiles(out.data() + b.recfcT.w_off, b.recfcT.NT, b.recfcT.Q, [&](int n, int k) -> float {
+                return (n < Hr && k < od) ? p.rec_fc_weight[(size_t)k * Hr + n] : 0.f;
+            });
+            maps(b.recfc_wg, [&](int r) { return r * Hr; }, ident, ident);
+        }
+        {
+            const int F = m.F, taps = m.taps;
+            maps(b.conv_wg, [&](int r) { return r * F * taps; }, [&](int n) { const int tap = n / F, ch = n % F; return ch * taps + tap; }, ident);
+        }
     }
     return "";
 }

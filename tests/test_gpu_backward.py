@@ -1,0 +1,214 @@
+"""The HIP training step (mtadgat_forward_train / mtadgat_backward behind torch.autograd.Function, _hipgrad.py)
+against autograd through the package's torch-op algebra (_torchpath.py, itself pinned to the oracle / the
+reference by the CPU tests) on the same device, same weights, same dropout masks.
+
+Gate: every parameter gradient within 1e-5 absolute + 1e-4 of the gradient's own scale (fp32 sums over up to
+b*W rows in a different order than autograd's), outputs of the training forward within 1e-5.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import Case
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    # name: (ctor kwargs, batch)
+    "small_v2": (dict(n_features=9, window_size=16, out_dim=3, kernel_size=5, feat_gat_embed_dim=5, time_gat_embed_dim=3,
+                      gru_hid_dim=33, forecast_n_layers=1, forecast_hid_dim=40, recon_hid_dim=35, dropout=0.2, alpha=0.1), 37),
+    "odd_shapes": (dict(n_features=12, window_size=30, out_dim=12, kernel_size=5, gru_hid_dim=40, forecast_n_layers=2,
+                        forecast_hid_dim=36, recon_hid_dim=44, dropout=0.3, alpha=0.2), 70),
+    "msl_shape": (dict(n_features=55, window_size=100, out_dim=1, kernel_size=7, gru_hid_dim=150, forecast_n_layers=3,
+                       forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 40),
+    "smd_shape": (dict(n_features=38, window_size=100, out_dim=38, kernel_size=7, gru_hid_dim=150, forecast_n_layers=3,
+                       forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 33),
+    "wide_nodes": (dict(n_features=70, window_size=120, out_dim=5, kernel_size=3, gru_hid_dim=64, forecast_n_layers=1,
+                        forecast_hid_dim=32, recon_hid_dim=96, dropout=0.1, alpha=0.2), 9),
+}
+
+
+def _model(kw, device, seed=0):
+    from mtad_gat import MTAD_GAT
+    torch.manual_seed(seed)
+    m = MTAD_GAT(**kw)
+    with torch.no_grad():
+        m.feature_gat.bias.normal_()
+        m.temporal_gat.bias.normal_()
+    return m.to(device)
+
+
+def _loss(preds, recons, x, y):
+    return torch.sqrt(F.mse_loss(y, preds)) + torch.sqrt(F.mse_loss(x[:, :, : recons.shape[2]], recons))
+
+
+def _grad_report(model, ref_grads, tol_abs=1e-5, tol_rel=1e-4):
+    rows, bad = [], []
+    for name, p in model.named_parameters():
+        g, r = p.grad, ref_grads[name]
+        if g is None:
+            bad.append(f"{name}: no gradient")
+            continue
+        d = (g - r).abs().max().item()
+        scale = r.abs().max().item()
+        rows.append(f"{name:45s} |diff|={d:.3e} scale={scale:.3e}")
+        if not (d <= tol_abs + tol_rel * scale) or not torch.isfinite(g).all():
+            bad.append(rows[-1])
+    return rows, bad
+
+
+def _reference_grads(model, x, y, masks=None):
+    """Autograd through the torch-op algebra on the same device / weights (and dropout masks)."""
+    import _torchpath
+    for p in model.parameters():
+        p.grad = None
+    pr, rc = _torchpath.forward(model, x, masks)
+    _loss(pr, rc, x, y).backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    return pr.detach(), rc.detach(), ref
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_gradients_match_autograd_eval_mode(name, gpu_device):
+    """eval() + grad enabled: the deterministic function (dropout off) through the HIP forward_train / backward."""
+    kw, b = CONFIGS[name]
+    model = _model(kw, gpu_device).eval()
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
+    y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
+    pr_ref, rc_ref, ref = _reference_grads(model, x, y)
+    pr, rc = model(x)
+    assert model.grad_path == "hip", model.grad_path
+    assert pr.requires_grad and rc.requires_grad
+    assert (pr - pr_ref).abs().max().item() <= 1e-5 and (rc - rc_ref).abs().max().item() <= 1e-5
+    with torch.no_grad():
+        pe, re_ = model(x)                                  # the inference kernels agree with the training forward
+    assert (pr - pe).abs().max().item() <= 1e-5 and (rc - re_).abs().max().item() <= 1e-5
+    _loss(pr, rc, x, y).backward()
+    rows, bad = _grad_report(model, ref)
+    print("\n".join(rows))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape"])
+def test_gradients_match_autograd_with_dropout(name, gpu_device):
+    """train(): dropout inside the kernels; the same keep-masks (exported by the library) injected into the
+    torch-op algebra must give the same outputs and gradients."""
+    kw, b = CONFIGS[name]
+    model = _model(kw, gpu_device).train()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
+    y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
+    torch.manual_seed(77)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())       # what _hipgrad.forward will draw
+    torch.manual_seed(77)
+    pr, rc = model(x)
+    assert model.grad_path == "hip"
+    masks = model._engine.dropout_masks(b, kw["dropout"], seed, gpu_device)
+    keep = torch.cat([m.reshape(-1) for m in [masks["feat"], masks["temp"]] + masks["fc"]]).mean().item()
+    assert abs(keep - (1.0 - kw["dropout"])) < 0.02, keep
+    _loss(pr, rc, x, y).backward()
+    got = {n: p.grad.clone() for n, p in model.named_parameters()}
+    pr_ref, rc_ref, ref = _reference_grads(model, x, y, masks)
+    assert (pr - pr_ref).abs().max().item() <= 1e-5 and (rc - rc_ref).abs().max().item() <= 1e-5
+    for n, p in model.named_parameters():
+        p.grad = got[n]
+    rows, bad = _grad_report(model, ref)
+    print("\n".join(rows))
+    assert not bad, "\n".join(bad)
+    # another call draws another seed -> other masks
+    pr2, _ = model(x)
+    assert not torch.equal(pr2, pr)
+
+
+def test_chunked_training_step_equals_single_chunk(gpu_device, monkeypatch):
+    """Batches above the chunk size are processed chunk by chunk with the chunk's forward recomputed in
+    backward; the counter-based dropout makes that the same function as the one-chunk step."""
+    import _hipgrad
+    kw, b = CONFIGS["odd_shapes"]
+    model = _model(kw, gpu_device).train()
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
+    y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(5)
+        pr, rc = model(x)
+        _loss(pr, rc, x, y).backward()
+        return pr.detach(), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    p1, g1 = step()
+    monkeypatch.setattr(_hipgrad, "TRAIN_CHUNK", 32)         # 70 windows -> 32 + 32 + 6
+    p2, g2 = step()
+    assert torch.equal(p1, p2)
+    for n in g1:
+        d = (g1[n] - g2[n]).abs().max().item()
+        assert d <= 1e-6 + 1e-5 * g1[n].abs().max().item(), (n, d)
+
+
+def test_backward_stage_diagnostics(gpu_device):
+    """Not a gate by itself: prints where the HIP training step and autograd part ways, stage by stage
+    (tape contents after the forward, workspace contents after the backward), for a linear loss whose
+    upstream gradients do not couple the windows."""
+    import _torchpath as tp
+    kw, b = CONFIGS["odd_shapes"]
+    b = 5
+    model = _model(kw, gpu_device).eval()
+    eng = model._sync_engine(gpu_device)
+    W, Fn, H = kw["window_size"], kw["n_features"], kw["gru_hid_dim"]
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(b, W, Fn, generator=g).to(gpu_device)
+    cp = torch.randn(b, kw["out_dim"], generator=g).to(gpu_device)
+    cr = torch.randn(b, W, kw["out_dim"], generator=g).to(gpu_device)
+    # torch side with retained intermediates
+    xc = tp.conv_stage(model, x); xc.retain_grad()
+    hf = tp.feature_gat_stage(model, xc); hf.retain_grad()
+    ht = tp.temporal_gat_stage(model, xc); ht.retain_grad()
+    hcat = torch.cat([xc, hf, ht], dim=2); hcat.retain_grad()
+    hend = tp.gru_stage(model, hcat); hend.retain_grad()
+    pr = tp.forecast_stage(model, hend)
+    rc = tp.recon_stage(model, hend)
+    ((pr * cp).sum() + (rc * cr).sum()).backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    # HIP side
+    prh, rch, tape = eng.forward_train(x, 0.0, 0)
+    offs, total = eng.grad_layout()
+    grads = torch.zeros(total, device=gpu_device)
+    eng.backward(x, 0.0, 0, cp.contiguous(), cr.contiguous(), tape, grads)
+    torch.cuda.synchronize()
+    to, wo = eng.train_layout(b)
+    ws = eng._bws
+    c = eng.cfg
+    Dp = (3 * Fn + 7) // 8 * 8
+    Hp = (H + 31) // 32 * 32
+    Fp = (Fn + 7) // 8 * 8
+    Wp = (W + 7) // 8 * 8
+    rep = []
+
+    def cmp(label, ours, theirs):
+        rep.append(f"{label:34s} |diff|={(ours - theirs).abs().max().item():.3e} scale={theirs.abs().max().item():.3e}")
+
+    cmp("fwd preds", prh, pr.detach())
+    cmp("fwd recons", rch, rc.detach())
+    hc = tape[to["hcat"]: to["hcat"] + b * W * Dp].view(b, W, Dp)
+    cmp("tape h_cat", hc[:, :, :3 * Fn], hcat.detach())
+    cmp("tape h_end", tape[to["hend"]: to["hend"] + b * Hp].view(b, Hp)[:, :H], hend.detach())
+    cmp("tape xcT", tape[to["xct"]: to["xct"] + b * Fn * Wp].view(b, Fn, Wp)[:, :, :W], xc.detach().permute(0, 2, 1))
+    cmp("ws d h_end", ws[wo["dhend"]: wo["dhend"] + b * Hp].view(b, Hp)[:, :H], hend.grad)
+    dhc = ws[wo["dhcat"]: wo["dhcat"] + b * W * Dp].view(b, W, Dp)
+    # d h_cat as the GRU backward leaves it = gradient through the GRU only (the attention layers' share is added later)
+    cmp("ws d h_cat[:, 2F:3F] (temporal out)", dhc[:, :, 2 * Fn:3 * Fn], ht.grad)
+    cmp("ws d h_cat[:, F:2F] (feature out)", dhc[:, :, Fn:2 * Fn], hf.grad)
+    dpre = ws[wo["dpre"]: wo["dpre"] + b * W * Fp].view(b, W, Fp)[:, :, :Fn]
+    cmp("ws d conv pre-activation", dpre, xc.grad * (xc.detach() > 0))
+    names = [n for n, _ in model.named_parameters()]
+    import _hipgrad
+    for p_, o in zip(_hipgrad.param_order(model), offs):
+        nm = [n for n, q in model.named_parameters() if q is p_][0]
+        cmp("grad " + nm, grads[o:o + p_.numel()].view(p_.shape), ref[nm])
+    print("\n".join(rep))
+    assert len(names) == len(offs)
