@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs a) {
             chn[u] = nc[u] - tapn[u] * a.F;
         }
     }
-    const bool need_t = (BMODE == 1) || a.ashift;
+    const bool need_t = (BMODE == 1) || a.bshift;
     int ts[4];                                        // step index within the window of this lane's 4 rows
 #pragma unroll
     for (int s = 0; s < 4; ++s) ts[s] = need_t ? (int)((rbeg + 4 * kk + s) % T) : 0;
@@ -69,13 +69,10 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs a) {
             const long rowc = rok ? row : a.R - 1;
             const int t = ts[s];
             // A
-            const bool aok = rok && !(a.ashift && t == T - 1);
-            long arow = rowc + (a.ashift ? 1 : 0);
-            arow = arow < a.R ? arow : a.R - 1;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float v = a.A[arow * a.lda + mc[u]];
-                av[u][s] = (aok && mcol[u] < a.M) ? v : 0.f;
+                const float v = a.A[rowc * a.lda + mc[u]];
+                av[u][s] = (rok && mcol[u] < a.M) ? v : 0.f;
             }
             // B
 #pragma unroll
@@ -90,7 +87,11 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs a) {
                     v = a.B[xr * a.F + chn[u]];
                     ok = ok && tin;
                 } else {
-                    v = a.B[rowc * a.ldb + nc[u]];
+                    // bshift: the row of the previous step (h_{t-1} next to the gradients of step t), zero at t = 0
+                    long br = rowc - (a.bshift ? 1 : 0);
+                    br = br < 0 ? 0 : br;
+                    v = a.B[br * a.ldb + nc[u]];
+                    ok = ok && !(a.bshift && t == 0);
                 }
                 v = ok ? v : 0.f;
                 bv[u][s] = (rok && ncol[u] == a.N) ? 1.f : v;            // the all-ones column: bias gradients

@@ -588,14 +588,14 @@ int run_rowgemm_T(Model& m, const LinTPlan& p, const float* X, long ldx, long R,
 }
 
 struct WgradIn {
-    const float* A = nullptr; long lda = 0; int ashift = 0;
-    const float* B = nullptr; long ldb = 0; int bmode = 0;
+    const float* A = nullptr; long lda = 0;
+    const float* B = nullptr; long ldb = 0; int bmode = 0; int bshift = 0;
     long R = 0; int T = 1;
 };
 int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, float* wpart, float* outW, float* outB, hipStream_t s) {
     WgradArgs a{};
-    a.A = in.A; a.lda = in.lda; a.M = p.M; a.ashift = in.ashift;
-    a.B = in.B; a.ldb = in.ldb; a.N = p.N; a.bmode = in.bmode;
+    a.A = in.A; a.lda = in.lda; a.M = p.M;
+    a.B = in.B; a.ldb = in.ldb; a.N = p.N; a.bmode = in.bmode; a.bshift = in.bshift;
     a.T = in.T; a.F = m.F; a.taps = m.taps; a.pad = m.pad;
     a.R = in.R;
     a.nslab = wgrad_slabs(in.R, p.Mp, p.Np);
@@ -790,7 +790,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         ga.DA = da; ga.Hp = r.Hp; ga.H = r.H; ga.T = W; ga.NCG = r.NCG; ga.B = n;
         K_TRY(launch_gru_bwd(ga, s), "decoder backward");
         WgradIn hh;
-        hh.A = da + r.Hp; hh.lda = 4L * r.Hp; hh.ashift = 1; hh.B = T + t.seq_d; hh.ldb = r.Hp; hh.R = RW; hh.T = W;
+        hh.A = da + r.Hp; hh.lda = 4L * r.Hp; hh.bshift = 1; hh.B = T + t.seq_d; hh.ldb = r.Hp; hh.R = RW; hh.T = W;
         if ((rc = run_wgrad(m, b.rec.wg_hh, hh, wpart, grads + gl.rec_whh, grads + gl.rec_bhh, s))) return rc;
         WgradIn ih;
         ih.A = da; ih.lda = 4L * r.Hp; ih.B = T + t.xdec; ih.ldb = g.Hp; ih.R = RW; ih.T = W;
@@ -808,7 +808,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         ga.DA = da; ga.Hp = g.Hp; ga.H = g.H; ga.T = W; ga.NCG = g.NCG; ga.B = n;
         K_TRY(launch_gru_bwd(ga, s), "gru backward");
         WgradIn hh;
-        hh.A = da + g.Hp; hh.lda = 4L * g.Hp; hh.ashift = 1; hh.B = T + t.seq_g; hh.ldb = g.Hp; hh.R = RW; hh.T = W;
+        hh.A = da + g.Hp; hh.lda = 4L * g.Hp; hh.bshift = 1; hh.B = T + t.seq_g; hh.ldb = g.Hp; hh.R = RW; hh.T = W;
         if ((rc = run_wgrad(m, b.gru.wg_hh, hh, wpart, grads + gl.gru_whh, grads + gl.gru_bhh, s))) return rc;
         WgradIn ih;
         ih.A = da; ih.lda = 4L * g.Hp; ih.B = hcat; ih.ldb = m.Dp; ih.R = RW; ih.T = W;

@@ -159,7 +159,8 @@ struct WgradArgs {
     const float* A;      // (R, lda), M valid columns
     long lda;
     int M;
-    int ashift;          // rows of A are taken one step later: A[row + 1], zero when row is the last step of its window
+    int bshift;          // bmode 0: B rows are taken one step earlier, B[row - 1], zero at the first step of a window
+                         // (the all-ones column is not shifted: bias gradients sum over every step)
     const float* B;      // bmode 0: (R, ldb), N valid columns
     long ldb;
     int N;

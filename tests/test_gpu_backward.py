@@ -62,8 +62,9 @@ def _reference_grads(model, x, y, masks=None):
     import _torchpath
     for p in model.parameters():
         p.grad = None
-    pr, rc = _torchpath.forward(model, x, masks)
-    _loss(pr, rc, x, y).backward()
+    with torch.backends.cudnn.flags(enabled=False):       # MIOpen's fused RNN refuses to back-propagate in eval mode
+        pr, rc = _torchpath.forward(model, x, masks)
+        _loss(pr, rc, x, y).backward()
     ref = {n: p.grad.clone() for n, p in model.named_parameters()}
     for p in model.parameters():
         p.grad = None
@@ -165,14 +166,15 @@ def test_backward_stage_diagnostics(gpu_device):
     cp = torch.randn(b, kw["out_dim"], generator=g).to(gpu_device)
     cr = torch.randn(b, W, kw["out_dim"], generator=g).to(gpu_device)
     # torch side with retained intermediates
-    xc = tp.conv_stage(model, x); xc.retain_grad()
-    hf = tp.feature_gat_stage(model, xc); hf.retain_grad()
-    ht = tp.temporal_gat_stage(model, xc); ht.retain_grad()
-    hcat = torch.cat([xc, hf, ht], dim=2); hcat.retain_grad()
-    hend = tp.gru_stage(model, hcat); hend.retain_grad()
-    pr = tp.forecast_stage(model, hend)
-    rc = tp.recon_stage(model, hend)
-    ((pr * cp).sum() + (rc * cr).sum()).backward()
+    with torch.backends.cudnn.flags(enabled=False):
+        xc = tp.conv_stage(model, x); xc.retain_grad()
+        hf = tp.feature_gat_stage(model, xc); hf.retain_grad()
+        ht = tp.temporal_gat_stage(model, xc); ht.retain_grad()
+        hcat = torch.cat([xc, hf, ht], dim=2); hcat.retain_grad()
+        hend = tp.gru_stage(model, hcat); hend.retain_grad()
+        pr = tp.forecast_stage(model, hend)
+        rc = tp.recon_stage(model, hend)
+        ((pr * cp).sum() + (rc * cr).sum()).backward()
     ref = {n: p.grad.clone() for n, p in model.named_parameters()}
     # HIP side
     prh, rch, tape = eng.forward_train(x, 0.0, 0)
