@@ -503,8 +503,8 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
-                    for (int j4 = 0; j4 < JPP; ++j4)
-                        if (JPP * pass + j4 < JPL) att[(li + RI * ii) * GB_APITCH + lj + RJ * j4] = acc[ii][JPP * pass + j4];
+                    for (int j4 = 0; j4 < JPP; ++j4)   // every column of the pass (stale LDS contents must not reach the MFMA)
+                        att[(li + RI * ii) * GB_APITCH + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 const int jn = min(64, Kp16 - pass * 64);

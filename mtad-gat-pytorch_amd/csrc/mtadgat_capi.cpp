@@ -300,6 +300,7 @@ int mtadgat_destroy(mtadgat_handle h) {
         (void)hipEventSynchronize(h->m.upload_ev);
         (void)hipEventDestroy(h->m.upload_ev);
     }
+    if (h->m.staging_pinned) (void)hipHostFree(h->m.staging_pinned);
     if (h->m.packed_dev) (void)hipFree(h->m.packed_dev);
     for (auto& v : h->m.ev)
         for (auto& p : v) {
@@ -333,14 +334,23 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream
         m.packed_device = dev;
     }
     hipStream_t s = (hipStream_t)stream;
-    // Stream-ordered upload without a device synchronisation: the packed image is handed to the handle's
-    // staging buffer, which outlives the copy (it is only replaced by the next load_weights, after that
-    // call has waited for this copy through the upload event).
+    // Stream-ordered upload without a device synchronisation: the packed image goes through a pinned staging
+    // buffer owned by the handle (an async copy from pageable memory is not reliably ordered with the kernels
+    // that follow on the stream); the buffer is only rewritten after the previous upload's event has fired.
     if (m.upload_ev) HIP_TRY(hipEventSynchronize(m.upload_ev));
     else HIP_TRY(hipEventCreateWithFlags(&m.upload_ev, hipEventDisableTiming));
-    m.staging.swap(host);
-    HIP_TRY(hipMemcpyAsync(m.packed_dev, m.staging.data(), m.packed_floats * sizeof(float), hipMemcpyHostToDevice, s));
+    if (m.staging_pinned && m.staging_floats < m.packed_floats) {
+        (void)hipHostFree(m.staging_pinned);
+        m.staging_pinned = nullptr;
+    }
+    if (!m.staging_pinned) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m.staging_pinned), m.packed_floats * sizeof(float), hipHostMallocDefault));
+        m.staging_floats = m.packed_floats;
+    }
+    std::memcpy(m.staging_pinned, host.data(), m.packed_floats * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(m.packed_dev, m.staging_pinned, m.packed_floats * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(m.upload_ev, s));
+    if (std::getenv("MTADGAT_SYNC_UPLOAD")) HIP_TRY(hipStreamSynchronize(s));      // debugging aid
     m.have_weights = true;
     return 0;
 }

@@ -403,8 +403,9 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 #pragma unroll
             for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
-                for (int j4 = 0; j4 < JPP; ++j4)
-                    if (JPP * pass + j4 < JPL) att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = acc[ii][JPP * pass + j4];
+                for (int j4 = 0; j4 < JPP; ++j4)       // all 64 key columns of the pass: the MFMA below reads whole 16-key groups, and
+                                                        // whatever the previous owner of this LDS left there (NaN patterns) times a zero row of V is not zero
+                    att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const int jn = min(64, K - pass * 64);

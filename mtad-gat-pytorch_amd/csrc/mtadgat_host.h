@@ -105,7 +105,8 @@ struct Model {
     size_t packed_floats = 0;
     float* packed_dev = nullptr;
     int packed_device = -1;          // device ordinal packed_dev was allocated on
-    std::vector<float> staging;      // host image of the last upload (source of the async copy)
+    float* staging_pinned = nullptr; // pinned host image of the last upload (source of the async copy)
+    size_t staging_floats = 0;
     hipEvent_t upload_ev = nullptr;  // recorded after the last upload
     bool have_weights = false;
     int64_t chunk = 65536;

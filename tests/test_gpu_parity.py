@@ -192,15 +192,17 @@ def test_weight_update_is_seen(gpu_device):
         p2, _ = model(x)
         assert torch.equal(p2, p0)
         # edits through .data do not bump autograd's version counter: the content fingerprint sees them
-        v = model.forecasting_model.layers[3].bias._version
-        model.forecasting_model.layers[3].bias.data.add_(2.0)
-        assert model.forecasting_model.layers[3].bias._version == v
+        bias = model.forecasting_model.layers[3].bias
+        orig = bias.detach().clone()
+        v = bias._version
+        bias.data.add_(2.0)
+        assert bias._version == v
         p3, _ = model(x)
         assert torch.allclose(p3, p0 + 2.0, atol=1e-6)
         # ... unless the caller opts out of the per-call check; then refresh_weights() is the contract
         model.check_weight_contents = False
         model(x)
-        model.forecasting_model.layers[3].bias.data.sub_(2.0)
+        bias.data.copy_(orig)
         assert torch.equal(model(x)[0], p3)
         model.refresh_weights()
         assert torch.equal(model(x)[0], p0)
