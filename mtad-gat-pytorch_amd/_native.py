@@ -221,7 +221,14 @@ class Engine:
     # -- weights ------------------------------------------------------------------------------
     def load_weights(self, sd, device):
         """sd: reference-format state_dict (any device); packs on the host, uploads on the current stream."""
-        host = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in sd.items()}
+        # one device-side concatenation + one transfer instead of a copy (and a sync) per tensor
+        keys = list(sd.keys())
+        flat = torch.cat([sd[k].detach().reshape(-1).to(torch.float32) for k in keys]).cpu()
+        host, off = {}, 0
+        for k in keys:
+            n = sd[k].numel()
+            host[k] = flat[off:off + n]
+            off += n
         p = Params()
 
         def ptr(key):
@@ -246,7 +253,7 @@ class Engine:
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
             _check(self.lib.mtadgat_load_weights(self.handle, ctypes.byref(p), ctypes.c_void_p(stream)), "load_weights")
-        self._keep = host
+        self._keep = flat
 
     # -- scratch ------------------------------------------------------------------------------
     def _workspace(self, batch, device):

@@ -4,7 +4,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 
 #include "mtadgat_host.h"
 
@@ -16,23 +15,26 @@ size_t align64(size_t v) { return (v + 63) / 64 * 64; }
 
 // tile format: [NT][Q][64 lanes][4]; lane (j = lane&31, g = lane>>5), element s holds
 // M[32n + j][8q + 4g + s] (zero outside the matrix)
-void pack_tiles(float* out, int NT, int Q, const std::function<float(int, int)>& get) {
+template <class Get>
+void pack_tiles(float* out, int NT, int Q, Get get) {
     for (int n = 0; n < NT; ++n)
-        for (int q = 0; q < Q; ++q)
+        for (int q = 0; q < Q; ++q) {
+            float* o = out + ((size_t)n * Q + q) * 256;
             for (int lane = 0; lane < 64; ++lane)
-                for (int s = 0; s < 4; ++s)
-                    out[(((size_t)n * Q + q) * 64 + lane) * 4 + s] = get(32 * n + (lane & 31), 8 * q + 4 * (lane >> 5) + s);
+                for (int s = 0; s < 4; ++s) o[lane * 4 + s] = get(32 * n + (lane & 31), 8 * q + 4 * (lane >> 5) + s);
+        }
 }
 
 // GRU stream format: [NCG][Q][3 gates][64 lanes][4]
-void pack_gru_tiles(float* out, int NCG, int Q, const std::function<float(int, int, int)>& get /*(gate,row,k)*/) {
+template <class Get>
+void pack_gru_tiles(float* out, int NCG, int Q, Get get /*(gate,row,k)*/) {
     for (int c = 0; c < NCG; ++c)
         for (int q = 0; q < Q; ++q)
-            for (int st = 0; st < 3; ++st)
+            for (int st = 0; st < 3; ++st) {
+                float* o = out + (((size_t)c * Q + q) * 3 + st) * 256;
                 for (int lane = 0; lane < 64; ++lane)
-                    for (int s = 0; s < 4; ++s)
-                        out[((((size_t)c * Q + q) * 3 + st) * 64 + lane) * 4 + s] =
-                            get(st, 32 * c + (lane & 31), 8 * q + 4 * (lane >> 5) + s);
+                    for (int s = 0; s < 4; ++s) o[lane * 4 + s] = get(st, 32 * c + (lane & 31), 8 * q + 4 * (lane >> 5) + s);
+            }
 }
 
 }  // namespace
@@ -499,23 +501,33 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
         if (!p.rec_w_ih[l] || !p.rec_w_hh[l] || !p.rec_b_ih[l] || !p.rec_b_hh[l]) return "null decoder parameter pointer";
         const GruPlan& g = m.rec[l];
         if (g.xmode == 1) {
-            // x_t[j] = h_end[(t*Hin + j) / T]: fold W_ih over the j that share an h_end entry
+            // x_t[j] = h_end[(t*Hin + j) / T]: fold W_ih over the j that share an h_end entry.  The j of one entry
+            // are consecutive, so every folded weight is a difference of two prefix sums over j (double)
             const int Hin = g.in_dim, T = m.W, H = g.H;
             const int NMp = 8 * g.Qx;
-            std::vector<double> csum((size_t)3 * H * NMp);
+            std::vector<double> pre((size_t)3 * H * (Hin + 1));
+            for (int r = 0; r < 3 * H; ++r) {
+                double acc = 0.0;
+                pre[(size_t)r * (Hin + 1)] = 0.0;
+                for (int j = 0; j < Hin; ++j) {
+                    acc += (double)p.rec_w_ih[l][(size_t)r * Hin + j];
+                    pre[(size_t)r * (Hin + 1) + j + 1] = acc;
+                }
+            }
             int* m0 = reinterpret_cast<int*>(out.data() + g.m0_off);
             for (int t = 0; t < T; ++t) {
                 const int lo = (int)(((long)t * Hin) / T);
                 m0[t] = lo;
-                std::fill(csum.begin(), csum.end(), 0.0);
-                for (int r = 0; r < 3 * H; ++r)
-                    for (int j = 0; j < Hin; ++j) {
-                        const int cc = (int)(((long)t * Hin + j) / T) - lo;
-                        csum[(size_t)r * NMp + cc] += (double)p.rec_w_ih[l][(size_t)r * Hin + j];
-                    }
                 pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qxp * 3 * 256, g.NCG, g.Qxp,
                                [&](int st, int r, int k) -> float {
-                                   return (r < H && k < NMp) ? (float)csum[((size_t)st * H + r) * NMp + k] : 0.f;
+                                   if (r >= H || k >= NMp) return 0.f;
+                                   // j with (t*Hin + j) / T == lo + k:  j in [(lo+k)*T - t*Hin, (lo+k+1)*T - t*Hin)
+                                   long j0 = (long)(lo + k) * T - (long)t * Hin, j1 = j0 + T;
+                                   j0 = j0 < 0 ? 0 : j0;
+                                   j1 = j1 > Hin ? Hin : j1;
+                                   if (j1 <= j0) return 0.f;
+                                   const double* pr = pre.data() + ((size_t)st * H + r) * (Hin + 1);
+                                   return (float)(pr[j1] - pr[j0]);
                                });
             }
         }
@@ -532,8 +544,7 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
     // ---- backward packs (transposed weights, un-scaled attention projections, gradient index maps)
     if (m.bw.supported) {
         const BwdPlan& b = m.bw;
-        auto maps = [&](const WgradPlan& wp, const std::function<int(int)>& rowW, const std::function<int(int)>& col,
-                        const std::function<int(int)>& rowB) {
+        auto maps = [&](const WgradPlan& wp, auto rowW, auto col, auto rowB) {
             int* rw = reinterpret_cast<int*>(out.data() + wp.rowW_off);
             int* cm = reinterpret_cast<int*>(out.data() + wp.col_off);
             int* rb = reinterpret_cast<int*>(out.data() + wp.rowB_off);
