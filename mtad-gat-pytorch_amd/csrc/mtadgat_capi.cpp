@@ -156,11 +156,24 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
 int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
-                  long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s, float* gates = nullptr) {
+                  long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s, float* gates = nullptr,
+                  float* xp = nullptr) {
     Scope sc(m, slot, s);
+    int xmode = g.xmode;
+    if (xp && g.has_xproj && g.xmode == 0) {
+        // small batch: all steps' input products as one throughput GEMM, the recurrence keeps only its h part
+        RowGemmArgs r{};
+        r.X = x; r.ldx = ldx; r.Kvalid = g.in_dim; r.Q = g.xproj.Q;
+        r.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.xproj.w_off);
+        r.bias = m.packed_dev + g.xproj.b_off;
+        r.Y = xp; r.ldy = 3L * g.Hp; r.Nvalid = 3 * g.Hp; r.vec_store = 1;
+        r.R = n * m.W; r.NT = g.xproj.NT; r.NT_rm = g.xproj.NT; r.group = 1; r.relu = 0;
+        K_TRY(launch_rowgemm(r, s), "gru input projection");
+        x = xp; ldx = 3L * g.Hp; xmode = 3;
+    }
     GruArgs a{};
     a.X = x; a.ldx = ldx; a.Kx = kx; a.Qx = g.Qx; a.Qxp = g.Qxp;
-    a.m0 = g.xmode == 1 ? reinterpret_cast<const int*>(m.packed_dev + g.m0_off) : nullptr;
+    a.m0 = xmode == 1 ? reinterpret_cast<const int*>(m.packed_dev + g.m0_off) : nullptr;
     a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx_off);
     a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
     a.bias = m.packed_dev + g.b_off;
@@ -178,10 +191,10 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     }
     if (gates) {     // training forward: keep the gate activations of every step
         a.Gates = gates;
-        K_TRY(launch_gru_train(a, g.NCG, g.xmode, fc != nullptr, s), "gru (training)");
+        K_TRY(launch_gru_train(a, g.NCG, xmode, fc != nullptr, s), "gru (training)");
         return 0;
     }
-    K_TRY(launch_gru(a, g.NCG, g.xmode, fc != nullptr, s), "gru");
+    K_TRY(launch_gru(a, g.NCG, xmode, fc != nullptr, s), "gru");
     return 0;
 }
 
@@ -195,7 +208,8 @@ int run_gru_stack(Model& m, const float* hcat, long ldx, int64_t n, float* hend,
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         float* seq = last ? nullptr : ws + ((l & 1) ? o.seq1 : o.seq0);
-        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s);
+        float* xp = (l == 0 && o.has_xp && n <= gru_split_max_windows()) ? ws + o.xp : nullptr;
+        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s, nullptr, xp);
         if (rc) return rc;
         x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;      // sequence buffers hold all Hp columns, padding lanes are exact zeros
     }
@@ -701,7 +715,7 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
     const GruPlan& g = m.gru[0];
     float* hend = T + t.hend;
-    if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g))) return rc;
+    if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g, T + t.xp))) return rc;
     // forecasting head: ReLU + dropout on the hidden layers (modules.py:307-311), activations kept
     {
         Scope sc(m, S_FC, s);

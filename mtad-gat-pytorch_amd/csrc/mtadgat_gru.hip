@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
     const long win = (long)blockIdx.x * 32 + i;
     const long winc = win < a.B ? win : a.B - 1;
     const int T = a.T, Qx = a.Qx;
-    const int Qxp = (XMODE == 1) ? 1 : a.Qxp;      // XMODE 0/2: a multiple of 3
+    const int Qxp = (XMODE == 1) ? 1 : (XMODE == 3 ? 0 : a.Qxp);      // XMODE 0/2: a multiple of 3; 3: no input chunks
     const int Qh = 4 * NCG;                        // recurrent chunks of a tile that can be non-zero
     const int Qhe = (a.H + 7) >> 3;                // ... as needed
     const int S3 = (Qxp + Qhe + 2) / 3 * 3;        // chunks per step: whole ring turns
@@ -348,10 +348,10 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
         const f32x4* __restrict__ nx = (XMODE == 0 || pt >= T) ? wx0 : pwx + wxskip;
         pwx = ws ? nx : pwx;
     };
-    const float* __restrict__ xbase = (XMODE == 0) ? a.X + winc * T * a.ldx + 4 * g : a.X + winc * a.ldx;
+    const float* __restrict__ xbase = (XMODE == 0 || XMODE == 3) ? a.X + winc * T * a.ldx + 4 * g : a.X + winc * a.ldx;
     auto loadx_t = [&](int t, int q) -> f32x4 {
         const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
-        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase + (long)t * a.ldx + 8 * qq);
+        if (XMODE == 0 || XMODE == 3) return *reinterpret_cast<const f32x4*>(xbase + (long)t * a.ldx + 8 * qq);
         const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
         f32x4 v;
         v[0] = xbase[min(k0, kmax)]; v[1] = xbase[min(k0 + 1, kmax)];
@@ -359,6 +359,17 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
         return v;
     };
     auto hread = [&](int q) -> f32x4 { return hs[(q < Qhe ? q : Qhe - 1) * 64 + lane]; };   // padding: any finite chunk
+    // XMODE 3: the input products W_i{r,z,n} x_t + b of all steps were computed beforehand by one throughput GEMM
+    // (k_rowgemm over the b*T rows): X = (B*T, 3*Hp) [r | z | n]; a step starts from this tile's 3 x 16 values.
+    // At small batches the recurrence is a latency chain -- the input chunks are half of its MFMAs.
+    f32x4 xp[3][4];
+    auto loadxp = [&](int t) {
+        const float* __restrict__ p = a.X + (winc * T + t) * a.ldx + 32 * c + 4 * g;
+#pragma unroll
+        for (int b3 = 0; b3 < 3; ++b3)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xp[b3][m] = *reinterpret_cast<const f32x4*>(p + b3 * a.Hp + 8 * m);
+    };
 
     f32x16 hown;                                   // this wave's tile of h
 #pragma unroll
@@ -367,8 +378,12 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
     for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 wr[3][3], xr[3];
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
+    if (XMODE == 3) {
+        loadxp(0);
+    } else {
 #pragma unroll
-    for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st);
+        for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st);
+    }
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
@@ -376,16 +391,26 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int col = 32 * c + 8 * m + 4 * g;
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + a.Hp + col);
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias + 2 * a.Hp + col);
             const f32x4 b3 = *reinterpret_cast<const f32x4*>(a.bias + 3 * a.Hp + col);
+            if (XMODE == 3) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                ar[4 * m + s4] = b0[s4];
-                az[4 * m + s4] = b1[s4];
-                anx[4 * m + s4] = b2[s4];
-                anh[4 * m + s4] = b3[s4];
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    ar[4 * m + s4] = xp[0][m][s4];
+                    az[4 * m + s4] = xp[1][m][s4];
+                    anx[4 * m + s4] = xp[2][m][s4];
+                    anh[4 * m + s4] = b3[s4];
+                }
+            } else {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + a.Hp + col);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias + 2 * a.Hp + col);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    ar[4 * m + s4] = b0[s4];
+                    az[4 * m + s4] = b1[s4];
+                    anx[4 * m + s4] = b2[s4];
+                    anh[4 * m + s4] = b3[s4];
+                }
             }
         }
         // chunk q of h_{t-1} is requested one chunk ahead of its MFMAs (LDS latency under the previous group)
@@ -431,11 +456,15 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
         // are the conservative join with the x loop's and the ring is drained every turn.
         if (XMODE != 1) hturn();                   // NH >= 3 there
         while (qh < NH) hturn();
-        // x chunks 0..2 of the next step: their latency hides under the gate math
+        // x chunks 0..2 (XMODE 3: the pre-projected tile) of the next step: their latency hides under the gate math
         {
             const int tn = t + 1 < T ? t + 1 : t;
+            if (XMODE == 3) {
+                loadxp(tn);
+            } else {
 #pragma unroll
-            for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st);
+                for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st);
+            }
         }
         // ---- gates (reference GRULayer / RNNDecoder: torch.nn.GRU equations, r|z|n)
 #pragma unroll
@@ -555,7 +584,7 @@ static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipSt
     const unsigned grid = (unsigned)((a.B + 31) / 32);
     const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
     if (lds > 64 * 1024) return -2;
-    const int xm = xmode == 0 ? 0 : (a.Qxp == 1 ? 1 : 2);
+    const int xm = xmode == 3 ? 3 : (xmode == 0 ? 0 : (a.Qxp == 1 ? 1 : 2));
     const bool save = a.Gates != nullptr;
 #define SPLIT_CASE(XM, F)                                                                                        \
     if (xm == XM && fc == F) {                                                                                   \
@@ -563,6 +592,7 @@ static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipSt
         else hipLaunchKernelGGL((k_gru_split<XM, F, false>), dim3(grid), dim3(64 * ncg), lds, s, a);             \
     }
     SPLIT_CASE(0, false) SPLIT_CASE(0, true) SPLIT_CASE(1, false) SPLIT_CASE(1, true) SPLIT_CASE(2, false) SPLIT_CASE(2, true)
+    SPLIT_CASE(3, false) SPLIT_CASE(3, true)
 #undef SPLIT_CASE
     LAUNCH_CHECK();
     return 0;
@@ -572,13 +602,21 @@ static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipSt
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     if (a.B <= 0) return 0;
     if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
-    if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
+    if (xmode == 3 && (a.ldx & 3) != 0) return -2;
+    if (xmode != 0 && xmode != 3 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
     if (ncg < 1) return -2;
     return launch_gru_split(a, ncg, xmode, fc, s);
 }
 
+// windows up to which the hidden-tile-split kernel is the faster one (a 32-window group per CU x 2)
+long gru_split_max_windows() { return 64L * cu_count(); }
+
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     if (a.B <= 0) return 0;
+    if (xmode == 3) {                // pre-projected input: only the split kernel takes it
+        if ((a.ldx & 3) != 0 || ncg < 1) return -2;
+        return launch_gru_split(a, ncg, xmode, fc, s);
+    }
     if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
     if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
     // Small batches: spread the 32-window groups over ncg waves each (k_gru_split) -- k_gru needs ~2 groups

@@ -32,15 +32,19 @@ struct GatPlan {
     size_t f_lds_bytes = 0;
 };
 
+struct LinPlan {
+    int in_dim = 0, out_dim = 0, NT = 0, Q = 0;
+    size_t w_off = 0, b_off = 0;
+};
+
 struct GruPlan {
     int in_dim = 0, H = 0, Hp = 0, NCG = 0, Qx = 0, Qxp = 0;   // Qxp: packed x chunks (1 or a multiple of 3)
     int xmode = 0;          // 0 rows, 1 reference decoder input (modules.py:279)
     size_t wx_off = 0, wh_off = 0, b_off = 0, m0_off = 0;
-};
-
-struct LinPlan {
-    int in_dim = 0, out_dim = 0, NT = 0, Q = 0;
-    size_t w_off = 0, b_off = 0;
+    // input projection of all steps as one row GEMM ahead of the recurrence (small batches, k_gru_split XMODE 3):
+    // rows (b*T, in_dim) -> (b*T, 3*Hp) [W_ir x + b_ir + b_hr | W_iz x + b_iz + b_hz | W_in x + b_in]
+    bool has_xproj = false;
+    LinPlan xproj;
 };
 
 // ---- backward (training) plans -------------------------------------------------------------------------
@@ -117,12 +121,13 @@ struct Model {
 
 struct Workspace {
     // offsets in floats for a chunk of `n` windows
-    size_t xc, xct, lct, rtt, lcf, rtf, hcat, hend, seq0, seq1, fc0, fc1, rseq0, rseq1, total;
+    size_t xc, xct, lct, rtt, lcf, rtf, hcat, hend, seq0, seq1, fc0, fc1, rseq0, rseq1, xp, total;
+    bool has_xp;         // room for the pre-projected GRU input (batches the hidden-tile-split kernel serves)
 };
 
 // activations kept between the training forward and the backward (caller-owned "tape"), offsets in floats
 struct Tape {
-    size_t hcat, xct, att_f, att_t, hend, gates_g, seq_g, gates_d, seq_d, xdec, total;
+    size_t hcat, xct, att_f, att_t, hend, gates_g, seq_g, gates_d, seq_d, xdec, xp, total;
     std::vector<size_t> fc_act;     // outputs of the hidden forecasting layers (after ReLU + dropout)
 };
 // scratch of the backward

@@ -231,6 +231,7 @@ int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
+long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
 int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
 int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s);

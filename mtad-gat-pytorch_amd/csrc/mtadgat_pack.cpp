@@ -127,6 +127,13 @@ std::string validate_and_plan(Model& m) {
         g.wx_off = take((size_t)g.NCG * g.Qxp * 3 * 256);
         g.wh_off = take((size_t)g.NCG * (4 * g.NCG + 2) * 3 * 256);   // 2 zero chunks per tile: k_gru_split's ring padding
         g.b_off = take((size_t)4 * g.Hp);
+        if (l == 0) {
+            g.has_xproj = true;
+            g.xproj.in_dim = g.in_dim; g.xproj.out_dim = 3 * g.Hp;
+            g.xproj.NT = 3 * g.Hp / 32; g.xproj.Q = (g.in_dim + 7) / 8;
+            g.xproj.w_off = take((size_t)g.xproj.NT * g.xproj.Q * 256);
+            g.xproj.b_off = take((size_t)3 * g.Hp);
+        }
     }
     // forecasting head
     m.fc.assign(c.forecast_n_linear, LinPlan());
@@ -304,6 +311,8 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     const bool rseq = m.rec.size() > 1;
     ws.rseq0 = take(rseq ? N * m.W * m.rec[0].Hp : 0);
     ws.rseq1 = take(m.rec.size() > 2 ? N * m.W * m.rec[0].Hp : 0);
+    ws.has_xp = m.gru[0].has_xproj && n <= 16384;          // 64 windows per CU x 256 CUs: above that k_gru streams x itself
+    ws.xp = take(ws.has_xp ? N * m.W * 3 * m.gru[0].Hp : 0);
     ws.total = off;
 }
 
@@ -337,6 +346,7 @@ void plan_tape(const Model& m, int64_t n, Tape& t) {
     t.gates_d = take(N * m.W * 4 * r.Hp);
     t.seq_d = take(N * m.W * r.Hp);
     t.xdec = take(N * m.W * g.Hp);
+    t.xp = take(N * m.W * 3 * g.Hp);
     t.fc_act.clear();
     for (size_t i = 0; i + 1 < m.fc.size(); ++i) t.fc_act.push_back(take(N * (size_t)m.fc[i].NT * 32));
     t.total = off;
@@ -464,6 +474,14 @@ static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_h
         b[1 * g.Hp + j] = j < H ? b_ih[H + j] + b_hh[H + j] : 0.f;
         b[2 * g.Hp + j] = j < H ? b_ih[2 * H + j] : 0.f;
         b[3 * g.Hp + j] = j < H ? b_hh[2 * H + j] : 0.f;
+    }
+    if (g.has_xproj) {
+        const int Hp = g.Hp;
+        pack_tiles(out.data() + g.xproj.w_off, g.xproj.NT, g.xproj.Q, [&](int n, int k) -> float {
+            const int blk = n / Hp, u = n % Hp;
+            return (blk < 3 && u < H && k < in) ? w_ih[((size_t)blk * H + u) * in + k] : 0.f;
+        });
+        std::memcpy(out.data() + g.xproj.b_off, b, sizeof(float) * 3 * Hp);
     }
 }
 
