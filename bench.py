@@ -41,6 +41,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T fp32 lane-ops/s
 
@@ -165,6 +166,29 @@ def sub_records(model, kw, dev):
         t = _timed(lambda: model(x256), dev, 20)
         out["batch256"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1),
                            "what": "one eval forward of the reference Predictor's fixed 256-window batch (prediction.py:31), MSL shape"}
+        # the flagship workload with bf16 MFMA operands (fp32 accumulate / state; 2e-2 parity class), own roofline
+        xb = torch.rand(65536, kw["window_size"], kw["n_features"], generator=g).to(dev)
+        model.precision = "bf16"
+        eng = model._sync_engine(dev)
+        t = _timed(lambda: model(xb), dev, 5, warm=2)
+        eng.profile_enable(True)
+        for _ in range(3):
+            model(xb)
+        torch.cuda.synchronize(dev)
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        model.precision = "auto"
+        fl = algorithmic_flops(kw)
+        ms_gru = (prof["gru"][0] + prof["recon"][0]) / 3
+        tf = (fl["gru"] + fl["recon"]) * 65536 / (ms_gru * 1e-3) / 1e12
+        out["bf16_operands_b65536"] = {
+            "ms": round(1e3 * t, 3), "windows_per_s": round(65536 / t, 1),
+            "kernel_ms": {k: round(v[0] / 3, 3) for k, v in prof.items() if v[1]},
+            "roofline": {"kernel": "k_gru (bf16 build)", "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4)},
+            "what": "the flagship workload (MSL shape, 65536 windows, fp32 tensors in/out) with precision='bf16': bf16 MFMA operands "
+                    "where a bf16 build of the kernel exists, fp32 accumulation, state, gates and softmax; <= 2e-2 of the fp32 reference"}
+        del xb
     # BASELINE config 3 shape: SMD machine-1-1, F=38 -> out 38, batch 256 (args.py:47), dropout 0.3
     kw3 = dict(kw, n_features=38, out_dim=38, dropout=0.3)
     torch.manual_seed(0)

@@ -112,6 +112,14 @@ int mtadgat_destroy(mtadgat_handle h);
  * whenever a parameter changed. */
 int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, void* stream);
 
+/* Arithmetic of the inference entry points (forward / forward_series / stage calls):
+ *   0 (default)  fp32 operands on the exact fp32 MFMA: <= 1e-5 of the reference's float32 forward
+ *   1            bf16 MFMA operands (weights packed to bf16 once per load_weights, activations rounded on the
+ *                way into the matrix unit), fp32 accumulation, fp32 recurrent state / gates / softmax:
+ *                <= 2e-2 of the fp32 reference on outputs of scale ~1 (BASELINE configs "bf16 inference").
+ * The training entry points always compute in fp32. */
+int mtadgat_set_precision(mtadgat_handle h, int mode);
+
 /* Bytes of device scratch forward() needs for a batch of `batch` windows
  * (intermediates of at most mtadgat_chunk_windows() windows are live at once). */
 size_t  mtadgat_workspace_bytes(mtadgat_handle h, int64_t batch);

@@ -178,6 +178,13 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
     a.bias = m.packed_dev + g.b_off;
     a.whs = 4 * g.NCG + 2;
+    if (m.precision == 1 && !gates) {       // bf16 operand build: the same streams in 16-feature chunks (inference only)
+        a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx16_off);
+        a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh16_off);
+        a.whs = 2 * g.NCG + 2;
+        a.Qxp = g.Qxp16;
+        a.bf16 = 1;
+    }
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
     a.Hend = hend; a.ldhe = ldhe;
     a.Seq = seq; a.ldseq = g.Hp;
@@ -366,6 +373,12 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream
     HIP_TRY(hipEventRecord(m.upload_ev, s));
     if (std::getenv("MTADGAT_SYNC_UPLOAD")) HIP_TRY(hipStreamSynchronize(s));      // debugging aid
     m.have_weights = true;
+    return 0;
+}
+
+int mtadgat_set_precision(mtadgat_handle h, int mode) {
+    if (!h || (mode != 0 && mode != 1)) return fail(MTADGAT_ERR_INVALID, "precision mode must be 0 (fp32) or 1 (bf16 operands)");
+    h->m.precision = mode;
     return 0;
 }
 

@@ -58,6 +58,33 @@ __device__ __forceinline__ void mfma4x3(const f32x4 (&w)[3], const f32x4 x, f32x
     }
 }
 
+// ---- bf16 operand mode (opt-in; fp32 accumulation, fp32 state / softmax / gates) ---------------------------
+// v_mfma_f32_32x32x16_bf16 contracts 16 features per instruction: lane (i, g) supplies 8 of them.  A "bf16
+// chunk" q is the pair of F-layout chunks 2q, 2q+1: element e of lane g is feature
+//     16 q + (e < 4 ? 4 g + e : 8 + 4 g + (e - 4))
+// i.e. exactly the eight fp32 values the lane already holds for those two chunks (its accumulator registers
+// 8(q&1)..8(q&1)+7 of tile q/2, or two float4 loads) -- converting them with v_cvt_pk_bf16_f32 gives the B
+// operand with no cross-lane traffic, and the weights are packed on the host in the same element order.
+// The 16-byte operand travels in an f32x4 container so that the weight ring code is shared with the fp32 build.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));        // v_cvt_pk_bf16_f32, round to nearest even
+}
+__device__ __forceinline__ f32x4 cvt8(const f32x4 lo, const f32x4 hi) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 r = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+    return __builtin_bit_cast(f32x4, r);
+}
+__device__ __forceinline__ f32x16 mfma_bf(const f32x4 w, const f32x4 x, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+// one chunk for three gate accumulators: fp32 build 4 x 3 MFMAs (8 features), bf16 build 3 MFMAs (16 features)
+template <bool BF>
+__device__ __forceinline__ void mfma_x3(const f32x4 (&w)[3], const f32x4 x, f32x16& a0, f32x16& a1, f32x16& a2);
+
 // four features k0..k0+3 of a row; zero beyond kvalid.  vec_ok: row base and k0 are 16-byte aligned
 __device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ row, int k0, int kvalid, bool vec_ok) {
     f32x4 v;
@@ -70,6 +97,17 @@ __device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ row, int k
         v[3] = (k0 + 3 < kvalid) ? row[k0 + 3] : 0.f;
     }
     return v;
+}
+
+template <>
+__device__ __forceinline__ void mfma_x3<false>(const f32x4 (&w)[3], const f32x4 x, f32x16& a0, f32x16& a1, f32x16& a2) {
+    mfma4x3(w, x, a0, a1, a2);
+}
+template <>
+__device__ __forceinline__ void mfma_x3<true>(const f32x4 (&w)[3], const f32x4 x, f32x16& a0, f32x16& a1, f32x16& a2) {
+    a0 = mfma_bf(w[0], x, a0);
+    a1 = mfma_bf(w[1], x, a1);
+    a2 = mfma_bf(w[2], x, a2);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -27,7 +27,9 @@ namespace mtadgat {
 // MW = 32-window groups per wave.  MW = 2 with one wave per SIMD beats two MW = 1 waves per SIMD (matrix
 // pipe 85 % vs 82 % busy on the GRU layer, 74 % vs 69 % on the decoder): the MFMAs of one wave issue back to back, interleaving two
 // waves leaves bubbles; each weight chunk is also fetched once for 64 windows.
-template <int NCG, int XMODE, bool FC, int DROP, int MW>
+// BF: bf16 operand build (v_mfma_f32_32x32x16_bf16, 16 features per chunk; fp32 accumulators, state and gates):
+// the same chunk sequence with half as many, twice as wide chunks -- see mtadgat_device.h for the element order.
+template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false>
 __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
     __shared__ float hn_s[MW][NCG][16][64];
     const int lane = threadIdx.x;
@@ -40,9 +42,10 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
     }
     const int T = a.T, Qx = a.Qx;
     const int Qxp = (XMODE == 1) ? 1 : a.Qxp;
-    constexpr int Qh = 4 * NCG;                   // recurrent chunks that can be non-zero
+    constexpr int Qh = BF ? 2 * NCG : 4 * NCG;    // recurrent chunks that can be non-zero
     constexpr int Qhe = Qh - DROP;                // ... and as used
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % 3 : Qhe % 3;   // ring phase advance per hidden tile
+    constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
 
     f32x16 h[MW][NCG];
@@ -92,12 +95,19 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
         return v;
     };
 
+    // B operand of packed input chunk q: fp32 build = the 8-feature chunk itself; bf16 build = chunks 2q, 2q+1 converted
+    // (XMODE 1: the single folded chunk, upper half zero)
+    auto loadxq = [&](int w, int t, int q) -> f32x4 {
+        if (!BF) return loadx_t(w, t, q);
+        if (XMODE == 1) return cvt8(loadx_t(w, t, q), f32x4{0.f, 0.f, 0.f, 0.f});
+        return cvt8(loadx_t(w, t, 2 * q), loadx_t(w, t, 2 * q + 1));
+    };
     f32x4 wr[3][3], xr[3][MW];
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
 #pragma unroll
     for (int st = 0; st < 3; ++st)
 #pragma unroll
-        for (int w = 0; w < MW; ++w) xr[st][w] = loadx_t(w, 0, st);
+        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, 0, st);
 
     for (int t = 0; t < T; ++t) {
         for (int c = 0; c < NCG; ++c) {
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
             // MFMAs and the next iteration waits for them.
             if (XMODE == 1) {
 #pragma unroll
-                for (int w = 0; w < MW; ++w) mfma4x3(wr[0], xr[0][w], ar[w], az[w], anx[w]);
+                for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[0], xr[0][w], ar[w], az[w], anx[w]);
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
@@ -132,10 +142,10 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
 #pragma unroll
                     for (int st = 0; st < 3; ++st) {
 #pragma unroll
-                        for (int w = 0; w < MW; ++w) mfma4x3(wr[st], xr[st][w], ar[w], az[w], anx[w]);
+                        for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[st], xr[st][w], ar[w], az[w], anx[w]);
                         wload(wr[st]);
 #pragma unroll
-                        for (int w = 0; w < MW; ++w) xr[st][w] = loadx_t(w, t, q0 + st + 3);
+                        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, t, q0 + st + 3);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -145,13 +155,22 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
 #pragma unroll
             for (int q = 0; q < Qhe; ++q) {
                 constexpr int X0 = (XMODE == 1) ? 1 : 0;
-                const int cq = q >> 2, m = q & 3, st = (X0 + q) % 3;
+                const int st = (X0 + q) % 3;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) {
                     f32x4 hv;
-                    hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
-                    hv[2] = h[w][cq][4 * m + 2]; hv[3] = h[w][cq][4 * m + 3];
-                    mfma4x3(wr[st], hv, ar[w], az[w], anh[w]);
+                    if (BF) {
+                        const int cq = q >> 1, e0 = 8 * (q & 1);
+                        f32x4 lo, hi;
+                        lo[0] = h[w][cq][e0 + 0]; lo[1] = h[w][cq][e0 + 1]; lo[2] = h[w][cq][e0 + 2]; lo[3] = h[w][cq][e0 + 3];
+                        hi[0] = h[w][cq][e0 + 4]; hi[1] = h[w][cq][e0 + 5]; hi[2] = h[w][cq][e0 + 6]; hi[3] = h[w][cq][e0 + 7];
+                        hv = cvt8(lo, hi);
+                    } else {
+                        const int cq = q >> 2, m = q & 3;
+                        hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
+                        hv[2] = h[w][cq][4 * m + 2]; hv[3] = h[w][cq][4 * m + 3];
+                    }
+                    mfma_x3<BF>(wr[st], hv, ar[w], az[w], anh[w]);
                 }
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -170,7 +189,7 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
 #pragma unroll
                 for (int st = 0; st < 3; ++st)
 #pragma unroll
-                    for (int w = 0; w < MW; ++w) xr[st][w] = loadx_t(w, tn, st);
+                    for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, tn, st);
             }
             // ---- gates.  h_old for this tile comes back from LDS (written at the end of step t-1);
             // every lane reads and writes only its own slots -> no cross-lane hazard
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
                 for (int o = 0; o < a.out_dim; ++o) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int q = 0; q < Qhe; ++q) {
+                    for (int q = 0; q < Qf; ++q) {
                         const int cq = q >> 2, m = q & 3;
                         const f32x4 wv = wf[q * 64 + o + 32 * g];
                         acc += wv[0] * h[w][cq][4 * m + 0] + wv[1] * h[w][cq][4 * m + 1] + wv[2] * h[w][cq][4 * m + 2] + wv[3] * h[w][cq][4 * m + 3];
@@ -240,9 +259,9 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) y[4 * m + s4] = bv[s4];
                     }
-                    const f32x4* __restrict__ wp = a.Wfc + ((long)n * Qh) * 64 + lane;
+                    const f32x4* __restrict__ wp = a.Wfc + ((long)n * (4 * NCG)) * 64 + lane;
 #pragma unroll
-                    for (int q = 0; q < Qhe; ++q) {
+                    for (int q = 0; q < Qf; ++q) {
                         const int cq = q >> 2, m = q & 3;
                         f32x4 hv;
                         hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
@@ -307,8 +326,8 @@ __global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(con
 // whole number of ring turns for any hidden size, which keeps NCG and H run-time values.
 // ---------------------------------------------------------------------------
 // SAVE (training): the gate activations r, z, n and q = W_hn h + b_hn of every step go to a.Gates for the backward.
-template <int XMODE, bool FC, bool SAVE = false>
-__global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
+template <int XMODE, bool FC, bool SAVE = false, bool BF = false>
+__global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     const int lane = threadIdx.x & 63;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,8 +337,8 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
     const long winc = win < a.B ? win : a.B - 1;
     const int T = a.T, Qx = a.Qx;
     const int Qxp = (XMODE == 1) ? 1 : (XMODE == 3 ? 0 : a.Qxp);      // XMODE 0/2: a multiple of 3; 3: no input chunks
-    const int Qh = 4 * NCG;                        // recurrent chunks of a tile that can be non-zero
-    const int Qhe = (a.H + 7) >> 3;                // ... as needed
+    const int Qh = 4 * NCG;                        // fp32 chunks of h (per-step Linear tiles)
+    const int Qhe = BF ? (a.H + 15) >> 4 : (a.H + 7) >> 3;     // recurrent chunks as needed (bf16 build: 16 features each)
     const int S3 = (Qxp + Qhe + 2) / 3 * 3;        // chunks per step: whole ring turns
     const int NH = S3 - Qxp;                       // h chunks per step incl. zero-weight padding
     f32x4* __restrict__ hs = reinterpret_cast<f32x4*>(gsm);                // [NCG][4][64] float4: h_{t-1}, F-layout
@@ -374,15 +393,23 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
     f32x16 hown;                                   // this wave's tile of h
 #pragma unroll
     for (int r = 0; r < 16; ++r) hown[r] = 0.f;
+    // hs: h_{t-1} as MFMA B operands -- fp32 build [NCG][4][64] float4 (F-layout chunks), bf16 build [NCG][2][64]
+    // 16-byte containers of 8 bf16 (converted once by the publishing wave)
+    constexpr int HSC = BF ? 2 : 4;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < HSC; ++m) hs[(c * HSC + m) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto loadxq = [&](int t, int q) -> f32x4 {
+        if (!BF) return loadx_t(t, q);
+        if (XMODE == 1) return cvt8(loadx_t(t, q), f32x4{0.f, 0.f, 0.f, 0.f});
+        return cvt8(loadx_t(t, 2 * q), loadx_t(t, 2 * q + 1));
+    };
     f32x4 wr[3][3], xr[3];
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
     if (XMODE == 3) {
         loadxp(0);
     } else {
 #pragma unroll
-        for (int st = 0; st < 3; ++st) xr[st] = loadx_t(0, st);
+        for (int st = 0; st < 3; ++st) xr[st] = loadxq(0, st);
     }
     __syncthreads();
 
@@ -418,13 +445,13 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
         int qh = 0;                                // next h chunk to consume
         if (XMODE == 1) {
             // first ring turn: the single x chunk, then h chunks 0 and 1
-            mfma4x3(wr[0], xr[0], ar, az, anx);
+            mfma_x3<BF>(wr[0], xr[0], ar, az, anx);
             wload(wr[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 1; st < 3; ++st) {
                 const f32x4 hn = hread(qh + 1);
-                mfma4x3(wr[st], hv, ar, az, anh);
+                mfma_x3<BF>(wr[st], hv, ar, az, anh);
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
                 hv = hn; ++qh;
@@ -433,9 +460,9 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
             for (int q0 = 0; q0 < Qxp; q0 += 3) {
 #pragma unroll
                 for (int st = 0; st < 3; ++st) {
-                    mfma4x3(wr[st], xr[st], ar, az, anx);
+                    mfma_x3<BF>(wr[st], xr[st], ar, az, anx);
                     wload(wr[st]);
-                    xr[st] = loadx_t(t, q0 + st + 3);
+                    xr[st] = loadxq(t, q0 + st + 3);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
 #pragma unroll
             for (int st = 0; st < 3; ++st) {
                 const f32x4 hn = hread(qh + st + 1);
-                mfma4x3(wr[st], hv, ar, az, anh);
+                mfma_x3<BF>(wr[st], hv, ar, az, anh);
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
                 hv = hn;
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
                 loadxp(tn);
             } else {
 #pragma unroll
-                for (int st = 0; st < 3; ++st) xr[st] = loadx_t(tn, st);
+                for (int st = 0; st < 3; ++st) xr[st] = loadxq(tn, st);
             }
         }
         // ---- gates (reference GRULayer / RNNDecoder: torch.nn.GRU equations, r|z|n)
@@ -494,8 +521,13 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
             hvv[m][0] = hown[4 * m + 0]; hvv[m][1] = hown[4 * m + 1]; hvv[m][2] = hown[4 * m + 2]; hvv[m][3] = hown[4 * m + 3];
         }
         __syncthreads();                           // B: every wave is done reading h_{t-1}
+        if (BF) {
+            hs[(c * 2 + 0) * 64 + lane] = cvt8(hvv[0], hvv[1]);
+            hs[(c * 2 + 1) * 64 + lane] = cvt8(hvv[2], hvv[3]);
+        } else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = hvv[m];
+            for (int m = 0; m < 4; ++m) hs[(c * 4 + m) * 64 + lane] = hvv[m];
+        }
         if (a.Seq && win < a.B) {
             float* sp = a.Seq + (win * T + t) * a.ldseq + 32 * c + 4 * g;
 #pragma unroll
@@ -549,35 +581,35 @@ __global__ __launch_bounds__(512, 3) void k_gru_split(const GruArgs a) {
     }
 }
 
-template <int NCG, int XMODE, int MW>
+template <int NCG, int XMODE, int MW, bool BF>
 static int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + 32 * MW - 1) / (32 * MW));
     if (!fc && drop == 0)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 0, MW>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 0, MW, BF>), dim3(grid), dim3(64), 0, s, a);
     else if (!fc)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 1, MW>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 1, MW, BF>), dim3(grid), dim3(64), 0, s, a);
     else if (drop == 0)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 0, MW>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 0, MW, BF>), dim3(grid), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 1, MW>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 1, MW, BF>), dim3(grid), dim3(64), 0, s, a);
     LAUNCH_CHECK();
     return 0;
 }
 
-template <int NCG>
+template <int NCG, bool BF>
 static int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, bool two, hipStream_t s) {
-    // trailing recurrent chunks that are pure padding: skip one when H <= 8*(4*NCG - 1)
-    const int drop = (a.H <= 8 * (4 * NCG - 1)) ? 1 : 0;
+    // trailing recurrent chunks that are pure padding: skip one when H <= 8*(4*NCG - 1)  (bf16: 16*(2*NCG - 1))
+    const int drop = BF ? ((a.H <= 16 * (2 * NCG - 1)) ? 1 : 0) : ((a.H <= 8 * (4 * NCG - 1)) ? 1 : 0);
     if constexpr (NCG <= 5) {           // two 32-window groups per wave: 8 KB of LDS per group and tile, 4 waves per CU
         if (two) {
-            if (xmode == 0) return launch_gru_mode<NCG, 0, 2>(a, fc, drop, s);
-            if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 2>(a, fc, drop, s);
-            return launch_gru_mode<NCG, 2, 2>(a, fc, drop, s);
+            if (xmode == 0) return launch_gru_mode<NCG, 0, 2, BF>(a, fc, drop, s);
+            if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 2, BF>(a, fc, drop, s);
+            return launch_gru_mode<NCG, 2, 2, BF>(a, fc, drop, s);
         }
     }
-    if (xmode == 0) return launch_gru_mode<NCG, 0, 1>(a, fc, drop, s);
-    if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 1>(a, fc, drop, s);
-    return launch_gru_mode<NCG, 2, 1>(a, fc, drop, s);
+    if (xmode == 0) return launch_gru_mode<NCG, 0, 1, BF>(a, fc, drop, s);
+    if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 1, BF>(a, fc, drop, s);
+    return launch_gru_mode<NCG, 2, 1, BF>(a, fc, drop, s);
 }
 
 static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
@@ -588,7 +620,9 @@ static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipSt
     const bool save = a.Gates != nullptr;
 #define SPLIT_CASE(XM, F)                                                                                        \
     if (xm == XM && fc == F) {                                                                                   \
-        if (save) hipLaunchKernelGGL((k_gru_split<XM, F, true>), dim3(grid), dim3(64 * ncg), lds, s, a);         \
+        if (a.bf16 && !save) hipLaunchKernelGGL((k_gru_split<XM, F, false, true>), dim3(grid), dim3(64 * ncg), lds, s, a); \
+        else if (a.bf16) return -2;                                                                              \
+        else if (save) hipLaunchKernelGGL((k_gru_split<XM, F, true>), dim3(grid), dim3(64 * ncg), lds, s, a);    \
         else hipLaunchKernelGGL((k_gru_split<XM, F, false>), dim3(grid), dim3(64 * ncg), lds, s, a);             \
     }
     SPLIT_CASE(0, false) SPLIT_CASE(0, true) SPLIT_CASE(1, false) SPLIT_CASE(1, true) SPLIT_CASE(2, false) SPLIT_CASE(2, true)
@@ -631,15 +665,28 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     }
     // two groups per wave once that still gives every SIMD a wave
     const bool two = (a.B + 31) / 32 >= 8L * n_cu;
+    if (a.bf16) {
+        switch (ncg) {
+            case 1: return launch_gru_ncg<1, true>(a, xmode, fc, two, s);
+            case 2: return launch_gru_ncg<2, true>(a, xmode, fc, two, s);
+            case 3: return launch_gru_ncg<3, true>(a, xmode, fc, two, s);
+            case 4: return launch_gru_ncg<4, true>(a, xmode, fc, two, s);
+            case 5: return launch_gru_ncg<5, true>(a, xmode, fc, two, s);
+            case 6: return launch_gru_ncg<6, true>(a, xmode, fc, two, s);
+            case 7: return launch_gru_ncg<7, true>(a, xmode, fc, two, s);
+            case 8: return launch_gru_ncg<8, true>(a, xmode, fc, two, s);
+            default: return -2;
+        }
+    }
     switch (ncg) {
-        case 1: return launch_gru_ncg<1>(a, xmode, fc, two, s);
-        case 2: return launch_gru_ncg<2>(a, xmode, fc, two, s);
-        case 3: return launch_gru_ncg<3>(a, xmode, fc, two, s);
-        case 4: return launch_gru_ncg<4>(a, xmode, fc, two, s);
-        case 5: return launch_gru_ncg<5>(a, xmode, fc, two, s);
-        case 6: return launch_gru_ncg<6>(a, xmode, fc, two, s);
-        case 7: return launch_gru_ncg<7>(a, xmode, fc, two, s);
-        case 8: return launch_gru_ncg<8>(a, xmode, fc, two, s);
+        case 1: return launch_gru_ncg<1, false>(a, xmode, fc, two, s);
+        case 2: return launch_gru_ncg<2, false>(a, xmode, fc, two, s);
+        case 3: return launch_gru_ncg<3, false>(a, xmode, fc, two, s);
+        case 4: return launch_gru_ncg<4, false>(a, xmode, fc, two, s);
+        case 5: return launch_gru_ncg<5, false>(a, xmode, fc, two, s);
+        case 6: return launch_gru_ncg<6, false>(a, xmode, fc, two, s);
+        case 7: return launch_gru_ncg<7, false>(a, xmode, fc, two, s);
+        case 8: return launch_gru_ncg<8, false>(a, xmode, fc, two, s);
         default: return -2;
     }
 }

@@ -45,6 +45,9 @@ struct GruPlan {
     // rows (b*T, in_dim) -> (b*T, 3*Hp) [W_ir x + b_ir + b_hr | W_iz x + b_iz + b_hz | W_in x + b_in]
     bool has_xproj = false;
     LinPlan xproj;
+    // bf16 operand packs (16-feature chunks, element order of mtadgat_device.h): same streams, half the bytes per feature
+    int Qxp16 = 0;          // packed input chunks (1, or a multiple of 3)
+    size_t wx16_off = 0, wh16_off = 0;
 };
 
 // ---- backward (training) plans -------------------------------------------------------------------------
@@ -113,6 +116,7 @@ struct Model {
     size_t staging_floats = 0;
     hipEvent_t upload_ev = nullptr;  // recorded after the last upload
     bool have_weights = false;
+    int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
     // profiling
     bool profile = false;

@@ -209,6 +209,7 @@ struct GruArgs {
     float* Ylast;        // (B, out_dim): the per-step Linear at the last step only, or null
     int out_dim;
     float* Gates;        // training: (B*T, 4*Hp) r | z | n | q kept for the backward (k_gru_split only), or null
+    int bf16;            // 1: Wx / Wh are bf16 packs (16-feature chunks): bf16 MFMA operands, fp32 accumulation and state
 };
 
 // compute units of the current device (cached per device ordinal)

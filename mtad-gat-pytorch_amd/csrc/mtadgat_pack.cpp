@@ -37,6 +37,29 @@ void pack_gru_tiles(float* out, int NCG, int Q, Get get /*(gate,row,k)*/) {
             }
 }
 
+inline uint16_t f2bf(float f) {                      // round to nearest even, as v_cvt_pk_bf16_f32
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+// feature index of element e of lane-half g inside a 16-feature bf16 chunk (mtadgat_device.h)
+inline int bf_k(int g, int e) { return e < 4 ? 4 * g + e : 8 + 4 * g + (e - 4); }
+
+// bf16 GRU stream: [NCG][Q16][3 gates][64 lanes][8 bf16]
+template <class Get>
+void pack_gru_tiles_bf16(float* out, int NCG, int Q, Get get /*(gate,row,k)*/) {
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
+    for (int c = 0; c < NCG; ++c)
+        for (int q = 0; q < Q; ++q)
+            for (int st = 0; st < 3; ++st) {
+                uint16_t* o = o16 + (((size_t)c * Q + q) * 3 + st) * 512;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) o[lane * 8 + e] = f2bf(get(st, 32 * c + (lane & 31), 16 * q + bf_k(lane >> 5, e)));
+            }
+}
+
 }  // namespace
 
 std::string validate_and_plan(Model& m) {
@@ -127,6 +150,9 @@ std::string validate_and_plan(Model& m) {
         g.wx_off = take((size_t)g.NCG * g.Qxp * 3 * 256);
         g.wh_off = take((size_t)g.NCG * (4 * g.NCG + 2) * 3 * 256);   // 2 zero chunks per tile: k_gru_split's ring padding
         g.b_off = take((size_t)4 * g.Hp);
+        g.Qxp16 = round_up((g.Qx + 1) / 2, 3);
+        g.wx16_off = take((size_t)g.NCG * g.Qxp16 * 3 * 256);
+        g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
         if (l == 0) {
             g.has_xproj = true;
             g.xproj.in_dim = g.in_dim; g.xproj.out_dim = 3 * g.Hp;
@@ -176,6 +202,9 @@ std::string validate_and_plan(Model& m) {
         }
         g.wh_off = take((size_t)g.NCG * (4 * g.NCG + 2) * 3 * 256);   // 2 zero chunks per tile: k_gru_split's ring padding
         g.b_off = take((size_t)4 * g.Hp);
+        g.Qxp16 = g.xmode == 1 ? (g.Qx == 1 ? 1 : round_up((g.Qx + 1) / 2, 3)) : round_up((g.Qx + 1) / 2, 3);
+        g.wx16_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 3 * 256);
+        g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
     }
     {
         LinPlan& p = m.rec_fc;
@@ -468,6 +497,14 @@ static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_h
     pack_gru_tiles(out.data() + g.wh_off, g.NCG, 4 * g.NCG + 2, [&](int st, int r, int k) -> float {
         return (r < H && k < H) ? w_hh[((size_t)st * H + r) * H + k] : 0.f;
     });
+    if (g.xmode == 0) {
+        pack_gru_tiles_bf16(out.data() + g.wx16_off, g.NCG, g.Qxp16, [&](int st, int r, int k) -> float {
+            return (r < H && k < in) ? w_ih[((size_t)st * H + r) * in + k] : 0.f;
+        });
+    }
+    pack_gru_tiles_bf16(out.data() + g.wh16_off, g.NCG, 2 * g.NCG + 2, [&](int st, int r, int k) -> float {
+        return (r < H && k < H) ? w_hh[((size_t)st * H + r) * H + k] : 0.f;
+    });
     float* b = out.data() + g.b_off;
     for (int j = 0; j < g.Hp; ++j) {
         b[0 * g.Hp + j] = j < H ? b_ih[j] + b_hh[j] : 0.f;
@@ -536,17 +573,18 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
             for (int t = 0; t < T; ++t) {
                 const int lo = (int)(((long)t * Hin) / T);
                 m0[t] = lo;
-                pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qxp * 3 * 256, g.NCG, g.Qxp,
-                               [&](int st, int r, int k) -> float {
-                                   if (r >= H || k >= NMp) return 0.f;
-                                   // j with (t*Hin + j) / T == lo + k:  j in [(lo+k)*T - t*Hin, (lo+k+1)*T - t*Hin)
-                                   long j0 = (long)(lo + k) * T - (long)t * Hin, j1 = j0 + T;
-                                   j0 = j0 < 0 ? 0 : j0;
-                                   j1 = j1 > Hin ? Hin : j1;
-                                   if (j1 <= j0) return 0.f;
-                                   const double* pr = pre.data() + ((size_t)st * H + r) * (Hin + 1);
-                                   return (float)(pr[j1] - pr[j0]);
-                               });
+                auto fold = [&](int st, int r, int k) -> float {
+                    if (r >= H || k >= NMp) return 0.f;
+                    // j with (t*Hin + j) / T == lo + k:  j in [(lo+k)*T - t*Hin, (lo+k+1)*T - t*Hin)
+                    long j0 = (long)(lo + k) * T - (long)t * Hin, j1 = j0 + T;
+                    j0 = j0 < 0 ? 0 : j0;
+                    j1 = j1 > Hin ? Hin : j1;
+                    if (j1 <= j0) return 0.f;
+                    const double* pr = pre.data() + ((size_t)st * H + r) * (Hin + 1);
+                    return (float)(pr[j1] - pr[j0]);
+                };
+                pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qxp * 3 * 256, g.NCG, g.Qxp, fold);
+                pack_gru_tiles_bf16(out.data() + g.wx16_off + (size_t)t * g.NCG * g.Qxp16 * 3 * 256, g.NCG, g.Qxp16, fold);
             }
         }
         pack_gru_layer(g, p.rec_w_ih[l], p.rec_w_hh[l], p.rec_b_ih[l], p.rec_b_hh[l], out);

@@ -218,3 +218,36 @@ def test_errors_are_loud(gpu_device):
         model(case.x[:, :-1].to(gpu_device))
     with pytest.raises(RuntimeError, match="GPU-side data path"):
         model.forward_series(torch.rand(300, case.kwargs["n_features"]))
+
+
+@pytest.mark.parametrize("name", ["msl_wide", "smap_wide", "smd_1_1_wide", "msl_c1"])
+def test_bf16_operand_mode_within_2e_2(name, gpu_device):
+    """precision = "bf16": bf16 MFMA operands with fp32 accumulation, fp32 recurrent state, gates and softmax.
+    Gate: abs err <= 2e-2 against the fp32 reference on the shipped checkpoints -- the
+    all-bf16 reference model itself is off by 3e-2 .. 1.1e-1 -- while the default fp32 build stays <= 1e-5."""
+    from helpers import WideCase
+    case = WideCase(name)
+    model = case.build_model().to(gpu_device)
+    x = case.x.to(gpu_device)
+    with torch.no_grad():
+        p32, r32 = model(x)
+        model.precision = "bf16"
+        pb, rb = model(x)
+        pa, ra = model(x.to(torch.bfloat16))              # "auto" semantics: bf16 tensors in -> bf16 operands, bf16 out
+        model.precision = "auto"
+        pa2, ra2 = model(x.to(torch.bfloat16))
+        big = torch.cat([x] * 60)[:17000].contiguous()    # > 16 k windows: the register-resident GRU kernels
+        model.precision = "bf16"
+        pbig, rbig = model(big)
+        model.precision = "fp32"
+        p32b, _ = model(x)
+    assert torch.equal(p32b, p32)
+    dp = (pb.cpu() - case.preds).abs().max().item()
+    dr = (rb.cpu() - case.recons).abs().max().item()
+    print(f"{name}: bf16 operands |preds-ref|={dp:.2e} |recons-ref|={dr:.2e}")
+    assert dp <= 2e-2 and dr <= 2e-2
+    assert not torch.equal(pb, p32)                                     # it really is a different arithmetic
+    assert pa.dtype == torch.bfloat16 and torch.equal(pa, pa2)
+    n = x.shape[0]
+    assert (pbig[:n].cpu() - case.preds).abs().max().item() <= 2e-2 and (rbig[:n].cpu() - case.recons).abs().max().item() <= 2e-2
+    assert (pa.float().cpu() - case.preds).abs().max().item() <= 3e-2 and (ra.float().cpu() - case.recons).abs().max().item() <= 3e-2
