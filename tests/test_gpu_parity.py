@@ -155,10 +155,11 @@ def test_full_machine_batch_matches(name, gpu_device):
 
 
 def test_bf16_io_smap_batch_4096(gpu_device):
-    """BASELINE config 1 (SMAP, F=25, W=100, bf16 inference, batch 4096): bf16 tensors in and out, fp32
-    arithmetic inside.  The result is exactly the fp32 path applied to the bf16-rounded input, rounded once
-    on the way out; against the un-rounded input the input rounding alone moves the outputs by up to 2.1e-2
-    over these 4096 windows (SURVEY section 8d measured 5e-3 on 16 windows and set the bf16 gate at 2e-2)."""
+    """BASELINE config 2 (SMAP, F=25, W=100, bf16 inference, batch 4096): bf16 tensors in and out.
+    precision "auto" (default) answers bf16 tensors with the bf16-operand kernels; precision "fp32" keeps fp32
+    arithmetic and only rounds the I/O: then the result is exactly the fp32 path applied to the bf16-rounded input,
+    rounded once on the way out.  Against the un-rounded fp32 input the input rounding alone moves the outputs by up
+    to 2.1e-2 over these 4096 windows (SURVEY section 8d measured 5e-3 on 16 windows and set the bf16 gate at 2e-2)."""
     case = Case("smap")
     model = case.build_model().to(gpu_device)
     g = torch.Generator().manual_seed(5)
@@ -169,13 +170,16 @@ def test_bf16_io_smap_batch_4096(gpu_device):
     xb = x.to(torch.bfloat16)
     with torch.no_grad():
         p32, r32 = model(x)
-        p16, r16 = model(xb)
+        p16, r16 = model(xb)                      # bf16 operands
+        model.precision = "fp32"
+        pf, rf = model(xb)                        # bf16 I/O, fp32 arithmetic
         pr, rr = model(xb.float())
-    assert p16.dtype == torch.bfloat16 and r16.dtype == torch.bfloat16
-    assert torch.equal(p16, pr.to(torch.bfloat16)) and torch.equal(r16, rr.to(torch.bfloat16))
-    assert (p16.float() - p32).abs().max().item() <= 5e-2 and (r16.float() - r32).abs().max().item() <= 5e-2
-    assert (p16[:n].float().cpu() - case.preds).abs().max().item() <= 2e-2
-    assert (r16[:n].float().cpu() - case.recons).abs().max().item() <= 2e-2
+    assert p16.dtype == torch.bfloat16 and r16.dtype == torch.bfloat16 and pf.dtype == torch.bfloat16
+    assert torch.equal(pf, pr.to(torch.bfloat16)) and torch.equal(rf, rr.to(torch.bfloat16))
+    for p_, r_ in ((p16, r16), (pf, rf)):
+        assert (p_.float() - p32).abs().max().item() <= 5e-2 and (r_.float() - r32).abs().max().item() <= 5e-2
+        assert (p_[:n].float().cpu() - case.preds).abs().max().item() <= 2e-2
+        assert (r_[:n].float().cpu() - case.recons).abs().max().item() <= 2e-2
 
 
 def test_weight_update_is_seen(gpu_device):
