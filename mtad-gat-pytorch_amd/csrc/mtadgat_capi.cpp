@@ -82,7 +82,13 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
         a.X = src.x + c0 * (int64_t)m.W * m.F;
     }
     a.B = n; a.W = m.W; a.F = m.F; a.Fp = m.Fp; a.taps = m.taps; a.pad = m.pad;
+    a.Fq = m.Fp;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w_off);
+    // bf16 operand build: inference forward only (hcat / y outputs), when the LDS-staged kernel applies
+    if (m.precision == 1 && !xc && !xct && (size_t)(32 + m.taps - 1) * (m.Fp16 + 4) * sizeof(float) <= 20 * 1024) {
+        a.bf16 = 1; a.Fq = m.Fp16;
+        a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w16_off);
+    }
     a.bias = m.packed_dev + m.conv_b_off;
     a.NT = m.convNT;
     a.XC = xc; a.XCT = xct; a.Wpad = m.Wp; a.HCAT = hcat; a.Dp = m.Dp; a.Y = y;
@@ -133,6 +139,10 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
     a.pbias = m.packed_dev + g.b_off;
     a.NT_L = g.NT_L; a.Q = g.Q; a.PT = g.PT; a.P8 = g.P8;
+    if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
+        a.bf16 = 1; a.Q = g.Q16;
+        a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
+    }
     a.bias = m.packed_dev + g.bias_off;
     a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
     a.nwin = n;

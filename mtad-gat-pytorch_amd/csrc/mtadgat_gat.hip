@@ -115,7 +115,9 @@ __device__ __forceinline__ float row_sum(float v) {
 
 // RJ = lanes along the key axis (16, or 8 when that pads K less: 55 features -> 56 instead of 64 keys);
 // RI = 64 / RJ lanes along the row axis; a wave owns RI*IBL = 16 query rows either way.
-template <int IBL, int JPL, int RJ>
+// BF: bf16 operand build of the projection (16 features per chunk, fp32 accumulation); the pair grid, softmax and
+// aggregation are fp32 either way.
+template <int IBL, int JPL, int RJ, bool BF = false>
 __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
@@ -262,8 +264,17 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 #pragma unroll
                 for (int u = 0; u < QB; ++u)
                     if (qb + u < Q) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * (qb + u) + 4 * g);
-                        o = mfma4(w[u], xv, o);
+                        if (BF) {
+                            // the upper half of the last chunk may lie past the row's zero padding: its weights are
+                            // zero, the read is clamped into the row so that it stays finite
+                            const int c1 = 16 * (qb + u) + 8 + 4 * g;
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(vrow + 16 * (qb + u) + 4 * g);
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(vrow + (c1 + 3 < vld ? c1 : vld - 4));
+                            o = mfma_bf(w[u], cvt8(lo, hi), o);
+                        } else {
+                            const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * (qb + u) + 4 * g);
+                            o = mfma4(w[u], xv, o);
+                        }
                         // the chunk QB further on replaces this one as soon as it has been issued
                         if (qb + QB + u < Q) w[u] = wp[(long)(qb + QB + u) * 64];
                     }
@@ -450,12 +461,14 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
 
 #define GAT_CASE(I, J, RJ)                                                                      \
     if (IBL == I && JPL == J && rj == RJ) {                                                     \
+        const void* fn_ = a.bf16 ? reinterpret_cast<const void*>(&k_gat<I, J, RJ, true>)        \
+                                 : reinterpret_cast<const void*>(&k_gat<I, J, RJ, false>);      \
         if (lds_bytes > 64 * 1024) {                                                            \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat<I, J, RJ>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            hipError_t e_ = hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e_ != hipSuccess) return (int)e_;                                               \
         }                                                                                       \
-        hipLaunchKernelGGL((k_gat<I, J, RJ>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);      \
+        if (a.bf16) hipLaunchKernelGGL((k_gat<I, J, RJ, true>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);  \
+        else hipLaunchKernelGGL((k_gat<I, J, RJ, false>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);        \
         launched = true;                                                                        \
     }
 

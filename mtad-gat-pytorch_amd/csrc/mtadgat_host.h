@@ -30,6 +30,8 @@ struct GatPlan {
     bool fused = false;
     int f_nw = 0, f_IBL = 0, f_JPL = 0, f_RJ = 16, f_vld = 0, f_lr = 0;
     size_t f_lds_bytes = 0;
+    int Q16 = 0;            // bf16 build of the fused projection: 16-feature chunks incl. the bias row
+    size_t w16_off = 0;
 };
 
 struct LinPlan {
@@ -104,6 +106,8 @@ struct Model {
     // conv
     int convNT = 0;
     size_t conv_w_off = 0, conv_b_off = 0;
+    int Fp16 = 0;                    // bf16 conv build: channels padded to 16
+    size_t conv_w16_off = 0;
     GatPlan feat, temp;
     std::vector<GruPlan> gru, rec;
     std::vector<LinPlan> fc;

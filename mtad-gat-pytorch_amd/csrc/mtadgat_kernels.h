@@ -57,7 +57,9 @@ struct ConvArgs {
     int gather;
     long B;
     int W, F, Fp, taps, pad;
-    const f32x4* Wp;     // packed (F x taps*Fp), NT tiles, Q = taps*Fp/8
+    int Fq;              // channel count the MFMA chunks run over: Fp (fp32 build), F rounded up to 16 (bf16 build)
+    int bf16;            // 1: Wp is the bf16 pack (k_conv_lds only)
+    const f32x4* Wp;     // packed (F x taps*Fq), NT tiles, Q = taps*Fq/8 (bf16: /16)
     const float* bias;   // NT*32
     int NT;
     float* XC;           // (B*W, Fp)   or null
@@ -94,6 +96,7 @@ struct GatArgs {
     int vld;             // LDS row stride of the staged V rows
     int lr_floats;       // LDS floats reserved for L' / R' (and the aliased softmax rows) ahead of the V rows
     const f32x4* Wp;     // packed projection tiles [2*NT_L][Q][64]: query-side tiles then key-side tiles
+    int bf16;            // 1: Wp is the bf16 pack, Q counts 16-feature chunks
     const float* pbias;  // projection bias, 2*NT_L*32
     int NT_L, Q, PT, P8;
     const float* bias;   // (K, K) attention bias or null

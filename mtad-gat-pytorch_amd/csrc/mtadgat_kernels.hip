@@ -201,14 +201,16 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
 // the wave copies the input rows its 32 output rows touch into LDS once with coalesced loads and
 // takes every MFMA B operand from there -- the straight-from-global version above re-reads each
 // input row `taps` times with 4-byte gathers (PMC: 5-9x FETCH amplification, TA-bound).
-template <int NTB>
+// BF: bf16 operand build -- 16 input channels per chunk (K index = tap * Fq + channel, Fq = F rounded up to 16),
+// the staged fp32 rows are converted on the way into the matrix unit, fp32 accumulation.
+template <int NTB, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
     // blockDim.x / 64 independent waves per workgroup, each with its own 32 output rows and LDS slice:
     // one-wave workgroups are launched too slowly to keep the matrix pipes fed at ~50 us per wave
     extern __shared__ __attribute__((aligned(16))) float xs_all[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = blockDim.x >> 6;
-    float* __restrict__ xs = xs_all + wv * ((32 + a.taps - 1) * (a.Fp + 4));
+    float* __restrict__ xs = xs_all + wv * ((32 + a.taps - 1) * (a.Fq + 4));
     const int i = lane & 31, g = lane >> 5;
     const long R = a.B * a.W;
     const long r0 = ((long)blockIdx.x * nwv + wv) * 32;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
     const long rowc = row < R ? row : R - 1;
     const long win = rowc / a.W;
     const int t = (int)(rowc - win * a.W);
-    const int Fld = a.Fp + 4;
+    const int Fld = a.Fq + 4;
     const int nrow = 32 + a.taps - 1;
     // source row of LDS row rr: flat row r0 - pad + rr of the (B*W, F) batch; in gather mode the windows
     // are views of the device-resident series (no (b, W, F) copy exists) and (window, t) advance together
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
         }
         return a.X + srow * a.F;
     };
-    if (Fld <= 64) {
+    if (a.F <= 64 && Fld <= 128) {
         // one element per lane and row; every load is unconditional (clamped column, a valid row for rows
         // outside the batch) and all of them are issued before the first LDS store: one memory round trip
         // per wave instead of one per row (a guarded load compiles to a branch + s_waitcnt vmcnt(0))
@@ -257,11 +259,15 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
         }
 #pragma unroll
         for (int rr = 0; rr < MAXR; ++rr)
-            if (rr < nrow && lane < Fld) xs[rr * Fld + lane] = v[rr];
+            if (rr < nrow) {
+                if (lane < Fld) xs[rr * Fld + lane] = v[rr];
+                if (lane + 64 < Fld) xs[rr * Fld + lane + 64] = 0.f;       // channel padding beyond 64 columns (bf16 build)
+            }
         for (int rr = MAXR; rr < nrow; ++rr) {
             bool ok;
             const float* __restrict__ src = src_row(rr, ok);
             if (lane < Fld) xs[rr * Fld + lane] = (ok && lane < a.F) ? src[lane] : 0.f;
+            if (lane + 64 < Fld) xs[rr * Fld + lane + 64] = 0.f;
         }
     } else {
         for (int rr = 0; rr < nrow; ++rr) {
@@ -271,21 +277,30 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
         }
     }
     __syncthreads();
-    const int QF = a.Fp >> 3;
+    const int QF = BF ? a.Fq >> 4 : a.Fq >> 3;
     const int Q = a.taps * QF;
     const f32x4* __restrict__ Wp = a.Wp;
     if (a.HCAT && row < R && g == 0)      // zero the alignment padding of the h_cat row (the GRU reads it unguarded)
         for (int c = 3 * a.F; c < a.Dp; ++c) a.HCAT[row * a.Dp + c] = 0.f;
-    // B operand of chunk (tap, cb): input row i + tap of the staged block, columns 8 cb + 4 g .. +3; rows
-    // of the neighbouring window count as zero padding (per window, modules.py:14,20)
+    // B operand of chunk (tap, cb): input row i + tap of the staged block, columns 8 cb + 4 g .. +3 (bf16 build: the
+    // lane's eight columns of the 16-channel chunk, converted); rows of the neighbouring window count as zero
+    // padding (per window, modules.py:14,20)
     const float* __restrict__ xrow = static_cast<const float*>(__builtin_assume_aligned(xs, 16)) + i * Fld + 4 * g;
     auto loadx = [&](int tap, int cb) -> f32x4 {
         const int tt = t + tap - a.pad;
-        f32x4 v = *reinterpret_cast<const f32x4*>(xrow + tap * Fld + 8 * cb);
         const bool ok = tt >= 0 && tt < a.W;
+        if (BF) {
+            f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + tap * Fld + 16 * cb);
+            f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + tap * Fld + 16 * cb + 8);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = ok ? lo[s4] : 0.f; hi[s4] = ok ? hi[s4] : 0.f; }
+            return cvt8(lo, hi);
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(xrow + tap * Fld + 8 * cb);
         v[0] = ok ? v[0] : 0.f; v[1] = ok ? v[1] : 0.f; v[2] = ok ? v[2] : 0.f; v[3] = ok ? v[3] : 0.f;
         return v;
     };
+    auto mm = [&](const f32x4 w, const f32x4 x, f32x16 acc) -> f32x16 { return BF ? mfma_bf(w, x, acc) : mfma4(w, x, acc); };
     for (int n0 = 0; n0 < a.NT; n0 += NTB) {
         f32x16 acc[NTB];
 #pragma unroll
@@ -312,7 +327,7 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
             if (++cb == QF) { cb = 0; ++tap; }
             __builtin_amdgcn_sched_barrier(0);      // keep the next chunk's weight loads ahead of these MFMAs
 #pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w0[nb], xv0, acc[nb]);
+            for (int nb = 0; nb < NTB; ++nb) acc[nb] = mm(w0[nb], xv0, acc[nb]);
             __builtin_amdgcn_sched_barrier(0);
             const int q2 = q + 2 < Q ? q + 2 : Q - 1;
 #pragma unroll
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
                 if (++cb == QF) { cb = 0; ++tap; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w1[nb], xv1, acc[nb]);
+                for (int nb = 0; nb < NTB; ++nb) acc[nb] = mm(w1[nb], xv1, acc[nb]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -402,14 +417,20 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     const long R = a.B * a.W;
     if (R <= 0) return 0;
     const unsigned grid = (unsigned)((R + 31) / 32);
-    const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fp + 4) * sizeof(float);
+    const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fq + 4) * sizeof(float);
+    if (a.bf16 && lds > 20 * 1024) return -2;
     if (lds <= 20 * 1024) {       // >= 8 waves per CU keep their tile in LDS
         const unsigned wpb = (grid >= 4096 && 4 * lds <= 64 * 1024) ? 4 : 1;     // waves per workgroup
         const unsigned g4 = (grid + wpb - 1) / wpb;
-        if (a.NT >= 2)
-            hipLaunchKernelGGL(k_conv_lds<2>, dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
+        if (a.bf16) {
+            if (a.NT >= 2)
+                hipLaunchKernelGGL((k_conv_lds<2, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
+            else
+                hipLaunchKernelGGL((k_conv_lds<1, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
+        } else if (a.NT >= 2)
+            hipLaunchKernelGGL((k_conv_lds<2, false>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
         else
-            hipLaunchKernelGGL(k_conv_lds<1>, dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
+            hipLaunchKernelGGL((k_conv_lds<1, false>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
     } else if (a.NT >= 2)
         hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(64), 0, s, a);
     else

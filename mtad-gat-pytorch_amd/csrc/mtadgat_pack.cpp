@@ -47,6 +47,18 @@ inline uint16_t f2bf(float f) {                      // round to nearest even, a
 // feature index of element e of lane-half g inside a 16-feature bf16 chunk (mtadgat_device.h)
 inline int bf_k(int g, int e) { return e < 4 ? 4 * g + e : 8 + 4 * g + (e - 4); }
 
+// bf16 tile format: [NT][Q16][64 lanes][8 bf16]; lane (j, g) element e holds M[32n + j][16q + bf_k(g, e)]
+template <class Get>
+void pack_tiles_bf16(float* out, int NT, int Q, Get get) {
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(out);
+    for (int n = 0; n < NT; ++n)
+        for (int q = 0; q < Q; ++q) {
+            uint16_t* o = o16 + ((size_t)n * Q + q) * 512;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) o[lane * 8 + e] = f2bf(get(32 * n + (lane & 31), 16 * q + bf_k(lane >> 5, e)));
+        }
+}
+
 // bf16 GRU stream: [NCG][Q16][3 gates][64 lanes][8 bf16]
 template <class Get>
 void pack_gru_tiles_bf16(float* out, int NCG, int Q, Get get /*(gate,row,k)*/) {
@@ -95,6 +107,8 @@ std::string validate_and_plan(Model& m) {
         const int Q = m.taps * m.Fp / 8;
         m.conv_w_off = take((size_t)m.convNT * Q * 256);
         m.conv_b_off = take((size_t)m.convNT * 32);
+        m.Fp16 = round_up(m.F, 16);
+        m.conv_w16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 256);
     }
     // GAT layers
     auto plan_gat = [&](GatPlan& g, int K, int D, int E) {
@@ -133,6 +147,8 @@ std::string validate_and_plan(Model& m) {
         g.w_off = take((size_t)g.NT * g.Q * 256);
         g.b_off = take((size_t)g.NT * 32);
         g.bias_off = take((size_t)K * K);
+        g.Q16 = g.fused ? (D + 1 + 15) / 16 : 0;
+        g.w16_off = take((size_t)g.NT * g.Q16 * 256);
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
@@ -482,6 +498,12 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
         if (k < D) return (float)rows[(size_t)n * D + k];
         return (g.fused && k == D) ? (float)bvec[n] : 0.f;       // fused kernel: bias = weight row D
     });
+    if (g.fused)
+        pack_tiles_bf16(out.data() + g.w16_off, g.NT, g.Q16, [&](int n, int k) -> float {
+            if (n >= NC) return 0.f;
+            if (k < D) return (float)rows[(size_t)n * D + k];
+            return k == D ? (float)bvec[n] : 0.f;
+        });
     for (int n = 0; n < NC; ++n) out[g.b_off + n] = (float)bvec[n];
     std::memcpy(out.data() + g.bias_off, bias, sizeof(float) * (size_t)g.K * g.K);
 }
@@ -536,6 +558,11 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
             return (n < F && ch < F && tap < taps) ? p.conv_weight[((size_t)n * F + ch) * taps + tap] : 0.f;
         });
         for (int n = 0; n < F; ++n) out[m.conv_b_off + n] = p.conv_bias[n];
+        const int Fp16 = m.Fp16;
+        pack_tiles_bf16(out.data() + m.conv_w16_off, m.convNT, taps * Fp16 / 16, [&](int n, int k) -> float {
+            const int tap = k / Fp16, ch = k % Fp16;
+            return (n < F && ch < F && tap < taps) ? p.conv_weight[((size_t)n * F + ch) * taps + tap] : 0.f;
+        });
     }
     pack_gat(m, m.feat, p.feat_lin_weight, p.feat_lin_bias, p.feat_a, p.feat_bias, out);
     pack_gat(m, m.temp, p.temp_lin_weight, p.temp_lin_bias, p.temp_a, p.temp_bias, out);
