@@ -209,6 +209,20 @@ int mtadgat_dropout_masks(mtadgat_handle h, int64_t batch, int64_t window0, floa
                           float* mask_feat_dev, float* mask_temp_dev, float* mask_fc_dev, void* stream);
 int mtadgat_train_layout(mtadgat_handle h, int64_t batch, int64_t* offsets_out, int max_n);
 
+/* ---- anomaly-score post-processing on the device (callers' data path) ------
+ * The arithmetic of Predictor.get_score (prediction.py:72-91) and of the threshold evaluation
+ * (eval_methods.py: find_epsilon :189-236, adjust_predicts :6-55 + calc_point2point :58-72 for one threshold --
+ * epsilon_eval -- or a whole sweep -- bf_search :117-158).  Device arrays in, small host tables out (these calls
+ * synchronise the stream); the scalar bookkeeping on top is mtad-gat-pytorch_amd/evaluation.py.  Status 0 / -1
+ * (bad argument) / -3 (HIP) / -5 (more anomaly segments than max_seg). */
+int mtadgat_eval_scores(const float* preds_dev, const float* recons_dev, const float* actual_dev, int64_t n, int d,
+                        int64_t ld_actual, const int* dims_dev, float gamma, float* per_dim_dev, float* global_dev, void* stream);
+int mtadgat_eval_moments(const float* e_dev, int64_t n, double* scratch_dev, double* out_host, void* stream);
+int mtadgat_eval_epsilon_table(const float* e_dev, int64_t n, const double* eps_host, int nz, int halo, double* scratch_dev,
+                               double* out_host, void* stream);
+int mtadgat_eval_point_adjust(const float* score_dev, const unsigned char* label_dev, int64_t n, const double* thr_host,
+                              int n_thr, int compare_f32, int max_seg, double* scratch_dev, double* out_host, void* stream);
+
 /* Per-kernel launch timing for bench.py's roofline leg: when enabled, forward()
  * brackets each kernel family with hipEvents on `stream`; mtadgat_profile_read
  * synchronises those events and returns accumulated milliseconds + launch counts

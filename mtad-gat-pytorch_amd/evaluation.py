@@ -1,0 +1,173 @@
+"""Anomaly-score post-processing on the GPU, under the reference's own function names.
+
+Mirrors `eval_methods.py` (find_epsilon :189-236, adjust_predicts :6-55, calc_point2point :58-72,
+epsilon_eval :164-186, bf_search :117-158) and the score arithmetic of `Predictor.get_score`
+(prediction.py:72-91) on device-resident arrays: the O(N) passes -- moments, the 19-z epsilon table with its
++-49-sample dilation, point-adjusted confusion counts for one threshold or a whole sweep -- are HIP kernels
+(csrc/mtadgat_eval.hip behind the `mtadgat_eval_*` C entry points); the scalar bookkeeping on top (which z /
+threshold wins, precision / recall / F1 from the counts) is done here in float64 exactly as the reference writes
+it.  Results equal the reference's dictionaries (tests/test_gpu_eval.py: the shipped MSL run's summary.txt).
+
+POT (`pot_eval`: SPOT's Grimshaw fit, spot.py) is not ported: it is a sequential scalar algorithm over the
+peaks only; the reference's implementation runs unchanged on `scores.cpu().numpy()`.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+import _native
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+def _lib():
+    lib = _native.load_library()
+    if not getattr(lib, "_eval_bound", False):
+        vp, i64, f32, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int
+        lib.mtadgat_eval_scores.argtypes = [vp, vp, vp, i64, ci, i64, vp, f32, vp, vp, vp]
+        lib.mtadgat_eval_moments.argtypes = [vp, i64, vp, _c_double_p, vp]
+        lib.mtadgat_eval_epsilon_table.argtypes = [vp, i64, _c_double_p, ci, ci, vp, _c_double_p, vp]
+        lib.mtadgat_eval_point_adjust.argtypes = [vp, vp, i64, _c_double_p, ci, ci, ci, vp, _c_double_p, vp]
+        lib._eval_bound = True
+    return lib
+
+
+def _dev1d(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise RuntimeError(f"{name} must be a tensor on the GPU (the evaluation kernels are HIP only)")
+    t = t.detach().reshape(-1)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"mtadgat {what} failed (status {rc})")
+
+
+def anomaly_scores(preds, recons, values, window_size, target_dims=None, gamma=1.0):
+    """a_i[d] = |y_hat_i[d] - x_{i+W}[d]| + gamma |recon_i[d] - x_{i+W}[d]| and its mean over d
+    (prediction.py:72-91, before the optional per-dimension scaling).  Returns (global (n,), per_dim (n, d))."""
+    lib = _lib()
+    n, d = preds.shape
+    actual = values[window_size:window_size + n].float().contiguous()
+    dims = None
+    if target_dims is not None:
+        dims = torch.tensor([target_dims] if isinstance(target_dims, int) else list(target_dims), dtype=torch.int32, device=preds.device)
+        if dims.numel() != d:
+            raise RuntimeError("target_dims do not match the model's out_dim")
+    elif actual.shape[1] != d:
+        raise RuntimeError("out_dim differs from the number of features: pass target_dims")
+    p, r = preds.float().contiguous(), recons.float().contiguous()
+    per_dim = torch.empty((n, d), dtype=torch.float32, device=preds.device)
+    glob = torch.empty((n,), dtype=torch.float32, device=preds.device)
+    with torch.cuda.device(preds.device):
+        _check(lib.mtadgat_eval_scores(p.data_ptr(), r.data_ptr(), actual.data_ptr(), n, d, actual.shape[1],
+                                       dims.data_ptr() if dims is not None else None, float(gamma), per_dim.data_ptr(),
+                                       glob.data_ptr(), _stream(preds)), "eval_scores")
+    return glob, per_dim
+
+
+def find_epsilon(errors, reg_level=1):
+    """Threshold of Hundman et al. as the reference computes it (eval_methods.py:189-236)."""
+    lib = _lib()
+    e = _dev1d(errors, torch.float32, "errors")
+    n = e.numel()
+    scratch = torch.empty(64 + 4 * 64, dtype=torch.float64, device=e.device)
+    mom = (ctypes.c_double * 2)()
+    with torch.cuda.device(e.device):
+        _check(lib.mtadgat_eval_moments(e.data_ptr(), n, scratch.data_ptr(), mom, _stream(e)), "eval_moments")
+    mean = mom[0] / n
+    sd = math.sqrt(max(mom[1] / n - mean * mean, 0.0))
+    zs = np.arange(2.5, 12, 0.5)
+    eps = mean + sd * zs
+    tab = (ctypes.c_double * (4 * len(zs)))()
+    with torch.cuda.device(e.device):
+        _check(lib.mtadgat_eval_epsilon_table(e.data_ptr(), n, eps.ctypes.data_as(_c_double_p), len(zs), 49, scratch.data_ptr(), tab,
+                                              _stream(e)), "eval_epsilon_table")
+    best, max_score = None, -10000000
+    for k in range(len(zs)):
+        ps, ps2, pc, dil = tab[4 * k], tab[4 * k + 1], tab[4 * k + 2], tab[4 * k + 3]
+        if dil > 0:
+            if pc > 0:
+                pm = ps / pc
+                psd = math.sqrt(max(ps2 / pc - pm * pm, 0.0))
+            else:
+                pm = psd = float("nan")
+            mean_perc_decrease = (mean - pm) / mean
+            sd_perc_decrease = (sd - psd) / sd
+            denom = 1 if reg_level == 0 else (dil if reg_level == 1 else dil ** 2)
+            score = (mean_perc_decrease + sd_perc_decrease) / denom
+            if score >= max_score and dil < n * 0.5:
+                max_score, best = score, float(eps[k])
+    if best is None:
+        best = float(e.max().item())
+    return best
+
+
+def point_adjust_counts(score, label, thresholds, compare_f32=False, max_segments=65536):
+    """adjust_predicts + calc_point2point for every threshold in one launch.
+    Returns an (n_thr, 6) float64 array: TP, TN, FP, FN, latency sum, detected segments."""
+    lib = _lib()
+    s = _dev1d(score, torch.float32, "score")
+    if label.dtype == torch.bool:
+        lab = _dev1d(label, torch.uint8, "label")
+    else:
+        lab = _dev1d((label > 0.1), torch.uint8, "label")
+    if lab.numel() != s.numel():
+        raise ValueError("score and label must have the same length")
+    thr = np.ascontiguousarray(np.asarray(thresholds, dtype=np.float64).reshape(-1))
+    nt = thr.size
+    scratch = torch.empty(7 * nt + max_segments + 2, dtype=torch.float64, device=s.device)
+    out = np.zeros((nt, 6), dtype=np.float64)
+    with torch.cuda.device(s.device):
+        _check(lib.mtadgat_eval_point_adjust(s.data_ptr(), lab.data_ptr(), s.numel(), thr.ctypes.data_as(_c_double_p), nt,
+                                             1 if compare_f32 else 0, max_segments, scratch.data_ptr(),
+                                             out.ctypes.data_as(_c_double_p), _stream(s)), "eval_point_adjust")
+    return out
+
+
+def _point2point(tp, tn, fp, fn):
+    precision = tp / (tp + fp + 0.00001)
+    recall = tp / (tp + fn + 0.00001)
+    f1 = 2 * precision * recall / (precision + recall + 0.00001)
+    return f1, precision, recall, tp, tn, fp, fn
+
+
+def epsilon_eval(train_scores, test_scores, test_labels, reg_level=1):
+    """eval_methods.py:164-186."""
+    best_epsilon = find_epsilon(train_scores, reg_level)
+    if test_labels is None:
+        return {"threshold": best_epsilon, "reg_level": reg_level}
+    c = point_adjust_counts(test_scores, test_labels, [best_epsilon])[0]
+    p_t = _point2point(c[0], c[1], c[2], c[3])
+    return {"f1": p_t[0], "precision": p_t[1], "recall": p_t[2], "TP": p_t[3], "TN": p_t[4], "FP": p_t[5], "FN": p_t[6],
+            "threshold": best_epsilon, "latency": c[4] / (c[5] + 1e-4), "reg_level": reg_level}
+
+
+def bf_search(score, label, start, end=None, step_num=1, display_freq=1, verbose=False):
+    """Best-F1 threshold sweep (eval_methods.py:117-158): all thresholds evaluated by one kernel launch."""
+    if step_num is None or end is None:
+        end = start
+        step_num = 1
+    search_step, search_range, search_lower_bound = step_num, end - start, start
+    threshold = search_lower_bound
+    thrs = []
+    for _ in range(search_step):                       # the reference accumulates the threshold in a Python float
+        threshold += search_range / float(search_step)
+        thrs.append(threshold)
+    counts = point_adjust_counts(score, label, thrs, compare_f32=True)      # float32 array > Python float: a float32 comparison
+    m, m_t, m_l = (-1.0, -1.0, -1.0), 0.0, 0
+    for thr, c in zip(thrs, counts):
+        target = _point2point(c[0], c[1], c[2], c[3])
+        if target[0] > m[0]:
+            m_t, m, m_l = thr, target, c[4] / (c[5] + 1e-4)
+    return {"f1": m[0], "precision": m[1], "recall": m[2], "TP": m[3], "TN": m[4], "FP": m[5], "FN": m[6], "threshold": m_t,
+            "latency": m_l}
