@@ -105,8 +105,11 @@ def find_epsilon(errors, reg_level=1):
             sd_perc_decrease = (sd - psd) / sd
             denom = 1 if reg_level == 0 else (dil if reg_level == 1 else dil ** 2)
             score = (mean_perc_decrease + sd_perc_decrease) / denom
-            if score >= max_score and dil < n * 0.5:
-                max_score, best = score, float(eps[k])
+            # `>=`: among equal scores the reference keeps the last z.  Two z with the same pruned set have the same
+            # score exactly in the reference; here their float64 sums come from atomics in varying order, so
+            # "equal" is taken with a 1e-9 relative margin.
+            if score >= max_score - 1e-9 * abs(max_score) and dil < n * 0.5:
+                max_score, best = max(score, max_score), float(eps[k])
     if best is None:
         best = float(e.max().item())
     return best
