@@ -112,6 +112,13 @@ int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nro
 int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, const float* v, int ldv, int64_t n, float* out,
                long so_w, long so_i, long so_d, hipStream_t s) {
     Scope sc(m, S_ATTEND, s);
+    if (g.K <= 512 && g.D <= 512 && !std::getenv("MTADGAT_OLD_ATTEND")) {
+        // LDS-tiled pair grid of the fused kernel over the HBM-resident projections (BASELINE config 4 shapes)
+        K_TRY(launch_gat_wide(lc, rt, g.ldl, g.rt_rows, g.Kp, g.PT, g.P8, m.packed_dev + g.bias_off, v, ldv, g.D, g.K, out, so_w,
+                              so_i, so_d, n, m.cfg.use_gatv2 ? 0 : 1, m.cfg.alpha, s),
+              "wide gat attention");
+        return 0;
+    }
     AttendArgs a{};
     a.LC = lc; a.RT = rt; a.ldl = g.ldl; a.rt_rows = g.rt_rows; a.Kp = g.Kp; a.PT = g.PT; a.P8 = g.P8;
     a.bias = m.packed_dev + g.bias_off;
@@ -267,13 +274,33 @@ int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, fl
         long ld = ldh;
         int kx = m.cfg.gru_hid_dim;
         // decoder layer 0 reads hend[m0(t) .. m0(t) + 8*Qx), clamped to the (zero padded) row inside the kernel
+        // recon_model.fc (modules.py:282): with few outputs (target dims of MSL / SMAP) it rides inside the recurrence;
+        // otherwise the last layer's states go to memory and the Linear is one throughput GEMM over the b*W rows --
+        // inside the step loop it would sit on the latency chain with 4 * Qh matrix instructions per 32 outputs
+        const bool hoist_fc = m.cfg.out_dim > 4 && recons != nullptr;
         for (int l = 0; l < L; ++l) {
             const bool last = (l == L - 1);
-            float* seq = last ? nullptr : ws + ((l & 1) ? o.rseq1 : o.rseq0);
-            int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr,
-                                   last ? recons : nullptr, last ? recons_last : nullptr, s);
+            const bool fc_in = last && !hoist_fc;
+            float* seq = (last && !hoist_fc) ? nullptr : ws + ((l & 1) ? o.rseq1 : o.rseq0);
+            int rc = run_gru_layer(m, S_RECON, m.rec[l], x, ld, kx, n, nullptr, 0, seq, fc_in ? &m.rec_fc : nullptr,
+                                   fc_in ? recons : nullptr, fc_in ? recons_last : nullptr, s);
             if (rc) return rc;
             x = seq; ld = m.rec[l].Hp; kx = m.rec[l].H;
+        }
+        if (hoist_fc) {
+            Scope sc(m, S_RECON, s);
+            const LinPlan& p = m.rec_fc;
+            RowGemmArgs a{};
+            a.X = x; a.ldx = ld; a.Kvalid = kx; a.Q = p.Q;
+            a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
+            a.bias = m.packed_dev + p.b_off;
+            a.Y = recons; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
+            a.vec_store = (p.out_dim % 4 == 0 && aligned16(recons)) ? 1 : 0;
+            a.R = n * (int64_t)m.W; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
+            K_TRY(launch_rowgemm(a, s), "reconstruction Linear");
+            if (recons_last)
+                K_TRY(launch_copy2d(recons + (int64_t)(m.W - 1) * p.out_dim, (long)m.W * p.out_dim, recons_last, p.out_dim, n, p.out_dim, s),
+                      "last reconstruction step");
         }
     }
     return 0;
@@ -316,10 +343,13 @@ int mtadgat_create(const mtadgat_config* cfg, mtadgat_handle* out) {
         plan_workspace(h->m, 1024, o);
         const double per_window = (double)o.total * sizeof(float) / 1024.0;
         size_t free_b = 0, total_b = 0;
-        const double budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) ? (double)total_b / 4 : 16.0 * 1024 * 1024 * 1024;
+        double budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) ? (double)total_b / 4 : 16.0 * 1024 * 1024 * 1024;
+        const bool unfused = !(h->m.temp.fused && h->m.feat.fused);
+        if (unfused) budget = std::min(budget, 6.0 * 1024 * 1024 * 1024);   // projections through HBM: a few hundred windows fill the machine
         int64_t c = (int64_t)(budget / per_window);
-        c = c / 2048 * 2048;
-        h->m.chunk = c < 2048 ? 2048 : (c > 65536 ? 65536 : c);
+        const int64_t gran = unfused ? 128 : 2048;
+        c = c / gran * gran;
+        h->m.chunk = c < gran ? gran : (c > 65536 ? 65536 : c);
     }
     *out = h;
     return 0;

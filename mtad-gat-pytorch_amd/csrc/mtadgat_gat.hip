@@ -459,6 +459,270 @@ __global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// gat (wide): graph attention for node counts beyond the per-window fused kernel (128 < K <= 512, BASELINE
+// config 4: 512 features / 256 time steps).  The projected L', R' come from k_rowgemm through HBM (LC row-major
+// per query node, RT key-node-minor -- what k_attend consumed); everything after that is the fused kernel's
+// machinery: a workgroup owns a block of up to 128 query rows of one window, stages the L' rows of its block and
+// the R' columns of ALL keys of one 32-column part in LDS, runs the same 2-D register-blocked pair grid (4 x 8
+// pairs per lane and 128-key pass, KP passes -> all K scores of a row stay in registers), then softmax and the
+// aggregation att V on the 16x16x4 MFMA with V staged through LDS 32 keys at a time for all waves.
+//   LDS: Ls [128][34] | Rs [KP*128][34]  (aliased afterwards by: att [NW][16][68] | Vs2 [32][D + 4])
+// ---------------------------------------------------------------------------
+struct GatWideArgs {
+    const float* LC;     // (B*K, ldl): [L'(PT) | c | pad]
+    const float* RT;     // (B, rt_rows, Kp): rows [0, PT) = R' (key minor), row PT = d
+    int ldl, rt_rows, Kp, PT, P8;
+    const float* bias;   // (K, K) or null
+    const float* V;      // (B*K, ldv) node rows
+    int ldv, D, K;
+    float* out;          // out[win*so_w + i*so_i + d*so_d]
+    long so_w, so_i, so_d;
+    long nwin;
+    int nblk;            // row blocks per window
+    int v1;
+    float alpha;
+};
+
+// KP = 4 (385..512 keys) keeps 128 score registers per lane: those workgroups have 4 waves (one per SIMD, 512 VGPRs)
+template <int KP, int DTMAX>
+__global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const GatWideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int IBL = 4, JPL = 8, RJ = 16, RI = 4, IBW = 16;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = nthr >> 6;
+    // XCD-aware map: the row blocks of one window run on the same XCD (dispatch ids b, b + 8, ...), so its R' / V
+    // are fetched from HBM once and served to the other row blocks from that XCD's L2
+    const long blk = blockIdx.x;
+    const long grp = blk / (8 * a.nblk);
+    const int within = (int)(blk - grp * (8 * a.nblk));
+    const long win = grp * 8 + (within & 7);
+    const int rb = within >> 3;
+    if (win >= a.nwin) return;
+    const int K = a.K, D = a.D, PT = a.PT;
+    const int i0b = rb * (NW * IBW);                       // first query row of this workgroup
+    const int KJ = KP * 128;                               // key slots
+    float* __restrict__ Ls = smem;                         // [NW*16][34]
+    float* __restrict__ Rs = Ls + NW * IBW * GAT_LLD;      // [KJ][34]
+    const int lj = lane % RJ, li = lane / RJ;
+    const float* __restrict__ LCw = a.LC + (win * K) * (long)a.ldl;
+    const float* __restrict__ RTw = a.RT + win * (long)a.rt_rows * a.Kp;
+
+    const int i0 = i0b + wave * IBW;
+    lds_cptr lp[IBL];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        lp[ii] = (lds_cptr)(Ls + (wave * IBW + li + RI * ii) * GAT_LLD);
+        asm volatile("" : "+v"(lp[ii]));
+    }
+    const lds_cptr rp0 = (lds_cptr)(Rs + lj * GAT_LLD);
+    float acc[KP][IBL][JPL];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) acc[kp][ii][jj] = 0.f;
+
+    const int ntile = PT >> 3, ptile = a.P8 >> 3;
+    const int nparts = (ntile + 3) >> 2;
+    for (int part = 0; part < nparts; ++part) {
+        // ---- stage this part: L' rows of the block (row-major source), R' columns of all keys (key-minor source)
+        const int c0 = 32 * part;
+        for (int u = tid; u < NW * IBW * 32; u += nthr) {
+            const int r = u >> 5, c = u & 31;
+            const int row = i0b + r;
+            const float v = (row < K && c0 + c < PT) ? LCw[(long)row * a.ldl + c0 + c] : 0.f;
+            Ls[r * GAT_LLD + c] = v;
+        }
+        for (int u = tid; u < KJ * 32; u += nthr) {
+            const int c = u / KJ, j = u - c * KJ;              // key fastest: coalesced reads of the key-minor rows
+            const float v = (j < K && c0 + c < PT) ? RTw[(long)(c0 + c) * a.Kp + j] : 0.f;
+            Rs[j * GAT_LLD + c] = v;
+        }
+        __syncthreads();
+        int ntl = ntile - 4 * part;
+        ntl = ntl > 4 ? 4 : ntl;
+        int npos = ptile - 4 * part;
+        npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            if (kp * 128 < K) {
+                f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
+                lds_cptr lq[IBL];
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
+                lds_cptr rq = rp0 + kp * 128 * GAT_LLD;
+                gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
+                int kt = 0;
+#pragma unroll 1
+                for (; kt < npos; ++kt) {
+                    gat_tile<IBL, JPL, RJ, false>(acc[kp], lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                    for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                    rq += 8;
+                }
+#pragma unroll 1
+                for (; kt < ntl; ++kt) {
+                    gat_tile<IBL, JPL, RJ, true>(acc[kp], lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                    for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                    rq += 8;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- scores -> softmax over all K keys of a row (16 lanes x KP*8 registers)
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        const int irow = i0 + li + RI * ii;
+        const int irc = irow < K ? irow : K - 1;
+        const float cv = LCw[(long)irc * a.ldl + PT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = kp * 128 + lj + RJ * jj;
+                const int jc = j < K ? j : K - 1;
+                float v = acc[kp][ii][jj] + cv + RTw[(long)PT * a.Kp + jc];
+                if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
+                if (a.bias) v += a.bias[(long)irc * K + jc];
+                v = j < K ? v : -INFINITY;
+                acc[kp][ii][jj] = v;
+                m = fmaxf(m, v);
+            }
+        m = row_max<RJ>(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = kp * 128 + lj + RJ * jj;
+                const float e = j < K ? soft_exp(acc[kp][ii][jj] - m) : 0.f;
+                acc[kp][ii][jj] = e;
+                sum += e;
+            }
+        sum = row_sum<RJ>(sum);
+        const float inv = soft_rcp(sum);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) acc[kp][ii][jj] = irow < K ? acc[kp][ii][jj] * inv : 0.f;
+    }
+    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j): out^T = V^T att^T on v_mfma_f32_16x16x4_f32 (as k_gat); the
+    // softmax rows go through this wave's LDS slice 64 keys at a time, V through a shared LDS tile 32 keys at a time
+    float* __restrict__ att = smem + wave * (IBW * GAT_APITCH);
+    const int vld2 = ((D + 15) & ~15) + 4;
+    float* __restrict__ Vs2 = smem + NW * IBW * GAT_APITCH;      // [32][vld2]
+    const int nr = lane & 15, kb = lane >> 4;
+    const int DT = (D + 15) >> 4;
+    f32x4 o[DTMAX];
+#pragma unroll
+    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ Vw = a.V + (win * K) * (long)a.ldv;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k0 = kp * 128 + half * 64;                 // 64 keys of att at a time
+            if (k0 < K) {
+                __syncthreads();                                 // everybody is done with the previous att / V tiles
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = acc[kp][ii][4 * half + j4];
+                for (int kq = 0; kq < 2; ++kq) {                 // V tiles of 32 keys
+                    const int kv = k0 + 32 * kq;
+                    if (kq) __syncthreads();
+                    if (kv < K) {
+                        for (int u = tid; u < 32 * (vld2 >> 2); u += nthr) {
+                            const int r = u / (vld2 >> 2), c4 = (u - r * (vld2 >> 2)) * 4;
+                            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                            if (kv + r < K) {
+                                const float* src = Vw + (long)(kv + r) * a.ldv + c4;
+#pragma unroll
+                                for (int s4 = 0; s4 < 4; ++s4) v[s4] = (c4 + s4 < D) ? src[s4] : 0.f;
+                            }
+                            *reinterpret_cast<f32x4*>(Vs2 + r * vld2 + c4) = v;
+                        }
+                    }
+                    __syncthreads();
+                    if (kv < K) {
+#pragma unroll
+                        for (int grp = 0; grp < 2; ++grp) {      // 16 keys per MFMA group
+                            const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 32 * kq + 16 * grp + 4 * kb);
+                            const float* __restrict__ vk = Vs2 + (16 * grp + 4 * kb) * vld2;
+#pragma unroll
+                            for (int dt = 0; dt < DTMAX; ++dt)
+                                if (dt < DT) {
+                                    float av[4];
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) av[t] = vk[t * vld2 + 16 * dt + nr];
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bq[t], o[dt], 0, 0, 0);
+                                }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    {
+        const int row = i0 + nr;
+        float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
+#pragma unroll
+        for (int dt = 0; dt < DTMAX; ++dt)
+            if (dt < DT) {
+                const int d0 = 16 * dt + 4 * kb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row < K && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = gate_sigmoid(o[dt][r]);
+            }
+    }
+}
+
+size_t gat_wide_lds(int K, int D, int nw) {
+    const int KP = (K + 127) / 128;
+    const size_t pair = (size_t)(nw * 16 + KP * 128) * GAT_LLD;
+    const size_t agg = (size_t)nw * 16 * GAT_APITCH + (size_t)32 * (((D + 15) & ~15) + 4);
+    return (pair > agg ? pair : agg) * sizeof(float);
+}
+
+int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int Kp, int PT, int P8, const float* bias,
+                    const float* V, int ldv, int D, int K, float* out, long so_w, long so_i, long so_d, long nwin, int v1,
+                    float alpha, hipStream_t s) {
+    if (nwin <= 0) return 0;
+    if (K > 512 || D > 512) return -2;
+    const int KP = (K + 127) / 128;
+    const int nw = KP == 4 ? 4 : (K >= 128 ? 8 : (K + 15) / 16);
+    GatWideArgs a{};
+    a.LC = LC; a.RT = RT; a.ldl = ldl; a.rt_rows = rt_rows; a.Kp = Kp; a.PT = PT; a.P8 = P8; a.bias = bias;
+    a.V = V; a.ldv = ldv; a.D = D; a.K = K; a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d; a.nwin = nwin;
+    a.nblk = (K + nw * 16 - 1) / (nw * 16);
+    a.v1 = v1; a.alpha = alpha;
+    const size_t lds = gat_wide_lds(K, D, nw);
+    if (lds > 160 * 1024) return -2;
+    const unsigned grid = (unsigned)(((nwin + 7) / 8 * 8) * a.nblk);
+    const int dtmax = D <= 256 ? 16 : 32;
+#define WIDE_CASE(N, DTM)                                                                                              \
+    if (KP == N && dtmax == DTM) {                                                                                     \
+        if (lds > 64 * 1024) {                                                                                         \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_wide<N, DTM>),                    \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e_ != hipSuccess) return (int)e_;                                                                      \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_gat_wide<N, DTM>), dim3(grid), dim3(64 * nw), lds, s, a);                                \
+    }
+    WIDE_CASE(1, 16) WIDE_CASE(2, 16) WIDE_CASE(3, 16) WIDE_CASE(4, 16) WIDE_CASE(1, 32) WIDE_CASE(2, 32) WIDE_CASE(3, 32) WIDE_CASE(4, 32)
+#undef WIDE_CASE
+    LAUNCH_CHECK();
+    return 0;
+}
+
 #define GAT_CASE(I, J, RJ)                                                                      \
     if (IBL == I && JPL == J && rj == RJ) {                                                     \
         const void* fn_ = a.bf16 ? reinterpret_cast<const void*>(&k_gat<I, J, RJ, true>)        \

@@ -419,7 +419,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)((R + 31) / 32);
     const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fq + 4) * sizeof(float);
     if (a.bf16 && lds > 20 * 1024) return -2;
-    if (lds <= 20 * 1024) {       // >= 8 waves per CU keep their tile in LDS
+    static const size_t lds_max = std::getenv("MTADGAT_CONV_LDS_MAX") ? (size_t)atol(std::getenv("MTADGAT_CONV_LDS_MAX")) : 20 * 1024;
+    if (lds <= lds_max || a.bf16) {       // >= 8 waves per CU keep their tile in LDS
+        if (lds > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         const unsigned wpb = (grid >= 4096 && 4 * lds <= 64 * 1024) ? 4 : 1;     // waves per workgroup
         const unsigned g4 = (grid + wpb - 1) / wpb;
         if (a.bf16) {

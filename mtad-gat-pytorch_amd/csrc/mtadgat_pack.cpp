@@ -353,9 +353,11 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     for (const LinPlan& p : m.fc) fcw = std::max(fcw, (size_t)p.NT * 32);
     ws.fc0 = take(N * fcw);
     ws.fc1 = take(N * fcw);
-    const bool rseq = m.rec.size() > 1;
+    // decoder state sequences: between stacked decoder layers, and -- when the per-step Linear has more than a
+    // few outputs -- of the last layer, so that recon_model.fc runs as one row GEMM after the recurrence
+    const bool rseq = m.rec.size() > 1 || m.cfg.out_dim > 4;
     ws.rseq0 = take(rseq ? N * m.W * m.rec[0].Hp : 0);
-    ws.rseq1 = take(m.rec.size() > 2 ? N * m.W * m.rec[0].Hp : 0);
+    ws.rseq1 = take((m.rec.size() > 2 || (m.rec.size() > 1 && m.cfg.out_dim > 4)) ? N * m.W * m.rec[0].Hp : 0);
     ws.has_xp = m.gru[0].has_xproj && n <= 16384;          // 64 windows per CU x 256 CUs: above that k_gru streams x itself
     ws.xp = take(ws.has_xp ? N * m.W * 3 * m.gru[0].Hp : 0);
     ws.total = off;
