@@ -529,26 +529,59 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
     const int ntile = PT >> 3, ptile = a.P8 >> 3;
     const int nparts = (ntile + 3) >> 2;
     for (int part = 0; part < nparts; ++part) {
-        // ---- stage this part: L' rows of the block (row-major source), R' columns of all keys (key-minor source)
+        // ---- stage this part: L' rows of the block (row-major source), R' columns of all keys (key-minor source).
+        // Every load is unconditional from a clamped address and all loads of a batch are issued before the first LDS
+        // store: one memory round trip per batch (a guarded load costs one per element)
         const int c0 = 32 * part;
-        for (int u = tid; u < NW * IBW * 32; u += nthr) {
-            const int r = u >> 5, c = u & 31;
-            const int row = i0b + r;
-            const float v = (row < K && c0 + c < PT) ? LCw[(long)row * a.ldl + c0 + c] : 0.f;
-            Ls[r * GAT_LLD + c] = v;
+        {
+            constexpr int EL = 8;                                  // (NW*16 rows x 32 columns) / (NW*64 threads)
+            float v[EL];
+#pragma unroll
+            for (int n = 0; n < EL; ++n) {
+                const int u = tid + n * nthr;
+                const int r = u >> 5, c = u & 31;
+                const int row = i0b + r;
+                const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;       // column PT (c_i) exists in every row
+                v[n] = LCw[(long)rc * a.ldl + cc];
+            }
+#pragma unroll
+            for (int n = 0; n < EL; ++n) {
+                const int u = tid + n * nthr;
+                const int r = u >> 5, c = u & 31;
+                Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? v[n] : 0.f;
+            }
         }
-        for (int u = tid; u < KJ * 32; u += nthr) {
-            const int c = u / KJ, j = u - c * KJ;              // key fastest: coalesced reads of the key-minor rows
-            const float v = (j < K && c0 + c < PT) ? RTw[(long)(c0 + c) * a.Kp + j] : 0.f;
-            Rs[j * GAT_LLD + c] = v;
+        {
+            constexpr int KJC = KP * 128;
+            constexpr int BATCH = 16;
+            const int total = KJC * 32;
+            for (int base = 0; base < total; base += BATCH * nthr) {
+                float v[BATCH];
+#pragma unroll
+                for (int n = 0; n < BATCH; ++n) {
+                    const int u = base + tid + n * nthr;
+                    const int uc = u < total ? u : total - 1;
+                    const int c = uc / KJC, j = uc - c * KJC;      // key fastest: coalesced reads of the key-minor rows
+                    const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;       // row PT (d_j) exists
+                    v[n] = RTw[(long)cc * a.Kp + jc];
+                }
+#pragma unroll
+                for (int n = 0; n < BATCH; ++n) {
+                    const int u = base + tid + n * nthr;
+                    if (u < total) {
+                        const int c = u / KJC, j = u - c * KJC;
+                        Rs[j * GAT_LLD + c] = (j < K && c0 + c < PT) ? v[n] : 0.f;
+                    }
+                }
+            }
         }
         __syncthreads();
         int ntl = ntile - 4 * part;
         ntl = ntl > 4 ? 4 : ntl;
         int npos = ptile - 4 * part;
         npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
-#pragma unroll
-        for (int kp = 0; kp < KP; ++kp) {
+        static_for<0, KP>([&](auto kpc) {
+            constexpr int kp = decltype(kpc)::value;
             if (kp * 128 < K) {
                 f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
                 lds_cptr lq[IBL];
@@ -572,7 +605,7 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
                     rq += 8;
                 }
             }
-        }
+        });
         __syncthreads();
     }
     // ---- scores -> softmax over all K keys of a row (16 lanes x KP*8 registers)
@@ -624,10 +657,9 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
 #pragma unroll
     for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ Vw = a.V + (win * K) * (long)a.ldv;
-#pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
+    static_for<0, 2 * KP>([&](auto khc) {
+        {
+            constexpr int kp = decltype(khc)::value >> 1, half = decltype(khc)::value & 1;
             const int k0 = kp * 128 + half * 64;                 // 64 keys of att at a time
             if (k0 < K) {
                 __syncthreads();                                 // everybody is done with the previous att / V tiles
@@ -670,7 +702,7 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
                 }
             }
         }
-    }
+    });
     {
         const int row = i0 + nr;
         float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;

@@ -122,26 +122,36 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
     const long rowc = row < R ? row : R - 1;
     const long win = rowc / a.W;
     const int t = (int)(rowc - win * a.W);
-    const float* __restrict__ xwin = a.X + win * (long)a.W * a.F;
+    // gather mode: the window is a view of the device-resident series (SlidingWindowDataset.__getitem__, utils.py:114-117)
+    const float* __restrict__ xwin = a.gather ? a.X + (a.starts ? a.starts[win] : a.start0 + win * a.stride) * (long)a.F
+                                              : a.X + win * (long)a.W * a.F;
     const int QF = a.Fp >> 3;
     const int Q = a.taps * QF;
     const f32x4* __restrict__ Wp = a.Wp;
 
     if (a.HCAT && row < R && g == 0)      // zero the alignment padding of the h_cat row (the GRU reads it unguarded)
         for (int c = 3 * a.F; c < a.Dp; ++c) a.HCAT[row * a.Dp + c] = 0.f;
+    // unconditional loads from clamped addresses, masked afterwards (a guarded load is a branch with a full memory
+    // round trip per chunk); one 16-byte load when the rows allow it
+    const bool xvec4 = (a.F & 3) == 0;
     auto loadx = [&](int q) -> f32x4 {
         const int tap = q / QF;
         const int cb = q - tap * QF;
         const int tt = t + tap - a.pad;
         const int c0 = 8 * cb + 4 * g;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (tt >= 0 && tt < a.W) {
-            const float* p = xwin + (long)tt * a.F + c0;
-            v[0] = (c0 + 0 < a.F) ? p[0] : 0.f;
-            v[1] = (c0 + 1 < a.F) ? p[1] : 0.f;
-            v[2] = (c0 + 2 < a.F) ? p[2] : 0.f;
-            v[3] = (c0 + 3 < a.F) ? p[3] : 0.f;
+        const bool tok = tt >= 0 && tt < a.W;
+        const int ttc = tt < 0 ? 0 : (tt < a.W ? tt : a.W - 1);
+        const float* p = xwin + (long)ttc * a.F;
+        f32x4 v;
+        if (xvec4) {
+            const int cc = c0 + 3 < a.F ? c0 : a.F - 4;
+            v = *reinterpret_cast<const f32x4*>(p + cc);
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) v[s4] = p[c0 + s4 < a.F ? c0 + s4 : a.F - 1];
         }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) v[s4] = (tok && c0 + s4 < a.F) ? v[s4] : 0.f;
         return v;
     };
 

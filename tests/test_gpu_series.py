@@ -95,3 +95,17 @@ def test_anomaly_scores_follow_get_score(setup, gpu_device):
                 ref[:, i] = a
             assert np.abs(per_dim.cpu().numpy() - ref).max() <= 1e-6
             assert np.abs(scores.cpu().numpy() - ref.mean(1)).max() <= 1e-6
+
+
+def test_forward_series_on_a_wide_model(gpu_device):
+    """More features than the LDS-staged convolution holds (F = 160): the straight-from-memory conv kernel must
+    honour the window gather too, and the attention layers run the wide (K > 128) kernel."""
+    from mtad_gat import MTAD_GAT
+    torch.manual_seed(3)
+    model = MTAD_GAT(n_features=160, window_size=20, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24).to(gpu_device).eval()
+    series = torch.rand(20 + 30, 160, device=gpu_device)
+    x = torch.stack([series[i:i + 20] for i in range(31)])
+    with torch.no_grad():
+        p0, r0 = model(x)
+        p1, r1 = model.forward_series(series)
+    assert torch.equal(p0, p1) and torch.equal(r0, r1)
