@@ -2,18 +2,25 @@
 # Regenerates the files under profiles/ on a GPU box:  bash profiles/collect.sh r02 <git rev>
 # (rocprofv3 passes are separate: --kernel-trace --stats, then one --pmc pass per counter group).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+REV=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench_line.json" 2> "$OUT/bench_stderr.log"
+# 1. kernel trace of the flagship forward (fp32), of the same workload with bf16 operands, and of the training step
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-sub > "$OUT/kt_bench_line.json" 2> /dev/null
 cp "$(find /tmp/kt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"
+rm -rf /tmp/ktb && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktb -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-sub --precision bf16 > "$OUT/kt_bf16_bench_line.json" 2> /dev/null
+cp "$(find /tmp/ktb -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bf16.csv"
+rm -rf /tmp/ktt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt -- python "$ROOT/profiles/train_step.py" 256 > "$OUT/train_step_256.txt" 2> /dev/null
+cp "$(find /tmp/ktt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_train256.csv"
+# 2. HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) and the SQ group
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python "$ROOT/bench.py" --steps 1 --warmup 1 --batch 65536 --no-cpu-baseline --no-sub > /dev/null 2>&1
   cp "$(find /tmp/pmc_$C -name '*counter_collection.csv' | head -1)" "$OUT/pmc_$C.csv"
 done
 rm -rf /tmp/pmc_sq && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-sub > /dev/null 2>&1
 cp "$(find /tmp/pmc_sq -name '*counter_collection.csv' | head -1)" "$OUT/pmc_SQ.csv"
-python "$ROOT/profiles/summarize.py" "$OUT" "$TAG" "${2:-unknown}"
+python "$ROOT/profiles/summarize.py" "$OUT" "$TAG" "$REV"

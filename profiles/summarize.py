@@ -32,6 +32,28 @@ with open(os.path.join(d, f"{tag}_kernel_trace_stats.txt"), "w") as f:
                 f"{float(r['MinNs'])/1e6:8.3f} {float(r['MaxNs'])/1e6:8.3f} {100*float(r['TotalDurationNs'])/tot:6.2f}\n")
 
 
+def stats_table(csv_name, out_name, header):
+    path = os.path.join(d, csv_name)
+    if not os.path.exists(path):
+        return
+    rows_ = list(csv.DictReader(open(path)))
+    tot_ = sum(float(r["TotalDurationNs"]) for r in rows_)
+    with open(os.path.join(d, out_name), "w") as f:
+        f.write(header + "\n")
+        f.write(f"{'kernel':70s} {'calls':>5s} {'total_ms':>9s} {'avg_ms':>8s} {'pct':>6s}\n")
+        for r in sorted(rows_, key=lambda r: -float(r["TotalDurationNs"])):
+            if float(r["TotalDurationNs"]) / tot_ < 2e-3:
+                continue
+            f.write(f"{r['Name'][:70]:70s} {int(r['Calls']):5d} {float(r['TotalDurationNs'])/1e6:9.3f} {float(r['AverageNs'])/1e6:8.3f} "
+                    f"{100*float(r['TotalDurationNs'])/tot_:6.2f}\n")
+
+
+stats_table("kernel_stats_bf16.csv", f"{tag}_kernel_trace_stats_bf16.txt",
+            "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sub --precision bf16   (MI355X, 65536 windows/step)")
+stats_table("kernel_stats_train256.csv", f"{tag}_kernel_trace_stats_train256.txt",
+            "# rocprofv3 --kernel-trace --stats -- python profiles/train_step.py 256   (SMD shape, batch 256, 23 training steps)")
+
+
 def pmc(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.Counter()
