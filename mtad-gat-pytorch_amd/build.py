@@ -25,23 +25,33 @@ def _stale():
 
 def build(force=False, verbose=True):
     """Compile the HIP kernels + C ABI into libmtadgat.so; returns the library path.
-    One hipcc per translation unit, run concurrently, then one link step."""
+    One hipcc per stale translation unit (source or any header newer than its object), run concurrently,
+    then one link step.  MTADGAT_EXTRA_FLAGS adds compiler flags (experiments)."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("MTADGAT_EXTRA_FLAGS", "").split()
     os.makedirs(OBJDIR, exist_ok=True)
-    procs = []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+    stamp = os.path.join(OBJDIR, ".flags")
+    flags_now = " ".join(FLAGS + extra)
+    flags_same = os.path.exists(stamp) and open(stamp).read() == flags_now
+    procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        srcp = os.path.join(CSRC, src)
+        if not force and flags_same and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(srcp), hdr_t):
+            continue
+        cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", srcp, "-o", obj]
         if verbose:
             print("[mtadgat] " + " ".join(cmd), file=sys.stderr)
-        procs.append((src, obj, subprocess.Popen(cmd)))
-    objs = []
-    for src, obj, p in procs:
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-        objs.append(obj)
+    open(stamp, "w").write(flags_now)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print("[mtadgat] " + " ".join(cmd), file=sys.stderr)

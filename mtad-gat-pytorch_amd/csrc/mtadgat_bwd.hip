@@ -144,6 +144,130 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs a) {
         }
 }
 
+
+// ---------------------------------------------------------------------------
+// wgrad, LDS-tiled (the one used): a workgroup of 4 waves owns a 128 x 128 block of d W (wave (wm, wn): 64 x 64 =
+// 2 x 2 MFMA tiles) and walks its row slab 16 rows at a time.  The 16 x 128 pieces of A and B are staged in LDS
+// by all 256 threads (coalesced dword loads, unconditional from clamped addresses, masked afterwards; the loader
+// modes -- im2col for the convolution, previous-step rows, the all-ones bias column -- are applied here), double
+// buffered so the loads of piece p + 1 fly during the MFMAs of piece p; every element of A and B is read from
+// memory once per block row / column instead of once per wave.  MFMA operands: lane (c, kk) reads
+// As[row 8 h + 4 kk + s][64 wm + 32 tm + c] -- 32 consecutive floats per half-wave, conflict free.
+// ---------------------------------------------------------------------------
+constexpr int WG_ROWS = 16;
+template <int BMODE>
+__global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
+    __shared__ float As[2][WG_ROWS][128];
+    __shared__ float Bs[2][WG_ROWS][128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c = lane & 31, kk = lane >> 5;
+    const int Nb = (a.Np + 127) >> 7;
+    const int mb = blockIdx.x / Nb, nb = blockIdx.x - mb * Nb;
+    const int slab = blockIdx.y;
+    const long rbeg = (long)slab * a.rows_per_slab;
+    const long rend = rbeg + a.rows_per_slab < a.R ? rbeg + a.rows_per_slab : a.R;
+    const int T = a.T > 0 ? a.T : 1;
+
+    // staging role: thread -> column (tid & 127) of rows (tid >> 7) + 2 e, e = 0..7
+    const int scol = tid & 127, srow0 = tid >> 7;
+    const int mcol = 128 * mb + scol, ncol = 128 * nb + scol;
+    const int mc = mcol < a.M ? mcol : a.M - 1;
+    const int nc = ncol < a.N ? ncol : a.N - 1;
+    int tapn = 0, chn = 0;
+    if (BMODE == 1) { tapn = nc / a.F; chn = nc - tapn * a.F; }
+    const bool need_t = (BMODE == 1) || a.bshift;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+
+    float av[8], bv[8];
+    auto gload = [&](long r0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long row = r0 + srow0 + 2 * e;
+            const bool rok = row < rend;
+            const long rowc = rok ? row : a.R - 1;
+            const float va = a.A[rowc * a.lda + mc];
+            av[e] = (rok && mcol < a.M) ? va : 0.f;
+            float vb;
+            bool ok = rok && ncol < a.N;
+            if (BMODE == 1) {
+                const int t = (int)((unsigned)rowc % (unsigned)T);      // R = windows * steps fits 32 bits
+                const int tt = t + tapn - a.pad;
+                long xr = rowc + tapn - a.pad;
+                xr = xr < 0 ? 0 : (xr < a.R ? xr : a.R - 1);
+                vb = a.B[xr * a.F + chn];
+                ok = ok && tt >= 0 && tt < T;
+            } else {
+                long br = rowc - (a.bshift ? 1 : 0);
+                br = br < 0 ? 0 : br;
+                vb = a.B[br * a.ldb + nc];
+                if (need_t) ok = ok && !(a.bshift && ((unsigned)rowc % (unsigned)T) == 0);
+            }
+            vb = ok ? vb : 0.f;
+            bv[e] = (rok && ncol == a.N) ? 1.f : vb;            // the all-ones column: bias gradients
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[buf][srow0 + 2 * e][scol] = av[e];
+            Bs[buf][srow0 + 2 * e][scol] = bv[e];
+        }
+    };
+
+    if (rbeg < rend) {
+        gload(rbeg);
+        sstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (long r = rbeg; r < rend; r += WG_ROWS) {
+            const bool more = r + WG_ROWS < rend;
+            if (more) gload(r + WG_ROWS);                    // in flight during the MFMAs below
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int lr = 8 * h + 4 * kk + s4;
+                    float af[2], bf[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        af[u] = As[buf][lr][64 * wm + 32 * u + c];
+                        bf[u] = Bs[buf][lr][64 * wn + 32 * u + c];
+                    }
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x], bf[y], acc[x][y], 0, 0, 0);
+                }
+            if (more) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    float* __restrict__ P = a.P + (long)slab * a.Mp * a.Np;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int m0 = 128 * mb + 64 * wm + 32 * x, n = 128 * nb + 64 * wn + 32 * y + c;
+            if (m0 < a.Mp && n < a.Np) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+                    P[(long)m * a.Np + n] = acc[x][y][q];
+                }
+            }
+        }
+}
+
 __global__ void k_wgrad_reduce(const WgradReduceArgs a) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int NN = a.N + 1;
@@ -162,11 +286,20 @@ __global__ void k_wgrad_reduce(const WgradReduceArgs a) {
 
 int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     if (a.R <= 0 || a.M <= 0 || a.N <= 0) return 0;
-    const dim3 grid((unsigned)(((a.Mp + 63) / 64) * ((a.Np + 63) / 64)), (unsigned)a.nslab);
-    if (a.bmode == 1)
-        hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_wgrad<0>, grid, dim3(64), 0, s, a);
+    static const bool direct = std::getenv("MTADGAT_WGRAD_DIRECT") != nullptr;      // first version, kept for A/B
+    if (direct) {
+        const dim3 grid((unsigned)(((a.Mp + 63) / 64) * ((a.Np + 63) / 64)), (unsigned)a.nslab);
+        if (a.bmode == 1)
+            hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_wgrad<0>, grid, dim3(64), 0, s, a);
+    } else {
+        const dim3 grid((unsigned)(((a.Mp + 127) / 128) * ((a.Np + 127) / 128)), (unsigned)a.nslab);
+        if (a.bmode == 1)
+            hipLaunchKernelGGL(k_wgrad_lds<1>, grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_wgrad_lds<0>, grid, dim3(256), 0, s, a);
+    }
     LAUNCH_CHECK();
     return 0;
 }

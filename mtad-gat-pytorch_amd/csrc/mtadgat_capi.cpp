@@ -677,7 +677,7 @@ int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, float* wpart, flo
     a.R = in.R;
     a.nslab = wgrad_slabs(in.R, p.Mp, p.Np);
     long rps = (in.R + a.nslab - 1) / a.nslab;
-    rps = (rps + 7) / 8 * 8;
+    rps = (rps + 15) / 16 * 16;
     a.rows_per_slab = rps;
     a.P = wpart; a.Mp = p.Mp; a.Np = p.Np;
     K_TRY(launch_wgrad(a, s), "weight-gradient GEMM");

@@ -117,8 +117,11 @@ __device__ __forceinline__ float row_sum(float v) {
 // RI = 64 / RJ lanes along the row axis; a wave owns RI*IBL = 16 query rows either way.
 // BF: bf16 operand build of the projection (16 features per chunk, fp32 accumulation); the pair grid, softmax and
 // aggregation are fp32 either way.
+#ifndef MTADGAT_GAT_MINW
+#define MTADGAT_GAT_MINW 4
+#endif
 template <int IBL, int JPL, int RJ, bool BF = false>
-__global__ __launch_bounds__(512, 4) void k_gat(const GatArgs a) {
+__global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
     constexpr int IBW = RI * IBL;                      // query rows per wave

@@ -365,9 +365,10 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
 
 
 int wgrad_slabs(long R, int Mp, int Np) {
-    const long tiles = (long)((Mp + 63) / 64) * ((Np + 63) / 64);
-    long s = 2048 / (tiles > 0 ? tiles : 1);
-    const long rmax = (R + 63) / 64;
+    // 128 x 128 output blocks (one workgroup of 4 waves each); enough row slabs for ~4 workgroups per CU
+    const long tiles = (long)((Mp + 127) / 128) * ((Np + 127) / 128);
+    long s = 1024 / (tiles > 0 ? tiles : 1);
+    const long rmax = (R + 127) / 128;
     if (s > rmax) s = rmax;
     if (s > 512) s = 512;
     return (int)(s < 1 ? 1 : s);
