@@ -155,10 +155,12 @@ __global__ __launch_bounds__(64) void k_wgrad(const WgradArgs a) {
 // As[row 8 h + 4 kk + s][64 wm + 32 tm + c] -- 32 consecutive floats per half-wave, conflict free.
 // ---------------------------------------------------------------------------
 constexpr int WG_ROWS = 16;
-template <int BMODE>
+// VEC: A and B rows are 16-byte aligned with row strides that are multiples of 4 floats (all internal buffers):
+// the pieces are staged with one float4 load per 4 columns (few, wide requests) instead of dword loads.
+template <int BMODE, bool VEC>
 __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
-    __shared__ float As[2][WG_ROWS][128];
-    __shared__ float Bs[2][WG_ROWS][128];
+    __shared__ __attribute__((aligned(16))) float As[2][WG_ROWS][128];
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_ROWS][128];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -188,7 +190,38 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
     float av[8], bv[8];
+    // vector staging role: thread -> float4 (tid & 31) of rows (tid >> 5) + 8 e, e = 0..1
+    const int vc4 = (tid & 31) * 4, vrow0 = tid >> 5;
     auto gload = [&](long r0) {
+        if (VEC) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const long row = r0 + vrow0 + 8 * e;
+                const bool rok = row < rend;
+                const long rowc = rok ? row : a.R - 1;
+                {
+                    const int col = 128 * mb + vc4;
+                    const int cc = col + 3 < (int)a.lda ? col : (int)a.lda - 4;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + rowc * a.lda + cc);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) av[4 * e + s4] = (rok && cc == col && col + s4 < a.M) ? v[s4] : 0.f;
+                }
+                {
+                    const int col = 128 * nb + vc4;
+                    const int cc = col + 3 < (int)a.ldb ? col : (int)a.ldb - 4;
+                    long br = rowc - (a.bshift ? 1 : 0);
+                    br = br < 0 ? 0 : br;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.B + br * a.ldb + cc);
+                    const bool tok = !(a.bshift && ((unsigned)rowc % (unsigned)T) == 0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const float x = (rok && tok && cc == col && col + s4 < a.N) ? v[s4] : 0.f;
+                        bv[4 * e + s4] = (rok && col + s4 == a.N) ? 1.f : x;       // the all-ones column
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const long row = r0 + srow0 + 2 * e;
@@ -216,6 +249,17 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
         }
     };
     auto sstore = [&](int buf) {
+        if (VEC) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                f32x4 va, vb;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { va[s4] = av[4 * e + s4]; vb[s4] = bv[4 * e + s4]; }
+                *reinterpret_cast<f32x4*>(&As[buf][vrow0 + 8 * e][vc4]) = va;
+                *reinterpret_cast<f32x4*>(&Bs[buf][vrow0 + 8 * e][vc4]) = vb;
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             As[buf][srow0 + 2 * e][scol] = av[e];
@@ -295,10 +339,14 @@ int launch_wgrad(const WgradArgs& a, hipStream_t s) {
             hipLaunchKernelGGL(k_wgrad<0>, grid, dim3(64), 0, s, a);
     } else {
         const dim3 grid((unsigned)(((a.Mp + 127) / 128) * ((a.Np + 127) / 128)), (unsigned)a.nslab);
+        const bool vec = a.bmode == 0 && (a.lda & 3) == 0 && (a.ldb & 3) == 0 && a.lda >= 4 && a.ldb >= 4 &&
+                         (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
         if (a.bmode == 1)
-            hipLaunchKernelGGL(k_wgrad_lds<1>, grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_wgrad_lds<1, false>), grid, dim3(256), 0, s, a);
+        else if (vec)
+            hipLaunchKernelGGL((k_wgrad_lds<0, true>), grid, dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL(k_wgrad_lds<0>, grid, dim3(256), 0, s, a);
+            hipLaunchKernelGGL((k_wgrad_lds<0, false>), grid, dim3(256), 0, s, a);
     }
     LAUNCH_CHECK();
     return 0;
