@@ -119,6 +119,9 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, vo
  *                <= 2e-2 of the fp32 reference on outputs of scale ~1 (BASELINE configs "bf16 inference").
  * The training entry points always compute in fp32. */
 int mtadgat_set_precision(mtadgat_handle h, int mode);
+/* The bf16 weight streams are packed by mtadgat_load_weights only while mode 1 is selected (select first, or load
+ * again after switching); 1 when they are present. */
+int mtadgat_bf16_ready(mtadgat_handle h);
 
 /* Bytes of device scratch forward() needs for a batch of `batch` windows
  * (intermediates of at most mtadgat_chunk_windows() windows are live at once). */

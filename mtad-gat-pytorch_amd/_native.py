@@ -62,6 +62,7 @@ def load_library():
     lib.mtadgat_workspace_bytes.argtypes = [vp, i64]
     lib.mtadgat_workspace_bytes.restype = sz
     lib.mtadgat_set_precision.argtypes = [vp, ctypes.c_int]
+    lib.mtadgat_bf16_ready.argtypes = [vp]
     lib.mtadgat_chunk_windows.argtypes = [vp]
     lib.mtadgat_chunk_windows.restype = i64
     lib.mtadgat_set_chunk_windows.argtypes = [vp, i64]
@@ -269,6 +270,9 @@ class Engine:
     def set_precision(self, bf16):
         """False: fp32 operands (<= 1e-5 parity); True: bf16 MFMA operands, fp32 accumulation / state (<= 2e-2)."""
         _check(self.lib.mtadgat_set_precision(self.handle, 1 if bf16 else 0), "set_precision")
+
+    def bf16_ready(self):
+        return bool(self.lib.mtadgat_bf16_ready(self.handle))
 
     def set_chunk_windows(self, n):
         _check(self.lib.mtadgat_set_chunk_windows(self.handle, int(n)), "set_chunk_windows")

@@ -310,6 +310,8 @@ int check_common(mtadgat_handle h, int64_t batch, void* ws, size_t ws_bytes, boo
     if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");
     if (batch < 0) return fail(MTADGAT_ERR_INVALID, "negative batch");
     if (!h->m.have_weights) return fail(MTADGAT_ERR_NOWEIGHTS, "mtadgat_load_weights has not been called");
+    if (h->m.precision == 1 && !h->m.bf16_packed)
+        return fail(MTADGAT_ERR_NOWEIGHTS, "bf16 precision selected after the weights were loaded: call mtadgat_load_weights again");
     if (need_ws && batch > 0) {
         if (!ws) return fail(MTADGAT_ERR_WORKSPACE, "workspace is NULL");
         if (!aligned16(ws)) return fail(MTADGAT_ERR_WORKSPACE, "workspace must be 16-byte aligned");
@@ -421,6 +423,10 @@ int mtadgat_set_precision(mtadgat_handle h, int mode) {
     h->m.precision = mode;
     return 0;
 }
+
+/* 1 when the bf16 weight streams are present in the packed image (they are packed by mtadgat_load_weights only
+ * while precision 1 is selected: call set_precision before load_weights, or load again after switching) */
+int mtadgat_bf16_ready(mtadgat_handle h) { return (h && h->m.have_weights && h->m.bf16_packed) ? 1 : 0; }
 
 int64_t mtadgat_chunk_windows(mtadgat_handle h) { return h ? h->m.chunk : 0; }
 int mtadgat_set_chunk_windows(mtadgat_handle h, int64_t w) {

@@ -120,6 +120,7 @@ struct Model {
     size_t staging_floats = 0;
     hipEvent_t upload_ev = nullptr;  // recorded after the last upload
     bool have_weights = false;
+    bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
     // profiling

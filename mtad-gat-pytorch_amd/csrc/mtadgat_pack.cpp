@@ -3,7 +3,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
+#include <thread>
 
 #include "mtadgat_host.h"
 
@@ -501,7 +504,7 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
         if (k < D) return (float)rows[(size_t)n * D + k];
         return (g.fused && k == D) ? (float)bvec[n] : 0.f;       // fused kernel: bias = weight row D
     });
-    if (g.fused)
+    if (g.fused && m.precision == 1)
         pack_tiles_bf16(out.data() + g.w16_off, g.NT, g.Q16, [&](int n, int k) -> float {
             if (n >= NC) return 0.f;
             if (k < D) return (float)rows[(size_t)n * D + k];
@@ -512,7 +515,7 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
 }
 
 static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
-                           std::vector<float>& out) {
+                           std::vector<float>& out, bool bf16) {
     const int H = g.H, in = g.in_dim;
     if (g.xmode == 0) {
         pack_gru_tiles(out.data() + g.wx_off, g.NCG, g.Qxp, [&](int st, int r, int k) -> float {
@@ -522,14 +525,15 @@ static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_h
     pack_gru_tiles(out.data() + g.wh_off, g.NCG, 4 * g.NCG + 2, [&](int st, int r, int k) -> float {
         return (r < H && k < H) ? w_hh[((size_t)st * H + r) * H + k] : 0.f;
     });
-    if (g.xmode == 0) {
+    if (g.xmode == 0 && bf16) {
         pack_gru_tiles_bf16(out.data() + g.wx16_off, g.NCG, g.Qxp16, [&](int st, int r, int k) -> float {
             return (r < H && k < in) ? w_ih[((size_t)st * H + r) * in + k] : 0.f;
         });
     }
-    pack_gru_tiles_bf16(out.data() + g.wh16_off, g.NCG, 2 * g.NCG + 2, [&](int st, int r, int k) -> float {
-        return (r < H && k < H) ? w_hh[((size_t)st * H + r) * H + k] : 0.f;
-    });
+    if (bf16)
+        pack_gru_tiles_bf16(out.data() + g.wh16_off, g.NCG, 2 * g.NCG + 2, [&](int st, int r, int k) -> float {
+            return (r < H && k < H) ? w_hh[((size_t)st * H + r) * H + k] : 0.f;
+        });
     float* b = out.data() + g.b_off;
     for (int j = 0; j < g.Hp; ++j) {
         b[0 * g.Hp + j] = j < H ? b_ih[j] + b_hh[j] : 0.f;
@@ -553,8 +557,16 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
     if (!p.conv_weight || !p.conv_bias || !p.feat_lin_weight || !p.feat_lin_bias || !p.feat_a || !p.feat_bias ||
         !p.temp_lin_weight || !p.temp_lin_bias || !p.temp_a || !p.temp_bias || !p.rec_fc_weight || !p.rec_fc_bias)
         return "null parameter pointer";
+    for (int l = 0; l < c.gru_n_layers; ++l)
+        if (!p.gru_w_ih[l] || !p.gru_w_hh[l] || !p.gru_b_ih[l] || !p.gru_b_hh[l]) return "null GRU parameter pointer";
+    for (int i = 0; i < c.forecast_n_linear; ++i)
+        if (!p.fc_weight[i] || !p.fc_bias[i]) return "null forecasting parameter pointer";
+    for (int l = 0; l < c.recon_n_layers; ++l)
+        if (!p.rec_w_ih[l] || !p.rec_w_hh[l] || !p.rec_b_ih[l] || !p.rec_b_hh[l]) return "null decoder parameter pointer";
+    // The regions of the packed image are independent: five host threads fill them concurrently (the image is
+    // re-packed after every optimizer step, so this sits on the training step's critical path).
     // conv: K index = tap*Fp + channel   (reference weight (F_out, F_in, k), modules.py:15)
-    {
+    auto job_conv_feat = [&]() {
         const int F = m.F, Fp = m.Fp, taps = m.taps;
         pack_tiles(out.data() + m.conv_w_off, m.convNT, taps * Fp / 8, [&](int n, int k) -> float {
             const int tap = k / Fp, ch = k % Fp;
@@ -562,19 +574,18 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
         });
         for (int n = 0; n < F; ++n) out[m.conv_b_off + n] = p.conv_bias[n];
         const int Fp16 = m.Fp16;
-        pack_tiles_bf16(out.data() + m.conv_w16_off, m.convNT, taps * Fp16 / 16, [&](int n, int k) -> float {
+        if (m.precision == 1) pack_tiles_bf16(out.data() + m.conv_w16_off, m.convNT, taps * Fp16 / 16, [&](int n, int k) -> float {
             const int tap = k / Fp16, ch = k % Fp16;
             return (n < F && ch < F && tap < taps) ? p.conv_weight[((size_t)n * F + ch) * taps + tap] : 0.f;
         });
-    }
-    pack_gat(m, m.feat, p.feat_lin_weight, p.feat_lin_bias, p.feat_a, p.feat_bias, out);
-    pack_gat(m, m.temp, p.temp_lin_weight, p.temp_lin_bias, p.temp_a, p.temp_bias, out);
-    for (int l = 0; l < c.gru_n_layers; ++l) {
-        if (!p.gru_w_ih[l] || !p.gru_w_hh[l] || !p.gru_b_ih[l] || !p.gru_b_hh[l]) return "null GRU parameter pointer";
-        pack_gru_layer(m.gru[l], p.gru_w_ih[l], p.gru_w_hh[l], p.gru_b_ih[l], p.gru_b_hh[l], out);
-    }
+        pack_gat(m, m.feat, p.feat_lin_weight, p.feat_lin_bias, p.feat_a, p.feat_bias, out);
+    };
+    auto job_temp_gru = [&]() {
+        pack_gat(m, m.temp, p.temp_lin_weight, p.temp_lin_bias, p.temp_a, p.temp_bias, out);
+        for (int l = 0; l < c.gru_n_layers; ++l) pack_gru_layer(m.gru[l], p.gru_w_ih[l], p.gru_w_hh[l], p.gru_b_ih[l], p.gru_b_hh[l], out, m.precision == 1);
+    };
+    auto job_heads = [&]() {
     for (int i = 0; i < c.forecast_n_linear; ++i) {
-        if (!p.fc_weight[i] || !p.fc_bias[i]) return "null forecasting parameter pointer";
         const LinPlan& lp = m.fc[i];
         const float* w = p.fc_weight[i];
         pack_tiles(out.data() + lp.w_off, lp.NT, lp.Q, [&](int n, int k) -> float {
@@ -583,7 +594,6 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
         for (int n = 0; n < lp.out_dim; ++n) out[lp.b_off + n] = p.fc_bias[i][n];
     }
     for (int l = 0; l < c.recon_n_layers; ++l) {
-        if (!p.rec_w_ih[l] || !p.rec_w_hh[l] || !p.rec_b_ih[l] || !p.rec_b_hh[l]) return "null decoder parameter pointer";
         const GruPlan& g = m.rec[l];
         if (g.xmode == 1) {
             // x_t[j] = h_end[(t*Hin + j) / T]: fold W_ih over the j that share an h_end entry.  The j of one entry
@@ -600,24 +610,30 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
                 }
             }
             int* m0 = reinterpret_cast<int*>(out.data() + g.m0_off);
-            for (int t = 0; t < T; ++t) {
-                const int lo = (int)(((long)t * Hin) / T);
-                m0[t] = lo;
-                auto fold = [&](int st, int r, int k) -> float {
-                    if (r >= H || k >= NMp) return 0.f;
-                    // j with (t*Hin + j) / T == lo + k:  j in [(lo+k)*T - t*Hin, (lo+k+1)*T - t*Hin)
-                    long j0 = (long)(lo + k) * T - (long)t * Hin, j1 = j0 + T;
-                    j0 = j0 < 0 ? 0 : j0;
-                    j1 = j1 > Hin ? Hin : j1;
-                    if (j1 <= j0) return 0.f;
-                    const double* pr = pre.data() + ((size_t)st * H + r) * (Hin + 1);
-                    return (float)(pr[j1] - pr[j0]);
-                };
-                pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qxp * 3 * 256, g.NCG, g.Qxp, fold);
-                pack_gru_tiles_bf16(out.data() + g.wx16_off + (size_t)t * g.NCG * g.Qxp16 * 3 * 256, g.NCG, g.Qxp16, fold);
-            }
+            std::vector<float> fw((size_t)3 * H * NMp);          // folded weights of one step: [gate*H + r][k]
+            auto steps = [&](int t_lo, int t_hi, std::vector<float>& f) {
+                for (int t = t_lo; t < t_hi; ++t) {
+                    const int lo = (int)(((long)t * Hin) / T);
+                    m0[t] = lo;
+                    for (int k = 0; k < NMp; ++k) {
+                        // j with (t*Hin + j) / T == lo + k:  j in [(lo+k)*T - t*Hin, (lo+k+1)*T - t*Hin)
+                        long j0 = (long)(lo + k) * T - (long)t * Hin, j1 = j0 + T;
+                        j0 = j0 < 0 ? 0 : j0;
+                        j1 = j1 > Hin ? Hin : j1;
+                        for (int r = 0; r < 3 * H; ++r)
+                            f[(size_t)r * NMp + k] = j1 > j0 ? (float)(pre[(size_t)r * (Hin + 1) + j1] - pre[(size_t)r * (Hin + 1) + j0]) : 0.f;
+                    }
+                    auto fold = [&](int st, int r, int k) -> float { return (r < H && k < NMp) ? f[((size_t)st * H + r) * NMp + k] : 0.f; };
+                    pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qxp * 3 * 256, g.NCG, g.Qxp, fold);
+                    if (m.precision == 1) pack_gru_tiles_bf16(out.data() + g.wx16_off + (size_t)t * g.NCG * g.Qxp16 * 3 * 256, g.NCG, g.Qxp16, fold);
+                }
+            };
+            std::vector<float> fw2(fw.size());
+            std::thread th(steps, T / 2, T, std::ref(fw2));
+            steps(0, T / 2, fw);
+            th.join();
         }
-        pack_gru_layer(g, p.rec_w_ih[l], p.rec_w_hh[l], p.rec_b_ih[l], p.rec_b_hh[l], out);
+        pack_gru_layer(g, p.rec_w_ih[l], p.rec_w_hh[l], p.rec_b_ih[l], p.rec_b_hh[l], out, m.precision == 1);
     }
     {
         const LinPlan& lp = m.rec_fc;
@@ -626,8 +642,10 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
         });
         for (int n = 0; n < lp.out_dim; ++n) out[lp.b_off + n] = p.rec_fc_bias[n];
     }
+    };
 
     // ---- backward packs (transposed weights, un-scaled attention projections, gradient index maps)
+    auto job_bwd = [&]() {
     if (m.bw.supported) {
         const BwdPlan& b = m.bw;
         auto maps = [&](const WgradPlan& wp, auto rowW, auto col, auto rowB) {
@@ -697,6 +715,20 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
             maps(b.conv_wg, [&](int r) { return r * F * taps; }, [&](int n) { const int tap = n / F, ch = n % F; return ch * taps + tap; }, ident);
         }
     }
+    };
+    if (std::getenv("MTADGAT_PACK_TIMING")) {
+        auto tm = [&](const char* n, auto&& f) {
+            auto t0 = std::chrono::steady_clock::now();
+            f();
+            fprintf(stderr, "[pack] %s %.3f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        };
+        tm("conv+feat", job_conv_feat); tm("temp+gru", job_temp_gru); tm("heads", job_heads); tm("bwd", job_bwd);
+    } else {
+        std::thread t1(job_conv_feat), t2(job_temp_gru), t3(job_heads);
+        job_bwd();
+        t1.join(); t2.join(); t3.join();
+    }
+    m.bf16_packed = (m.precision == 1);
     return "";
 }
 

@@ -259,8 +259,9 @@ class MTAD_GAT(nn.Module):
         Only needed with `check_weight_contents = False` after edits autograd's version counter does not see."""
         object.__setattr__(self, "_weights_key", None)
 
-    def _sync_engine(self, device):
-        """Engine (on `device`) whose packed weights match the current parameters (repacked when any changed)."""
+    def _sync_engine(self, device, bf16=False):
+        """Engine (on `device`) whose packed weights match the current parameters (repacked when any changed), with
+        the requested arithmetic selected (the bf16 weight streams are packed on first use only)."""
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
@@ -275,7 +276,8 @@ class MTAD_GAT(nn.Module):
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
         if self.check_weight_contents:
             key = key + (self._fingerprint(params),)
-        if key != self._weights_key:
+        self._engine.set_precision(bf16)
+        if key != self._weights_key or (bf16 and not self._engine.bf16_ready()):
             self._engine.load_weights(self.state_dict(), device)
             object.__setattr__(self, "_weights_key", key)
         return self._engine
@@ -303,8 +305,7 @@ class MTAD_GAT(nn.Module):
             raise NotImplementedError(
                 "stage calls run the eval-mode HIP kernels; train-mode (dropout / gradients) is supported through "
                 "MTAD_GAT.forward() -- call model.eval() for per-stage inference")
-        eng = self._sync_engine(x.device)
-        eng.set_precision(self._use_bf16(x))
+        eng = self._sync_engine(x.device, self._use_bf16(x))
         x = x.detach().contiguous().float()
         if name == "conv":
             return eng.conv(x)
@@ -339,8 +340,7 @@ class MTAD_GAT(nn.Module):
             import _torchpath
             preds, recons = _torchpath.forward(self, x.float())
             return (preds.to(x.dtype), recons.to(x.dtype)) if x.dtype != torch.float32 else (preds, recons)
-        eng = self._sync_engine(x.device)
-        eng.set_precision(self._use_bf16(x))
+        eng = self._sync_engine(x.device, self._use_bf16(x))
         if self.training or self._wants_grad(x):
             # training step (Trainer.fit, training.py:100-130) or any call that will be differentiated:
             # HIP forward that keeps what the HIP backward needs, dropout in the kernels
@@ -362,8 +362,7 @@ class MTAD_GAT(nn.Module):
         prediction.py:43-55); consecutive windows share W-1 rows, so ~W times fewer input bytes are read.
         Returns (predictions (b, out_dim), recons (b, W, out_dim))."""
         self._require_gpu(series, "forward_series")
-        eng = self._sync_engine(series.device)
-        eng.set_precision(self._use_bf16(series))
+        eng = self._sync_engine(series.device, self._use_bf16(series))
         with torch.no_grad():
             p, r, _ = eng.forward_series(series.contiguous().float(), starts, start, stride, count)
         return p, r
@@ -381,8 +380,7 @@ class MTAD_GAT(nn.Module):
         n = values.shape[0] - self.window_size
         if n <= 0:
             raise RuntimeError("series shorter than window_size + 1")
-        eng = self._sync_engine(values.device)
-        eng.set_precision(self._use_bf16(values))
+        eng = self._sync_engine(values.device, self._use_bf16(values))
         with torch.no_grad():
             p, _, last = eng.forward_series(values.contiguous().float(), None, 0, 1, n + 1, want_recons=False, want_last=True)
         return p[:n], last[1:n + 1]
