@@ -154,7 +154,7 @@ def _timed(fn, dev, iters, warm=3):
     return (time.perf_counter() - t0) / iters
 
 
-def sub_records(model, kw, dev):
+def sub_records(model, kw, dev, args_precision="fp32"):
     """Measurements of the other BASELINE configurations, outside the timed region (N=1 only)."""
     import torch.nn.functional as F
     from mtad_gat import MTAD_GAT
@@ -166,6 +166,10 @@ def sub_records(model, kw, dev):
         t = _timed(lambda: model(x256), dev, 20)
         out["batch256"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1),
                            "what": "one eval forward of the reference Predictor's fixed 256-window batch (prediction.py:31), MSL shape"}
+        model.precision = "bf16"
+        t = _timed(lambda: model(x256), dev, 20)
+        model.precision = args_precision
+        out["batch256_bf16"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1), "what": "the same with bf16 MFMA operands"}
         # the flagship workload with bf16 MFMA operands (fp32 accumulate / state; 2e-2 parity class), own roofline
         xb = torch.rand(65536, kw["window_size"], kw["n_features"], generator=g).to(dev)
         model.precision = "bf16"
@@ -206,6 +210,12 @@ def sub_records(model, kw, dev):
         opt.step()
 
     t = _timed(step, dev, 10)
+    m3.precision = "bf16"
+    tb = _timed(step, dev, 10)
+    m3.precision = "auto"
+    out["train_step_bf16"] = {"ms": round(1e3 * tb, 3), "windows_per_s": round(256 / tb, 1), "grad_path": getattr(m3, "grad_path", "hip"),
+                              "what": "the same step with precision='bf16': the four recurrences on bf16 MFMA operands (fp32 accumulation, "
+                                      "state and gate arithmetic), the rest fp32 (BASELINE config 3: bf16 train loop)"}
     out["train_step"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1),
                          "grad_path": getattr(m3, "grad_path", "hip"),
                          "what": "SMD shape (F=38, W=100, out=38), batch 256, dropout 0.3: forward + RMSE losses + backward + Adam "
@@ -357,7 +367,7 @@ def main():
                       "note": "whole-forward algorithmic bytes rate per GPU vs HBM peak; the path is compute-bound"}
         if world == 1 and not args.no_sub:
             try:
-                res["sub"] = sub_records(model, kw, dev)
+                res["sub"] = sub_records(model, kw, dev, args.precision)
             except Exception as e:
                 res["sub"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:

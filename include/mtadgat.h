@@ -117,7 +117,9 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, vo
  *   1            bf16 MFMA operands (weights packed to bf16 once per load_weights, activations rounded on the
  *                way into the matrix unit), fp32 accumulation, fp32 recurrent state / gates / softmax:
  *                <= 2e-2 of the fp32 reference on outputs of scale ~1 (BASELINE configs "bf16 inference").
- * The training entry points always compute in fp32. */
+ * The training entry points follow the same switch for their four recurrences (GRU layer and decoder, forward and
+ * back-propagation through time: bf16 MFMA operands, fp32 accumulation / state / gate arithmetic); convolution,
+ * attention, the Linear layers and every weight-gradient GEMM stay fp32. */
 int mtadgat_set_precision(mtadgat_handle h, int mode);
 /* The bf16 weight streams are packed by mtadgat_load_weights only while mode 1 is selected (select first, or load
  * again after switching); 1 when they are present. */

@@ -403,9 +403,12 @@ int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, fl
 // transposed recurrent product on the MFMA (same chunk / lane mapping as the forward).  d a_* of every step
 // are written out for the weight-gradient GEMMs and the input-gradient rowgemm.
 // ---------------------------------------------------------------------------
+// BF: bf16 operand build of the transposed recurrent product (the gate-gradient blocks are converted once by the
+// publishing wave, W_hh^T comes as a bf16 pack of 16-feature chunks); fp32 accumulation and gate arithmetic.
+template <bool BF>
 __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];
-    f32x4* __restrict__ das = reinterpret_cast<f32x4*>(gsm);          // [3][NCG][4][64]
+    f32x4* __restrict__ das = reinterpret_cast<f32x4*>(gsm);          // fp32: [3][NCG][4][64] float4; bf16: [3][NCG][2][64] containers
     const int lane = threadIdx.x & 63;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NCG = a.NCG;
@@ -413,8 +416,9 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
     const long win = (long)blockIdx.x * 32 + i;
     const long winc = win < a.B ? win : a.B - 1;
     const int T = a.T, Hp = a.Hp;
-    const int NQ = 12 * NCG;
-    const int Q4 = 4 * NCG;
+    constexpr int CPT = BF ? 2 : 4;                                   // chunks per 32-unit tile
+    constexpr int RING = BF ? 3 : 4;
+    const int NQ = 3 * CPT * NCG;
     const f32x4* __restrict__ W = a.WhT + (long)c * NQ * 64 + lane;
     const int col0 = 32 * c + 4 * g;
 
@@ -430,9 +434,9 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
             for (int s4 = 0; s4 < 4; ++s4) dh[4 * m + s4] = v[s4];
         }
     }
-    f32x4 wr[4];
+    f32x4 wr[RING];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) wr[u] = W[u * 64];
+    for (int u = 0; u < RING; ++u) wr[u] = W[u * 64];
 
     for (int t = T - 1; t >= 0; --t) {
         const long row = winc * T + t;
@@ -482,20 +486,29 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
                 *reinterpret_cast<f32x4*>(op + 3 * Hp + 8 * m) = dnh4[m];
             }
         }
+        if (BF) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            das[((0 * NCG + c) * 4 + m) * 64 + lane] = dar4[m];
-            das[((1 * NCG + c) * 4 + m) * 64 + lane] = daz4[m];
-            das[((2 * NCG + c) * 4 + m) * 64 + lane] = dnh4[m];
+            for (int mm = 0; mm < 2; ++mm) {
+                das[((0 * NCG + c) * 2 + mm) * 64 + lane] = cvt8(dar4[2 * mm], dar4[2 * mm + 1]);
+                das[((1 * NCG + c) * 2 + mm) * 64 + lane] = cvt8(daz4[2 * mm], daz4[2 * mm + 1]);
+                das[((2 * NCG + c) * 2 + mm) * 64 + lane] = cvt8(dnh4[2 * mm], dnh4[2 * mm + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                das[((0 * NCG + c) * 4 + m) * 64 + lane] = dar4[m];
+                das[((1 * NCG + c) * 4 + m) * 64 + lane] = daz4[m];
+                das[((2 * NCG + c) * 4 + m) * 64 + lane] = dnh4[m];
+            }
         }
         __syncthreads();
         f32x16 acc = dhz;
-        for (int q0 = 0; q0 < NQ; q0 += 4) {
+        for (int q0 = 0; q0 < NQ; q0 += RING) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RING; ++u) {
                 const f32x4 xv = das[(q0 + u) * 64 + lane];
-                acc = mfma4(wr[u], xv, acc);
-                int qn = q0 + u + 4;
+                acc = BF ? mfma_bf(wr[u], xv, acc) : mfma4(wr[u], xv, acc);
+                int qn = q0 + u + RING;
                 qn = qn >= NQ ? qn - NQ : qn;
                 wr[u] = W[qn * 64];
             }
@@ -503,7 +516,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
         dh = acc;
         __syncthreads();
     }
-    (void)Q4;
 }
 
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
@@ -511,10 +523,14 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)3 * a.NCG * 4 * 64 * sizeof(f32x4);
     if (a.NCG < 1 || a.NCG > 8 || lds > 160 * 1024) return -2;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(a.bf16 ? reinterpret_cast<const void*>(&k_gru_bwd<true>) : reinterpret_cast<const void*>(&k_gru_bwd<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_gru_bwd, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
+    if (a.bf16)
+        hipLaunchKernelGGL(k_gru_bwd<true>, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
+    else
+        hipLaunchKernelGGL(k_gru_bwd<false>, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
     LAUNCH_CHECK();
     return 0;
 }

@@ -195,7 +195,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh_off);
     a.bias = m.packed_dev + g.b_off;
     a.whs = 4 * g.NCG + 2;
-    if (m.precision == 1 && !gates) {       // bf16 operand build: the same streams in 16-feature chunks (inference only)
+    if (m.precision == 1) {       // bf16 operand build: the same streams in 16-feature chunks (inference, and the bf16 training step)
         a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx16_off);
         a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh16_off);
         a.whs = 2 * g.NCG + 2;
@@ -651,6 +651,8 @@ int check_train(mtadgat_handle h, int64_t batch, float p) {
     if (!h->m.have_weights) return fail(MTADGAT_ERR_NOWEIGHTS, "mtadgat_load_weights has not been called");
     if (!h->m.bw.supported) return fail(MTADGAT_ERR_UNSUPPORTED, "no HIP backward for this configuration: " + h->m.bw.why);
     if (!(p >= 0.f && p < 1.f)) return fail(MTADGAT_ERR_INVALID, "dropout probability must be in [0, 1)");
+    if (h->m.precision == 1 && !h->m.bf16_packed)
+        return fail(MTADGAT_ERR_NOWEIGHTS, "bf16 precision selected after the weights were loaded: call mtadgat_load_weights again");
     return 0;
 }
 
@@ -871,6 +873,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
         ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.rec.whT_off);
         ga.DA = da; ga.Hp = r.Hp; ga.H = r.H; ga.T = W; ga.NCG = r.NCG; ga.B = n;
+        if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.rec.whT16_off); }
         K_TRY(launch_gru_bwd(ga, s), "decoder backward");
         WgradIn hh;
         hh.A = da + r.Hp; hh.lda = 4L * r.Hp; hh.bshift = 1; hh.B = T + t.seq_d; hh.ldb = r.Hp; hh.R = RW; hh.T = W;
@@ -889,6 +892,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
         ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.gru.whT_off);
         ga.DA = da; ga.Hp = g.Hp; ga.H = g.H; ga.T = W; ga.NCG = g.NCG; ga.B = n;
+        if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.gru.whT16_off); }
         K_TRY(launch_gru_bwd(ga, s), "gru backward");
         WgradIn hh;
         hh.A = da + g.Hp; hh.lda = 4L * g.Hp; hh.bshift = 1; hh.B = T + t.seq_g; hh.ldb = g.Hp; hh.R = RW; hh.T = W;

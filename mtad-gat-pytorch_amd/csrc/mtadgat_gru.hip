@@ -621,7 +621,7 @@ static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipSt
 #define SPLIT_CASE(XM, F)                                                                                        \
     if (xm == XM && fc == F) {                                                                                   \
         if (a.bf16 && !save) hipLaunchKernelGGL((k_gru_split<XM, F, false, true>), dim3(grid), dim3(64 * ncg), lds, s, a); \
-        else if (a.bf16) return -2;                                                                              \
+        else if (a.bf16) hipLaunchKernelGGL((k_gru_split<XM, F, true, true>), dim3(grid), dim3(64 * ncg), lds, s, a);      \
         else if (save) hipLaunchKernelGGL((k_gru_split<XM, F, true>), dim3(grid), dim3(64 * ncg), lds, s, a);    \
         else hipLaunchKernelGGL((k_gru_split<XM, F, false>), dim3(grid), dim3(64 * ncg), lds, s, a);             \
     }

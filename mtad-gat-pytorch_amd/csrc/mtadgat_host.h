@@ -76,6 +76,7 @@ struct GatBwdPlan {
 };
 struct GruBwdPlan {
     size_t whT_off = 0;             // W_hh^T tiles for k_gru_bwd
+    size_t whT16_off = 0;           // ... as a bf16 pack (bf16 training)
     LinTPlan wihT;                  // d x = d a W_ih
     WgradPlan wg_ih, wg_hh;
 };

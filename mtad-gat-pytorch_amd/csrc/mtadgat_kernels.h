@@ -155,6 +155,7 @@ struct GruBwdArgs {
     float* DA;           // (B*T, 4*Hp) out: dn_x | dr | dz | dn_h  (pre-activation gradients)
     int Hp, H, T, NCG;
     long B;
+    int bf16;            // 1: WhT is the bf16 pack [NCG][6*NCG][64] of 16-feature chunks
 };
 
 // dW[m][n] = sum_rows A[row][m] * B[row][n]   (+ a virtual all-ones column n == N: bias gradients)
