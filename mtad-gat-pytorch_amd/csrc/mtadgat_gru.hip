@@ -29,15 +29,22 @@ namespace mtadgat {
 // waves leaves bubbles; each weight chunk is also fetched once for 64 windows.
 // BF: bf16 operand build (v_mfma_f32_32x32x16_bf16, 16 features per chunk; fp32 accumulators, state and gates):
 // the same chunk sequence with half as many, twice as wide chunks -- see mtadgat_device.h for the element order.
+// MW = 2 launches 4 such waves per workgroup (one per SIMD): they are independent except that the per-step barrier
+// keeps them within a few chunks of each other, so the packed-weight chunks one wave pulls from L2 are still in the
+// CU's vector L1 when the other three ask for them (as separate one-wave workgroups they drift apart and every wave
+// streams the whole 1.9 MB / 1 MB image from L2 each step).
 template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false>
-__global__ __launch_bounds__(64, ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
-    __shared__ float hn_s[MW][NCG][16][64];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float hn_dyn[];
+    constexpr int WPB = MW == 2 ? 4 : 1;
+    const int lane = threadIdx.x & 63;
+    const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float (*hn_s)[NCG][16][64] = reinterpret_cast<float (*)[NCG][16][64]>(hn_dyn + (size_t)wv * MW * NCG * 1024);
     const int i = lane & 31, g = lane >> 5;
     long win[MW], winc[MW];
 #pragma unroll
     for (int w = 0; w < MW; ++w) {
-        win[w] = ((long)blockIdx.x * MW + w) * 32 + i;
+        win[w] = (((long)blockIdx.x * WPB + wv) * MW + w) * 32 + i;
         winc[w] = win[w] < a.B ? win[w] : a.B - 1;
     }
     const int T = a.T, Qx = a.Qx;
@@ -583,15 +590,23 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
 
 template <int NCG, int XMODE, int MW, bool BF>
 static int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.B + 32 * MW - 1) / (32 * MW));
-    if (!fc && drop == 0)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 0, MW, BF>), dim3(grid), dim3(64), 0, s, a);
-    else if (!fc)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, false, 1, MW, BF>), dim3(grid), dim3(64), 0, s, a);
-    else if (drop == 0)
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 0, MW, BF>), dim3(grid), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, true, 1, MW, BF>), dim3(grid), dim3(64), 0, s, a);
+    constexpr int WPB = MW == 2 ? 4 : 1;
+    const unsigned grid = (unsigned)((a.B + 32 * MW * WPB - 1) / (32 * MW * WPB));
+    const size_t lds = (size_t)WPB * MW * NCG * 1024 * sizeof(float);
+#define GRU_LAUNCH(FCV, DR)                                                                                            \
+    {                                                                                                                  \
+        if (lds > 64 * 1024) {                                                                                         \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru<NCG, XMODE, FCV, DR, MW, BF>),   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e_ != hipSuccess) return (int)e_;                                                                      \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, FCV, DR, MW, BF>), dim3(grid), dim3(64 * WPB), lds, s, a);               \
+    }
+    if (!fc && drop == 0) GRU_LAUNCH(false, 0)
+    else if (!fc) GRU_LAUNCH(false, 1)
+    else if (drop == 0) GRU_LAUNCH(true, 0)
+    else GRU_LAUNCH(true, 1)
+#undef GRU_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }
