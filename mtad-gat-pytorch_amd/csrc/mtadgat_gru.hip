@@ -51,7 +51,11 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
     const int Qxp = (XMODE == 1) ? 1 : a.Qxp;
     constexpr int Qh = BF ? 2 * NCG : 4 * NCG;    // recurrent chunks that can be non-zero
     constexpr int Qhe = Qh - DROP;                // ... and as used
-    constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % 3 : Qhe % 3;   // ring phase advance per hidden tile
+    // ring depth: 3 chunks of weights in flight for the fp32 build (36 MFMAs x 64 cycles ~ 2.3k cycles of cover);
+    // the bf16 build needs 6 (a chunk is 3 x MW MFMAs of 32 cycles: three of them would cover < 600 cycles of an
+    // L2 round trip and the kernel waits for every chunk)
+    constexpr int R = BF ? 6 : 3;
+    constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
     constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
 
@@ -109,10 +113,11 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
         if (XMODE == 1) return cvt8(loadx_t(w, t, q), f32x4{0.f, 0.f, 0.f, 0.f});
         return cvt8(loadx_t(w, t, 2 * q), loadx_t(w, t, 2 * q + 1));
     };
-    f32x4 wr[3][3], xr[3][MW];
-    wload(wr[0]); wload(wr[1]); wload(wr[2]);
+    f32x4 wr[R][3], xr[R][MW];
 #pragma unroll
-    for (int st = 0; st < 3; ++st)
+    for (int st = 0; st < R; ++st) wload(wr[st]);
+#pragma unroll
+    for (int st = 0; st < R; ++st)
 #pragma unroll
         for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, 0, st);
 
@@ -145,14 +150,14 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
-                for (int q0 = 0; q0 < Qxp; q0 += 3) {
+                for (int q0 = 0; q0 < Qxp; q0 += R) {
 #pragma unroll
-                    for (int st = 0; st < 3; ++st) {
+                    for (int st = 0; st < R; ++st) {
 #pragma unroll
                         for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[st], xr[st][w], ar[w], az[w], anx[w]);
                         wload(wr[st]);
 #pragma unroll
-                        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, t, q0 + st + 3);
+                        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, t, q0 + st + R);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -162,7 +167,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
 #pragma unroll
             for (int q = 0; q < Qhe; ++q) {
                 constexpr int X0 = (XMODE == 1) ? 1 : 0;
-                const int st = (X0 + q) % 3;
+                const int st = (X0 + q) % R;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) {
                     f32x4 hv;
@@ -182,19 +187,23 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // bring the ring back to phase 0 for the next tile: a compile-time register renaming
-            if (ROT == 1) {
+            // bring the ring back to phase 0 for the next tile: a compile-time register renaming (rotate by ROT stages)
+            if (ROT != 0) {
+                f32x4 tmp[R][3];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) { const f32x4 t0 = wr[0][u]; wr[0][u] = wr[1][u]; wr[1][u] = wr[2][u]; wr[2][u] = t0; }
-            } else if (ROT == 2) {
+                for (int st = 0; st < R; ++st)
 #pragma unroll
-                for (int u = 0; u < 3; ++u) { const f32x4 t0 = wr[0][u]; wr[0][u] = wr[2][u]; wr[2][u] = wr[1][u]; wr[1][u] = t0; }
+                    for (int u = 0; u < 3; ++u) tmp[st][u] = wr[(st + ROT) % R][u];
+#pragma unroll
+                for (int st = 0; st < R; ++st)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) wr[st][u] = tmp[st][u];
             }
             // x chunks 0..2 of the next tile / step: their latency hides under the gate math
             {
                 const int tn = (c == NCG - 1) ? (t + 1 < T ? t + 1 : t) : t;
 #pragma unroll
-                for (int st = 0; st < 3; ++st)
+                for (int st = 0; st < R; ++st)
 #pragma unroll
                     for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, tn, st);
             }
@@ -668,6 +677,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     }
     if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
     if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
+    if (a.bf16 && a.Qxp != 1 && a.Qxp % 6 != 0) return -2;      // bf16 build of k_gru: ring of 6
     // Small batches: spread the 32-window groups over ncg waves each (k_gru_split) -- k_gru needs ~2 groups
     // per SIMD to fill the machine and leaves it mostly idle below that.  Measured on MI355X (W=100, F=55,
     // H=150, GRU + decoder): 256 windows 12.0 -> 4.9 ms, 16 k windows 12.2 -> 9.9 ms, 32 k windows 12.2 vs 19.6

@@ -169,7 +169,7 @@ std::string validate_and_plan(Model& m) {
         g.wx_off = take((size_t)g.NCG * g.Qxp * 3 * 256);
         g.wh_off = take((size_t)g.NCG * (4 * g.NCG + 2) * 3 * 256);   // 2 zero chunks per tile: k_gru_split's ring padding
         g.b_off = take((size_t)4 * g.Hp);
-        g.Qxp16 = round_up((g.Qx + 1) / 2, 3);
+        g.Qxp16 = round_up((g.Qx + 1) / 2, 6);       // whole turns of the bf16 weight ring (6 stages; k_gru_split: 3)
         g.wx16_off = take((size_t)g.NCG * g.Qxp16 * 3 * 256);
         g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
         if (l == 0) {
@@ -221,7 +221,7 @@ std::string validate_and_plan(Model& m) {
         }
         g.wh_off = take((size_t)g.NCG * (4 * g.NCG + 2) * 3 * 256);   // 2 zero chunks per tile: k_gru_split's ring padding
         g.b_off = take((size_t)4 * g.Hp);
-        g.Qxp16 = g.xmode == 1 ? (g.Qx == 1 ? 1 : round_up((g.Qx + 1) / 2, 3)) : round_up((g.Qx + 1) / 2, 3);
+        g.Qxp16 = g.xmode == 1 ? (g.Qx == 1 ? 1 : round_up((g.Qx + 1) / 2, 6)) : round_up((g.Qx + 1) / 2, 6);
         g.wx16_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 3 * 256);
         g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
     }
