@@ -140,6 +140,12 @@ int mtadgat_forward(mtadgat_handle h, const float* x_dev, int64_t batch,
                     float* preds_dev, float* recons_dev, float* hend_dev,
                     void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* mtadgat_forward with the input given as bfloat16 (batch, W, F): the convolution reads it directly, no fp32 copy
+ * of x is made (BASELINE "bf16 inference"; outputs stay float32).  MTADGAT_ERR_UNSUPPORTED for n_features beyond
+ * the LDS-staged convolution. */
+int mtadgat_forward_xbf16(mtadgat_handle h, const void* x_bf16_dev, int64_t batch, float* preds_dev, float* recons_dev,
+                          float* hend_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* Same as mtadgat_forward, with the windows gathered on the GPU from a device-resident series instead of
  * materialised by the caller: window w = series rows [s_w, s_w + W), s_w = starts_dev[w] when starts_dev is
  * not NULL, else start0 + w * stride.  Replaces SlidingWindowDataset.__getitem__ + default collate feeding

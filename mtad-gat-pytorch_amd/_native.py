@@ -67,6 +67,7 @@ def load_library():
     lib.mtadgat_chunk_windows.restype = i64
     lib.mtadgat_set_chunk_windows.argtypes = [vp, i64]
     lib.mtadgat_forward.argtypes = [vp, vp, i64, vp, vp, vp, vp, sz, vp]
+    lib.mtadgat_forward_xbf16.argtypes = [vp, vp, i64, vp, vp, vp, vp, sz, vp]
     lib.mtadgat_forward_series.argtypes = [vp, vp, i64, vp, i64, i64, i64, vp, vp, vp, vp, sz, vp]
     lib.mtadgat_conv.argtypes = [vp, vp, i64, vp, vp, sz, vp]
     lib.mtadgat_gat.argtypes = [vp, ctypes.c_int, vp, i64, vp, vp, sz, vp]
@@ -287,12 +288,18 @@ class Engine:
     def forward(self, x, want_hend=False):
         c = self.cfg
         b = x.shape[0]
-        xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
+        fn = self.lib.mtadgat_forward
+        if x.dtype == torch.bfloat16:       # read directly by the convolution: no fp32 copy of the batch
+            if x.device.type != "cuda" or not x.is_contiguous() or tuple(x.shape) != (b, c.window_size, c.n_features):
+                raise RuntimeError("bfloat16 input must be a contiguous (b, W, F) tensor on the GPU")
+            xp, fn = ctypes.c_void_p(x.data_ptr()), self.lib.mtadgat_forward_xbf16
+        else:
+            xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
         preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=x.device)
         recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=x.device)
         hend = torch.empty((b, c.gru_hid_dim), dtype=torch.float32, device=x.device) if want_hend else None
         ws, need = self._workspace(b, x.device)
-        self._call(self.lib.mtadgat_forward, "forward", x.device, xp, b, _dev_ptr(preds, "preds"),
+        self._call(fn, "forward", x.device, xp, b, _dev_ptr(preds, "preds"),
                    _dev_ptr(recons, "recons"), _dev_ptr(hend, "hend") if want_hend else None,
                    _dev_ptr(ws, "workspace"), need)
         return (preds, recons, hend) if want_hend else (preds, recons)

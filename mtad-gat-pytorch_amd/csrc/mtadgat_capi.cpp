@@ -65,6 +65,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // ---- stage launch helpers; all pointers device, n windows ------------------------------------
 // where the windows come from: a materialised (n, W, F) tensor, or views of a device-resident series
 struct XSource {
+    int x_bf16 = 0;                  // x points at bfloat16 elements
     const float* x = nullptr;        // windows (n, W, F) -- or the series when gather != 0
     int gather = 0;
     const int64_t* starts = nullptr;
@@ -78,9 +79,12 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
         a.X = src.x; a.gather = 1;
         a.starts = src.starts ? reinterpret_cast<const long*>(src.starts + c0) : nullptr;
         a.start0 = src.start0 + c0 * src.stride; a.stride = src.stride;
+    } else if (src.x_bf16) {
+        a.X = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(src.x) + c0 * (int64_t)m.W * m.F);
     } else {
         a.X = src.x + c0 * (int64_t)m.W * m.F;
     }
+    a.x_bf16 = src.x_bf16;
     a.B = n; a.W = m.W; a.F = m.F; a.Fp = m.Fp; a.taps = m.taps; a.pad = m.pad;
     a.Fq = m.Fp;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w_off);
@@ -492,6 +496,16 @@ int mtadgat_forward(mtadgat_handle h, const float* x, int64_t batch, float* pred
                     void* ws_, size_t ws_bytes, void* stream) {
     XSource src;
     src.x = x;
+    return forward_impl(h, src, batch, preds, recons, nullptr, hend_out, ws_, ws_bytes, stream);
+}
+
+int mtadgat_forward_xbf16(mtadgat_handle h, const void* x_bf16, int64_t batch, float* preds, float* recons, float* hend_out,
+                          void* ws_, size_t ws_bytes, void* stream) {
+    if (h && (size_t)(32 + h->m.taps - 1) * (std::max(h->m.Fp, h->m.Fp16) + 4) * sizeof(float) > 20 * 1024)
+        return fail(MTADGAT_ERR_UNSUPPORTED, "bfloat16 input is read by the LDS-staged convolution only (n_features too large): pass float32");
+    XSource src;
+    src.x = static_cast<const float*>(x_bf16);
+    src.x_bf16 = 1;
     return forward_impl(h, src, batch, preds, recons, nullptr, hend_out, ws_, ws_bytes, stream);
 }
 

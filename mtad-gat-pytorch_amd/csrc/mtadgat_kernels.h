@@ -59,6 +59,7 @@ struct ConvArgs {
     int W, F, Fp, taps, pad;
     int Fq;              // channel count the MFMA chunks run over: Fp (fp32 build), F rounded up to 16 (bf16 build)
     int bf16;            // 1: Wp is the bf16 pack (k_conv_lds only)
+    int x_bf16;          // 1: X holds bfloat16 (read directly by k_conv_lds; no fp32 copy of the input exists)
     const f32x4* Wp;     // packed (F x taps*Fq), NT tiles, Q = taps*Fq/8 (bf16: /16)
     const float* bias;   // NT*32
     int NT;

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
         gw = f0 / a.W;
         gt = (int)(f0 - gw * a.W);
     }
-    auto src_row = [&](int rr, bool& ok) -> const float* {
+    // element offset of the source row (the input is fp32, or -- x_bf16 -- bfloat16 read directly: no cast pass over x)
+    auto src_row = [&](int rr, bool& ok) -> long {
         const long flat = r0 - a.pad + rr;
         ok = flat >= 0 && flat < R;
         long srow = ok ? flat : 0;
@@ -248,7 +249,12 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
             srow = s0 + gt;
             if (flat >= 0 && ++gt == a.W) { gt = 0; ++gw; }      // rows are visited in increasing order, once each
         }
-        return a.X + srow * a.F;
+        return srow * a.F;
+    };
+    const unsigned short* __restrict__ Xh = reinterpret_cast<const unsigned short*>(a.X);
+    auto xload = [&](long off) -> float {
+        if (a.x_bf16) return __builtin_bit_cast(float, (unsigned)Xh[off] << 16);
+        return a.X[off];
     };
     if (a.F <= 64 && Fld <= 128) {
         // one element per lane and row; every load is unconditional (clamped column, a valid row for rows
@@ -262,8 +268,8 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
             v[rr] = 0.f;
             if (rr < nrow) {                              // wave-uniform
                 bool ok;
-                const float* __restrict__ src = src_row(rr, ok);
-                const float t = src[colc];
+                const long src = src_row(rr, ok);
+                const float t = xload(src + colc);
                 v[rr] = (ok && lane < a.F) ? t : 0.f;
             }
         }
@@ -275,15 +281,15 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
             }
         for (int rr = MAXR; rr < nrow; ++rr) {
             bool ok;
-            const float* __restrict__ src = src_row(rr, ok);
-            if (lane < Fld) xs[rr * Fld + lane] = (ok && lane < a.F) ? src[lane] : 0.f;
+            const long src = src_row(rr, ok);
+            if (lane < Fld) xs[rr * Fld + lane] = (ok && lane < a.F) ? xload(src + lane) : 0.f;
             if (lane + 64 < Fld) xs[rr * Fld + lane + 64] = 0.f;
         }
     } else {
         for (int rr = 0; rr < nrow; ++rr) {
             bool ok;
-            const float* __restrict__ src = src_row(rr, ok);
-            for (int col = lane; col < Fld; col += 64) xs[rr * Fld + col] = (ok && col < a.F) ? src[col] : 0.f;
+            const long src = src_row(rr, ok);
+            for (int col = lane; col < Fld; col += 64) xs[rr * Fld + col] = (ok && col < a.F) ? xload(src + col) : 0.f;
         }
     }
     __syncthreads();
@@ -428,9 +434,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     if (R <= 0) return 0;
     const unsigned grid = (unsigned)((R + 31) / 32);
     const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fq + 4) * sizeof(float);
-    if (a.bf16 && lds > 20 * 1024) return -2;
+    if ((a.bf16 || a.x_bf16) && lds > 20 * 1024) return -2;
     static const size_t lds_max = std::getenv("MTADGAT_CONV_LDS_MAX") ? (size_t)atol(std::getenv("MTADGAT_CONV_LDS_MAX")) : 20 * 1024;
-    if (lds <= lds_max || a.bf16) {       // >= 8 waves per CU keep their tile in LDS
+    if (lds <= lds_max || a.bf16 || a.x_bf16) {       // >= 8 waves per CU keep their tile in LDS
         if (lds > 64 * 1024) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

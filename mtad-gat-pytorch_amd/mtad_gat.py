@@ -348,7 +348,10 @@ class MTAD_GAT(nn.Module):
             preds, recons = _hipgrad.forward(self, eng, x)
         else:
             with torch.no_grad():
-                preds, recons = eng.forward(x.contiguous().float())
+                # bfloat16 batches go to the kernels as they are (the convolution converts while staging) when the
+                # LDS-staged convolution applies; everything else is handed over as float32
+                direct = x.dtype == torch.bfloat16 and self.n_features <= 64 and self.conv.kernel_size <= 31
+                preds, recons = eng.forward(x.contiguous() if direct else x.contiguous().float())
         if x.dtype in (torch.bfloat16, torch.float16):
             # reduced-precision I/O (BASELINE config "bf16 inference"): results in the caller's dtype
             return preds.to(x.dtype), recons.to(x.dtype)
