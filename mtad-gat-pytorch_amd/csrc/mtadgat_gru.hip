@@ -33,7 +33,11 @@ namespace mtadgat {
 // keeps them within a few chunks of each other, so the packed-weight chunks one wave pulls from L2 are still in the
 // CU's vector L1 when the other three ask for them (as separate one-wave workgroups they drift apart and every wave
 // streams the whole 1.9 MB / 1 MB image from L2 each step).
-template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false>
+// QXC > 0 (bf16 build, row input): the QXC packed input chunks of a step stay in registers for all hidden tiles and
+// are replaced by the next step's while the last tile consumes them -- read once per step instead of once per tile.
+// With the MFMAs 16x cheaper the five re-reads of x (5 x 67 KB per window: they miss the L2, the XCD's waves stream
+// more than its 4 MB between two tiles) made the bf16 build HBM-bound at ~4 TB/s.
+template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false, int QXC = 0>
 __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float hn_dyn[];
     constexpr int WPB = MW == 2 ? 4 : 1;
@@ -48,13 +52,14 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
         winc[w] = win[w] < a.B ? win[w] : a.B - 1;
     }
     const int T = a.T, Qx = a.Qx;
-    const int Qxp = (XMODE == 1) ? 1 : a.Qxp;
+    const int Qxp = (XMODE == 1) ? 1 : ((BF && XMODE == 0 && QXC > 0) ? QXC : a.Qxp);
     constexpr int Qh = BF ? 2 * NCG : 4 * NCG;    // recurrent chunks that can be non-zero
     constexpr int Qhe = Qh - DROP;                // ... and as used
     // ring depth: 3 chunks of weights in flight for the fp32 build (36 MFMAs x 64 cycles ~ 2.3k cycles of cover);
     // the bf16 build needs 6 (a chunk is 3 x MW MFMAs of 32 cycles: three of them would cover < 600 cycles of an
     // L2 round trip and the kernel waits for every chunk)
-    constexpr int R = BF ? 6 : 3;
+    constexpr bool XR = BF && XMODE == 0 && QXC > 0;
+    constexpr int R = (BF && !XR) ? 6 : 3;
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
     constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
@@ -113,16 +118,18 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
         if (XMODE == 1) return cvt8(loadx_t(w, t, q), f32x4{0.f, 0.f, 0.f, 0.f});
         return cvt8(loadx_t(w, t, 2 * q), loadx_t(w, t, 2 * q + 1));
     };
-    f32x4 wr[R][3], xr[R][MW];
+    constexpr int NXR = XR ? QXC : R;               // input operand registers: the whole step (XR) or the ring
+    f32x4 wr[R][3], xr[NXR][MW];
 #pragma unroll
     for (int st = 0; st < R; ++st) wload(wr[st]);
 #pragma unroll
-    for (int st = 0; st < R; ++st)
+    for (int st = 0; st < NXR; ++st)
 #pragma unroll
         for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, 0, st);
 
     for (int t = 0; t < T; ++t) {
-        for (int c = 0; c < NCG; ++c) {
+        auto tile_body = [&](const int c, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
             f32x16 ar[MW], az[MW], anx[MW], anh[MW];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -149,6 +156,21 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
                 for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[0], xr[0][w], ar[w], az[w], anx[w]);
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
+            } else if (XR) {
+                const int tnx = t + 1 < T ? t + 1 : t;
+#pragma unroll
+                for (int q = 0; q < NXR; ++q) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int st = q % R;
+#pragma unroll
+                    for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[st], xr[q][w], ar[w], az[w], anx[w]);
+                    wload(wr[st]);
+                    if (LAST) {                       // compile-time: only the last tile's code carries these loads
+#pragma unroll
+                        for (int w = 0; w < MW; ++w) xr[q][w] = loadxq(w, tnx, q);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
                 for (int q0 = 0; q0 < Qxp; q0 += R) {
 #pragma unroll
@@ -200,8 +222,8 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
                     for (int u = 0; u < 3; ++u) wr[st][u] = tmp[st][u];
             }
             // x chunks 0..2 of the next tile / step: their latency hides under the gate math
-            {
-                const int tn = (c == NCG - 1) ? (t + 1 < T ? t + 1 : t) : t;
+            if (!XR) {
+                const int tn = LAST ? (t + 1 < T ? t + 1 : t) : t;
 #pragma unroll
                 for (int st = 0; st < R; ++st)
 #pragma unroll
@@ -222,7 +244,9 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hn_s[w][c][r][lane] = ar[w][r];
             }
-        }
+        };
+        for (int c = 0; c + 1 < NCG; ++c) tile_body(c, std::false_type{});
+        tile_body(NCG - 1, std::true_type{});
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < MW; ++w)
@@ -611,11 +635,30 @@ static int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
         }                                                                                                              \
         hipLaunchKernelGGL((k_gru<NCG, XMODE, FCV, DR, MW, BF>), dim3(grid), dim3(64 * WPB), lds, s, a);               \
     }
+#define GRU_LAUNCH_XR(DR, QX)                                                                                          \
+    {                                                                                                                  \
+        if (lds > 64 * 1024) {                                                                                         \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru<NCG, 0, false, DR, 2, true, QX>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+            if (e_ != hipSuccess) return (int)e_;                                                                      \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_gru<NCG, 0, false, DR, 2, true, QX>), dim3(grid), dim3(64 * WPB), lds, s, a);            \
+    }
+    if constexpr (BF && XMODE == 0 && MW == 2 && NCG <= 5) {
+        static const bool stream_x = std::getenv("MTADGAT_GRU_STREAM_X") != nullptr;      // A/B switch
+        if (!fc && !stream_x && (a.Qxp == 6 || a.Qxp == 12)) {
+            if (a.Qxp == 6) { if (drop == 0) GRU_LAUNCH_XR(0, 6) else GRU_LAUNCH_XR(1, 6) }
+            else { if (drop == 0) GRU_LAUNCH_XR(0, 12) else GRU_LAUNCH_XR(1, 12) }
+            LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (!fc && drop == 0) GRU_LAUNCH(false, 0)
     else if (!fc) GRU_LAUNCH(false, 1)
     else if (drop == 0) GRU_LAUNCH(true, 0)
     else GRU_LAUNCH(true, 1)
 #undef GRU_LAUNCH
+#undef GRU_LAUNCH_XR
     LAUNCH_CHECK();
     return 0;
 }
