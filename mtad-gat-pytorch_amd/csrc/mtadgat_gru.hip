@@ -55,11 +55,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
     const int Qxp = (XMODE == 1) ? 1 : ((BF && XMODE == 0 && QXC > 0) ? QXC : a.Qxp);
     constexpr int Qh = BF ? 2 * NCG : 4 * NCG;    // recurrent chunks that can be non-zero
     constexpr int Qhe = Qh - DROP;                // ... and as used
-    // ring depth: 3 chunks of weights in flight for the fp32 build (36 MFMAs x 64 cycles ~ 2.3k cycles of cover);
-    // the bf16 build needs 6 (a chunk is 3 x MW MFMAs of 32 cycles: three of them would cover < 600 cycles of an
-    // L2 round trip and the kernel waits for every chunk)
+    // ring depth: 3 chunks of weights in flight (fp32: 36 MFMAs x 64 cycles ~ 2.3k cycles of cover).  A ring of 6 was
+    // tried for the bf16 build, whose chunks are 8x shorter: no gain -- that build was bound by the input re-reads (XR)
     constexpr bool XR = BF && XMODE == 0 && QXC > 0;
-    constexpr int R = (BF && !XR) ? 6 : 3;
+    constexpr int R = 3;
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
     constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
@@ -720,7 +719,6 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     }
     if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
     if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
-    if (a.bf16 && a.Qxp != 1 && a.Qxp % 6 != 0) return -2;      // bf16 build of k_gru: ring of 6
     // Small batches: spread the 32-window groups over ncg waves each (k_gru_split) -- k_gru needs ~2 groups
     // per SIMD to fill the machine and leaves it mostly idle below that.  Measured on MI355X (W=100, F=55,
     // H=150, GRU + decoder): 256 windows 12.0 -> 4.9 ms, 16 k windows 12.2 -> 9.9 ms, 32 k windows 12.2 vs 19.6
