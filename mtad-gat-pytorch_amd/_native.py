@@ -10,7 +10,7 @@ import os
 import torch  # must be imported before the library: both bind libamdhip64.so.7, torch's copy wins
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmtadgat.so")
+_LIB_PATH = os.environ.get("MTADGAT_LIB") or os.path.join(_HERE, "libmtadgat.so")      # MTADGAT_LIB: A/B builds of the library
 MAX_LAYERS = 8
 PROFILE_SLOTS = 6
 

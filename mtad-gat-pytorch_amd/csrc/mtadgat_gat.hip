@@ -95,6 +95,25 @@ __device__ __forceinline__ void gat_tile(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Experiment switch (-DMTADGAT_GAT_LEAN=1, with -DMTADGAT_GAT_MINW=6 -DMTADGAT_GAT_QB=4): one register set for the
+// pair loads instead of two -- ~25 fewer VGPRs, so that three 8-wave workgroups fit a CU and the other waves of
+// the SIMD, not a second register set, cover the LDS latency.
+#ifndef MTADGAT_GAT_LEAN
+#define MTADGAT_GAT_LEAN 0
+#endif
+#if MTADGAT_GAT_LEAN
+template <int IBL, int JPL, int RJ, bool NEG>
+__device__ __forceinline__ void gat_tile_lean(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
+#pragma unroll
+    for (int st = 1; st <= 4; ++st) {
+        gat_step<IBL, JPL, NEG>(acc, lA, rA);
+        __builtin_amdgcn_sched_barrier(0);
+        gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 2 * st);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+#endif
+
 // all-reduce over the RJ (16 or 8) adjacent lanes that hold one query row
 template <int RJ>
 __device__ __forceinline__ float row_max(float v) {
@@ -125,7 +144,10 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
     constexpr int IBW = RI * IBL;                      // query rows per wave
-    constexpr int QB = 8;                              // weight chunks held in registers per task batch
+#ifndef MTADGAT_GAT_QB
+#define MTADGAT_GAT_QB 8
+#endif
+    constexpr int QB = MTADGAT_GAT_QB;                 // weight chunks held in registers per task batch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
@@ -311,14 +333,22 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
             // keeps two register copies of the accumulators (and spills)
 #pragma unroll 1
             for (; kt < npos; ++kt) {
+#if MTADGAT_GAT_LEAN
+                gat_tile_lean<IBL, JPL, RJ, false>(acc, lA, rA, lq, rq);
+#else
                 gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
+#endif
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                 rq += 8;
             }
 #pragma unroll 1
             for (; kt < ntl; ++kt) {
+#if MTADGAT_GAT_LEAN
+                gat_tile_lean<IBL, JPL, RJ, true>(acc, lA, rA, lq, rq);
+#else
                 gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
+#endif
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                 rq += 8;

@@ -1,353 +1,11 @@
-// k_gru / k_gru_split: GRU layer and reconstruction decoder + launchers
+// k_gru_split (hidden-tile-split recurrence for small batches and the training forward) + the GRU launchers;
+// k_gru itself lives in mtadgat_gru_impl.h / mtadgat_gru_{f32,bf16}.hip
 #include "mtadgat_device.h"
 
 namespace mtadgat {
 
-// ---------------------------------------------------------------------------
-// GRU: 32 (MW = 1) or 64 (MW = 2) windows per wave, hidden state resident in registers in F-layout for
-// all T steps; W_ih / W_hh streamed from L2 in packed order; gates r|z|n as
-// torch.nn.GRU (reference GRULayer.forward modules.py:235-238, RNNDecoder
-// modules.py:255-257).  Optional per-step Linear on the new hidden state
-// (ReconstructionModel.fc, modules.py:282).
-//   XMODE 0: input rows from memory, X[(win*T + t)*ldx + k]
-//   XMODE 1: the reference's decoder input h_end.repeat_interleave(W).view(b,W,-1)
-//            (modules.py:279): x_t[j] = hin[(t*Hin + j) / T]; only NM <= 8*Qx distinct
-//            hin entries m0[t] .. m0[t]+NM-1 occur at step t, and the packed "Wx" for
-//            step t holds W_ih summed over the j that map to each of them.
-// ---------------------------------------------------------------------------
-// XMODE 0: input rows X[(win*T + t)*ldx + k], packed x part has Qxp = 3n chunks (zero chunks past Qx)
-// XMODE 1: decoder input (see above) with exactly one 8-wide chunk per step (NM <= 8)
-// XMODE 2: decoder input with Qxp = 3n chunks
-// DROP   : trailing all-padding chunks of the recurrent part that are skipped (H <= 8*(4*NCG - DROP))
-// Input rows must be 16-byte aligned (XMODE 0) and zero padded as far as the loads reach; every load
-// in the loop nest is unconditional and the nest has no data-dependent control flow, so the compiler
-// can count the outstanding loads exactly and waits with vmcnt(N > 0): the weight ring stays full.
-// (With guarded loads it fell back to vmcnt(0..2) before every MFMA group: 79k instead of 31k cycles
-// per hidden tile and step.)
-// MW = 32-window groups per wave.  MW = 2 with one wave per SIMD beats two MW = 1 waves per SIMD (matrix
-// pipe 85 % vs 82 % busy on the GRU layer, 74 % vs 69 % on the decoder): the MFMAs of one wave issue back to back, interleaving two
-// waves leaves bubbles; each weight chunk is also fetched once for 64 windows.
-// BF: bf16 operand build (v_mfma_f32_32x32x16_bf16, 16 features per chunk; fp32 accumulators, state and gates):
-// the same chunk sequence with half as many, twice as wide chunks -- see mtadgat_device.h for the element order.
-// MW = 2 launches 4 such waves per workgroup (one per SIMD): they are independent except that the per-step barrier
-// keeps them within a few chunks of each other, so the packed-weight chunks one wave pulls from L2 are still in the
-// CU's vector L1 when the other three ask for them (as separate one-wave workgroups they drift apart and every wave
-// streams the whole 1.9 MB / 1 MB image from L2 each step).
-// QXC > 0 (bf16 build, row input): the QXC packed input chunks of a step stay in registers for all hidden tiles and
-// are replaced by the next step's while the last tile consumes them -- read once per step instead of once per tile.
-// With the MFMAs 16x cheaper the five re-reads of x (5 x 67 KB per window: they miss the L2, the XCD's waves stream
-// more than its 4 MB between two tiles) made the bf16 build HBM-bound at ~4 TB/s.
-template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false, int QXC = 0>
-__global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float hn_dyn[];
-    constexpr int WPB = MW == 2 ? 4 : 1;
-    const int lane = threadIdx.x & 63;
-    const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float (*hn_s)[NCG][16][64] = reinterpret_cast<float (*)[NCG][16][64]>(hn_dyn + (size_t)wv * MW * NCG * 1024);
-    const int i = lane & 31, g = lane >> 5;
-    long win[MW], winc[MW];
-#pragma unroll
-    for (int w = 0; w < MW; ++w) {
-        win[w] = (((long)blockIdx.x * WPB + wv) * MW + w) * 32 + i;
-        winc[w] = win[w] < a.B ? win[w] : a.B - 1;
-    }
-    const int T = a.T, Qx = a.Qx;
-    const int Qxp = (XMODE == 1) ? 1 : ((BF && XMODE == 0 && QXC > 0) ? QXC : a.Qxp);
-    constexpr int Qh = BF ? 2 * NCG : 4 * NCG;    // recurrent chunks that can be non-zero
-    constexpr int Qhe = Qh - DROP;                // ... and as used
-    // ring depth: 3 chunks of weights in flight (fp32: 36 MFMAs x 64 cycles ~ 2.3k cycles of cover).  A ring of 6 was
-    // tried for the bf16 build, whose chunks are 8x shorter: no gain -- that build was bound by the input re-reads (XR)
-    constexpr bool XR = BF && XMODE == 0 && QXC > 0;
-    constexpr int R = 3;
-    constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
-    constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
-    const int S = Qxp + Qhe;
-
-    f32x16 h[MW][NCG];
-#pragma unroll
-    for (int w = 0; w < MW; ++w)
-#pragma unroll
-        for (int c = 0; c < NCG; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[w][c][r] = 0.f;
-
-    // ---- weight stream: one continuous sequence of chunks [tile c][x chunks 0..Qxp) [h chunks 0..Qhe)
-    // per step, fetched through a 3-stage register ring that never drains: the cursor runs 3 chunks
-    // (36 MFMAs ~ 2.3k cycles) ahead of the MFMAs across the x/h, tile and step boundaries.
-    // (A variant with per-tile base pointers + compile-time offsets instead of the cursor needed ~20 more
-    // VGPRs and measured slower.)
-    // prefetch cursor: wave-uniform running pointers into the two packed streams (they stay in SGPRs; the
-    // per-lane part of every weight address is the constant lane*16 bytes), advanced by one chunk per fetch
-    int pc = 0, ps = 0, pt = 0;
-    const f32x4* __restrict__ pwx = a.Wx;          // next input-part chunk to fetch
-    const f32x4* __restrict__ pwh = a.Wh;          // next recurrent-part chunk to fetch
-    auto wload = [&](f32x4 (&dst)[3]) {
-        const bool isx = ps < Qxp;
-        const f32x4* __restrict__ p = (isx ? pwx : pwh) + lane;
-        dst[0] = p[0]; dst[1] = p[64]; dst[2] = p[128];
-        pwx += isx ? 192 : 0;
-        pwh += isx ? 0 : 192;
-        const bool ws = (ps + 1 == S);             // end of this tile's chunk sequence
-        ps = ws ? 0 : ps + 1;
-        pwh += ws ? (a.whs - Qhe) * 192 : 0;       // skip the unused all-padding chunks of the tile
-        const bool wc = ws && (pc + 1 == NCG);     // end of the step
-        pc = ws ? (wc ? 0 : pc + 1) : pc;
-        pt = wc ? pt + 1 : pt;
-        pwh = wc ? a.Wh : pwh;
-        // input-part weights: per step for the decoder ([t][c][Qxp], contiguous), shared by all steps otherwise
-        pwx = wc ? ((XMODE == 0 || pt >= T) ? a.Wx : pwx) : pwx;
-    };
-    const float* xbase[MW];
-#pragma unroll
-    for (int w = 0; w < MW; ++w) xbase[w] = (XMODE == 0) ? a.X + winc[w] * T * a.ldx + 4 * g : a.X + winc[w] * a.ldx;
-    auto loadx_t = [&](int w, int t, int q) -> f32x4 {
-        const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
-        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase[w] + (long)t * a.ldx + 8 * qq);
-        const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
-        f32x4 v;
-        v[0] = xbase[w][min(k0, kmax)]; v[1] = xbase[w][min(k0 + 1, kmax)];
-        v[2] = xbase[w][min(k0 + 2, kmax)]; v[3] = xbase[w][min(k0 + 3, kmax)];
-        return v;
-    };
-
-    // B operand of packed input chunk q: fp32 build = the 8-feature chunk itself; bf16 build = chunks 2q, 2q+1 converted
-    // (XMODE 1: the single folded chunk, upper half zero)
-    auto loadxq = [&](int w, int t, int q) -> f32x4 {
-        if (!BF) return loadx_t(w, t, q);
-        if (XMODE == 1) return cvt8(loadx_t(w, t, q), f32x4{0.f, 0.f, 0.f, 0.f});
-        return cvt8(loadx_t(w, t, 2 * q), loadx_t(w, t, 2 * q + 1));
-    };
-    constexpr int NXR = XR ? QXC : R;               // input operand registers: the whole step (XR) or the ring
-    f32x4 wr[R][3], xr[NXR][MW];
-#pragma unroll
-    for (int st = 0; st < R; ++st) wload(wr[st]);
-#pragma unroll
-    for (int st = 0; st < NXR; ++st)
-#pragma unroll
-        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, 0, st);
-
-    for (int t = 0; t < T; ++t) {
-        auto tile_body = [&](const int c, auto last_tag) {
-            constexpr bool LAST = decltype(last_tag)::value;
-            f32x16 ar[MW], az[MW], anx[MW], anh[MW];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int col = 32 * c + 8 * m + 4 * g;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + col);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + a.Hp + col);
-                const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias + 2 * a.Hp + col);
-                const f32x4 b3 = *reinterpret_cast<const f32x4*>(a.bias + 3 * a.Hp + col);
-#pragma unroll
-                for (int w = 0; w < MW; ++w)
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        ar[w][4 * m + s4] = b0[s4];
-                        az[w][4 * m + s4] = b1[s4];
-                        anx[w][4 * m + s4] = b2[s4];
-                        anh[w][4 * m + s4] = b3[s4];
-                    }
-            }
-            // ---- input part: W_i{r,z,n} x_t.  sched_barrier pins "MFMAs of chunk j, then the loads that
-            // refill its ring stage": left alone the scheduler sinks all loads of an iteration below its
-            // MFMAs and the next iteration waits for them.
-            if (XMODE == 1) {
-#pragma unroll
-                for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[0], xr[0][w], ar[w], az[w], anx[w]);
-                wload(wr[0]);
-                __builtin_amdgcn_sched_barrier(0);
-            } else if (XR) {
-                const int tnx = t + 1 < T ? t + 1 : t;
-#pragma unroll
-                for (int q = 0; q < NXR; ++q) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int st = q % R;
-#pragma unroll
-                    for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[st], xr[q][w], ar[w], az[w], anx[w]);
-                    wload(wr[st]);
-                    if (LAST) {                       // compile-time: only the last tile's code carries these loads
-#pragma unroll
-                        for (int w = 0; w < MW; ++w) xr[q][w] = loadxq(w, tnx, q);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                for (int q0 = 0; q0 < Qxp; q0 += R) {
-#pragma unroll
-                    for (int st = 0; st < R; ++st) {
-#pragma unroll
-                        for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[st], xr[st][w], ar[w], az[w], anx[w]);
-                        wload(wr[st]);
-#pragma unroll
-                        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, t, q0 + st + R);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            // ---- recurrent part: W_h{r,z,n} h_{t-1}  (h_0 = 0 contributes nothing at t = 0; kept so the
-            // weight stream stays continuous).  Ring stage of h chunk q is static: (x chunks + q) % 3.
-#pragma unroll
-            for (int q = 0; q < Qhe; ++q) {
-                constexpr int X0 = (XMODE == 1) ? 1 : 0;
-                const int st = (X0 + q) % R;
-#pragma unroll
-                for (int w = 0; w < MW; ++w) {
-                    f32x4 hv;
-                    if (BF) {
-                        const int cq = q >> 1, e0 = 8 * (q & 1);
-                        f32x4 lo, hi;
-                        lo[0] = h[w][cq][e0 + 0]; lo[1] = h[w][cq][e0 + 1]; lo[2] = h[w][cq][e0 + 2]; lo[3] = h[w][cq][e0 + 3];
-                        hi[0] = h[w][cq][e0 + 4]; hi[1] = h[w][cq][e0 + 5]; hi[2] = h[w][cq][e0 + 6]; hi[3] = h[w][cq][e0 + 7];
-                        hv = cvt8(lo, hi);
-                    } else {
-                        const int cq = q >> 2, m = q & 3;
-                        hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
-                        hv[2] = h[w][cq][4 * m + 2]; hv[3] = h[w][cq][4 * m + 3];
-                    }
-                    mfma_x3<BF>(wr[st], hv, ar[w], az[w], anh[w]);
-                }
-                wload(wr[st]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // bring the ring back to phase 0 for the next tile: a compile-time register renaming (rotate by ROT stages)
-            if (ROT != 0) {
-                f32x4 tmp[R][3];
-#pragma unroll
-                for (int st = 0; st < R; ++st)
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) tmp[st][u] = wr[(st + ROT) % R][u];
-#pragma unroll
-                for (int st = 0; st < R; ++st)
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) wr[st][u] = tmp[st][u];
-            }
-            // x chunks 0..2 of the next tile / step: their latency hides under the gate math
-            if (!XR) {
-                const int tn = LAST ? (t + 1 < T ? t + 1 : t) : t;
-#pragma unroll
-                for (int st = 0; st < R; ++st)
-#pragma unroll
-                    for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, tn, st);
-            }
-            // ---- gates.  h_old for this tile comes back from LDS (written at the end of step t-1);
-            // every lane reads and writes only its own slots -> no cross-lane hazard
-#pragma unroll
-            for (int w = 0; w < MW; ++w) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float hold = (t > 0) ? hn_s[w][c][r][lane] : 0.f;
-                    const float rg = gate_sigmoid(ar[w][r]);
-                    const float zg = gate_sigmoid(az[w][r]);
-                    const float ng = gate_tanh(anx[w][r] + rg * anh[w][r]);
-                    ar[w][r] = __builtin_fmaf(zg, hold - ng, ng);          // (1 - z) n + z h
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hn_s[w][c][r][lane] = ar[w][r];
-            }
-        };
-        for (int c = 0; c + 1 < NCG; ++c) tile_body(c, std::false_type{});
-        tile_body(NCG - 1, std::true_type{});
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < MW; ++w)
-#pragma unroll
-            for (int c = 0; c < NCG; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h[w][c][r] = hn_s[w][c][r][lane];
-
-#pragma unroll
-        for (int w = 0; w < MW; ++w) {
-            if (a.Seq && win[w] < a.B) {
-                float* sp = a.Seq + (win[w] * T + t) * a.ldseq;
-#pragma unroll
-                for (int c = 0; c < NCG; ++c)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        f32x4 v;
-                        v[0] = h[w][c][4 * m + 0]; v[1] = h[w][c][4 * m + 1]; v[2] = h[w][c][4 * m + 2]; v[3] = h[w][c][4 * m + 3];
-                        *reinterpret_cast<f32x4*>(sp + 32 * c + 8 * m + 4 * g) = v;
-                    }
-            }
-            if (FC && (a.Yfc != nullptr || t == T - 1) && a.out_dim <= 4) {
-                // few outputs (target dims of MSL / SMAP: 1): a 32-output MFMA tile per step would cost 4*Qhe
-                // matrix instructions for one useful column.  Dot products on the VALU instead: lane (i, g)
-                // covers its 16 features of every tile, the two halves meet through one cross-lane add.
-                const f32x4* __restrict__ wf = a.Wfc;         // tile 0: [Qh][64 lanes][4], lane (o, g) = W[o][8q + 4g + s]
-                float* yp = (a.Yfc && win[w] < a.B) ? a.Yfc + (win[w] * T + t) * (long)a.out_dim : nullptr;
-                float* yl = (a.Ylast && t == T - 1 && win[w] < a.B) ? a.Ylast + win[w] * (long)a.out_dim : nullptr;
-                for (int o = 0; o < a.out_dim; ++o) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int q = 0; q < Qf; ++q) {
-                        const int cq = q >> 2, m = q & 3;
-                        const f32x4 wv = wf[q * 64 + o + 32 * g];
-                        acc += wv[0] * h[w][cq][4 * m + 0] + wv[1] * h[w][cq][4 * m + 1] + wv[2] * h[w][cq][4 * m + 2] + wv[3] * h[w][cq][4 * m + 3];
-                    }
-                    acc += __shfl_xor(acc, 32);
-                    const float y = acc + a.bfc[o];
-                    if (g == 0) {
-                        if (yp) yp[o] = y;
-                        if (yl) yl[o] = y;
-                    }
-                }
-            } else if (FC && (a.Yfc != nullptr || t == T - 1)) {
-                for (int n = 0; n < a.NTfc; ++n) {
-                    f32x16 y;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bfc + 32 * n + 8 * m + 4 * g);
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) y[4 * m + s4] = bv[s4];
-                    }
-                    const f32x4* __restrict__ wp = a.Wfc + ((long)n * (4 * NCG)) * 64 + lane;
-#pragma unroll
-                    for (int q = 0; q < Qf; ++q) {
-                        const int cq = q >> 2, m = q & 3;
-                        f32x4 hv;
-                        hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
-                        hv[2] = h[w][cq][4 * m + 2]; hv[3] = h[w][cq][4 * m + 3];
-                        y = mfma4(wp[q * 64], hv, y);
-                    }
-                    if (win[w] < a.B) {
-                        float* yp = a.Yfc ? a.Yfc + (win[w] * T + t) * (long)a.out_dim : nullptr;
-                        float* yl = (a.Ylast && t == T - 1) ? a.Ylast + win[w] * (long)a.out_dim : nullptr;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int o = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * g;
-                            if (o < a.out_dim) {
-                                if (yp) yp[o] = y[r];
-                                if (yl) yl[o] = y[r];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < MW; ++w) {
-        if (a.Hend && win[w] < a.B) {
-            float* hp = a.Hend + win[w] * a.ldhe;
-            if (a.ldhe >= a.Hp) {        // internal buffer: all Hp columns (the padding lanes of h are exact zeros)
-#pragma unroll
-                for (int c = 0; c < NCG; ++c)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        f32x4 v;
-                        v[0] = h[w][c][4 * m + 0]; v[1] = h[w][c][4 * m + 1]; v[2] = h[w][c][4 * m + 2]; v[3] = h[w][c][4 * m + 3];
-                        *reinterpret_cast<f32x4*>(hp + 32 * c + 8 * m + 4 * g) = v;
-                    }
-            } else {
-#pragma unroll
-                for (int c = 0; c < NCG; ++c)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * g;
-                        if (j < a.H) hp[j] = h[w][c][r];
-                    }
-            }
-        }
-    }
-}
+int launch_gru_big_f32(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
+int launch_gru_big_bf16(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // GRU, hidden-tile split: a workgroup owns 32 windows, wave c the 32 hidden units of tile c (all three
@@ -620,64 +278,6 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
     }
 }
 
-template <int NCG, int XMODE, int MW, bool BF>
-static int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
-    constexpr int WPB = MW == 2 ? 4 : 1;
-    const unsigned grid = (unsigned)((a.B + 32 * MW * WPB - 1) / (32 * MW * WPB));
-    const size_t lds = (size_t)WPB * MW * NCG * 1024 * sizeof(float);
-#define GRU_LAUNCH(FCV, DR)                                                                                            \
-    {                                                                                                                  \
-        if (lds > 64 * 1024) {                                                                                         \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru<NCG, XMODE, FCV, DR, MW, BF>),   \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-            if (e_ != hipSuccess) return (int)e_;                                                                      \
-        }                                                                                                              \
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, FCV, DR, MW, BF>), dim3(grid), dim3(64 * WPB), lds, s, a);               \
-    }
-#define GRU_LAUNCH_XR(DR, QX)                                                                                          \
-    {                                                                                                                  \
-        if (lds > 64 * 1024) {                                                                                         \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru<NCG, 0, false, DR, 2, true, QX>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-            if (e_ != hipSuccess) return (int)e_;                                                                      \
-        }                                                                                                              \
-        hipLaunchKernelGGL((k_gru<NCG, 0, false, DR, 2, true, QX>), dim3(grid), dim3(64 * WPB), lds, s, a);            \
-    }
-    if constexpr (BF && XMODE == 0 && MW == 2 && NCG <= 5) {
-        static const bool stream_x = std::getenv("MTADGAT_GRU_STREAM_X") != nullptr;      // A/B switch
-        if (!fc && !stream_x && (a.Qxp == 6 || a.Qxp == 12)) {
-            if (a.Qxp == 6) { if (drop == 0) GRU_LAUNCH_XR(0, 6) else GRU_LAUNCH_XR(1, 6) }
-            else { if (drop == 0) GRU_LAUNCH_XR(0, 12) else GRU_LAUNCH_XR(1, 12) }
-            LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    if (!fc && drop == 0) GRU_LAUNCH(false, 0)
-    else if (!fc) GRU_LAUNCH(false, 1)
-    else if (drop == 0) GRU_LAUNCH(true, 0)
-    else GRU_LAUNCH(true, 1)
-#undef GRU_LAUNCH
-#undef GRU_LAUNCH_XR
-    LAUNCH_CHECK();
-    return 0;
-}
-
-template <int NCG, bool BF>
-static int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, bool two, hipStream_t s) {
-    // trailing recurrent chunks that are pure padding: skip one when H <= 8*(4*NCG - 1)  (bf16: 16*(2*NCG - 1))
-    const int drop = BF ? ((a.H <= 16 * (2 * NCG - 1)) ? 1 : 0) : ((a.H <= 8 * (4 * NCG - 1)) ? 1 : 0);
-    if constexpr (NCG <= 5) {           // two 32-window groups per wave: 8 KB of LDS per group and tile, 4 waves per CU
-        if (two) {
-            if (xmode == 0) return launch_gru_mode<NCG, 0, 2, BF>(a, fc, drop, s);
-            if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 2, BF>(a, fc, drop, s);
-            return launch_gru_mode<NCG, 2, 2, BF>(a, fc, drop, s);
-        }
-    }
-    if (xmode == 0) return launch_gru_mode<NCG, 0, 1, BF>(a, fc, drop, s);
-    if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 1, BF>(a, fc, drop, s);
-    return launch_gru_mode<NCG, 2, 1, BF>(a, fc, drop, s);
-}
-
 static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + 31) / 32);
     const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
@@ -731,30 +331,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     }
     // two groups per wave once that still gives every SIMD a wave
     const bool two = (a.B + 31) / 32 >= 8L * n_cu;
-    if (a.bf16) {
-        switch (ncg) {
-            case 1: return launch_gru_ncg<1, true>(a, xmode, fc, two, s);
-            case 2: return launch_gru_ncg<2, true>(a, xmode, fc, two, s);
-            case 3: return launch_gru_ncg<3, true>(a, xmode, fc, two, s);
-            case 4: return launch_gru_ncg<4, true>(a, xmode, fc, two, s);
-            case 5: return launch_gru_ncg<5, true>(a, xmode, fc, two, s);
-            case 6: return launch_gru_ncg<6, true>(a, xmode, fc, two, s);
-            case 7: return launch_gru_ncg<7, true>(a, xmode, fc, two, s);
-            case 8: return launch_gru_ncg<8, true>(a, xmode, fc, two, s);
-            default: return -2;
-        }
-    }
-    switch (ncg) {
-        case 1: return launch_gru_ncg<1, false>(a, xmode, fc, two, s);
-        case 2: return launch_gru_ncg<2, false>(a, xmode, fc, two, s);
-        case 3: return launch_gru_ncg<3, false>(a, xmode, fc, two, s);
-        case 4: return launch_gru_ncg<4, false>(a, xmode, fc, two, s);
-        case 5: return launch_gru_ncg<5, false>(a, xmode, fc, two, s);
-        case 6: return launch_gru_ncg<6, false>(a, xmode, fc, two, s);
-        case 7: return launch_gru_ncg<7, false>(a, xmode, fc, two, s);
-        case 8: return launch_gru_ncg<8, false>(a, xmode, fc, two, s);
-        default: return -2;
-    }
+    return a.bf16 ? launch_gru_big_bf16(a, ncg, xmode, fc, two, s) : launch_gru_big_f32(a, ncg, xmode, fc, two, s);
 }
 
 }  // namespace mtadgat
