@@ -33,22 +33,22 @@ def param_order(model):
 
 class _HipStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, x, p, seed, *params):
+    def forward(ctx, eng, x, p, seed, w0, *params):
         b = x.shape[0]
         chunks = [(lo, min(lo + TRAIN_CHUNK, b)) for lo in range(0, b, TRAIN_CHUNK)] or [(0, 0)]
         tape = None
         if len(chunks) == 1:
-            preds, recons, tape = eng.forward_train(x, p, seed, 0)
+            preds, recons, tape = eng.forward_train(x, p, seed, w0)
         else:
             outs = []
             scratch = getattr(eng, "_train_tape", None)
             for lo, hi in chunks:
-                pr, rc, scratch = eng.forward_train(x[lo:hi], p, seed, lo, tape=scratch)
+                pr, rc, scratch = eng.forward_train(x[lo:hi], p, seed, w0 + lo, tape=scratch)
                 outs.append((pr, rc))
             preds = torch.cat([o[0] for o in outs])
             recons = torch.cat([o[1] for o in outs])
             eng._train_tape = scratch            # reused by backward's recomputation
-        ctx.eng, ctx.p, ctx.seed, ctx.chunks, ctx.tape = eng, p, seed, chunks, tape
+        ctx.eng, ctx.p, ctx.seed, ctx.w0, ctx.chunks, ctx.tape = eng, p, seed, w0, chunks, tape
         ctx.save_for_backward(x)
         ctx.shapes = [(q.shape, q.numel()) for q in params]
         return preds, recons
@@ -63,16 +63,16 @@ class _HipStep(torch.autograd.Function):
         d_recons = d_recons.contiguous().float()
         if x.shape[0]:
             if ctx.tape is not None:
-                eng.backward(x, ctx.p, ctx.seed, d_preds, d_recons, ctx.tape, grads, 0)
+                eng.backward(x, ctx.p, ctx.seed, d_preds, d_recons, ctx.tape, grads, ctx.w0)
             else:
                 scratch = getattr(eng, "_train_tape", None)
                 for lo, hi in ctx.chunks:
                     xc = x[lo:hi]
-                    _, _, scratch = eng.forward_train(xc, ctx.p, ctx.seed, lo, tape=scratch)
-                    eng.backward(xc, ctx.p, ctx.seed, d_preds[lo:hi].contiguous(), d_recons[lo:hi].contiguous(), scratch, grads, lo)
+                    _, _, scratch = eng.forward_train(xc, ctx.p, ctx.seed, ctx.w0 + lo, tape=scratch)
+                    eng.backward(xc, ctx.p, ctx.seed, d_preds[lo:hi].contiguous(), d_recons[lo:hi].contiguous(), scratch, grads, ctx.w0 + lo)
         ctx.tape = None
         out = [grads[o:o + n].view(shape) for o, (shape, n) in zip(offs, ctx.shapes)]
-        return (None, None, None, None, *out)
+        return (None, None, None, None, None, *out)
 
 
 def forward(model, eng, x):
@@ -87,7 +87,14 @@ def forward(model, eng, x):
         return _torchpath.forward(model, x.float())
     object.__setattr__(model, "grad_path", "hip")
     p = float(model.dropout_p) if model.training else 0.0
-    # one seed per call from torch's (CPU) generator: runs are reproducible under torch.manual_seed
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
+    # one seed per call from torch's (CPU) generator: runs are reproducible under torch.manual_seed.  A caller that
+    # shards one logical batch over several ranks sets `model.dropout_stream = (seed, first_global_window)` for the
+    # call (sharding.dp_training_step does): the masks are keyed by the global window index, so the shards draw
+    # exactly the masks the single-process step over the whole batch would.
+    override = getattr(model, "dropout_stream", None)
+    if override is not None:
+        seed, w0 = int(override[0]), int(override[1])
+    else:
+        seed, w0 = (int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0), 0
     params = param_order(model)
-    return _HipStep.apply(eng, x.detach().contiguous().float(), p, seed, *params)
+    return _HipStep.apply(eng, x.detach().contiguous().float(), p, seed, w0, *params)

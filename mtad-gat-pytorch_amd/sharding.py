@@ -55,7 +55,22 @@ def dp_training_step(model, x, y, optimizer, target_dims=None):
     """
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     optimizer.zero_grad()
-    preds, recons = model(x)
+    if distributed and x.device.type == "cuda":
+        # one dropout stream for the logical batch: rank 0's seed, this shard's first global window index (equal
+        # shards up to one window, see shard_range) -> the masks of the single-process step over the whole batch
+        meta = torch.zeros(2, dtype=torch.int64, device=x.device)
+        if dist.get_rank() == 0:
+            meta[0] = int(torch.randint(0, 2 ** 62, (1,)).item())
+        dist.broadcast(meta, src=0)
+        counts = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(dist.get_world_size())]
+        dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+        first = int(sum(int(c.item()) for c in counts[: dist.get_rank()]))
+        object.__setattr__(model, "dropout_stream", (int(meta[0].item()), first))
+    try:
+        preds, recons = model(x)
+    finally:
+        if getattr(model, "dropout_stream", None) is not None:
+            object.__setattr__(model, "dropout_stream", None)
     xt = x
     if target_dims is not None:
         xt = x[:, :, target_dims]

@@ -258,3 +258,35 @@ def test_bf16_training_step_tracks_the_fp32_step(name, gpu_device):
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0]
+
+
+def test_sharded_dropout_stream_equals_the_single_process_step(gpu_device):
+    """`model.dropout_stream = (seed, first_global_window)` (what sharding.dp_training_step sets per rank): two
+    shards of a batch draw exactly the masks of the one-process step over the whole batch -- outputs bit-equal,
+    gradients of a shard-additive loss equal up to the summation order."""
+    kw, b = CONFIGS["odd_shapes"]
+    model = _model(kw, gpu_device).train()
+    g = torch.Generator().manual_seed(15)
+    x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
+    cp = torch.randn(b, kw["out_dim"], generator=g).to(gpu_device)
+    cr = torch.randn(b, kw["window_size"], kw["out_dim"], generator=g).to(gpu_device)
+
+    def run(lo, hi):
+        object.__setattr__(model, "dropout_stream", (4242, lo))
+        pr, rc = model(x[lo:hi].contiguous())
+        ((pr * cp[lo:hi]).sum() + (rc * cr[lo:hi]).sum()).backward()
+        object.__setattr__(model, "dropout_stream", None)
+        return pr.detach(), rc.detach()
+
+    for p in model.parameters():
+        p.grad = None
+    p_all, r_all = run(0, b)
+    g_all = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    pa, ra = run(0, 41)
+    pb, rb = run(41, b)                                   # gradients accumulate in .grad across the two shards
+    assert torch.equal(torch.cat([pa, pb]), p_all) and torch.equal(torch.cat([ra, rb]), r_all)
+    for n, p in model.named_parameters():
+        d = (p.grad - g_all[n]).abs().max().item()
+        assert d <= 1e-6 + 1e-5 * g_all[n].abs().max().item(), (n, d)
