@@ -175,12 +175,41 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
     return run_attend(m, g, lc, rt, v, ldv, n, out, so_w, so_i, so_d, s);
 }
 
+// the small-batch fp32 recurrence kernels apply to a single-layer stack whose weights fit a wave's registers
+bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n) {
+    static const bool off = std::getenv("MTADGAT_NO_GRU16") != nullptr;
+    return !off && m.precision == 0 && stack.size() == 1 && stack[0].has16 && n <= G16_MAX_WINDOWS;
+}
+
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
 int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
                   long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s, float* gates = nullptr,
-                  float* xp = nullptr) {
+                  float* xp = nullptr, bool g16 = false) {
     Scope sc(m, slot, s);
     int xmode = g.xmode;
+    if (g16) {
+        // small batch, fp32: input products of all steps ahead of the recurrence, 16-window groups with register-resident
+        // weights (mtadgat_gru16.hip); a per-step Linear is the caller's row GEMM over `seq`
+        if (!xp || !g.has16 || fc) return fail(MTADGAT_ERR_INVALID, "internal: k_gru16 without its buffers");
+        if (g.xmode == 0) {
+            RowGemmArgs r{};
+            r.X = x; r.ldx = ldx; r.Kvalid = g.in_dim; r.Q = g.xproj.Q;
+            r.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.xproj.w_off);
+            r.bias = m.packed_dev + g.xproj.b_off;
+            r.Y = xp; r.ldy = 3L * g.Hp; r.Nvalid = 3 * g.Hp; r.vec_store = 1;
+            r.R = n * m.W; r.NT = g.xproj.NT; r.NT_rm = g.xproj.NT; r.group = 1; r.relu = 0;
+            K_TRY(launch_rowgemm(r, s), "gru input projection");
+        } else {
+            K_TRY(launch_xproj_dec(x, ldx, kx, m.packed_dev + g.fold_off, reinterpret_cast<const int*>(m.packed_dev + g.m0_off),
+                                   m.packed_dev + g.b_off, g.Hp, m.W, n, xp, s), "decoder input projection");
+        }
+        Gru16Args a{};
+        a.XP = xp; a.W16 = m.packed_dev + g.g16_off; a.bias = m.packed_dev + g.b_off;
+        a.Hp = g.Hp; a.KS = g.KS16; a.NT16 = g.NT16; a.T = m.W; a.B = n;
+        a.Hend = hend; a.ldhe = ldhe; a.ncol = (int)std::min<long>(ldhe, g.Hp); a.Seq = seq; a.Gates = gates;
+        K_TRY(launch_gru16(a, s), "gru (16-window groups)");
+        return 0;
+    }
     if (xp && g.has_xproj && g.xmode == 0) {
         // small batch: all steps' input products as one throughput GEMM, the recurrence keeps only its h part
         RowGemmArgs r{};
@@ -236,8 +265,9 @@ int run_gru_stack(Model& m, const float* hcat, long ldx, int64_t n, float* hend,
     for (int l = 0; l < L; ++l) {
         const bool last = (l == L - 1);
         float* seq = last ? nullptr : ws + ((l & 1) ? o.seq1 : o.seq0);
-        float* xp = (l == 0 && o.has_xp && n <= gru_split_max_windows()) ? ws + o.xp : nullptr;
-        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s, nullptr, xp);
+        const bool g16 = use_g16(m, m.gru, n) && o.has_xp;
+        float* xp = (l == 0 && o.has_xp && (g16 || n <= gru_split_max_windows())) ? ws + o.xp : nullptr;
+        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s, nullptr, xp, g16);
         if (rc) return rc;
         x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;      // sequence buffers hold all Hp columns, padding lanes are exact zeros
     }
@@ -281,6 +311,30 @@ int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, fl
         // recon_model.fc (modules.py:282): with few outputs (target dims of MSL / SMAP) it rides inside the recurrence;
         // otherwise the last layer's states go to memory and the Linear is one throughput GEMM over the b*W rows --
         // inside the step loop it would sit on the latency chain with 4 * Qh matrix instructions per 32 outputs
+        if (use_g16(m, m.rec, n) && o.rec16) {
+            // small batch: k_gru16 keeps the states (or, when only the last step is wanted, the last state) and
+            // recon_model.fc is a row GEMM over them
+            Scope sc(m, S_RECON, s);
+            const GruPlan& g = m.rec[0];
+            const LinPlan& p = m.rec_fc;
+            float* seq = ws + o.rseq0;
+            int rc = run_gru_layer(m, S_RECON, g, x, ld, kx, n, recons ? nullptr : seq, g.Hp, recons ? seq : nullptr, nullptr, nullptr, nullptr, s,
+                                   nullptr, ws + o.xp, true);
+            if (rc) return rc;
+            RowGemmArgs a{};
+            a.X = seq; a.ldx = g.Hp; a.Kvalid = g.H; a.Q = p.Q;
+            a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
+            a.bias = m.packed_dev + p.b_off;
+            float* y = recons ? recons : recons_last;
+            a.Y = y; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
+            a.vec_store = (p.out_dim % 4 == 0 && aligned16(y)) ? 1 : 0;
+            a.R = recons ? n * (int64_t)m.W : n; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
+            K_TRY(launch_rowgemm(a, s), "reconstruction Linear");
+            if (recons && recons_last)
+                K_TRY(launch_copy2d(recons + (int64_t)(m.W - 1) * p.out_dim, (long)m.W * p.out_dim, recons_last, p.out_dim, n, p.out_dim, s),
+                      "last reconstruction step");
+            return 0;
+        }
         const bool hoist_fc = m.cfg.out_dim > 4 && recons != nullptr;
         for (int l = 0; l < L; ++l) {
             const bool last = (l == L - 1);
@@ -346,8 +400,8 @@ int mtadgat_create(const mtadgat_config* cfg, mtadgat_handle* out) {
     // quarter of the device memory (16 GB when no device can be queried)
     {
         Workspace o;
-        plan_workspace(h->m, 1024, o);
-        const double per_window = (double)o.total * sizeof(float) / 1024.0;
+        plan_workspace(h->m, 65536, o);       // large batches: without the small-batch extras (pre-projected inputs, decoder states)
+        const double per_window = (double)o.total * sizeof(float) / 65536.0;
         size_t free_b = 0, total_b = 0;
         double budget = (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) ? (double)total_b / 4 : 16.0 * 1024 * 1024 * 1024;
         const bool unfused = !(h->m.temp.fused && h->m.feat.fused);
@@ -790,7 +844,8 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
     const GruPlan& g = m.gru[0];
     float* hend = T + t.hend;
-    if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g, T + t.xp))) return rc;
+    if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g, T + t.xp,
+                            use_g16(m, m.gru, n)))) return rc;
     // forecasting head: ReLU + dropout on the hidden layers (modules.py:307-311), activations kept
     {
         Scope sc(m, S_FC, s);
@@ -821,7 +876,20 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     }
     // reconstruction decoder, all steps kept
     const GruPlan& r = m.rec[0];
-    if ((rc = run_gru_layer(m, S_RECON, r, hend, g.Hp, m.cfg.gru_hid_dim, n, nullptr, 0, T + t.seq_d, &m.rec_fc, recons, nullptr, s, T + t.gates_d)))
+    if (use_g16(m, m.rec, n)) {
+        if ((rc = run_gru_layer(m, S_RECON, r, hend, g.Hp, m.cfg.gru_hid_dim, n, nullptr, 0, T + t.seq_d, nullptr, nullptr, nullptr, s, T + t.gates_d,
+                                T + t.xp, true))) return rc;
+        Scope sc(m, S_RECON, s);
+        const LinPlan& p = m.rec_fc;
+        RowGemmArgs a{};
+        a.X = T + t.seq_d; a.ldx = r.Hp; a.Kvalid = r.H; a.Q = p.Q;
+        a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
+        a.bias = m.packed_dev + p.b_off;
+        a.Y = recons; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
+        a.vec_store = (p.out_dim % 4 == 0 && aligned16(recons)) ? 1 : 0;
+        a.R = n * (int64_t)W; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
+        K_TRY(launch_rowgemm(a, s), "reconstruction Linear (training)");
+    } else if ((rc = run_gru_layer(m, S_RECON, r, hend, g.Hp, m.cfg.gru_hid_dim, n, nullptr, 0, T + t.seq_d, &m.rec_fc, recons, nullptr, s, T + t.gates_d)))
         return rc;
     K_TRY(launch_xdec(hend, g.Hp, m.cfg.gru_hid_dim, W, n, T + t.xdec, g.Hp, s), "decoder input");
     return 0;
@@ -883,12 +951,19 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         WgradIn in;
         in.A = d_recons; in.lda = od; in.B = T + t.seq_d; in.ldb = r.Hp; in.R = RW; in.T = W;
         if ((rc = run_wgrad(m, b.recfc_wg, in, wpart, grads + gl.rec_fc_w, grads + gl.rec_fc_b, s))) return rc;
+        if (use_g16(m, m.rec, n)) {
+            Gru16BwdArgs ga{};
+            ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
+            ga.W16T = m.packed_dev + r.g16T_off; ga.DA = da; ga.Hp = r.Hp; ga.KS = r.KS16; ga.NT16 = r.NT16; ga.T = W; ga.B = n;
+            K_TRY(launch_gru16_bwd(ga, s), "decoder backward (16-window groups)");
+        } else {
         GruBwdArgs ga{};
         ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
         ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.rec.whT_off);
         ga.DA = da; ga.Hp = r.Hp; ga.H = r.H; ga.T = W; ga.NCG = r.NCG; ga.B = n;
         if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.rec.whT16_off); }
         K_TRY(launch_gru_bwd(ga, s), "decoder backward");
+        }
         WgradIn hh;
         hh.A = da + r.Hp; hh.lda = 4L * r.Hp; hh.bshift = 1; hh.B = T + t.seq_d; hh.ldb = r.Hp; hh.R = RW; hh.T = W;
         if ((rc = run_wgrad(m, b.rec.wg_hh, hh, wpart, grads + gl.rec_whh, grads + gl.rec_bhh, s))) return rc;
@@ -902,12 +977,19 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
     // ---- 3. GRU layer (modules.py:235-238)
     float* dhcat = ws + w.dhcat;
     {
+        if (use_g16(m, m.gru, n)) {
+            Gru16BwdArgs ga{};
+            ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
+            ga.W16T = m.packed_dev + g.g16T_off; ga.DA = da; ga.Hp = g.Hp; ga.KS = g.KS16; ga.NT16 = g.NT16; ga.T = W; ga.B = n;
+            K_TRY(launch_gru16_bwd(ga, s), "gru backward (16-window groups)");
+        } else {
         GruBwdArgs ga{};
         ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
         ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.gru.whT_off);
         ga.DA = da; ga.Hp = g.Hp; ga.H = g.H; ga.T = W; ga.NCG = g.NCG; ga.B = n;
         if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.gru.whT16_off); }
         K_TRY(launch_gru_bwd(ga, s), "gru backward");
+        }
         WgradIn hh;
         hh.A = da + g.Hp; hh.lda = 4L * g.Hp; hh.bshift = 1; hh.B = T + t.seq_g; hh.ldb = g.Hp; hh.R = RW; hh.T = W;
         if ((rc = run_wgrad(m, b.gru.wg_hh, hh, wpart, grads + gl.gru_whh, grads + gl.gru_bhh, s))) return rc;

@@ -50,7 +50,13 @@ struct GruPlan {
     // bf16 operand packs (16-feature chunks, element order of mtadgat_device.h): same streams, half the bytes per feature
     int Qxp16 = 0;          // packed input chunks (1, or a multiple of 3)
     size_t wx16_off = 0, wh16_off = 0;
+    // small-batch recurrence (k_gru16 / k_gru16_bwd): W_hh and W_hh^T as 16x16x4 A operands [NT16][3][KS16][64]; the
+    // decoder's folded input weights plain, [T][3][Hp][8]
+    bool has16 = false;
+    int KS16 = 0, NT16 = 0;
+    size_t g16_off = 0, g16T_off = 0, fold_off = 0;
 };
+constexpr int64_t G16_MAX_WINDOWS = 4096;      // 16 windows per workgroup x 256 CUs: beyond that the throughput kernels take over
 
 // ---- backward (training) plans -------------------------------------------------------------------------
 // transposed Linear for the data gradient d X = d Y W through k_rowgemm: rows of the pack = input features
@@ -133,6 +139,7 @@ struct Workspace {
     // offsets in floats for a chunk of `n` windows
     size_t xc, xct, lct, rtt, lcf, rtf, hcat, hend, seq0, seq1, fc0, fc1, rseq0, rseq1, xp, total;
     bool has_xp;         // room for the pre-projected GRU input (batches the hidden-tile-split kernel serves)
+    bool rec16;          // room for the decoder's pre-projected input and state sequence (k_gru16)
 };
 
 // activations kept between the training forward and the backward (caller-owned "tape"), offsets in floats

@@ -217,6 +217,32 @@ struct GruArgs {
     int bf16;            // 1: Wx / Wh are bf16 packs (16-feature chunks): bf16 MFMA operands, fp32 accumulation and state
 };
 
+// small-batch recurrences (mtadgat_gru16.hip): 16 windows per workgroup, one wave per 16-unit hidden tile, weights in registers
+struct Gru16Args {
+    const float* XP;     // (B*T, 3*Hp): input products of every step incl. biases [r | z | n]
+    const float* W16;    // [NT16][3][KS][64]: W_hh as v_mfma_f32_16x16x4_f32 A operands
+    const float* bias;   // [4][Hp]; row 3 = b_hn
+    int Hp, KS, NT16, T; // KS = ceil(H / 4) k-steps, NT16 = ceil(H / 16) tiles (one wave each, at most 10)
+    long B;
+    float* Hend;         // (B, ldhe) or null; columns below ncol are written
+    long ldhe;
+    int ncol;
+    float* Seq;          // (B*T, Hp) or null
+    float* Gates;        // training: (B*T, 4*Hp) r | z | n | q, or null
+};
+struct Gru16BwdArgs {
+    const float* Gates;  // (B*T, 4*Hp)
+    const float* Seq;    // (B*T, Hp)
+    const float* DHseq;  // (B*T, lddh) or null
+    long lddh;
+    const float* DHend;  // (B, ldde) or null
+    long ldde;
+    const float* W16T;   // [NT16][3][KS][64]: W_hh^T per gate block [dr | dz | dnh]
+    float* DA;           // (B*T, 4*Hp) out: dn_x | dr | dz | dn_h
+    int Hp, KS, NT16, T;
+    long B;
+};
+
 // compute units of the current device (cached per device ordinal)
 inline int cu_count() {
     static int cache[64] = {0};
@@ -242,6 +268,10 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
 long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
+int launch_gru16(const Gru16Args& a, hipStream_t s);
+int launch_gru16_bwd(const Gru16BwdArgs& a, hipStream_t s);
+int launch_xproj_dec(const float* hend, long ldh, int Hin, const float* fold, const int* m0, const float* bias, int Hp, int T, long B,
+                     float* XP, hipStream_t s);
 int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
 int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s);
 size_t gat_bwd_att_lds(int K, int D, int vld, int nwa);

@@ -155,6 +155,14 @@ std::string validate_and_plan(Model& m) {
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
+    auto plan16 = [&](GruPlan& g) {
+        const int Hp16 = round_up(g.H, 16);
+        if (Hp16 > 160 || (g.xmode == 1 && g.Qx != 1)) return;       // weights must fit the wave's registers; 8 folded columns
+        g.has16 = true; g.KS16 = (g.H + 3) / 4; g.NT16 = Hp16 / 16;
+        g.g16_off = take((size_t)g.NT16 * 3 * g.KS16 * 64);
+        g.g16T_off = take((size_t)g.NT16 * 3 * g.KS16 * 64);
+        if (g.xmode == 1) g.fold_off = take((size_t)m.W * 3 * g.Hp * 8);
+    };
     // GRU stack
     m.gru.assign(c.gru_n_layers, GruPlan());
     for (int l = 0; l < c.gru_n_layers; ++l) {
@@ -178,6 +186,7 @@ std::string validate_and_plan(Model& m) {
             g.xproj.NT = 3 * g.Hp / 32; g.xproj.Q = (g.in_dim + 7) / 8;
             g.xproj.w_off = take((size_t)g.xproj.NT * g.xproj.Q * 256);
             g.xproj.b_off = take((size_t)3 * g.Hp);
+            plan16(g);
         }
     }
     // forecasting head
@@ -224,6 +233,7 @@ std::string validate_and_plan(Model& m) {
         g.Qxp16 = g.xmode == 1 ? (g.Qx == 1 ? 1 : round_up((g.Qx + 1) / 2, 6)) : round_up((g.Qx + 1) / 2, 6);
         g.wx16_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 3 * 256);
         g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
+        if (l == 0) plan16(g);
     }
     {
         LinPlan& p = m.rec_fc;
@@ -359,11 +369,13 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     ws.fc1 = take(N * fcw);
     // decoder state sequences: between stacked decoder layers, and -- when the per-step Linear has more than a
     // few outputs -- of the last layer, so that recon_model.fc runs as one row GEMM after the recurrence
-    const bool rseq = m.rec.size() > 1 || m.cfg.out_dim > 4;
+    const bool rec16 = m.rec.size() == 1 && m.rec[0].has16 && n <= G16_MAX_WINDOWS;
+    ws.rec16 = rec16;
+    const bool rseq = m.rec.size() > 1 || m.cfg.out_dim > 4 || rec16;
     ws.rseq0 = take(rseq ? N * m.W * m.rec[0].Hp : 0);
     ws.rseq1 = take((m.rec.size() > 2 || (m.rec.size() > 1 && m.cfg.out_dim > 4)) ? N * m.W * m.rec[0].Hp : 0);
     ws.has_xp = m.gru[0].has_xproj && n <= 16384;          // 64 windows per CU x 256 CUs: above that k_gru streams x itself
-    ws.xp = take(ws.has_xp ? N * m.W * 3 * m.gru[0].Hp : 0);
+    ws.xp = take((ws.has_xp || rec16) ? N * m.W * 3 * std::max(m.gru[0].Hp, m.rec[0].Hp) : 0);
     ws.total = off;
 }
 
@@ -398,7 +410,7 @@ void plan_tape(const Model& m, int64_t n, Tape& t) {
     t.gates_d = take(N * m.W * 4 * r.Hp);
     t.seq_d = take(N * m.W * r.Hp);
     t.xdec = take(N * m.W * g.Hp);
-    t.xp = take(N * m.W * 3 * g.Hp);
+    t.xp = take(N * m.W * 3 * std::max(g.Hp, r.Hp));
     t.fc_act.clear();
     for (size_t i = 0; i + 1 < m.fc.size(); ++i) t.fc_act.push_back(take(N * (size_t)m.fc[i].NT * 32));
     t.total = off;
@@ -542,6 +554,20 @@ static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_h
         b[2 * g.Hp + j] = j < H ? b_ih[2 * H + j] : 0.f;
         b[3 * g.Hp + j] = j < H ? b_hh[2 * H + j] : 0.f;
     }
+    if (g.has16) {
+        float* w = out.data() + g.g16_off;
+        float* wT = out.data() + g.g16T_off;
+        for (int tile = 0; tile < g.NT16; ++tile)
+            for (int gate = 0; gate < 3; ++gate)
+                for (int s = 0; s < g.KS16; ++s)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int unit = 16 * tile + (lane & 15), k = 4 * s + (lane >> 4);
+                        const bool ok = unit < H && k < H;
+                        const size_t o = (((size_t)tile * 3 + gate) * g.KS16 + s) * 64 + lane;
+                        w[o] = ok ? w_hh[((size_t)gate * H + unit) * H + k] : 0.f;
+                        wT[o] = ok ? w_hh[((size_t)gate * H + k) * H + unit] : 0.f;
+                    }
+    }
     if (g.has_xproj) {
         const int Hp = g.Hp;
         pack_tiles(out.data() + g.xproj.w_off, g.xproj.NT, g.xproj.Q, [&](int n, int k) -> float {
@@ -627,6 +653,12 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
                     auto fold = [&](int st, int r, int k) -> float { return (r < H && k < NMp) ? f[((size_t)st * H + r) * NMp + k] : 0.f; };
                     pack_gru_tiles(out.data() + g.wx_off + (size_t)t * g.NCG * g.Qxp * 3 * 256, g.NCG, g.Qxp, fold);
                     if (m.precision == 1) pack_gru_tiles_bf16(out.data() + g.wx16_off + (size_t)t * g.NCG * g.Qxp16 * 3 * 256, g.NCG, g.Qxp16, fold);
+                    if (g.has16) {
+                        float* fo = out.data() + g.fold_off + (size_t)t * 3 * g.Hp * 8;
+                        for (int st = 0; st < 3; ++st)
+                            for (int r = 0; r < H; ++r)
+                                for (int k = 0; k < 8; ++k) fo[((size_t)st * g.Hp + r) * 8 + k] = f[((size_t)st * H + r) * NMp + k];
+                    }
                 }
             };
             std::vector<float> fw2(fw.size());

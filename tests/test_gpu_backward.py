@@ -93,6 +93,31 @@ def test_gradients_match_autograd_eval_mode(name, gpu_device):
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes"])
+def test_gradients_match_autograd_above_the_small_batch_kernels(name, gpu_device):
+    """Up to 4096 windows the fp32 recurrences run in 16-window groups (k_gru16 / k_gru16_bwd), above that on the
+    hidden-tile-split kernels (k_gru_split / k_gru_bwd): the same check on a 4100-window batch, and the two kernel
+    families against each other on the shared windows."""
+    kw, _ = CONFIGS[name]
+    b = 4100
+    model = _model(kw, gpu_device).eval()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
+    y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
+    pr_ref, rc_ref, ref = _reference_grads(model, x, y)
+    pr, rc = model(x)
+    assert model.grad_path == "hip", model.grad_path
+    assert (pr - pr_ref).abs().max().item() <= 1e-5 and (rc - rc_ref).abs().max().item() <= 1e-5
+    with torch.no_grad():
+        pe, re_ = model(x)
+        ps, rs = model(x[:512])                              # small batch: the 16-window-group kernels
+    assert (pr - pe).abs().max().item() <= 1e-5 and (rc - re_).abs().max().item() <= 1e-5
+    assert (ps - pe[:512]).abs().max().item() <= 1e-5 and (rs - re_[:512]).abs().max().item() <= 1e-5
+    _loss(pr, rc, x, y).backward()
+    rows, bad = _grad_report(model, ref)
+    assert not bad, "\n".join(bad)
+
+
 @pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape"])
 def test_gradients_match_autograd_with_dropout(name, gpu_device):
     """train(): dropout inside the kernels; the same keep-masks (exported by the library) injected into the

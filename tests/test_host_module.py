@@ -145,8 +145,10 @@ def test_create_validates_and_plans_without_a_gpu():
     ws256 = lib.mtadgat_workspace_bytes(h, 256)
     assert 0 < ws1 < ws256
     # fused front at (W=100, F=55): h_cat (shared with the stage entry points' xc / xc^T copies) + h_end ~ 69 KB / window;
-    # batches the hidden-tile-split GRU serves (<= 16 384 windows) add the pre-projected GRU input, W * 3 * Hp floats
-    assert 60_000 + 192_000 < ws256 / 256 < 80_000 + 192_000
+    # batches the hidden-tile-split GRU serves (<= 16 384 windows) add the pre-projected GRU input, W * 3 * Hp floats, and
+    # batches of the 16-window-group recurrences (<= 4096 windows) the decoder's state sequence, W * Hp floats
+    assert 60_000 + 192_000 + 64_000 < ws256 / 256 < 80_000 + 192_000 + 64_000
+    assert 60_000 + 192_000 < lib.mtadgat_workspace_bytes(h, 8192) / 8192 < 80_000 + 192_000
     assert 60_000 < lib.mtadgat_workspace_bytes(h, 65536) / 65536 < 80_000
     chunk = lib.mtadgat_chunk_windows(h)
     assert lib.mtadgat_workspace_bytes(h, 10 * chunk) == lib.mtadgat_workspace_bytes(h, chunk)
