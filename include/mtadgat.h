@@ -112,6 +112,20 @@ int mtadgat_destroy(mtadgat_handle h);
  * whenever a parameter changed. */
 int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, void* stream);
 
+/* The same for parameters that are already in device memory -- the training loop's optimizer.step() followed by a
+ * forward (training.py:127 -> :110): `flat_dev` holds all parameters back to back in the field order of
+ * mtadgat_params (the order of the flat gradient buffer, mtadgat_grad_offsets / mtadgat_grad_floats), and the tile
+ * image is rebuilt from it by kernels on `stream`; nothing but the sign pattern of the two attention vectors `a`
+ * (a few hundred bytes; it fixes the column order of the folded GATv2 projection) travels to the host.  Requires one
+ * earlier mtadgat_load_weights on this device and precision mode 0; MTADGAT_ERR_UNSUPPORTED otherwise (callers then
+ * use mtadgat_load_weights).  The bf16 weight streams are not maintained: mtadgat_bf16_ready turns 0. */
+int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64_t n_floats, void* stream);
+
+/* Diagnostic: copies the packed weight image (mtadgat_packed_floats floats) to host memory after synchronising
+ * `stream` -- the tests compare the device-side re-pack with the host packer through it. */
+int64_t mtadgat_packed_floats(mtadgat_handle h);
+int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, void* stream);
+
 /* Arithmetic of the inference entry points (forward / forward_series / stage calls):
  *   0 (default)  fp32 operands on the exact fp32 MFMA: <= 1e-5 of the reference's float32 forward
  *   1            bf16 MFMA operands (weights packed to bf16 once per load_weights, activations rounded on the

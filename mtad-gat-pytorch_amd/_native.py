@@ -59,6 +59,10 @@ def load_library():
     lib.mtadgat_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
     lib.mtadgat_destroy.argtypes = [vp]
     lib.mtadgat_load_weights.argtypes = [vp, ctypes.POINTER(Params), vp]
+    lib.mtadgat_update_weights_device.argtypes = [vp, vp, i64, vp]
+    lib.mtadgat_packed_floats.argtypes = [vp]
+    lib.mtadgat_packed_floats.restype = i64
+    lib.mtadgat_read_packed.argtypes = [vp, vp, i64, vp]
     lib.mtadgat_workspace_bytes.argtypes = [vp, i64]
     lib.mtadgat_workspace_bytes.restype = sz
     lib.mtadgat_set_precision.argtypes = [vp, ctypes.c_int]
@@ -222,8 +226,50 @@ class Engine:
         return {"feat": mf, "temp": mt, "fc": [mfc[i] for i in range(nh)]}
 
     # -- weights ------------------------------------------------------------------------------
-    def load_weights(self, sd, device):
-        """sd: reference-format state_dict (any device); packs on the host, uploads on the current stream."""
+    def flat_keys(self):
+        """state_dict keys in the field order of mtadgat_params (= the flat parameter / gradient buffer)."""
+        names = ["conv.conv.weight", "conv.conv.bias"]
+        for g in ("feature_gat", "temporal_gat"):
+            names += [f"{g}.lin.weight", f"{g}.lin.bias", f"{g}.a", f"{g}.bias"]
+        for l in range(self.cfg.gru_n_layers):
+            names += [f"gru.gru.{k}_l{l}" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        for i in range(self.cfg.forecast_n_linear):
+            names += [f"forecasting_model.layers.{i}.weight", f"forecasting_model.layers.{i}.bias"]
+        for l in range(self.cfg.recon_n_layers):
+            names += [f"recon_model.decoder.rnn.{k}_l{l}" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        return names + ["recon_model.fc.weight", "recon_model.fc.bias"]
+
+    def update_weights_device(self, sd, device):
+        """Re-pack from parameters that live on `device` without leaving it (after an optimizer step).  False when the
+        library declines (no earlier host-side load, bf16 image, ...): the caller then uses load_weights."""
+        if self._keep is None or os.environ.get("MTADGAT_HOST_PACK"):
+            return False
+        flat = torch.cat([sd[k].detach().reshape(-1).to(torch.float32) for k in self.flat_keys()])
+        if flat.device != device:
+            return False
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = self.lib.mtadgat_update_weights_device(self.handle, ctypes.c_void_p(flat.data_ptr()), flat.numel(), ctypes.c_void_p(stream))
+        if rc == -2:          # MTADGAT_ERR_UNSUPPORTED
+            return False
+        _check(rc, "update_weights_device")
+        self._flat_dev = flat     # read by the kernels queued on the stream
+        return True
+
+    def read_packed(self, device):
+        """Diagnostic: the packed weight image as a CPU tensor."""
+        n = self.lib.mtadgat_packed_floats(self.handle)
+        out = torch.empty(n, dtype=torch.float32)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _check(self.lib.mtadgat_read_packed(self.handle, ctypes.c_void_p(out.data_ptr()), n, ctypes.c_void_p(stream)), "read_packed")
+        return out
+
+    def load_weights(self, sd, device, allow_device_pack=True):
+        """sd: reference-format state_dict (any device).  The first load packs on the host and uploads on the current
+        stream; later ones (fp32 image, parameters on the GPU) re-pack on the device."""
+        if allow_device_pack and self.update_weights_device(sd, device):
+            return
         # one device-side concatenation + one transfer instead of a copy (and a sync) per tensor
         keys = list(sd.keys())
         flat = torch.cat([sd[k].detach().reshape(-1).to(torch.float32) for k in keys]).cpu()

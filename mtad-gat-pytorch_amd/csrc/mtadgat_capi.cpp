@@ -415,8 +415,29 @@ int mtadgat_create(const mtadgat_config* cfg, mtadgat_handle* out) {
     return 0;
 }
 
+static void free_device_tables(Model& m) {
+    DevTables& t = m.dt;
+    int cur = 0;
+    const bool sw = t.device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != t.device;
+    if (sw) (void)hipSetDevice(t.device);
+    if (t.gidx_dev) (void)hipFree(t.gidx_dev);
+    if (t.foldcode_dev) (void)hipFree(t.foldcode_dev);
+    for (int i = 0; i < 2; ++i) {
+        if (t.gatcode_dev[i]) (void)hipFree(t.gatcode_dev[i]);
+        if (t.colk_dev[i]) (void)hipFree(t.colk_dev[i]);
+        t.gatcode_dev[i] = t.colk_dev[i] = nullptr;
+    }
+    if (t.pin) (void)hipHostFree(t.pin);
+    if (sw) (void)hipSetDevice(cur);
+    t.gidx_dev = t.foldcode_dev = nullptr;
+    t.pin = nullptr;
+    t.ready = false;
+    t.device = -1;
+}
+
 int mtadgat_destroy(mtadgat_handle h) {
     if (!h) return 0;
+    free_device_tables(h->m);
     if (h->m.upload_ev) {
         (void)hipEventSynchronize(h->m.upload_ev);
         (void)hipEventDestroy(h->m.upload_ev);
@@ -473,6 +494,113 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream
     HIP_TRY(hipEventRecord(m.upload_ev, s));
     if (std::getenv("MTADGAT_SYNC_UPLOAD")) HIP_TRY(hipStreamSynchronize(s));      // debugging aid
     m.have_weights = true;
+    return 0;
+}
+
+/* Re-packs the weight image from a flat device buffer of the parameters (mtadgat_params field order = the order of
+ * the flat gradient buffer, see mtadgat_grad_offsets) without a round trip through the host: the training loop's
+ * optimizer.step() -> forward.  Needs one previous mtadgat_load_weights on this device (it lays down the padding
+ * and the index maps) and the fp32 image (precision 0).  The only host involvement is the sign pattern of the two
+ * attention vectors `a` (a few hundred bytes, one stream synchronisation): it decides the column order of the
+ * folded GATv2 projection. */
+int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64_t n_floats, void* stream) {
+    if (!h || !flat_dev) return fail(MTADGAT_ERR_INVALID, "null argument");
+    Model& m = h->m;
+    if (!m.have_weights || !m.packed_dev) return fail(MTADGAT_ERR_NOWEIGHTS, "update_weights_device needs a previous load_weights");
+    if (m.precision != 0) return fail(MTADGAT_ERR_UNSUPPORTED, "device-side re-packing covers the fp32 image only");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != m.packed_device) return fail(MTADGAT_ERR_INVALID, "the weights live on another device");
+    DevTables& t = m.dt;
+    hipStream_t s = (hipStream_t)stream;
+    auto upload = [&](int*& dst, const std::vector<int>& v) -> int {
+        if (v.empty()) return 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dst), v.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (!t.ready || t.device != dev) {
+        free_device_tables(m);
+        std::string err = build_device_tables(m);
+        if (!err.empty()) return fail(MTADGAT_ERR_UNSUPPORTED, err);
+        int rc;
+        if ((rc = upload(t.gidx_dev, t.gidx)) || (rc = upload(t.gatcode_dev[0], t.gatcode[0])) || (rc = upload(t.gatcode_dev[1], t.gatcode[1])) ||
+            (rc = upload(t.foldcode_dev, t.foldcode))) return rc;
+        for (int which = 0; which < 2; ++which) {
+            const GatPlan& g = which == 0 ? m.feat : m.temp;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.colk_dev[which]), (size_t)(g.ldl + 16) * sizeof(int)));
+            t.colk[which].clear();
+        }
+        t.pin_floats = (size_t)2 * (m.feat.ldl + m.temp.ldl + 64) + 2 * (size_t)(m.feat.E + m.temp.E);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&t.pin), t.pin_floats * sizeof(float), hipHostMallocDefault));
+        t.device = dev;
+        t.ready = true;
+    }
+    if (n_floats != t.fo.total) return fail(MTADGAT_ERR_INVALID, "flat parameter buffer: wrong number of floats");
+    // column order of the GATv2 projections: the signs of a, through pinned memory
+    if (m.cfg.use_gatv2) {
+        float* a0 = t.pin;
+        float* a1 = t.pin + m.feat.E;
+        HIP_TRY(hipMemcpyAsync(a0, flat_dev + t.fo.a[0], (size_t)m.feat.E * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(a1, flat_dev + t.fo.a[1], (size_t)m.temp.E * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        int* up = reinterpret_cast<int*>(t.pin + m.feat.E + m.temp.E);
+        for (int which = 0; which < 2; ++which) {
+            GatPlan& g = which == 0 ? m.feat : m.temp;
+            std::vector<int> colk;
+            int P8 = 0, PT = 0;
+            gat_column_order(which == 0 ? a0 : a1, g.E, m.cfg.alpha, colk, P8, PT);
+            if (PT >= g.ldl) return fail(MTADGAT_ERR_INVALID, "internal: sorted projection columns exceed the plan");
+            if (colk != t.colk[which] || P8 != g.P8 || PT != g.PT) {
+                g.P8 = P8; g.PT = PT;
+                std::memcpy(up, colk.data(), colk.size() * sizeof(int));
+                HIP_TRY(hipMemcpyAsync(t.colk_dev[which], up, colk.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                t.colk[which] = colk;
+            }
+            up += g.ldl + 16;
+        }
+    }
+    K_TRY(launch_pack_gather(flat_dev, t.gidx_dev, m.packed_dev, (long)m.packed_floats, s), "weight gather");
+    for (int which = 0; which < 2; ++which) {
+        const GatPlan& g = which == 0 ? m.feat : m.temp;
+        PackGatArgs a{};
+        a.flat = flat_dev; a.lin_w = t.fo.lin_w[which]; a.lin_b = t.fo.lin_b[which]; a.a = t.fo.a[which];
+        a.E = g.E; a.D = g.D; a.KS = g.ldl; a.PT = g.PT; a.v2 = m.cfg.use_gatv2 ? 1 : 0; a.fused = g.fused ? 1 : 0;
+        a.alpha = m.cfg.alpha; a.colk = t.colk_dev[which]; a.code = t.gatcode_dev[which];
+        a.n_code = g.NT * g.Q * 256; a.n_bias = g.NT * 32;
+        a.w_out = m.packed_dev + g.w_off; a.b_out = m.packed_dev + g.b_off;
+        K_TRY(launch_pack_gat(a, s), "graph-attention projection pack");
+    }
+    for (size_t l = 0; l < m.gru.size(); ++l) {
+        const GruPlan& g = m.gru[l];
+        K_TRY(launch_pack_gru_bias(flat_dev, t.fo.gru_bih[l], t.fo.gru_bhh[l], g.H, g.Hp, m.packed_dev + g.b_off,
+                                   g.has_xproj ? m.packed_dev + g.xproj.b_off : nullptr, s), "gru bias pack");
+    }
+    for (size_t l = 0; l < m.rec.size(); ++l) {
+        const GruPlan& g = m.rec[l];
+        K_TRY(launch_pack_gru_bias(flat_dev, t.fo.rec_bih[l], t.fo.rec_bhh[l], g.H, g.Hp, m.packed_dev + g.b_off,
+                                   g.has_xproj ? m.packed_dev + g.xproj.b_off : nullptr, s), "decoder bias pack");
+    }
+    if (m.rec[0].xmode == 1) {
+        const GruPlan& g = m.rec[0];
+        PackFoldArgs a{};
+        a.flat = flat_dev; a.wih = t.fo.rec_wih[0]; a.Hin = g.in_dim; a.T = m.W; a.H = g.H; a.Hp = g.Hp; a.NMp = 8 * g.Qx;
+        a.code = t.foldcode_dev; a.tile_floats = (long)g.NCG * g.Qxp * 3 * 256;
+        a.tiles_out = m.packed_dev + g.wx_off; a.fold_out = g.has16 ? m.packed_dev + g.fold_off : nullptr;
+        K_TRY(launch_pack_fold(a, s), "decoder input fold");
+    }
+    m.bf16_packed = false;
+    return 0;
+}
+
+int64_t mtadgat_packed_floats(mtadgat_handle h) { return h ? (int64_t)h->m.packed_floats : 0; }
+int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, void* stream) {
+    if (!h || !dst_host) return fail(MTADGAT_ERR_INVALID, "null argument");
+    Model& m = h->m;
+    if (!m.have_weights || !m.packed_dev) return fail(MTADGAT_ERR_NOWEIGHTS, "no weights loaded");
+    if (n_floats != (int64_t)m.packed_floats) return fail(MTADGAT_ERR_INVALID, "wrong size");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(dst_host, m.packed_dev, m.packed_floats * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

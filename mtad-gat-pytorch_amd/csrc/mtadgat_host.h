@@ -107,6 +107,32 @@ struct BwdPlan {
     GradLayout gl;
 };
 
+// offsets (floats) of every reference parameter in the flat parameter buffer of mtadgat_update_weights_device: the
+// fields of mtadgat_params in declaration order (the order of the flat gradient buffer)
+struct FlatOffsets {
+    int64_t conv_w = 0, conv_b = 0;
+    int64_t lin_w[2] = {0, 0}, lin_b[2] = {0, 0}, a[2] = {0, 0}, bias[2] = {0, 0};   // [0] feature, [1] temporal
+    std::vector<int64_t> gru_wih, gru_whh, gru_bih, gru_bhh, fc_w, fc_b, rec_wih, rec_whh, rec_bih, rec_bhh;
+    int64_t rec_fc_w = 0, rec_fc_b = 0, total = 0;
+};
+// device-side re-packing (mtadgat_packdev.hip): index tables built once on the host by running the host packer over
+// parameters whose values are their own flat indices
+struct DevTables {
+    bool ready = false;
+    FlatOffsets fo;
+    std::vector<int> gidx;            // [packed_floats]: flat parameter index copied to this position, or -1 (left alone)
+    std::vector<int> gatcode[2];      // [NT*Q*256] of a layer's projection tiles: row * (D + 1) + k + 1, or 0
+    std::vector<int> foldcode;        // [NCG*Qxp*3*256] of one step's folded decoder input tiles: (gate*H + r) * NMp + k + 1, or 0
+    std::vector<int> colk[2];         // current embedding-column order of the two layers (sorted by the sign of a)
+    int* gidx_dev = nullptr;
+    int* gatcode_dev[2] = {nullptr, nullptr};
+    int* foldcode_dev = nullptr;
+    int* colk_dev[2] = {nullptr, nullptr};
+    float* pin = nullptr;             // pinned staging: the two a vectors coming down, the column orders going up
+    size_t pin_floats = 0;
+    int device = -1;
+};
+
 struct Model {
     mtadgat_config cfg{};
     int F = 0, W = 0, Fp = 0, Wp = 0, Dp = 0, taps = 0, pad = 0;
@@ -130,6 +156,7 @@ struct Model {
     bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
+    DevTables dt;
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[MTADGAT_PROFILE_SLOTS];
@@ -154,6 +181,10 @@ struct BwdWorkspace {
 };
 
 std::string validate_and_plan(Model& m);                       // "" on success
+FlatOffsets flat_offsets(const Model& m);
+void params_from_flat(const Model& m, const FlatOffsets& fo, const float* flat, mtadgat_params& p);
+std::string build_device_tables(Model& m);                     // host side of DevTables ("" on success)
+void gat_column_order(const float* a, int E, double alpha, std::vector<int>& colk, int& P8, int& PT);
 void plan_workspace(const Model& m, int64_t n, Workspace& ws); // sizes for n windows
 void plan_tape(const Model& m, int64_t n, Tape& t);
 void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w);

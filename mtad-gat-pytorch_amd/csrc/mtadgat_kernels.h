@@ -243,6 +243,29 @@ struct Gru16BwdArgs {
     long B;
 };
 
+// device-side re-packing (mtadgat_packdev.hip); offsets are floats into the flat parameter buffer
+struct PackGatArgs {
+    const float* flat;
+    long lin_w, lin_b, a;
+    int E, D, KS, PT;    // KS = projected columns per side (ldl); PT: see GatArgs
+    int v2, fused;
+    double alpha;
+    const int* colk;     // [PT] embedding column of sorted column n, or -1 (padding)
+    const int* code;     // [n_code] tile position -> row * (D + 1) + k + 1, or 0
+    int n_code, n_bias;
+    float* w_out;        // projection tiles
+    float* b_out;        // [n_bias] bias vector of the un-fused path
+};
+struct PackFoldArgs {
+    const float* flat;
+    long wih;
+    int Hin, T, H, Hp, NMp;
+    const int* code;     // [tile_floats] position in one step's tiles -> (gate*H + r) * NMp + k + 1, or 0
+    long tile_floats;
+    float* tiles_out;    // [T][tile_floats]
+    float* fold_out;     // [T][3][Hp][8] or null
+};
+
 // compute units of the current device (cached per device ordinal)
 inline int cu_count() {
     static int cache[64] = {0};
@@ -268,6 +291,10 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
 long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
+int launch_pack_gather(const float* flat, const int* gidx, float* img, long n, hipStream_t s);
+int launch_pack_gat(const PackGatArgs& a, hipStream_t s);
+int launch_pack_gru_bias(const float* flat, long bih, long bhh, int H, int Hp, float* b, float* bx, hipStream_t s);
+int launch_pack_fold(const PackFoldArgs& a, hipStream_t s);
 int launch_gru16(const Gru16Args& a, hipStream_t s);
 int launch_gru16_bwd(const Gru16BwdArgs& a, hipStream_t s);
 int launch_xproj_dec(const float* hend, long ldh, int Hin, const float* fold, const int* m0, const float* bias, int Hp, int T, long B,

@@ -463,6 +463,18 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
     w.total = off;
 }
 
+// embedding columns with a'_k = (1 - alpha)/2 a_k >= 0 first (padded to a multiple of 8), then the negative ones
+void gat_column_order(const float* a, int E, double alpha, std::vector<int>& colk, int& P8, int& PT) {
+    std::vector<int> pos, neg;
+    for (int k = 0; k < E; ++k) (((1.0 - alpha) * 0.5 * (double)a[k]) >= 0.0 ? pos : neg).push_back(k);
+    P8 = round_up((int)pos.size(), 8);
+    const int N8 = round_up((int)neg.size(), 8);
+    PT = P8 + N8;
+    colk.assign(PT, -1);
+    for (size_t n = 0; n < pos.size(); ++n) colk[n] = pos[n];
+    for (size_t n = 0; n < neg.size(); ++n) colk[P8 + n] = neg[n];
+}
+
 static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_b, const float* a, const float* bias,
                      std::vector<float>& out) {
     const int E = g.E, D = g.D;
@@ -474,14 +486,8 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
         // e_ij = a . LeakyReLU(W_l v_i + W_r v_j + b)          (reference modules.py:74-77, :174-177)
         //      = c_i + d_j + sum_k a'_k |L_ik + R_jk|,  LeakyReLU(u) = (1+alpha)/2 u + (1-alpha)/2 |u|
         const int lin_in = 2 * D;
-        std::vector<int> pos, neg;
-        for (int k = 0; k < E; ++k) (((1.0 - alpha) * 0.5 * (double)a[k]) >= 0.0 ? pos : neg).push_back(k);
-        g.P8 = round_up((int)pos.size(), 8);
-        const int N8 = round_up((int)neg.size(), 8);
-        g.PT = g.P8 + N8;
-        std::vector<int> colk(g.PT, -1);
-        for (size_t n = 0; n < pos.size(); ++n) colk[n] = pos[n];
-        for (size_t n = 0; n < neg.size(); ++n) colk[g.P8 + n] = neg[n];
+        std::vector<int> colk;
+        gat_column_order(a, E, alpha, colk, g.P8, g.PT);
         for (int n = 0; n < g.PT; ++n) {
             const int k = colk[n];
             if (k < 0) continue;
@@ -767,6 +773,115 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
         t1.join(); t2.join(); t3.join();
     }
     m.bf16_packed = (m.precision == 1);
+    return "";
+}
+
+
+// ---- device-side re-packing: host tables ---------------------------------------------------------------
+FlatOffsets flat_offsets(const Model& m) {
+    const mtadgat_config& c = m.cfg;
+    FlatOffsets f;
+    int64_t go = 0;
+    auto take = [&](int64_t n) { int64_t o = go; go += n; return o; };
+    f.conv_w = take((int64_t)m.F * m.F * m.taps); f.conv_b = take(m.F);
+    for (int which = 0; which < 2; ++which) {
+        const GatPlan& g = which == 0 ? m.feat : m.temp;
+        const int lin_in = c.use_gatv2 ? 2 * g.D : g.D;
+        f.lin_w[which] = take((int64_t)g.E * lin_in); f.lin_b[which] = take(g.E);
+        f.a[which] = take(c.use_gatv2 ? g.E : 2 * g.E); f.bias[which] = take((int64_t)g.K * g.K);
+    }
+    for (int l = 0; l < c.gru_n_layers; ++l) {
+        const int in = m.gru[l].in_dim, H = m.gru[l].H;
+        f.gru_wih.push_back(take((int64_t)3 * H * in)); f.gru_whh.push_back(take((int64_t)3 * H * H));
+        f.gru_bih.push_back(take(3 * H)); f.gru_bhh.push_back(take(3 * H));
+    }
+    for (const LinPlan& p : m.fc) { f.fc_w.push_back(take((int64_t)p.out_dim * p.in_dim)); f.fc_b.push_back(take(p.out_dim)); }
+    for (int l = 0; l < c.recon_n_layers; ++l) {
+        const int in = m.rec[l].in_dim, H = m.rec[l].H;
+        f.rec_wih.push_back(take((int64_t)3 * H * in)); f.rec_whh.push_back(take((int64_t)3 * H * H));
+        f.rec_bih.push_back(take(3 * H)); f.rec_bhh.push_back(take(3 * H));
+    }
+    f.rec_fc_w = take((int64_t)c.out_dim * c.recon_hid_dim); f.rec_fc_b = take(c.out_dim);
+    f.total = go;
+    return f;
+}
+
+void params_from_flat(const Model& m, const FlatOffsets& f, const float* flat, mtadgat_params& p) {
+    std::memset(&p, 0, sizeof(p));
+    p.conv_weight = flat + f.conv_w; p.conv_bias = flat + f.conv_b;
+    p.feat_lin_weight = flat + f.lin_w[0]; p.feat_lin_bias = flat + f.lin_b[0]; p.feat_a = flat + f.a[0]; p.feat_bias = flat + f.bias[0];
+    p.temp_lin_weight = flat + f.lin_w[1]; p.temp_lin_bias = flat + f.lin_b[1]; p.temp_a = flat + f.a[1]; p.temp_bias = flat + f.bias[1];
+    for (size_t l = 0; l < m.gru.size(); ++l) {
+        p.gru_w_ih[l] = flat + f.gru_wih[l]; p.gru_w_hh[l] = flat + f.gru_whh[l];
+        p.gru_b_ih[l] = flat + f.gru_bih[l]; p.gru_b_hh[l] = flat + f.gru_bhh[l];
+    }
+    for (size_t i = 0; i < m.fc.size(); ++i) { p.fc_weight[i] = flat + f.fc_w[i]; p.fc_bias[i] = flat + f.fc_b[i]; }
+    for (size_t l = 0; l < m.rec.size(); ++l) {
+        p.rec_w_ih[l] = flat + f.rec_wih[l]; p.rec_w_hh[l] = flat + f.rec_whh[l];
+        p.rec_b_ih[l] = flat + f.rec_bih[l]; p.rec_b_hh[l] = flat + f.rec_bhh[l];
+    }
+    p.rec_fc_weight = flat + f.rec_fc_w; p.rec_fc_bias = flat + f.rec_fc_b;
+}
+
+// The gather table is obtained from the host packer itself: it is run over parameters whose value is their flat index
+// + 1 (exact in fp32 below 2^24), so every position of the image that is a plain copy of a parameter names its
+// source, whatever tile format it sits in.  Regions whose content is computed (scaled / sorted / summed / folded) are
+// excluded -- the kernels of mtadgat_packdev.hip fill them -- and everything else (zero padding, index maps) is left
+// as the first host-side load wrote it.
+std::string build_device_tables(Model& m) {
+    DevTables& t = m.dt;
+    if (m.precision != 0) return "device-side re-packing covers the fp32 image only";
+    t.fo = flat_offsets(m);
+    if (t.fo.total != m.bw.gl.total) return "internal: flat parameter layout mismatch";
+    if (t.fo.total >= (1 << 24)) return "model too large for the index-encoded gather table";
+    std::vector<float> synth((size_t)t.fo.total);
+    for (int64_t i = 0; i < t.fo.total; ++i) synth[(size_t)i] = (float)(i + 1);
+    mtadgat_params p;
+    params_from_flat(m, t.fo, synth.data(), p);
+    const int keep[4] = {m.feat.PT, m.feat.P8, m.temp.PT, m.temp.P8};
+    const bool keep_bf = m.bf16_packed;
+    std::vector<float> img;
+    std::string err = pack_weights(m, p, img);
+    m.feat.PT = keep[0]; m.feat.P8 = keep[1]; m.temp.PT = keep[2]; m.temp.P8 = keep[3];
+    m.bf16_packed = keep_bf;
+    if (!err.empty()) return err;
+    t.gidx.assign(m.packed_floats, -1);
+    for (size_t i = 0; i < m.packed_floats; ++i) {
+        const float v = img[i];
+        if (v >= 1.f && v <= (float)t.fo.total && v == std::floor(v)) t.gidx[i] = (int)v - 1;
+    }
+    auto exclude = [&](size_t off, size_t n) { std::fill(t.gidx.begin() + off, t.gidx.begin() + off + n, -1); };
+    for (int which = 0; which < 2; ++which) {
+        const GatPlan& g = which == 0 ? m.feat : m.temp;
+        exclude(g.w_off, (size_t)g.NT * g.Q * 256);
+        exclude(g.b_off, (size_t)g.NT * 32);
+        const int D = g.D, NC = 2 * g.ldl;
+        std::vector<float> code((size_t)g.NT * g.Q * 256, 0.f);
+        pack_tiles(code.data(), g.NT, g.Q, [&](int n, int k) -> float { return (n < NC && k <= D) ? (float)((size_t)n * (D + 1) + k + 1) : 0.f; });
+        t.gatcode[which].assign(code.size(), 0);
+        for (size_t i = 0; i < code.size(); ++i) t.gatcode[which][i] = (int)code[i];
+    }
+    auto gru_excl = [&](const GruPlan& g) {
+        exclude(g.b_off, (size_t)4 * g.Hp);
+        if (g.has_xproj) exclude(g.xproj.b_off, (size_t)3 * g.Hp);
+    };
+    for (const GruPlan& g : m.gru) gru_excl(g);
+    for (const GruPlan& g : m.rec) gru_excl(g);
+    t.foldcode.clear();
+    {
+        const GruPlan& g = m.rec[0];
+        if (g.xmode == 1) {
+            exclude(g.wx_off, (size_t)m.W * g.NCG * g.Qxp * 3 * 256);
+            if (g.has16) exclude(g.fold_off, (size_t)m.W * 3 * g.Hp * 8);
+            const int NMp = 8 * g.Qx, H = g.H;
+            std::vector<float> code((size_t)g.NCG * g.Qxp * 3 * 256, 0.f);
+            pack_gru_tiles(code.data(), g.NCG, g.Qxp, [&](int st, int r, int k) -> float {
+                return (r < H && k < NMp) ? (float)(((size_t)st * H + r) * NMp + k + 1) : 0.f;
+            });
+            t.foldcode.assign(code.size(), 0);
+            for (size_t i = 0; i < code.size(); ++i) t.foldcode[i] = (int)code[i];
+        }
+    }
     return "";
 }
 

@@ -1,0 +1,149 @@
+// Re-packing of the weight image on the device (mtadgat_update_weights_device): after an optimizer step the
+// parameters are already in HBM, and the 1.9 MB tile image is rebuilt from them by a handful of small kernels instead
+// of a device -> host copy, a host-side pack and an upload (reference training.py:127: optimizer.step() between two
+// forwards).  Same arithmetic as the host packer (mtadgat_pack.cpp), in the same order, in double where it is.
+#include "mtadgat_device.h"
+
+namespace mtadgat {
+
+// every position of the image that is a plain copy of a parameter
+__global__ void k_pack_gather(const float* __restrict__ flat, const int* __restrict__ gidx, float* __restrict__ img, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int g = gidx[i];
+    if (g >= 0) img[i] = flat[g];
+}
+
+// row n (of the 2 * KS projected columns), input feature k (k == D: the bias entry) of a graph-attention layer's
+// folded projection (pack_gat): GATv2 columns scaled by |a'_k| in sign-sorted order, column PT = the linear part
+// summed over the embedding; GAT v1: the two rank-1 columns
+__device__ float gat_row_value(const PackGatArgs& a, int n, int k) {
+#pragma clang fp contract(off)          // the host packer's products and sums, not fused ones
+    const int side = n >= a.KS ? 1 : 0, nn = side ? n - a.KS : n;
+    const int D = a.D, E = a.E;
+    const float* __restrict__ lw = a.flat + a.lin_w;
+    const float* __restrict__ lb = a.flat + a.lin_b;
+    const float* __restrict__ av = a.flat + a.a;
+    if (a.v2) {
+        const int lin_in = 2 * D;
+        if (nn < a.PT) {
+            const int kk = a.colk[nn];
+            if (kk < 0) return 0.f;
+            const double s = fabs((1.0 - a.alpha) * 0.5 * (double)av[kk]);
+            if (k < D) return (float)(s * (double)lw[(long)kk * lin_in + side * D + k]);
+            return side == 0 ? (float)(s * (double)lb[kk]) : 0.f;
+        }
+        if (nn == a.PT) {
+            const double hl = (1.0 + a.alpha) * 0.5;
+            double acc = 0.0;
+            if (k < D) {
+                for (int e = 0; e < E; ++e) acc += hl * (double)av[e] * (double)lw[(long)e * lin_in + side * D + k];
+            } else if (side == 0) {
+                for (int e = 0; e < E; ++e) acc += hl * (double)av[e] * (double)lb[e];
+            }
+            return (float)acc;
+        }
+        return 0.f;
+    }
+    if (nn != 0) return 0.f;
+    double acc = 0.0;
+    if (k < D) {
+        for (int e = 0; e < E; ++e) acc += (double)av[side * E + e] * (double)lw[(long)e * D + k];
+    } else {
+        for (int e = 0; e < E; ++e) acc += (double)av[side * E + e] * (double)lb[e];
+    }
+    return (float)acc;
+}
+
+__global__ void k_pack_gat(const PackGatArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n_code) {
+        const int c = a.code[i];
+        float v = 0.f;
+        if (c > 0) {
+            const int n = (c - 1) / (a.D + 1), k = (c - 1) - n * (a.D + 1);
+            if (k < a.D || a.fused) v = gat_row_value(a, n, k);      // the bias rides as weight row D in the fused kernel only
+        }
+        a.w_out[i] = v;
+    }
+    if (i < a.n_bias) a.b_out[i] = i < 2 * a.KS ? gat_row_value(a, i, a.D) : 0.f;
+}
+
+// [b_ir + b_hr | b_iz + b_hz | b_in | b_hn] rows of Hp (and their copy as the bias of the hoisted input projection)
+__global__ void k_pack_gru_bias(const float* __restrict__ flat, long bih, long bhh, int H, int Hp, float* __restrict__ b, float* __restrict__ bx) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Hp) return;
+    const bool ok = j < H;
+    const float* __restrict__ bi = flat + bih;
+    const float* __restrict__ bh = flat + bhh;
+    const float v0 = ok ? bi[j] + bh[j] : 0.f, v1 = ok ? bi[H + j] + bh[H + j] : 0.f, v2 = ok ? bi[2 * H + j] : 0.f, v3 = ok ? bh[2 * H + j] : 0.f;
+    b[j] = v0; b[Hp + j] = v1; b[2 * Hp + j] = v2; b[3 * Hp + j] = v3;
+    if (bx) { bx[j] = v0; bx[Hp + j] = v1; bx[2 * Hp + j] = v2; }
+}
+
+// decoder input x_t[j] = h_end[(t Hin + j) / T] (reference modules.py:279): the columns of W_ih that share an h_end
+// entry summed per step (double), into the per-step tiles of k_gru's folded input and the plain array of k_gru16
+__device__ float fold_value(const float* __restrict__ wih, int Hin, int T, int R, int t, int k) {
+#pragma clang fp contract(off)
+    const int lo = (int)(((long)t * Hin) / T);
+    long j0 = (long)(lo + k) * T - (long)t * Hin, j1 = j0 + T;
+    j0 = j0 < 0 ? 0 : j0;
+    j1 = j1 > Hin ? Hin : j1;
+    double acc = 0.0;
+    for (long j = j0; j < j1; ++j) acc += (double)wih[(long)R * Hin + j];
+    return (float)acc;
+}
+
+__global__ void k_pack_fold(const PackFoldArgs a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float* __restrict__ wih = a.flat + a.wih;
+    const long n_tiles = (long)a.T * a.tile_floats;
+    if (i < n_tiles) {
+        const int t = (int)(i / a.tile_floats);
+        const int c = a.code[i - (long)t * a.tile_floats];
+        float v = 0.f;
+        if (c > 0) {
+            const int R = (c - 1) / a.NMp, k = (c - 1) - R * a.NMp;
+            v = fold_value(wih, a.Hin, a.T, R, t, k);
+        }
+        a.tiles_out[i] = v;
+        return;
+    }
+    const long j = i - n_tiles;
+    if (a.fold_out && j < (long)a.T * 3 * a.Hp * 8) {
+        const int k = (int)(j & 7);
+        const long q = j >> 3;
+        const int u = (int)(q % a.Hp);
+        const long q2 = q / a.Hp;
+        const int st = (int)(q2 % 3), t = (int)(q2 / 3);
+        a.fold_out[j] = u < a.H ? fold_value(wih, a.Hin, a.T, st * a.H + u, t, k) : 0.f;
+    }
+}
+
+int launch_pack_gather(const float* flat, const int* gidx, float* img, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_pack_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, gidx, img, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_pack_gat(const PackGatArgs& a, hipStream_t s) {
+    const int n = a.n_code > a.n_bias ? a.n_code : a.n_bias;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_pack_gat, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_pack_gru_bias(const float* flat, long bih, long bhh, int H, int Hp, float* b, float* bx, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_gru_bias, dim3((unsigned)((Hp + 63) / 64)), dim3(64), 0, s, flat, bih, bhh, H, Hp, b, bx);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_pack_fold(const PackFoldArgs& a, hipStream_t s) {
+    const long n = (long)a.T * a.tile_floats + (a.fold_out ? (long)a.T * 3 * a.Hp * 8 : 0);
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_pack_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mtadgat
