@@ -181,6 +181,12 @@ bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n) {
     return !off && m.precision == 0 && stack.size() == 1 && stack[0].has16 && n <= G16_MAX_WINDOWS;
 }
 
+// ... and below G1_MAX_WINDOWS a workgroup takes one window at a time
+bool use_g1(int64_t n) {
+    static const bool off = std::getenv("MTADGAT_NO_GRU1") != nullptr;
+    return !off && n <= G1_MAX_WINDOWS;
+}
+
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
 int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
                   long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s, float* gates = nullptr,
@@ -206,7 +212,12 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         Gru16Args a{};
         a.XP = xp; a.W16 = m.packed_dev + g.g16_off; a.bias = m.packed_dev + g.b_off;
         a.Hp = g.Hp; a.KS = g.KS16; a.NT16 = g.NT16; a.T = m.W; a.B = n;
-        a.Hend = hend; a.ldhe = ldhe; a.ncol = (int)std::min<long>(ldhe, g.Hp); a.Seq = seq; a.Gates = gates;
+        a.Hend = hend; a.ldhe = ldhe; a.ncol = (int)std::min<long>(ldhe, g.Hp); a.Seq = seq; a.Gates = gates; a.H = g.H;
+        if (use_g1(n)) {
+            a.W16 = m.packed_dev + g.g1_off;
+            K_TRY(launch_gru1(a, s), "gru (window per workgroup)");
+            return 0;
+        }
         K_TRY(launch_gru16(a, s), "gru (16-window groups)");
         return 0;
     }
@@ -1082,7 +1093,11 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         if (use_g16(m, m.rec, n)) {
             Gru16BwdArgs ga{};
             ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
-            ga.W16T = m.packed_dev + r.g16T_off; ga.DA = da; ga.Hp = r.Hp; ga.KS = r.KS16; ga.NT16 = r.NT16; ga.T = W; ga.B = n;
+            ga.W16T = m.packed_dev + r.g16T_off; ga.DA = da; ga.Hp = r.Hp; ga.KS = r.KS16; ga.NT16 = r.NT16; ga.T = W; ga.B = n; ga.H = r.H;
+            if (use_g1(n)) {
+                ga.W16T = m.packed_dev + r.g1T_off;
+                K_TRY(launch_gru1_bwd(ga, s), "decoder backward (window per workgroup)");
+            } else
             K_TRY(launch_gru16_bwd(ga, s), "decoder backward (16-window groups)");
         } else {
         GruBwdArgs ga{};
@@ -1108,7 +1123,11 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         if (use_g16(m, m.gru, n)) {
             Gru16BwdArgs ga{};
             ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
-            ga.W16T = m.packed_dev + g.g16T_off; ga.DA = da; ga.Hp = g.Hp; ga.KS = g.KS16; ga.NT16 = g.NT16; ga.T = W; ga.B = n;
+            ga.W16T = m.packed_dev + g.g16T_off; ga.DA = da; ga.Hp = g.Hp; ga.KS = g.KS16; ga.NT16 = g.NT16; ga.T = W; ga.B = n; ga.H = g.H;
+            if (use_g1(n)) {
+                ga.W16T = m.packed_dev + g.g1T_off;
+                K_TRY(launch_gru1_bwd(ga, s), "gru backward (window per workgroup)");
+            } else
             K_TRY(launch_gru16_bwd(ga, s), "gru backward (16-window groups)");
         } else {
         GruBwdArgs ga{};

@@ -275,4 +275,214 @@ int launch_xproj_dec(const float* hend, long ldh, int Hin, const float* fold, co
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gru1 / k_gru1_bwd: one window per workgroup (persistent over the batch), for batches of up to a few windows per
+// CU.  The fp32 MFMA rate equals the fp32 VALU rate on this chip (64 FLOP / clk / SIMD), and the vector pipe has no
+// minimum N: a workgroup keeps W_hh in the registers of its (at most 8) waves -- lane = one of the 3H gate rows, one
+// VGPR per hidden index -- and multiplies it with the ONE state vector of its window, so 256 windows use 256 CUs for
+// 100 short steps instead of 16 CUs for 100 long ones.  The state reaches the multiply through DPP: every 16-lane
+// row holds h[16 c .. 16 c + 15] in one VGPR per c, and `v_fmac_f32_dpp acc, h_c, w_k row_newbcast:i` feeds lane i
+// of the row to all its lanes -- one instruction per hidden index, no LDS read per index.
+//   per step: FMA phase (pre-activations of the 3H rows -> LDS) | barrier | gate phase (lanes < Hp: one hidden unit
+//   each, state in a register; h_t -> LDS, global stores) | barrier.
+// ---------------------------------------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void fmac_bcast(float& acc, float h, float w) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(h), "v"(w), "n"(I));
+}
+template <int KSM, int C = 0>
+__device__ __forceinline__ void fma_rows(float (&acc)[4], const float (&hreg)[KSM], const float (&w)[16 * KSM]) {
+    if constexpr (C < KSM) {
+        fmac_bcast<0>(acc[0], hreg[C], w[16 * C + 0]);   fmac_bcast<1>(acc[1], hreg[C], w[16 * C + 1]);
+        fmac_bcast<2>(acc[2], hreg[C], w[16 * C + 2]);   fmac_bcast<3>(acc[3], hreg[C], w[16 * C + 3]);
+        fmac_bcast<4>(acc[0], hreg[C], w[16 * C + 4]);   fmac_bcast<5>(acc[1], hreg[C], w[16 * C + 5]);
+        fmac_bcast<6>(acc[2], hreg[C], w[16 * C + 6]);   fmac_bcast<7>(acc[3], hreg[C], w[16 * C + 7]);
+        fmac_bcast<8>(acc[0], hreg[C], w[16 * C + 8]);   fmac_bcast<9>(acc[1], hreg[C], w[16 * C + 9]);
+        fmac_bcast<10>(acc[2], hreg[C], w[16 * C + 10]); fmac_bcast<11>(acc[3], hreg[C], w[16 * C + 11]);
+        fmac_bcast<12>(acc[0], hreg[C], w[16 * C + 12]); fmac_bcast<13>(acc[1], hreg[C], w[16 * C + 13]);
+        fmac_bcast<14>(acc[2], hreg[C], w[16 * C + 14]); fmac_bcast<15>(acc[3], hreg[C], w[16 * C + 15]);
+        fma_rows<KSM, C + 1>(acc, hreg, w);
+    }
+}
+
+// KSM = ceil(H / 16) groups of 16 hidden indices held in registers
+template <bool SAVE, int KSM>
+__global__ __launch_bounds__(512) void k_gru1(const Gru16Args a) {
+    __shared__ float hs[2][16 * KSM];
+    __shared__ float pre[512];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, Hp = a.Hp, H = a.H, HK = 16 * KSM;
+    // FMA role: gate row R = tid of the 3H rows [r | z | n]
+    const int R = tid;
+    const bool rvalid = R < 3 * H;
+    const int gate = rvalid ? R / H : 0, unit = rvalid ? R - gate * H : 0;
+    float w[16 * KSM];
+    {
+        const float* __restrict__ wp = a.W16 + (long)wave * HK * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16 * KSM; ++k) w[k] = wp[k * 64];
+    }
+    const float bhn = a.bias[3 * Hp + unit];
+    const int xoff = gate * Hp + unit;                 // input product of this row (gates r, z)
+    // gate role: hidden unit u = tid
+    const int u = tid;
+    const bool gl = u < Hp, gv = u < H;
+    const int uc = gv ? u : 0;
+
+    for (long win = blockIdx.x; win < a.B; win += gridDim.x) {
+        const float* __restrict__ xrow = a.XP + win * (long)T * (3L * Hp);
+        for (int i = tid; i < 2 * HK; i += blockDim.x) (&hs[0][0])[i] = 0.f;      // h_0 = 0 (and the padding of both buffers)
+        float hown = 0.f;
+        float xa = rvalid && gate < 2 ? xrow[xoff] : 0.f;       // step 0
+        float xn = gv ? xrow[2 * Hp + uc] : 0.f;
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            const float* __restrict__ hc = hs[t & 1];
+            float* __restrict__ hn = hs[(t & 1) ^ 1];
+            float hreg[KSM];
+#pragma unroll
+            for (int c = 0; c < KSM; ++c) hreg[c] = hc[16 * c + (lane & 15)];
+            float acc[4] = {gate == 2 ? bhn : xa, 0.f, 0.f, 0.f};
+            const int tn = t + 1 < T ? t + 1 : t;
+            const float xa_n = xrow[(long)tn * (3L * Hp) + xoff];              // next step's values: in flight under the FMAs
+            const float xn_n = xrow[(long)tn * (3L * Hp) + 2 * Hp + uc];
+            fma_rows<KSM>(acc, hreg, w);
+            pre[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            __syncthreads();
+            if (gl) {
+                float rg = 0.f, zg = 0.f, ng = 0.f, q = 0.f;
+                if (gv) {
+                    rg = gate_sigmoid(pre[u]);
+                    zg = gate_sigmoid(pre[H + u]);
+                    q = pre[2 * H + u];
+                    ng = gate_tanh(xn + rg * q);
+                    hown = __builtin_fmaf(zg, hown - ng, ng);
+                }
+                if (u < HK) hn[u] = hown;
+                const long row = win * T + t;
+                if (a.Seq) a.Seq[row * Hp + u] = hown;
+                if (SAVE) {
+                    float* __restrict__ gp = a.Gates + row * (4L * Hp) + u;
+                    gp[0] = rg; gp[Hp] = zg; gp[2 * Hp] = ng; gp[3 * Hp] = q;
+                }
+            }
+            xa = rvalid && gate < 2 ? xa_n : 0.f;
+            xn = xn_n;
+            __syncthreads();
+        }
+        if (a.Hend && u < a.ncol) a.Hend[win * a.ldhe + u] = gl ? hown : 0.f;
+    }
+}
+
+// BPTT: 16-lane row rr of the workgroup = (gate block p = rr % 3, 16 outputs j of the hidden state); lane holds
+// W_hh[p H + k][j] for all k.  dh_{t-1}[j] = dh_t[j] z_t[j] + sum_p sum_k W_hh[p H + k][j] da_p[k].
+template <int KSM>
+__global__ __launch_bounds__(512) void k_gru1_bwd(const Gru16BwdArgs a) {
+    __shared__ float das[3][16 * KSM];
+    __shared__ float part[3][16 * KSM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = a.T, Hp = a.Hp, H = a.H, HK = 16 * KSM;
+    const int rr = tid >> 4, p = rr % 3, jb = rr / 3;
+    const int j = 16 * jb + (tid & 15);
+    const bool jvalid = jb < (H + 15) / 16;
+    float w[16 * KSM];
+    {
+        const float* __restrict__ wp = a.W16T + (long)wave * HK * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16 * KSM; ++k) w[k] = wp[k * 64];
+    }
+    const int u = tid;
+    const bool gl = u < Hp, gv = u < H;
+    const int uc = gl ? u : 0;
+
+    for (long win = blockIdx.x; win < a.B; win += gridDim.x) {
+        float dhz = (a.DHend && gl) ? a.DHend[win * a.ldde + uc] : 0.f;         // carries dh into the step below
+        for (int i = tid; i < 3 * HK; i += blockDim.x) { (&part[0][0])[i] = 0.f; (&das[0][0])[i] = 0.f; }
+        // operands of step T-1
+        long row = win * T + (T - 1);
+        float r_ = 0.f, z_ = 0.f, n_ = 0.f, q_ = 0.f, hp_ = 0.f, ds_ = 0.f;
+        auto fetch = [&](long rw, int t) {
+            const float* __restrict__ gp = a.Gates + rw * (4L * Hp) + uc;
+            r_ = gp[0]; z_ = gp[Hp]; n_ = gp[2 * Hp]; q_ = gp[3 * Hp];
+            hp_ = a.Seq[(rw - (t > 0 ? 1 : 0)) * (long)Hp + uc];
+            hp_ = t > 0 ? hp_ : 0.f;
+            ds_ = a.DHseq ? a.DHseq[rw * a.lddh + uc] : 0.f;
+        };
+        fetch(row, T - 1);
+        __syncthreads();
+        for (int t = T - 1; t >= 0; --t) {
+            row = win * T + t;
+            if (gl) {
+                float dh = dhz + (u < HK ? (part[0][u] + part[1][u]) + part[2][u] : 0.f) + ds_;
+                dh = gv ? dh : 0.f;
+                const float dan = dh * (1.f - z_) * (1.f - n_ * n_);
+                const float daz = dh * (hp_ - n_) * z_ * (1.f - z_);
+                const float dar = dan * q_ * r_ * (1.f - r_);
+                const float dnh = dan * r_;
+                dhz = dh * z_;
+                float* __restrict__ op = a.DA + row * (4L * Hp) + u;
+                op[0] = gv ? dan : 0.f; op[Hp] = gv ? dar : 0.f; op[2 * Hp] = gv ? daz : 0.f; op[3 * Hp] = gv ? dnh : 0.f;
+                if (u < HK) { das[0][u] = gv ? dar : 0.f; das[1][u] = gv ? daz : 0.f; das[2][u] = gv ? dnh : 0.f; }
+            }
+            __syncthreads();
+            if (t > 0) fetch(row - 1, t - 1);                 // next step's operands: in flight under the FMAs
+            float hreg[KSM];
+#pragma unroll
+            for (int c = 0; c < KSM; ++c) hreg[c] = das[p][16 * c + (lane & 15)];
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            fma_rows<KSM>(acc, hreg, w);
+            if (jvalid) part[p][j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            __syncthreads();
+        }
+    }
+}
+
+template <class F>
+static int g1_dispatch(int H, F&& go) {
+    const int ks = (H + 15) / 16;
+    if (ks <= 3) go(std::integral_constant<int, 3>());
+    else if (ks <= 6) go(std::integral_constant<int, 6>());
+    else if (ks <= 8) go(std::integral_constant<int, 8>());
+    else if (ks <= 10) go(std::integral_constant<int, 10>());
+    else return -2;
+    return 0;
+}
+
+// W16 / W16T of the args point at the k_gru1 packs here: [waves][16 * g1_ksm(H)][64]
+int launch_gru1(const Gru16Args& a, hipStream_t s) {
+    if (a.B <= 0) return 0;
+    const int nw = g1_waves(a.H, a.Hp, false);
+    if (a.H < 1 || a.H > 160 || nw > 8) return -2;
+    const long cap = cu_count();                      // one workgroup per CU (its registers hold W_hh), persistent over the batch
+    const unsigned grid = (unsigned)(a.B < cap ? a.B : cap);
+    int rc = g1_dispatch(a.H, [&](auto ksm) {
+        constexpr int KSM = decltype(ksm)::value;
+        if (a.Gates)
+            hipLaunchKernelGGL((k_gru1<true, KSM>), dim3(grid), dim3(64 * nw), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_gru1<false, KSM>), dim3(grid), dim3(64 * nw), 0, s, a);
+    });
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gru1_bwd(const Gru16BwdArgs& a, hipStream_t s) {
+    if (a.B <= 0) return 0;
+    const int nw = g1_waves(a.H, a.Hp, true);
+    if (a.H < 1 || a.H > 160 || nw > 8) return -2;
+    const long cap = cu_count();
+    const unsigned grid = (unsigned)(a.B < cap ? a.B : cap);
+    int rc = g1_dispatch(a.H, [&](auto ksm) {
+        constexpr int KSM = decltype(ksm)::value;
+        hipLaunchKernelGGL((k_gru1_bwd<KSM>), dim3(grid), dim3(64 * nw), 0, s, a);
+    });
+    if (rc) return rc;
+    LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace mtadgat

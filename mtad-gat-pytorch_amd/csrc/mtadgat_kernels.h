@@ -223,6 +223,7 @@ struct Gru16Args {
     const float* W16;    // [NT16][3][KS][64]: W_hh as v_mfma_f32_16x16x4_f32 A operands
     const float* bias;   // [4][Hp]; row 3 = b_hn
     int Hp, KS, NT16, T; // KS = ceil(H / 4) k-steps, NT16 = ceil(H / 16) tiles (one wave each, at most 10)
+    int H;               // k_gru1: hidden size (W16 then is the k_gru1 pack [waves][16 * g1_ksm(H)][64])
     long B;
     float* Hend;         // (B, ldhe) or null; columns below ncol are written
     long ldhe;
@@ -240,8 +241,19 @@ struct Gru16BwdArgs {
     const float* W16T;   // [NT16][3][KS][64]: W_hh^T per gate block [dr | dz | dnh]
     float* DA;           // (B*T, 4*Hp) out: dn_x | dr | dz | dn_h
     int Hp, KS, NT16, T;
+    int H;               // k_gru1_bwd (W16T then is its pack)
     long B;
 };
+// k_gru1 / k_gru1_bwd geometry, shared with the packer: groups of 16 hidden indices held in registers, waves per workgroup
+inline int g1_ksm(int H) {
+    const int ks = (H + 15) / 16;
+    return ks <= 3 ? 3 : ks <= 6 ? 6 : ks <= 8 ? 8 : 10;
+}
+inline int g1_waves(int H, int Hp, bool bwd) {
+    const int rows = bwd ? (3 * ((H + 15) / 16) + 3) / 4 : (3 * H + 63) / 64;      // bwd: 16-lane rows = (gate block, 16 outputs)
+    const int gate = (Hp + 63) / 64;                                                   // lanes of the gate phase
+    return rows > gate ? rows : gate;
+}
 
 // device-side re-packing (mtadgat_packdev.hip); offsets are floats into the flat parameter buffer
 struct PackGatArgs {
@@ -296,6 +308,8 @@ int launch_pack_gat(const PackGatArgs& a, hipStream_t s);
 int launch_pack_gru_bias(const float* flat, long bih, long bhh, int H, int Hp, float* b, float* bx, hipStream_t s);
 int launch_pack_fold(const PackFoldArgs& a, hipStream_t s);
 int launch_gru16(const Gru16Args& a, hipStream_t s);
+int launch_gru1(const Gru16Args& a, hipStream_t s);
+int launch_gru1_bwd(const Gru16BwdArgs& a, hipStream_t s);
 int launch_gru16_bwd(const Gru16BwdArgs& a, hipStream_t s);
 int launch_xproj_dec(const float* hend, long ldh, int Hin, const float* fold, const int* m0, const float* bias, int Hp, int T, long B,
                      float* XP, hipStream_t s);

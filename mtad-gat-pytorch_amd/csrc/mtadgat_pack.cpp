@@ -162,6 +162,8 @@ std::string validate_and_plan(Model& m) {
         g.g16_off = take((size_t)g.NT16 * 3 * g.KS16 * 64);
         g.g16T_off = take((size_t)g.NT16 * 3 * g.KS16 * 64);
         if (g.xmode == 1) g.fold_off = take((size_t)m.W * 3 * g.Hp * 8);
+        g.g1_off = take((size_t)g1_waves(g.H, g.Hp, false) * 16 * g1_ksm(g.H) * 64);
+        g.g1T_off = take((size_t)g1_waves(g.H, g.Hp, true) * 16 * g1_ksm(g.H) * 64);
     };
     // GRU stack
     m.gru.assign(c.gru_n_layers, GruPlan());
@@ -573,6 +575,23 @@ static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_h
                         w[o] = ok ? w_hh[((size_t)gate * H + unit) * H + k] : 0.f;
                         wT[o] = ok ? w_hh[((size_t)gate * H + k) * H + unit] : 0.f;
                     }
+    }
+    if (g.has16) {
+        const int HK = 16 * g1_ksm(H), nwf = g1_waves(H, g.Hp, false), nwb = g1_waves(H, g.Hp, true), jbs = (H + 15) / 16;
+        float* w = out.data() + g.g1_off;
+        for (int wv = 0; wv < nwf; ++wv)
+            for (int k = 0; k < HK; ++k)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int R = wv * 64 + lane;
+                    w[((size_t)wv * HK + k) * 64 + lane] = (R < 3 * H && k < H) ? w_hh[(size_t)R * H + k] : 0.f;
+                }
+        float* wT = out.data() + g.g1T_off;
+        for (int wv = 0; wv < nwb; ++wv)
+            for (int k = 0; k < HK; ++k)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int rr = (wv * 64 + lane) >> 4, p = rr % 3, jb = rr / 3, j = 16 * jb + (lane & 15);
+                    wT[((size_t)wv * HK + k) * 64 + lane] = (jb < jbs && j < H && k < H) ? w_hh[((size_t)p * H + k) * H + j] : 0.f;
+                }
     }
     if (g.has_xproj) {
         const int Hp = g.Hp;

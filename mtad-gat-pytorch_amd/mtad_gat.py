@@ -226,6 +226,9 @@ class MTAD_GAT(nn.Module):
             # operands, fp32 accumulation / state / softmax, <= 2e-2), "auto" = bf16 exactly when the caller hands
             # over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
             object.__setattr__(self, "precision", "auto")
+        if "bf16_train_min_batch" not in self.__dict__:
+            # training steps below this many windows run in fp32 even when bf16 is requested (see forward)
+            object.__setattr__(self, "bf16_train_min_batch", 4097)
         if "check_weight_contents" not in self.__dict__:
             # True: every GPU call fingerprints the parameter *contents* (one small reduction + a host
             # sync), so in-place edits that bypass autograd's version counter (`p.data.mul_()`,
@@ -340,8 +343,12 @@ class MTAD_GAT(nn.Module):
             import _torchpath
             preds, recons = _torchpath.forward(self, x.float())
             return (preds.to(x.dtype), recons.to(x.dtype)) if x.dtype != torch.float32 else (preds, recons)
-        eng = self._sync_engine(x.device, self._use_bf16(x))
-        if self.training or self._wants_grad(x):
+        grad_step = self.training or self._wants_grad(x)
+        # training steps of up to 4096 windows: the fp32 16-window-group recurrences with device-side re-packing are
+        # faster than the bf16 build of the throughput kernels, so a bf16 request is served in fp32 there
+        bf16 = self._use_bf16(x) and not (grad_step and x.shape[0] < self.bf16_train_min_batch)
+        eng = self._sync_engine(x.device, bf16)
+        if grad_step:
             # training step (Trainer.fit, training.py:100-130) or any call that will be differentiated:
             # HIP forward that keeps what the HIP backward needs, dropout in the kernels
             import _hipgrad

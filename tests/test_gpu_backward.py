@@ -249,6 +249,7 @@ def test_bf16_training_step_tracks_the_fp32_step(name, gpu_device):
     percent of the fp32 step's in norm; a few Adam steps still learn."""
     kw, b = CONFIGS[name]
     model = _model(kw, gpu_device).train()
+    model.bf16_train_min_batch = 0        # by default steps of <= 4096 windows are served by the (faster) fp32 small-batch kernels
     g = torch.Generator().manual_seed(14)
     x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
     y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
