@@ -176,9 +176,13 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 }
 
 // the small-batch fp32 recurrence kernels apply to a single-layer stack whose weights fit a wave's registers
-bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n) {
+// (inference in the bf16 mode uses k_gru1 up to 1024 windows -- faster there than the bf16 build of the throughput
+// kernels, and exact; the training step keeps the bf16 recurrences it was asked for)
+bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n, bool training = false) {
     static const bool off = std::getenv("MTADGAT_NO_GRU16") != nullptr;
-    return !off && m.precision == 0 && stack.size() == 1 && stack[0].has16 && n <= G16_MAX_WINDOWS;
+    if (off || stack.size() != 1 || !stack[0].has16) return false;
+    if (m.precision == 1) return !training && n <= 1024;
+    return n <= G16_MAX_WINDOWS;
 }
 
 // ... and below G1_MAX_WINDOWS a workgroup takes one window at a time
@@ -984,7 +988,7 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     const GruPlan& g = m.gru[0];
     float* hend = T + t.hend;
     if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g, T + t.xp,
-                            use_g16(m, m.gru, n)))) return rc;
+                            use_g16(m, m.gru, n, true)))) return rc;
     // forecasting head: ReLU + dropout on the hidden layers (modules.py:307-311), activations kept
     {
         Scope sc(m, S_FC, s);
@@ -1015,7 +1019,7 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     }
     // reconstruction decoder, all steps kept
     const GruPlan& r = m.rec[0];
-    if (use_g16(m, m.rec, n)) {
+    if (use_g16(m, m.rec, n, true)) {
         if ((rc = run_gru_layer(m, S_RECON, r, hend, g.Hp, m.cfg.gru_hid_dim, n, nullptr, 0, T + t.seq_d, nullptr, nullptr, nullptr, s, T + t.gates_d,
                                 T + t.xp, true))) return rc;
         Scope sc(m, S_RECON, s);
@@ -1090,7 +1094,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         WgradIn in;
         in.A = d_recons; in.lda = od; in.B = T + t.seq_d; in.ldb = r.Hp; in.R = RW; in.T = W;
         if ((rc = run_wgrad(m, b.recfc_wg, in, wpart, grads + gl.rec_fc_w, grads + gl.rec_fc_b, s))) return rc;
-        if (use_g16(m, m.rec, n)) {
+        if (use_g16(m, m.rec, n, true)) {
             Gru16BwdArgs ga{};
             ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
             ga.W16T = m.packed_dev + r.g16T_off; ga.DA = da; ga.Hp = r.Hp; ga.KS = r.KS16; ga.NT16 = r.NT16; ga.T = W; ga.B = n; ga.H = r.H;
@@ -1120,7 +1124,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
     // ---- 3. GRU layer (modules.py:235-238)
     float* dhcat = ws + w.dhcat;
     {
-        if (use_g16(m, m.gru, n)) {
+        if (use_g16(m, m.gru, n, true)) {
             Gru16BwdArgs ga{};
             ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
             ga.W16T = m.packed_dev + g.g16T_off; ga.DA = da; ga.Hp = g.Hp; ga.KS = g.KS16; ga.NT16 = g.NT16; ga.T = W; ga.B = n; ga.H = g.H;
