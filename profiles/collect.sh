@@ -16,6 +16,8 @@ rm -rf /tmp/ktb && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/
 cp "$(find /tmp/ktb -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bf16.csv"
 rm -rf /tmp/ktt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt -- python "$ROOT/profiles/train_step.py" 256 > "$OUT/train_step_256.txt" 2> /dev/null
 cp "$(find /tmp/ktt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_train256.csv"
+rm -rf /tmp/ktf && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -- python "$ROOT/profiles/forward_small.py" 256 > "$OUT/forward_256.txt" 2> /dev/null
+cp "$(find /tmp/ktf -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_fwd256.csv"
 # 2. HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) and the SQ group
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python "$ROOT/bench.py" --steps 1 --warmup 1 --batch 65536 --no-cpu-baseline --no-sub > /dev/null 2>&1

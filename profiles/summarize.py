@@ -54,6 +54,13 @@ stats_table("kernel_stats_train256.csv", f"{tag}_kernel_trace_stats_train256.txt
             "# rocprofv3 --kernel-trace --stats -- python profiles/train_step.py 256   (SMD shape, batch 256, 23 training steps)")
 
 
+stats_table("kernel_stats_fwd256.csv", f"{tag}_kernel_trace_stats_fwd256.txt",
+            "# rocprofv3 --kernel-trace --stats -- python profiles/forward_small.py 256   (MSL shape, 55 eval forwards of 256 windows)")
+for extra in ("train_step_256.txt", "forward_256.txt"):
+    if os.path.exists(os.path.join(d, extra)):
+        open(os.path.join(d, f"{tag}_{extra}"), "w").write(open(os.path.join(d, extra)).read())
+
+
 def pmc(path):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.Counter()
