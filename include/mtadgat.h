@@ -121,6 +121,11 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, vo
  * use mtadgat_load_weights).  The bf16 weight streams are not maintained: mtadgat_bf16_ready turns 0. */
 int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64_t n_floats, void* stream);
 
+/* Bit-exact 64-bit checksum of a list of device tensors of 32-bit elements (the model's parameters), written to
+ * *out_dev on `stream`: one launch.  The Python module compares it between calls to notice in-place parameter edits
+ * that autograd's version counters do not see (p.data.mul_(), nn.init.*_(p.data)). */
+int mtadgat_params_fingerprint(const void* const* tensors_dev, const int64_t* n_elements, int n_tensors, uint64_t* out_dev, void* stream);
+
 /* Diagnostic: copies the packed weight image (mtadgat_packed_floats floats) to host memory after synchronising
  * `stream` -- the tests compare the device-side re-pack with the host packer through it. */
 int64_t mtadgat_packed_floats(mtadgat_handle h);

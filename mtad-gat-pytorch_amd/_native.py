@@ -60,6 +60,7 @@ def load_library():
     lib.mtadgat_destroy.argtypes = [vp]
     lib.mtadgat_load_weights.argtypes = [vp, ctypes.POINTER(Params), vp]
     lib.mtadgat_update_weights_device.argtypes = [vp, vp, i64, vp]
+    lib.mtadgat_params_fingerprint.argtypes = [vp, vp, ctypes.c_int, vp, vp]
     lib.mtadgat_packed_floats.argtypes = [vp]
     lib.mtadgat_packed_floats.restype = i64
     lib.mtadgat_read_packed.argtypes = [vp, vp, i64, vp]
@@ -255,6 +256,23 @@ class Engine:
         _check(rc, "update_weights_device")
         self._flat_dev = flat     # read by the kernels queued on the stream
         return True
+
+    def fingerprint(self, params, device):
+        """Bit-exact checksum of the parameter tensors (one kernel + one 8-byte read-back)."""
+        n = len(params)
+        cache = getattr(self, "_fp_cache", None)
+        key = tuple(p.data_ptr() for p in params)
+        if cache is None or cache[0] != key:
+            ptrs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
+            counts = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+            out = torch.zeros(1, dtype=torch.int64, device=device)
+            cache = (key, ptrs, counts, out)
+            self._fp_cache = cache
+        _, ptrs, counts, out = cache
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream().cuda_stream
+            _check(self.lib.mtadgat_params_fingerprint(ptrs, counts, n, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)), "fingerprint")
+        return int(out.item())
 
     def read_packed(self, device):
         """Diagnostic: the packed weight image as a CPU tensor."""

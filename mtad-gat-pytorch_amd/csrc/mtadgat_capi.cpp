@@ -608,6 +608,25 @@ int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64
     return 0;
 }
 
+int mtadgat_params_fingerprint(const void* const* tensors_dev, const int64_t* n_elements, int n_tensors, uint64_t* out_dev, void* stream) {
+    if (!tensors_dev || !n_elements || !out_dev || n_tensors < 0) return fail(MTADGAT_ERR_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(uint64_t), s));
+    long base = 0;
+    for (int t0 = 0; t0 < n_tensors; t0 += FINGERPRINT_MAX_TENSORS) {
+        FingerprintArgs a{};
+        const int nt = std::min(FINGERPRINT_MAX_TENSORS, n_tensors - t0);
+        for (int t = 0; t < nt; ++t) {
+            a.ptr[t] = tensors_dev[t0 + t];
+            a.count[t] = (long)n_elements[t0 + t];
+            a.base[t] = base;
+            base += a.count[t];
+        }
+        K_TRY(launch_fingerprint(a, nt, reinterpret_cast<unsigned long long*>(out_dev), s), "parameter fingerprint");
+    }
+    return 0;
+}
+
 int64_t mtadgat_packed_floats(mtadgat_handle h) { return h ? (int64_t)h->m.packed_floats : 0; }
 int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, void* stream) {
     if (!h || !dst_host) return fail(MTADGAT_ERR_INVALID, "null argument");

@@ -278,6 +278,13 @@ struct PackFoldArgs {
     float* fold_out;     // [T][3][Hp][8] or null
 };
 
+constexpr int FINGERPRINT_MAX_TENSORS = 48;
+struct FingerprintArgs {
+    const void* ptr[FINGERPRINT_MAX_TENSORS];
+    long count[FINGERPRINT_MAX_TENSORS];    // 32-bit elements
+    long base[FINGERPRINT_MAX_TENSORS];     // global index of the tensor's first element
+};
+
 // compute units of the current device (cached per device ordinal)
 inline int cu_count() {
     static int cache[64] = {0};
@@ -303,6 +310,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
 long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
+int launch_fingerprint(const FingerprintArgs& a, int n_tensors, unsigned long long* out, hipStream_t s);
 int launch_pack_gather(const float* flat, const int* gidx, float* img, long n, hipStream_t s);
 int launch_pack_gat(const PackGatArgs& a, hipStream_t s);
 int launch_pack_gru_bias(const float* flat, long bih, long bhh, int H, int Hp, float* b, float* bx, hipStream_t s);

@@ -20,7 +20,8 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
     const f32x4* __restrict__ Wp = a.Wp;
     const int Q = a.Q;
 
-    for (int n0 = 0; n0 < a.NT; n0 += NTB) {
+    // few rows (small batches): the output tiles are spread over gridDim.y waves so that the launch fills the machine
+    for (int n0 = blockIdx.y * NTB; n0 < a.NT; n0 += NTB * gridDim.y) {
         f32x16 acc[NTB];
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb)
@@ -419,9 +420,15 @@ __global__ void k_transpose_win(const float* __restrict__ src, long lds, float* 
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     if (a.R <= 0) return 0;
     const unsigned grid = (unsigned)((a.R + 31) / 32);
-    if (a.NT >= 4)
-        hipLaunchKernelGGL(k_rowgemm<4>, dim3(grid), dim3(64), 0, s, a);
-    else if (a.NT >= 2)
+    const long groups4 = (a.NT + 3) / 4;
+    if (a.NT >= 2 && (long)grid * groups4 < 1024) {
+        // a latency chain on a few waves (a head Linear on 256 rows): one output tile per wave
+        hipLaunchKernelGGL(k_rowgemm<1>, dim3(grid, (unsigned)a.NT), dim3(64), 0, s, a);
+    } else if (a.NT >= 4) {
+        const long want = (4096 + grid - 1) / grid;                 // ~4 waves per SIMD
+        const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
+        hipLaunchKernelGGL(k_rowgemm<4>, dim3(grid, split), dim3(64), 0, s, a);
+    } else if (a.NT >= 2)
         hipLaunchKernelGGL(k_rowgemm<2>, dim3(grid), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(k_rowgemm<1>, dim3(grid), dim3(64), 0, s, a);

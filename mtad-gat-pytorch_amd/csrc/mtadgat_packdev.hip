@@ -120,6 +120,30 @@ __global__ void k_pack_fold(const PackFoldArgs a) {
     }
 }
 
+// bit-exact checksum of a list of parameter tensors: sum of (32-bit pattern x an odd multiplier derived from the
+// global element index) mod 2^64 -- any change of any single element changes it
+__global__ void k_fingerprint(const FingerprintArgs a, unsigned long long* __restrict__ out) {
+    const int t = blockIdx.y;
+    const unsigned* __restrict__ p = reinterpret_cast<const unsigned*>(a.ptr[t]);
+    const long n = a.count[t], base = a.base[t];
+    unsigned long long acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned long long g = (unsigned long long)(base + i);
+        const unsigned long long mult = (((unsigned long long)mix32((unsigned)g * 2654435761u ^ 0x5EEDu) << 20) ^ (g * 0x9E3779B97F4A7C15ull)) | 1ull;
+        acc += (unsigned long long)p[i] * mult;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+int launch_fingerprint(const FingerprintArgs& a, int n_tensors, unsigned long long* out, hipStream_t s) {
+    if (n_tensors <= 0) return 0;
+    hipLaunchKernelGGL(k_fingerprint, dim3(16, (unsigned)n_tensors), dim3(256), 0, s, a, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_pack_gather(const float* flat, const int* gidx, float* img, long n, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_pack_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, gidx, img, n);

@@ -278,7 +278,10 @@ class MTAD_GAT(nn.Module):
             object.__setattr__(self, "_weights_key", None)
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
         if self.check_weight_contents:
-            key = key + (self._fingerprint(params),)
+            if all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+                key = key + (self._engine.fingerprint(params, device),)
+            else:
+                key = key + (self._fingerprint(params),)
         self._engine.set_precision(bf16)
         if key != self._weights_key or (bf16 and not self._engine.bf16_ready()):
             self._engine.load_weights(self.state_dict(), device)
