@@ -81,6 +81,41 @@ __device__ __forceinline__ f32x4 cvt8(const f32x4 lo, const f32x4 hi) {
 __device__ __forceinline__ f32x16 mfma_bf(const f32x4 w, const f32x4 x, f32x16 acc) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
 }
+// ---- split-bf16 operand mode ("x3"): fp32-class accuracy on the bf16 matrix pipe ---------------------------------
+// On gfx950 the fp32 MFMA shares the fp32 vector datapath: it runs at the VALU rate (64 FLOP/clk/SIMD) and does NOT
+// overlap with VALU work of other waves (profiles/r02_mfma_valu_overlap.txt: 1-10 %), while the bf16 MFMA is 16x
+// faster per flop and overlaps (~80 %).  Every fp32 value is the exact sum of three bf16 pieces to 2^-24 relative
+// (x = hi + mid + lo, each piece the bf16 rounding of the remaining residual), so
+//     w x  ~=  wh xh + wh xm + wm xh + wm xm + wh xl + wl xh          (dropped terms <= 2^-24 |w x| each)
+// is six v_mfma_f32_32x32x16_bf16 (16 features, 6 x 32 cycles) in place of eight v_mfma_f32_32x32x2_f32 (8 x 64
+// cycles) for the same 16 features: 2.7x less pipe time, on a pipe that runs beside the VALU.  Products of bf16 pairs
+// are exact in fp32 and the accumulation is the same fp32 accumulation, so the result differs from the fp32 MFMA's by
+// a few 2^-24 per product.  Weights are split once per load (k_split3), activations where they are consumed.
+__device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, f32x4& hi, f32x4& mid, f32x4& lo) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 h, m, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float v0 = p < 2 ? a[2 * p] : b[2 * p - 4], v1 = p < 2 ? a[2 * p + 1] : b[2 * p - 3];
+        const unsigned hw = pack_bf16(v0, v1);
+        const float r0 = v0 - __builtin_bit_cast(float, hw << 16), r1 = v1 - __builtin_bit_cast(float, hw & 0xffff0000u);
+        const unsigned mw = pack_bf16(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, mw << 16), s1 = r1 - __builtin_bit_cast(float, mw & 0xffff0000u);
+        h[p] = hw; m[p] = mw; l[p] = pack_bf16(s0, s1);
+    }
+    hi = __builtin_bit_cast(f32x4, h); mid = __builtin_bit_cast(f32x4, m); lo = __builtin_bit_cast(f32x4, l);
+}
+// w: the three pieces of the weight word (hi, mid, lo); x likewise
+__device__ __forceinline__ f32x16 mfma_s3(const f32x4 (&w)[3], const f32x4 (&x)[3], f32x16 acc) {
+    acc = mfma_bf(w[0], x[2], acc);
+    acc = mfma_bf(w[2], x[0], acc);
+    acc = mfma_bf(w[1], x[1], acc);
+    acc = mfma_bf(w[0], x[1], acc);
+    acc = mfma_bf(w[1], x[0], acc);
+    acc = mfma_bf(w[0], x[0], acc);
+    return acc;
+}
+
 // one chunk for three gate accumulators: fp32 build 4 x 3 MFMAs (8 features), bf16 build 3 MFMAs (16 features)
 template <bool BF>
 __device__ __forceinline__ void mfma_x3(const f32x4 (&w)[3], const f32x4 x, f32x16& a0, f32x16& a1, f32x16& a2);
