@@ -129,6 +129,9 @@ int mtadgat_params_fingerprint(const void* const* tensors_dev, const int64_t* n_
 /* Diagnostic: copies the packed weight image (mtadgat_packed_floats floats) to host memory after synchronising
  * `stream` -- the tests compare the device-side re-pack with the host packer through it. */
 int64_t mtadgat_packed_floats(mtadgat_handle h);
+/* (offset, length) pairs in floats of the image regions that are derived on the device from other regions of the image
+ * (the split-bf16 packs); returns their number (at most max_pairs are written) */
+int mtadgat_derived_regions(mtadgat_handle h, int64_t* out_pairs, int max_pairs);
 int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, void* stream);
 
 /* Arithmetic of the inference entry points (forward / forward_series / stage calls):

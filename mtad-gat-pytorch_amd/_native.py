@@ -64,6 +64,7 @@ def load_library():
     lib.mtadgat_packed_floats.argtypes = [vp]
     lib.mtadgat_packed_floats.restype = i64
     lib.mtadgat_read_packed.argtypes = [vp, vp, i64, vp]
+    lib.mtadgat_derived_regions.argtypes = [vp, ctypes.POINTER(i64), ctypes.c_int]
     lib.mtadgat_workspace_bytes.argtypes = [vp, i64]
     lib.mtadgat_workspace_bytes.restype = sz
     lib.mtadgat_set_precision.argtypes = [vp, ctypes.c_int]
@@ -283,6 +284,12 @@ class Engine:
             _check(self.lib.mtadgat_read_packed(self.handle, ctypes.c_void_p(out.data_ptr()), n, ctypes.c_void_p(stream)), "read_packed")
         return out
 
+    def derived_regions(self):
+        """(offset, length) pairs in floats of the image regions derived on the device from other regions (split-bf16 packs)."""
+        buf = (ctypes.c_int64 * 64)()
+        n = self.lib.mtadgat_derived_regions(self.handle, buf, 32)
+        return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(min(n, 32))]
+
     def load_weights(self, sd, device, allow_device_pack=True):
         """sd: reference-format state_dict (any device).  The first load packs on the host and uploads on the current
         stream; later ones (fp32 image, parameters on the GPU) re-pack on the device."""
@@ -332,9 +339,10 @@ class Engine:
             self._ws = ws
         return ws, need
 
-    def set_precision(self, bf16):
-        """False: fp32 operands (<= 1e-5 parity); True: bf16 MFMA operands, fp32 accumulation / state (<= 2e-2)."""
-        _check(self.lib.mtadgat_set_precision(self.handle, 1 if bf16 else 0), "set_precision")
+    def set_precision(self, mode):
+        """0 / False: fp32 MFMA operands (<= 1e-5 parity); 1 / True: bf16 MFMA operands, fp32 accumulation / state
+        (<= 2e-2); 2: fp32-class results through split-bf16 operands on the large-batch kernels (<= 1e-5)."""
+        _check(self.lib.mtadgat_set_precision(self.handle, int(mode)), "set_precision")
 
     def bf16_ready(self):
         return bool(self.lib.mtadgat_bf16_ready(self.handle))

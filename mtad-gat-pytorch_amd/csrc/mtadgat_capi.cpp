@@ -250,6 +250,16 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.Qxp = g.Qxp16;
         a.bf16 = 1;
     }
+    if (m.precision == 2 && !gates && xmode != 3 && (g.NCG == 4 || g.NCG == 5) && (n + 31) / 32 > 2L * cu_count() &&
+        (g.Qxp16 == 1 || g.Qxp16 % 2 == 0)) {
+        // large batch, split-bf16 operands: fp32-class results from the bf16 matrix pipe (k_gru X3 build)
+        a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx3_off);
+        a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh3_off);
+        a.whs = 2 * g.NCG + 2;
+        a.Qxp = g.Qxp16;
+        a.bf16 = 1;
+        a.x3 = 1;
+    }
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
     a.Hend = hend; a.ldhe = ldhe;
     a.Seq = seq; a.ldseq = g.Hp;
@@ -468,6 +478,19 @@ int mtadgat_destroy(mtadgat_handle h) {
     return 0;
 }
 
+// split-bf16 packs of the large-batch recurrences, derived on the device from the fp32 packs of the image
+static int run_split3(Model& m, hipStream_t s) {
+    auto one = [&](const GruPlan& g) -> int {
+        const long outer_x = (long)(g.xmode == 1 ? m.W : 1) * g.NCG;
+        K_TRY(launch_split3(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, 3, s), "split-bf16 input weights");
+        K_TRY(launch_split3(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, s), "split-bf16 recurrent weights");
+        return 0;
+    };
+    for (const GruPlan& g : m.gru) { int rc = one(g); if (rc) return rc; }
+    for (const GruPlan& g : m.rec) { int rc = one(g); if (rc) return rc; }
+    return 0;
+}
+
 int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream) {
     if (!h || !p) return fail(MTADGAT_ERR_INVALID, "null argument");
     Model& m = h->m;
@@ -507,6 +530,7 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream
     std::memcpy(m.staging_pinned, host.data(), m.packed_floats * sizeof(float));
     HIP_TRY(hipMemcpyAsync(m.packed_dev, m.staging_pinned, m.packed_floats * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(m.upload_ev, s));
+    { int rc = run_split3(m, s); if (rc) return rc; }
     if (std::getenv("MTADGAT_SYNC_UPLOAD")) HIP_TRY(hipStreamSynchronize(s));      // debugging aid
     m.have_weights = true;
     return 0;
@@ -522,7 +546,7 @@ int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64
     if (!h || !flat_dev) return fail(MTADGAT_ERR_INVALID, "null argument");
     Model& m = h->m;
     if (!m.have_weights || !m.packed_dev) return fail(MTADGAT_ERR_NOWEIGHTS, "update_weights_device needs a previous load_weights");
-    if (m.precision != 0) return fail(MTADGAT_ERR_UNSUPPORTED, "device-side re-packing covers the fp32 image only");
+    if (m.precision == 1) return fail(MTADGAT_ERR_UNSUPPORTED, "device-side re-packing covers the fp32 image only");
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != m.packed_device) return fail(MTADGAT_ERR_INVALID, "the weights live on another device");
@@ -627,6 +651,25 @@ int mtadgat_params_fingerprint(const void* const* tensors_dev, const int64_t* n_
     return 0;
 }
 
+/* (offset, length) pairs, in floats, of the regions of the packed image that are derived on the device from other
+ * regions (the split-bf16 packs); returns the number of pairs */
+int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
+    if (!h || !out) return 0;
+    const Model& m = h->m;
+    int n = 0;
+    auto add = [&](size_t off, size_t len) {
+        if (n < max_pairs) { out[2 * n] = (int64_t)off; out[2 * n + 1] = (int64_t)len; }
+        ++n;
+    };
+    auto one = [&](const GruPlan& g) {
+        add(g.wx3_off, (size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 9 * 256);
+        add(g.wh3_off, (size_t)g.NCG * (2 * g.NCG + 2) * 9 * 256);
+    };
+    for (const GruPlan& g : m.gru) one(g);
+    for (const GruPlan& g : m.rec) one(g);
+    return n;
+}
+
 int64_t mtadgat_packed_floats(mtadgat_handle h) { return h ? (int64_t)h->m.packed_floats : 0; }
 int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, void* stream) {
     if (!h || !dst_host) return fail(MTADGAT_ERR_INVALID, "null argument");
@@ -639,7 +682,8 @@ int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, voi
 }
 
 int mtadgat_set_precision(mtadgat_handle h, int mode) {
-    if (!h || (mode != 0 && mode != 1)) return fail(MTADGAT_ERR_INVALID, "precision mode must be 0 (fp32) or 1 (bf16 operands)");
+    if (!h || mode < 0 || mode > 2)
+        return fail(MTADGAT_ERR_INVALID, "precision mode must be 0 (fp32 MFMA), 1 (bf16 operands) or 2 (fp32 through split-bf16 operands)");
     h->m.precision = mode;
     return 0;
 }

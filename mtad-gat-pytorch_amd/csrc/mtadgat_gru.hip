@@ -6,6 +6,7 @@ namespace mtadgat {
 
 int launch_gru_big_f32(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
 int launch_gru_big_bf16(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
+int launch_gru_big_x3(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // GRU, hidden-tile split: a workgroup owns 32 windows, wave c the 32 hidden units of tile c (all three
@@ -331,6 +332,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     }
     // two groups per wave once that still gives every SIMD a wave
     const bool two = (a.B + 31) / 32 >= 8L * n_cu;
+    if (a.x3) return launch_gru_big_x3(a, ncg, xmode, fc, two, s);
     return a.bf16 ? launch_gru_big_bf16(a, ncg, xmode, fc, two, s) : launch_gru_big_f32(a, ncg, xmode, fc, two, s);
 }
 

@@ -40,8 +40,12 @@ namespace mtadgat {
 // are replaced by the next step's while the last tile consumes them -- read once per step instead of once per tile.
 // With the MFMAs 16x cheaper the five re-reads of x (5 x 67 KB per window: they miss the L2, the XCD's waves stream
 // more than its 4 MB between two tiles) made the bf16 build HBM-bound at ~4 TB/s.
-template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false, int QXC = 0>
-__global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 1)) void k_gru(const GruArgs a) {
+// X3 (with BF geometry): split-bf16 operands (mtadgat_device.h): every weight chunk comes as three bf16 pieces per
+// gate, every activation chunk is split into three pieces where it is consumed, six bf16 MFMAs per gate and chunk --
+// fp32-class results on the bf16 matrix pipe.  Two ring stages (a chunk is 36 MFMAs = 1.15 k cycles of cover).
+template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false, int QXC = 0, bool X3 = false>
+__global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3) ? 2 : 1)) void k_gru(const GruArgs a) {
+    static_assert(!X3 || (BF && QXC == 0), "split-bf16 build uses the bf16 chunk geometry");
     extern __shared__ __attribute__((aligned(16))) float hn_dyn[];
     constexpr int WPB = MW == 2 ? 4 : 1;
     const int lane = threadIdx.x & 63;
@@ -61,7 +65,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
     // ring depth: 3 chunks of weights in flight (fp32: 36 MFMAs x 64 cycles ~ 2.3k cycles of cover).  A ring of 6 was
     // tried for the bf16 build, whose chunks are 8x shorter: no gain -- that build was bound by the input re-reads (XR)
     constexpr bool XR = BF && XMODE == 0 && QXC > 0;
-    constexpr int R = 3;
+    constexpr int R = X3 ? 2 : 3;
+    constexpr int NP = X3 ? 3 : 1;                // operand pieces per weight word
+    constexpr int WN = 3 * NP;                    // 16-byte words per chunk and lane: [gate][piece]
+    constexpr int XW = X3 ? 2 : 1;                // registers of an input chunk: the two fp32 halves (X3) or the operand itself
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
     constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
@@ -84,15 +91,16 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
     int pc = 0, ps = 0, pt = 0;
     const f32x4* __restrict__ pwx = a.Wx;          // next input-part chunk to fetch
     const f32x4* __restrict__ pwh = a.Wh;          // next recurrent-part chunk to fetch
-    auto wload = [&](f32x4 (&dst)[3]) {
+    auto wload = [&](f32x4 (&dst)[WN]) {
         const bool isx = ps < Qxp;
         const f32x4* __restrict__ p = (isx ? pwx : pwh) + lane;
-        dst[0] = p[0]; dst[1] = p[64]; dst[2] = p[128];
-        pwx += isx ? 192 : 0;
-        pwh += isx ? 0 : 192;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) dst[j] = p[64 * j];
+        pwx += isx ? 64 * WN : 0;
+        pwh += isx ? 0 : 64 * WN;
         const bool ws = (ps + 1 == S);             // end of this tile's chunk sequence
         ps = ws ? 0 : ps + 1;
-        pwh += ws ? (a.whs - Qhe) * 192 : 0;       // skip the unused all-padding chunks of the tile
+        pwh += ws ? (a.whs - Qhe) * (64 * WN) : 0; // skip the unused all-padding chunks of the tile
         const bool wc = ws && (pc + 1 == NCG);     // end of the step
         pc = ws ? (wc ? 0 : pc + 1) : pc;
         pt = wc ? pt + 1 : pt;
@@ -115,19 +123,40 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
 
     // B operand of packed input chunk q: fp32 build = the 8-feature chunk itself; bf16 build = chunks 2q, 2q+1 converted
     // (XMODE 1: the single folded chunk, upper half zero)
-    auto loadxq = [&](int w, int t, int q) -> f32x4 {
-        if (!BF) return loadx_t(w, t, q);
-        if (XMODE == 1) return cvt8(loadx_t(w, t, q), f32x4{0.f, 0.f, 0.f, 0.f});
-        return cvt8(loadx_t(w, t, 2 * q), loadx_t(w, t, 2 * q + 1));
+    auto loadxq = [&](f32x4 (&dst)[XW], int w, int t, int q) {
+        if (X3) {                                   // the fp32 halves; split into pieces where consumed
+            dst[0] = loadx_t(w, t, XMODE == 1 ? q : 2 * q);
+            dst[XW - 1] = XMODE == 1 ? f32x4{0.f, 0.f, 0.f, 0.f} : loadx_t(w, t, 2 * q + 1);
+        } else if (!BF) dst[0] = loadx_t(w, t, q);
+        else if (XMODE == 1) dst[0] = cvt8(loadx_t(w, t, q), f32x4{0.f, 0.f, 0.f, 0.f});
+        else dst[0] = cvt8(loadx_t(w, t, 2 * q), loadx_t(w, t, 2 * q + 1));
+    };
+    // one chunk into the three gate accumulators
+    auto gates3 = [&](const f32x4 (&wv)[WN], const f32x4 (&xv)[XW], f32x16& g0, f32x16& g1, f32x16& g2) {
+        if constexpr (X3) {
+            f32x4 xs[3];
+            split3(xv[0], xv[XW - 1], xs[0], xs[1], xs[2]);
+            const f32x4 w0[3] = {wv[0], wv[1], wv[2]}, w1[3] = {wv[3], wv[4], wv[5]}, w2[3] = {wv[6], wv[7], wv[8]};
+            // term by term across the gates: consecutive MFMAs never depend on each other
+            g0 = mfma_bf(w0[0], xs[2], g0); g1 = mfma_bf(w1[0], xs[2], g1); g2 = mfma_bf(w2[0], xs[2], g2);
+            g0 = mfma_bf(w0[2], xs[0], g0); g1 = mfma_bf(w1[2], xs[0], g1); g2 = mfma_bf(w2[2], xs[0], g2);
+            g0 = mfma_bf(w0[1], xs[1], g0); g1 = mfma_bf(w1[1], xs[1], g1); g2 = mfma_bf(w2[1], xs[1], g2);
+            g0 = mfma_bf(w0[0], xs[1], g0); g1 = mfma_bf(w1[0], xs[1], g1); g2 = mfma_bf(w2[0], xs[1], g2);
+            g0 = mfma_bf(w0[1], xs[0], g0); g1 = mfma_bf(w1[1], xs[0], g1); g2 = mfma_bf(w2[1], xs[0], g2);
+            g0 = mfma_bf(w0[0], xs[0], g0); g1 = mfma_bf(w1[0], xs[0], g1); g2 = mfma_bf(w2[0], xs[0], g2);
+        } else {
+            const f32x4 w3[3] = {wv[0], wv[1], wv[2]};
+            mfma_x3<BF>(w3, xv[0], g0, g1, g2);
+        }
     };
     constexpr int NXR = XR ? QXC : R;               // input operand registers: the whole step (XR) or the ring
-    f32x4 wr[R][3], xr[NXR][MW];
+    f32x4 wr[R][WN], xr[NXR][MW][XW];
 #pragma unroll
     for (int st = 0; st < R; ++st) wload(wr[st]);
 #pragma unroll
     for (int st = 0; st < NXR; ++st)
 #pragma unroll
-        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, 0, st);
+        for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, 0, st);
 
     for (int t = 0; t < T; ++t) {
         auto tile_body = [&](const int c, auto last_tag) {
@@ -155,7 +184,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
             // MFMAs and the next iteration waits for them.
             if (XMODE == 1) {
 #pragma unroll
-                for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[0], xr[0][w], ar[w], az[w], anx[w]);
+                for (int w = 0; w < MW; ++w) gates3(wr[0], xr[0][w], ar[w], az[w], anx[w]);
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
             } else if (XR) {
@@ -165,11 +194,11 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
                     constexpr int dummy = 0; (void)dummy;
                     const int st = q % R;
 #pragma unroll
-                    for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[st], xr[q][w], ar[w], az[w], anx[w]);
+                    for (int w = 0; w < MW; ++w) gates3(wr[st], xr[q][w], ar[w], az[w], anx[w]);
                     wload(wr[st]);
                     if (LAST) {                       // compile-time: only the last tile's code carries these loads
 #pragma unroll
-                        for (int w = 0; w < MW; ++w) xr[q][w] = loadxq(w, tnx, q);
+                        for (int w = 0; w < MW; ++w) loadxq(xr[q][w], w, tnx, q);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -178,10 +207,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
 #pragma unroll
                     for (int st = 0; st < R; ++st) {
 #pragma unroll
-                        for (int w = 0; w < MW; ++w) mfma_x3<BF>(wr[st], xr[st][w], ar[w], az[w], anx[w]);
+                        for (int w = 0; w < MW; ++w) gates3(wr[st], xr[st][w], ar[w], az[w], anx[w]);
                         wload(wr[st]);
 #pragma unroll
-                        for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, t, q0 + st + R);
+                        for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, t, q0 + st + R);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -194,34 +223,35 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
                 const int st = (X0 + q) % R;
 #pragma unroll
                 for (int w = 0; w < MW; ++w) {
-                    f32x4 hv;
+                    f32x4 hv[XW];
                     if (BF) {
                         const int cq = q >> 1, e0 = 8 * (q & 1);
                         f32x4 lo, hi;
                         lo[0] = h[w][cq][e0 + 0]; lo[1] = h[w][cq][e0 + 1]; lo[2] = h[w][cq][e0 + 2]; lo[3] = h[w][cq][e0 + 3];
                         hi[0] = h[w][cq][e0 + 4]; hi[1] = h[w][cq][e0 + 5]; hi[2] = h[w][cq][e0 + 6]; hi[3] = h[w][cq][e0 + 7];
-                        hv = cvt8(lo, hi);
+                        if (X3) { hv[0] = lo; hv[XW - 1] = hi; }
+                        else hv[0] = cvt8(lo, hi);
                     } else {
                         const int cq = q >> 2, m = q & 3;
-                        hv[0] = h[w][cq][4 * m + 0]; hv[1] = h[w][cq][4 * m + 1];
-                        hv[2] = h[w][cq][4 * m + 2]; hv[3] = h[w][cq][4 * m + 3];
+                        hv[0][0] = h[w][cq][4 * m + 0]; hv[0][1] = h[w][cq][4 * m + 1];
+                        hv[0][2] = h[w][cq][4 * m + 2]; hv[0][3] = h[w][cq][4 * m + 3];
                     }
-                    mfma_x3<BF>(wr[st], hv, ar[w], az[w], anh[w]);
+                    gates3(wr[st], hv, ar[w], az[w], anh[w]);
                 }
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // bring the ring back to phase 0 for the next tile: a compile-time register renaming (rotate by ROT stages)
             if (ROT != 0) {
-                f32x4 tmp[R][3];
+                f32x4 tmp[R][WN];
 #pragma unroll
                 for (int st = 0; st < R; ++st)
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) tmp[st][u] = wr[(st + ROT) % R][u];
+                    for (int u = 0; u < WN; ++u) tmp[st][u] = wr[(st + ROT) % R][u];
 #pragma unroll
                 for (int st = 0; st < R; ++st)
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) wr[st][u] = tmp[st][u];
+                    for (int u = 0; u < WN; ++u) wr[st][u] = tmp[st][u];
             }
             // x chunks 0..2 of the next tile / step: their latency hides under the gate math
             if (!XR) {
@@ -229,7 +259,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
 #pragma unroll
                 for (int st = 0; st < R; ++st)
 #pragma unroll
-                    for (int w = 0; w < MW; ++w) xr[st][w] = loadxq(w, tn, st);
+                    for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, tn, st);
             }
             // ---- gates.  h_old for this tile comes back from LDS (written at the end of step t-1);
             // every lane reads and writes only its own slots -> no cross-lane hazard
@@ -352,7 +382,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1) ? 2 : 
     }
 }
 
-template <int NCG, int XMODE, int MW, bool BF>
+template <int NCG, int XMODE, int MW, bool BF, bool X3 = false>
 inline int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
     constexpr int WPB = MW == 2 ? 4 : 1;
     const unsigned grid = (unsigned)((a.B + 32 * MW * WPB - 1) / (32 * MW * WPB));
@@ -360,11 +390,11 @@ inline int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
 #define GRU_LAUNCH(FCV, DR)                                                                                            \
     {                                                                                                                  \
         if (lds > 64 * 1024) {                                                                                         \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru<NCG, XMODE, FCV, DR, MW, BF>),   \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru<NCG, XMODE, FCV, DR, MW, BF, 0, X3>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
             if (e_ != hipSuccess) return (int)e_;                                                                      \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_gru<NCG, XMODE, FCV, DR, MW, BF>), dim3(grid), dim3(64 * WPB), lds, s, a);               \
+        hipLaunchKernelGGL((k_gru<NCG, XMODE, FCV, DR, MW, BF, 0, X3>), dim3(grid), dim3(64 * WPB), lds, s, a);        \
     }
 #define GRU_LAUNCH_XR(DR, QX)                                                                                          \
     {                                                                                                                  \
@@ -375,7 +405,7 @@ inline int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
         }                                                                                                              \
         hipLaunchKernelGGL((k_gru<NCG, 0, false, DR, 2, true, QX>), dim3(grid), dim3(64 * WPB), lds, s, a);            \
     }
-    if constexpr (BF && XMODE == 0 && MW == 2 && NCG <= 5) {
+    if constexpr (BF && !X3 && XMODE == 0 && MW == 2 && NCG <= 5) {
         static const bool stream_x = std::getenv("MTADGAT_GRU_STREAM_X") != nullptr;      // A/B switch
         if (!fc && !stream_x && (a.Qxp == 6 || a.Qxp == 12)) {
             if (a.Qxp == 6) { if (drop == 0) GRU_LAUNCH_XR(0, 6) else GRU_LAUNCH_XR(1, 6) }
@@ -394,22 +424,31 @@ inline int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
     return 0;
 }
 
-template <int NCG, bool BF>
+template <int NCG, bool BF, bool X3 = false>
 inline int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, bool two, hipStream_t s) {
     // trailing recurrent chunks that are pure padding: skip one when H <= 8*(4*NCG - 1)  (bf16: 16*(2*NCG - 1))
     const int drop = BF ? ((a.H <= 16 * (2 * NCG - 1)) ? 1 : 0) : ((a.H <= 8 * (4 * NCG - 1)) ? 1 : 0);
     if constexpr (NCG <= 5) {           // two 32-window groups per wave: 8 KB of LDS per group and tile, 4 waves per CU
         if (two) {
-            if (xmode == 0) return launch_gru_mode<NCG, 0, 2, BF>(a, fc, drop, s);
-            if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 2, BF>(a, fc, drop, s);
-            return launch_gru_mode<NCG, 2, 2, BF>(a, fc, drop, s);
+            if (xmode == 0) return launch_gru_mode<NCG, 0, 2, BF, X3>(a, fc, drop, s);
+            if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 2, BF, X3>(a, fc, drop, s);
+            return launch_gru_mode<NCG, 2, 2, BF, X3>(a, fc, drop, s);
         }
     }
-    if (xmode == 0) return launch_gru_mode<NCG, 0, 1, BF>(a, fc, drop, s);
-    if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 1, BF>(a, fc, drop, s);
-    return launch_gru_mode<NCG, 2, 1, BF>(a, fc, drop, s);
+    if (xmode == 0) return launch_gru_mode<NCG, 0, 1, BF, X3>(a, fc, drop, s);
+    if (a.Qxp == 1) return launch_gru_mode<NCG, 1, 1, BF, X3>(a, fc, drop, s);
+    return launch_gru_mode<NCG, 2, 1, BF, X3>(a, fc, drop, s);
 }
 
+
+// split-bf16 build: the hidden sizes of the shipped configurations (tiles 4 and 5) only
+inline int launch_gru_big_split(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s) {
+    switch (ncg) {
+        case 4: return launch_gru_ncg<4, true, true>(a, xmode, fc, two, s);
+        case 5: return launch_gru_ncg<5, true, true>(a, xmode, fc, two, s);
+        default: return -2;
+    }
+}
 
 template <bool BF>
 inline int launch_gru_big_t(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s) {

@@ -182,6 +182,8 @@ std::string validate_and_plan(Model& m) {
         g.Qxp16 = round_up((g.Qx + 1) / 2, 6);       // whole turns of the bf16 weight ring (6 stages; k_gru_split: 3)
         g.wx16_off = take((size_t)g.NCG * g.Qxp16 * 3 * 256);
         g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
+        g.wx3_off = take((size_t)g.NCG * g.Qxp16 * 9 * 256);
+        g.wh3_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 9 * 256);
         if (l == 0) {
             g.has_xproj = true;
             g.xproj.in_dim = g.in_dim; g.xproj.out_dim = 3 * g.Hp;
@@ -235,6 +237,8 @@ std::string validate_and_plan(Model& m) {
         g.Qxp16 = g.xmode == 1 ? (g.Qx == 1 ? 1 : round_up((g.Qx + 1) / 2, 6)) : round_up((g.Qx + 1) / 2, 6);
         g.wx16_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 3 * 256);
         g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
+        g.wx3_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 9 * 256);
+        g.wh3_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 9 * 256);
         if (l == 0) plan16(g);
     }
     {
@@ -849,7 +853,7 @@ void params_from_flat(const Model& m, const FlatOffsets& f, const float* flat, m
 // as the first host-side load wrote it.
 std::string build_device_tables(Model& m) {
     DevTables& t = m.dt;
-    if (m.precision != 0) return "device-side re-packing covers the fp32 image only";
+    if (m.precision == 1) return "device-side re-packing covers the fp32 image only";
     t.fo = flat_offsets(m);
     if (t.fo.total != m.bw.gl.total) return "internal: flat parameter layout mismatch";
     if (t.fo.total >= (1 << 24)) return "model too large for the index-encoded gather table";

@@ -120,6 +120,36 @@ __global__ void k_pack_fold(const PackFoldArgs a) {
     }
 }
 
+// fp32 tile packs -> split-bf16 packs (mtadgat_device.h, "x3"): bf16 chunk qd of a tile pairs the fp32 chunks 2 qd and
+// 2 qd + 1 of the same lane (that IS the element order of the bf16 operand), each value becomes three bf16 pieces.
+// src [outer][Qs][G][64] f32x4, dst [outer][Qd][G][3 pieces][64] 16-byte words
+__global__ void k_split3(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n_outer, int Qs, int Qd, int G) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = n_outer * Qd * G * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long r = idx >> 6;
+    const int g = (int)(r % G);
+    const long r2 = r / G;
+    const int qd = (int)(r2 % Qd);
+    const long o = r2 / Qd;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a = 2 * qd < Qs ? src[((o * Qs + 2 * qd) * G + g) * 64 + lane] : z;
+    const f32x4 b = 2 * qd + 1 < Qs ? src[((o * Qs + 2 * qd + 1) * G + g) * 64 + lane] : z;
+    f32x4 hi, mid, lo;
+    split3(a, b, hi, mid, lo);
+    f32x4* __restrict__ d = dst + (((o * Qd + qd) * G + g) * 3) * 64 + lane;
+    d[0] = hi; d[64] = mid; d[128] = lo;
+}
+int launch_split3(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, hipStream_t s) {
+    const long total = n_outer * Qd * G * 64;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_split3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), n_outer, Qs, Qd, G);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // bit-exact checksum of a list of parameter tensors: sum of (32-bit pattern x an odd multiplier derived from the
 // global element index) mod 2^64 -- any change of any single element changes it
 __global__ void k_fingerprint(const FingerprintArgs a, unsigned long long* __restrict__ out) {

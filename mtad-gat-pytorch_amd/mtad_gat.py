@@ -222,9 +222,11 @@ class MTAD_GAT(nn.Module):
         object.__setattr__(self, "_weights_key", None)
         object.__setattr__(self, "_fp_vec", None)
         if "precision" not in self.__dict__:
-            # arithmetic of GPU inference: "fp32" (exact fp32 MFMA, <= 1e-5 of the reference), "bf16" (bf16 MFMA
-            # operands, fp32 accumulation / state / softmax, <= 2e-2), "auto" = bf16 exactly when the caller hands
-            # over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
+            # arithmetic of GPU inference: "fp32" (<= 1e-5 of the reference: fp32 accumulation everywhere; the large-batch
+            # kernels form their products from split-bf16 operands on the bf16 matrix pipe, which reproduces the
+            # fp32-MFMA result to ~2e-7 -- DESIGN.md section 4), "fp32_strict" (v_mfma_f32 / fp32 VALU only), "bf16"
+            # (bf16 MFMA operands, fp32 accumulation / state / softmax, <= 2e-2), "auto" = bf16 exactly when the
+            # caller hands over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
             object.__setattr__(self, "precision", "auto")
         if "bf16_train_min_batch" not in self.__dict__:
             # training steps below this many windows run in fp32 even when bf16 is requested (see forward)
@@ -282,15 +284,16 @@ class MTAD_GAT(nn.Module):
                 key = key + (self._engine.fingerprint(params, device),)
             else:
                 key = key + (self._fingerprint(params),)
-        self._engine.set_precision(bf16)
+        mode = 1 if bf16 else (0 if self.precision == "fp32_strict" else 2)
+        self._engine.set_precision(mode)
         if key != self._weights_key or (bf16 and not self._engine.bf16_ready()):
             self._engine.load_weights(self.state_dict(), device)
             object.__setattr__(self, "_weights_key", key)
         return self._engine
 
     def _use_bf16(self, x):
-        if self.precision not in ("auto", "fp32", "bf16"):
-            raise ValueError("MTAD_GAT.precision must be 'auto', 'fp32' or 'bf16'")
+        if self.precision not in ("auto", "fp32", "fp32_strict", "bf16"):
+            raise ValueError("MTAD_GAT.precision must be 'auto', 'fp32', 'fp32_strict' or 'bf16'")
         return self.precision == "bf16" or (self.precision == "auto" and x.dtype == torch.bfloat16)
 
     def _wants_grad(self, x):

@@ -51,6 +51,8 @@ def test_device_repack_equals_the_host_packer(name, gpu_device):
         # attention columns are bit-identical; the folded decoder input sums the same terms in another order (host:
         # differences of prefix sums) -- last-bit differences only
         mism = img_dev.view(torch.int32) != img_host.view(torch.int32)
+        for off, n in eng.derived_regions():      # split-bf16 packs: produced from the fp32 packs by the same kernel on both paths
+            mism[off:off + n] = False
         assert mism.float().mean().item() < 0.02, (name, rnd, int(mism.sum()))
         if mism.any():
             a, b = img_dev[mism], img_host[mism]
