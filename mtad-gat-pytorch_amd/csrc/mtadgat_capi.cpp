@@ -93,6 +93,14 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
         a.bf16 = 1; a.Fq = m.Fp16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w16_off);
     }
+    // split-bf16 operands (default fp32 arithmetic of large batches): same geometry, fp32-class results
+    // (measured 3.36 vs 3.37 ms at the flagship shape: the convolution is bound by its staging and stores, not by the matrix
+    // pipe -- kept behind a switch)
+    static const bool conv_x3 = std::getenv("MTADGAT_CONV_X3") != nullptr;
+    if (conv_x3 && m.precision == 2 && !src.x_bf16 && n >= 4096 && (size_t)(32 + m.taps - 1) * (m.Fp16 + 4) * sizeof(float) <= 20 * 1024) {
+        a.bf16 = 2; a.Fq = m.Fp16;
+        a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w3_off);
+    }
     a.bias = m.packed_dev + m.conv_b_off;
     a.NT = m.convNT;
     a.XC = xc; a.XCT = xct; a.Wpad = m.Wp; a.HCAT = hcat; a.Dp = m.Dp; a.Y = y;
@@ -153,6 +161,14 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
+    } else if (m.precision == 2 && n >= 4096 && g.D >= 80 && !std::getenv("MTADGAT_GAT_FP32")) {
+        // large batches, long node vectors (feature layer: D = W = 100): split-bf16 operands for the projection -- fp32-class
+        // L' / R' on the bf16 matrix pipe, which runs beside the pair grid (the fp32 MFMA does not).  Measured at (W=100,
+        // F=55): feature layer 5.90 -> 5.12 ms; the temporal layer (D = 55: four 16-feature chunks for 56 features, and
+        // the larger pair-grid register block leaves no room for the pieces -- 19 spilled VGPRs) 7.44 -> 7.63 ms, so it
+        // stays on the fp32 MFMA
+        a.bf16 = 2; a.Q = g.Q16;
+        a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w3_off);
     }
     a.bias = m.packed_dev + g.bias_off;
     a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
@@ -488,6 +504,10 @@ static int run_split3(Model& m, hipStream_t s) {
     };
     for (const GruPlan& g : m.gru) { int rc = one(g); if (rc) return rc; }
     for (const GruPlan& g : m.rec) { int rc = one(g); if (rc) return rc; }
+    for (const GatPlan* g : {&m.feat, &m.temp})
+        if (g->fused) K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, s), "split-bf16 projection weights");
+    K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, s),
+          "split-bf16 conv weights");
     return 0;
 }
 
@@ -667,6 +687,9 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     };
     for (const GruPlan& g : m.gru) one(g);
     for (const GruPlan& g : m.rec) one(g);
+    add(m.conv_w3_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
+    add(m.feat.w3_off, (size_t)m.feat.NT * m.feat.Q16 * 3 * 256);
+    add(m.temp.w3_off, (size_t)m.temp.NT * m.temp.Q16 * 3 * 256);
     return n;
 }
 

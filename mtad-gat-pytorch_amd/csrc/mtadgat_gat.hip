@@ -139,7 +139,10 @@ __device__ __forceinline__ float row_sum(float v) {
 #ifndef MTADGAT_GAT_MINW
 #define MTADGAT_GAT_MINW 4
 #endif
-template <int IBL, int JPL, int RJ, bool BF = false>
+// X3 (with BF): split-bf16 operands for the projection (mtadgat_device.h) -- three weight pieces per chunk, the node rows
+// split where they are consumed: fp32-class L' / R' from the bf16 matrix pipe, which (unlike the fp32 MFMA) runs beside
+// the pair grid of the other waves.
+template <int IBL, int JPL, int RJ, bool BF = false, bool X3 = false>
 __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
 #ifndef MTADGAT_GAT_QB
 #define MTADGAT_GAT_QB 8
 #endif
-    constexpr int QB = MTADGAT_GAT_QB;                 // weight chunks held in registers per task batch
+    constexpr int QB = X3 ? 4 : MTADGAT_GAT_QB;        // weight chunks held in registers per task batch
+    constexpr int NP = X3 ? 3 : 1;                     // 16-byte words per weight chunk and lane
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
@@ -172,13 +176,15 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     // that ends the previous VALU phase, for part 0 before the window is staged -- so the L2 round trip is
     // not on the critical path of the MFMA phase.  (The projection bias is row D of the packed weights,
     // multiplied by a constant-one column of Vs: no separate bias loads.)
-    f32x4 w[QB];
+    f32x4 w[QB][NP];
     auto prefetch = [&](int part) {
         if (wave < ntask) {
             const int wtile = wave >= NTn ? a.NT_L + part : part;
-            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * (64 * NP) + lane;
 #pragma unroll
-            for (int u = 0; u < QB; ++u) w[u] = wp[(long)(u < Q ? u : Q - 1) * 64];
+            for (int u = 0; u < QB; ++u)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) w[u][pc] = wp[((long)(u < Q ? u : Q - 1) * NP + pc) * 64];
         }
     };
 
@@ -277,10 +283,12 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
             const int wtile = keyside ? a.NT_L + part : part;
             const int node = nt * 32 + i;
             const float* __restrict__ vrow = Vs + (node < K ? node : K - 1) * vld;
-            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
+            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * (64 * NP) + lane;
             if (task != wave) {                    // more tiles than waves: later tasks pay their own round trip
 #pragma unroll
-                for (int u = 0; u < QB; ++u) w[u] = wp[(long)(u < Q ? u : Q - 1) * 64];
+                for (int u = 0; u < QB; ++u)
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) w[u][pc] = wp[((long)(u < Q ? u : Q - 1) * NP + pc) * 64];
             }
             f32x16 o;
 #pragma unroll
@@ -294,14 +302,25 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
                             // zero, the read is clamped into the row so that it stays finite
                             const int c1 = 16 * (qb + u) + 8 + 4 * g;
                             const f32x4 lo = *reinterpret_cast<const f32x4*>(vrow + 16 * (qb + u) + 4 * g);
-                            const f32x4 hi = *reinterpret_cast<const f32x4*>(vrow + (c1 + 3 < vld ? c1 : vld - 4));
-                            o = mfma_bf(w[u], cvt8(lo, hi), o);
+                            f32x4 hi = *reinterpret_cast<const f32x4*>(vrow + (c1 + 3 < vld ? c1 : vld - 4));
+                            if constexpr (X3) {
+                                // (a clamped upper half would carry real values here: its weights are zero, but the three
+                                // pieces of a wrong value are still finite -- nothing to mask)
+                                f32x4 xs[3];
+                                split3(lo, hi, xs[0], xs[1], xs[2]);
+                                o = mfma_s3(w[u], xs, o);
+                            } else {
+                                o = mfma_bf(w[u][0], cvt8(lo, hi), o);
+                            }
                         } else {
                             const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * (qb + u) + 4 * g);
-                            o = mfma4(w[u], xv, o);
+                            o = mfma4(w[u][0], xv, o);
                         }
                         // the chunk QB further on replaces this one as soon as it has been issued
-                        if (qb + QB + u < Q) w[u] = wp[(long)(qb + QB + u) * 64];
+                        if (qb + QB + u < Q) {
+#pragma unroll
+                            for (int pc = 0; pc < NP; ++pc) w[u][pc] = wp[((long)(qb + QB + u) * NP + pc) * 64];
+                        }
                     }
             }
             if (node < K) {
@@ -790,13 +809,15 @@ int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int 
 
 #define GAT_CASE(I, J, RJ)                                                                      \
     if (IBL == I && JPL == J && rj == RJ) {                                                     \
-        const void* fn_ = a.bf16 ? reinterpret_cast<const void*>(&k_gat<I, J, RJ, true>)        \
-                                 : reinterpret_cast<const void*>(&k_gat<I, J, RJ, false>);      \
+        const void* fn_ = a.bf16 == 2 ? reinterpret_cast<const void*>(&k_gat<I, J, RJ, true, true>)  \
+                          : a.bf16 ? reinterpret_cast<const void*>(&k_gat<I, J, RJ, true>)      \
+                                   : reinterpret_cast<const void*>(&k_gat<I, J, RJ, false>);    \
         if (lds_bytes > 64 * 1024) {                                                            \
             hipError_t e_ = hipFuncSetAttribute(fn_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e_ != hipSuccess) return (int)e_;                                               \
         }                                                                                       \
-        if (a.bf16) hipLaunchKernelGGL((k_gat<I, J, RJ, true>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);  \
+        if (a.bf16 == 2) hipLaunchKernelGGL((k_gat<I, J, RJ, true, true>), dim3(grid), dim3(64 * nw), lds_bytes, s, a); \
+        else if (a.bf16) hipLaunchKernelGGL((k_gat<I, J, RJ, true>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);  \
         else hipLaunchKernelGGL((k_gat<I, J, RJ, false>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);        \
         launched = true;                                                                        \
     }

@@ -149,6 +149,52 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             mfma_x3<BF>(w3, xv[0], g0, g1, g2);
         }
     };
+    // X3, two window groups per wave: software pipeline -- the 18 MFMAs of one (chunk, group) item run while the VALU
+    // splits the operand of the next item (the wave issues in order: a split placed after the MFMAs of its own item
+    // would wait behind them with the matrix pipe idle for ~220 cycles per item)
+    constexpr bool PIPE = X3 && MW == 2;
+    auto mfma18 = [&](const f32x4 (&wv)[WN], const f32x4 (&xs)[3], f32x16& g0, f32x16& g1, f32x16& g2) {
+        if constexpr (X3) {
+            g0 = mfma_bf(wv[0], xs[2], g0); g1 = mfma_bf(wv[3], xs[2], g1); g2 = mfma_bf(wv[6], xs[2], g2);
+            g0 = mfma_bf(wv[2], xs[0], g0); g1 = mfma_bf(wv[5], xs[0], g1); g2 = mfma_bf(wv[8], xs[0], g2);
+            g0 = mfma_bf(wv[1], xs[1], g0); g1 = mfma_bf(wv[4], xs[1], g1); g2 = mfma_bf(wv[7], xs[1], g2);
+            g0 = mfma_bf(wv[0], xs[1], g0); g1 = mfma_bf(wv[3], xs[1], g1); g2 = mfma_bf(wv[6], xs[1], g2);
+            g0 = mfma_bf(wv[1], xs[0], g0); g1 = mfma_bf(wv[4], xs[0], g1); g2 = mfma_bf(wv[7], xs[0], g2);
+            g0 = mfma_bf(wv[0], xs[0], g0); g1 = mfma_bf(wv[3], xs[0], g1); g2 = mfma_bf(wv[6], xs[0], g2);
+        }
+    };
+    // the six product terms in triples (one MFMA per gate), the four value pairs of the next operand's split between
+    // them; sched_barrier keeps the source order (the group-barrier solver gave up on whole stages)
+    auto stage = [&](const f32x4 (&wv)[WN], const f32x4 (&xs)[3], f32x16& g0, f32x16& g1, f32x16& g2, const f32x4 ra, const f32x4 rb,
+                     f32x4 (&xn)[3]) {
+        if constexpr (X3) {
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            u4 hw, mw, lw;
+            auto pair = [&](const int pp) {
+                const float v0 = pp < 2 ? ra[2 * pp] : rb[2 * pp - 4], v1 = pp < 2 ? ra[2 * pp + 1] : rb[2 * pp - 3];
+                const unsigned hh = pack_bf16(v0, v1);
+                const float r0 = v0 - __builtin_bit_cast(float, hh << 16), r1 = v1 - __builtin_bit_cast(float, hh & 0xffff0000u);
+                const unsigned mm = pack_bf16(r0, r1);
+                const float s0 = r0 - __builtin_bit_cast(float, mm << 16), s1 = r1 - __builtin_bit_cast(float, mm & 0xffff0000u);
+                hw[pp] = hh; mw[pp] = mm; lw[pp] = pack_bf16(s0, s1);
+            };
+            auto triple = [&](const int wi, const int xi) {
+                g0 = mfma_bf(wv[wi], xs[xi], g0); g1 = mfma_bf(wv[3 + wi], xs[xi], g1); g2 = mfma_bf(wv[6 + wi], xs[xi], g2);
+            };
+            triple(0, 2); __builtin_amdgcn_sched_barrier(0); pair(0); __builtin_amdgcn_sched_barrier(0);
+            triple(2, 0); __builtin_amdgcn_sched_barrier(0); pair(1); __builtin_amdgcn_sched_barrier(0);
+            triple(1, 1); __builtin_amdgcn_sched_barrier(0); pair(2); __builtin_amdgcn_sched_barrier(0);
+            triple(0, 1); __builtin_amdgcn_sched_barrier(0); pair(3); __builtin_amdgcn_sched_barrier(0);
+            triple(1, 0);
+            triple(0, 0);
+            xn[0] = __builtin_bit_cast(f32x4, hw); xn[1] = __builtin_bit_cast(f32x4, mw); xn[2] = __builtin_bit_cast(f32x4, lw);
+        }
+    };
+    auto hraw = [&](int w, int q, f32x4& lo, f32x4& hi) {        // h chunk q of group w: the two fp32 halves
+        const int cq = q >> 1, e0 = 8 * (q & 1);
+        lo[0] = h[w][cq][e0 + 0]; lo[1] = h[w][cq][e0 + 1]; lo[2] = h[w][cq][e0 + 2]; lo[3] = h[w][cq][e0 + 3];
+        hi[0] = h[w][cq][e0 + 4]; hi[1] = h[w][cq][e0 + 5]; hi[2] = h[w][cq][e0 + 6]; hi[3] = h[w][cq][e0 + 7];
+    };
     constexpr int NXR = XR ? QXC : R;               // input operand registers: the whole step (XR) or the ring
     f32x4 wr[R][WN], xr[NXR][MW][XW];
 #pragma unroll
@@ -182,7 +228,34 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             // ---- input part: W_i{r,z,n} x_t.  sched_barrier pins "MFMAs of chunk j, then the loads that
             // refill its ring stage": left alone the scheduler sinks all loads of an iteration below its
             // MFMAs and the next iteration waits for them.
-            if (XMODE == 1) {
+            f32x4 xs0[3], xs1[3];                 // PIPE: split operands of the current / next item
+            if constexpr (PIPE && XMODE == 1) {
+                f32x4 lo, hi;
+                split3(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1], xs0[2]);
+                stage(wr[0], xs0, ar[0], az[0], anx[0], xr[0][MW - 1][0], xr[0][MW - 1][XW - 1], xs1);
+                hraw(0, 0, lo, hi);
+                stage(wr[0], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], lo, hi, xs0);
+                wload(wr[0]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (PIPE) {
+                split3(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1], xs0[2]);
+                for (int q0 = 0; q0 < Qxp; q0 += R) {
+#pragma unroll
+                    for (int st = 0; st < R; ++st) {
+                        stage(wr[st], xs0, ar[0], az[0], anx[0], xr[st][MW - 1][0], xr[st][MW - 1][XW - 1], xs1);
+                        stage(wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
+                        wload(wr[st]);
+#pragma unroll
+                        for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, t, q0 + st + R);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                {   // the last stage split a pad chunk: the first recurrent item instead
+                    f32x4 lo, hi;
+                    hraw(0, 0, lo, hi);
+                    split3(lo, hi, xs0[0], xs0[1], xs0[2]);
+                }
+            } else if (XMODE == 1) {
 #pragma unroll
                 for (int w = 0; w < MW; ++w) gates3(wr[0], xr[0][w], ar[w], az[w], anx[w]);
                 wload(wr[0]);
@@ -217,6 +290,24 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             }
             // ---- recurrent part: W_h{r,z,n} h_{t-1}  (h_0 = 0 contributes nothing at t = 0; kept so the
             // weight stream stays continuous).  Ring stage of h chunk q is static: (x chunks + q) % 3.
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int q = 0; q < Qhe; ++q) {
+                    constexpr int X0 = (XMODE == 1) ? 1 : 0;
+                    const int st = (X0 + q) % R;
+                    f32x4 lo, hi;
+                    hraw(MW - 1, q, lo, hi);
+                    stage(wr[st], xs0, ar[0], az[0], anh[0], lo, hi, xs1);
+                    if (q + 1 < Qhe) {
+                        hraw(0, q + 1, lo, hi);
+                        stage(wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1], lo, hi, xs0);
+                    } else {
+                        mfma18(wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1]);
+                    }
+                    wload(wr[st]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < Qhe; ++q) {
                 constexpr int X0 = (XMODE == 1) ? 1 : 0;

@@ -32,6 +32,7 @@ struct GatPlan {
     size_t f_lds_bytes = 0;
     int Q16 = 0;            // bf16 build of the fused projection: 16-feature chunks incl. the bias row
     size_t w16_off = 0;
+    size_t w3_off = 0;      // split-bf16 pack [tile][Q16][piece][64] of the fused projection, derived on the device
 };
 
 struct LinPlan {
@@ -146,6 +147,8 @@ struct Model {
     size_t conv_w_off = 0, conv_b_off = 0;
     int Fp16 = 0;                    // bf16 conv build: channels padded to 16
     size_t conv_w16_off = 0;
+    size_t conv_wf16_off = 0;        // fp32 tiles in the 16-channel geometry (source of the split-bf16 pack)
+    size_t conv_w3_off = 0;          // split-bf16 pack [tile][chunk][piece][64], derived on the device
     GatPlan feat, temp;
     std::vector<GruPlan> gru, rec;
     std::vector<LinPlan> fc;

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
 // input row `taps` times with 4-byte gathers (PMC: 5-9x FETCH amplification, TA-bound).
 // BF: bf16 operand build -- 16 input channels per chunk (K index = tap * Fq + channel, Fq = F rounded up to 16),
 // the staged fp32 rows are converted on the way into the matrix unit, fp32 accumulation.
-template <int NTB, bool BF = false>
+// X3 (with the bf16 chunk geometry): split-bf16 operands -- three weight pieces per chunk, the staged fp32 input split
+// where it is consumed, six bf16 MFMAs per chunk and tile (mtadgat_device.h)
+template <int NTB, bool BF = false, bool X3 = false>
 __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
     // blockDim.x / 64 independent waves per workgroup, each with its own 32 output rows and LDS slice:
     // one-wave workgroups are launched too slowly to keep the matrix pipes fed at ~50 us per wave
@@ -303,6 +305,16 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
     // lane's eight columns of the 16-channel chunk, converted); rows of the neighbouring window count as zero
     // padding (per window, modules.py:14,20)
     const float* __restrict__ xrow = static_cast<const float*>(__builtin_assume_aligned(xs, 16)) + i * Fld + 4 * g;
+    constexpr int NP = X3 ? 3 : 1;
+    auto loadx3 = [&](int tap, int cb, f32x4 (&xs)[3]) {
+        const int tt = t + tap - a.pad;
+        const bool ok = tt >= 0 && tt < a.W;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(xrow + tap * Fld + 16 * cb);
+        f32x4 hi = *reinterpret_cast<const f32x4*>(xrow + tap * Fld + 16 * cb + 8);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = ok ? lo[s4] : 0.f; hi[s4] = ok ? hi[s4] : 0.f; }
+        split3(lo, hi, xs[0], xs[1], xs[2]);
+    };
     auto loadx = [&](int tap, int cb) -> f32x4 {
         const int tt = t + tap - a.pad;
         const bool ok = tt >= 0 && tt < a.W;
@@ -328,15 +340,41 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
             const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
-            wq[nb] = Wp + ((long)n * Q) * 64 + lane;
+            wq[nb] = Wp + ((long)n * Q) * (64 * NP) + lane;
         }
         // two register sets in turn (no copies): the weights of chunk q + 1 are in flight during the MFMAs
         // of chunk q
+        int tap = 0, cb = 0;
+        if constexpr (X3) {
+            // chunk = [piece][64 lanes] words; the pieces of chunk q + 1 are requested before the MFMAs of chunk q
+            f32x4 wa[NTB][3], wb[NTB][3];
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) wa[nb][pc] = wq[nb][pc * 64];
+            for (int q = 0; q < Q; ++q) {
+                const int q1 = q + 1 < Q ? q + 1 : q;
+#pragma unroll
+                for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) wb[nb][pc] = wq[nb][((long)q1 * 3 + pc) * 64];
+                f32x4 xs[3];
+                loadx3(tap, cb, xs);
+                if (++cb == QF) { cb = 0; ++tap; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma_s3(wa[nb], xs, acc[nb]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) wa[nb][pc] = wb[nb][pc];
+            }
+        }
         f32x4 w0[NTB], w1[NTB];
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) w0[nb] = wq[nb][0];
-        int tap = 0, cb = 0;
-        for (int q = 0; q < Q; q += 2) {
+        for (int q = 0; !X3 && q < Q; q += 2) {
             const int q1 = q + 1 < Q ? q + 1 : q;
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) w1[nb] = wq[nb][(long)q1 * 64];
@@ -450,7 +488,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         }
         const unsigned wpb = (grid >= 4096 && 4 * lds <= 64 * 1024) ? 4 : 1;     // waves per workgroup
         const unsigned g4 = (grid + wpb - 1) / wpb;
-        if (a.bf16) {
+        if (a.bf16 == 2) {         // split-bf16 operands
+            if (a.NT >= 2)
+                hipLaunchKernelGGL((k_conv_lds<2, true, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
+            else
+                hipLaunchKernelGGL((k_conv_lds<1, true, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
+        } else if (a.bf16) {
             if (a.NT >= 2)
                 hipLaunchKernelGGL((k_conv_lds<2, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
             else

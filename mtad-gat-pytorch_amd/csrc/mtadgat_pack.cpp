@@ -112,6 +112,8 @@ std::string validate_and_plan(Model& m) {
         m.conv_b_off = take((size_t)m.convNT * 32);
         m.Fp16 = round_up(m.F, 16);
         m.conv_w16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 256);
+        m.conv_wf16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 8) * 256);
+        m.conv_w3_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
     }
     // GAT layers
     auto plan_gat = [&](GatPlan& g, int K, int D, int E) {
@@ -152,6 +154,7 @@ std::string validate_and_plan(Model& m) {
         g.bias_off = take((size_t)K * K);
         g.Q16 = g.fused ? (D + 1 + 15) / 16 : 0;
         g.w16_off = take((size_t)g.NT * g.Q16 * 256);
+        g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
@@ -630,6 +633,10 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
         });
         for (int n = 0; n < F; ++n) out[m.conv_b_off + n] = p.conv_bias[n];
         const int Fp16 = m.Fp16;
+        pack_tiles(out.data() + m.conv_wf16_off, m.convNT, taps * Fp16 / 8, [&](int n, int k) -> float {
+            const int tap = k / Fp16, ch = k % Fp16;
+            return (n < F && ch < F && tap < taps) ? p.conv_weight[((size_t)n * F + ch) * taps + tap] : 0.f;
+        });
         if (m.precision == 1) pack_tiles_bf16(out.data() + m.conv_w16_off, m.convNT, taps * Fp16 / 16, [&](int n, int k) -> float {
             const int tap = k / Fp16, ch = k % Fp16;
             return (n < F && ch < F && tap < taps) ? p.conv_weight[((size_t)n * F + ch) * taps + tap] : 0.f;

@@ -110,13 +110,16 @@ def test_ragged_batches_and_chunking(name, gpu_device):
     assert model(x[:0])[0].shape == (0, case.kwargs["out_dim"])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32_strict"])
 @pytest.mark.parametrize("name", ["msl", "syn_v2_embed"])
-def test_large_batch_kernels_match_small_batch_kernels(name, gpu_device):
-    """Batches above 16 k windows run the register-resident GRU (k_gru), smaller ones the hidden-tile-split
-    one (k_gru_split); the fixture windows embedded in a 20 000-window batch must still match the reference,
-    and the large batch must agree with the same windows run as a small batch."""
+def test_large_batch_kernels_match_small_batch_kernels(name, precision, gpu_device):
+    """Batches above 16 k windows run the register-resident GRU (k_gru: by default its split-bf16 build -- three bf16
+    pieces per operand on the bf16 matrix pipe --, with precision "fp32_strict" the fp32-MFMA build), smaller ones the
+    small-batch kernels; the fixture windows embedded in a 20 000-window batch must still match the reference, and
+    the large batch must agree with the same windows run as a small batch."""
     case = Case(name)
     model = case.build_model().to(gpu_device)
+    model.precision = precision
     g = torch.Generator().manual_seed(11)
     W, F = case.kwargs["window_size"], case.kwargs["n_features"]
     x = torch.rand(20000, W, F, generator=g)
@@ -132,12 +135,15 @@ def test_large_batch_kernels_match_small_batch_kernels(name, gpu_device):
     assert (r_big[19000:19300] - r_small).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32_strict"])
 @pytest.mark.parametrize("name", ["msl", "syn_v2_embed"])
-def test_full_machine_batch_matches(name, gpu_device):
+def test_full_machine_batch_matches(name, precision, gpu_device):
     """From 65 536 windows on, the GRU kernels take two 32-window groups per wave (one wave per SIMD); a
-    ragged batch of that size must still carry the fixture windows and agree with a small-batch run."""
+    ragged batch of that size must still carry the fixture windows and agree with a small-batch run -- in the default
+    arithmetic (split-bf16 operands in k_gru and the feature layer's projection) and in "fp32_strict"."""
     case = Case(name)
     model = case.build_model().to(gpu_device)
+    model.precision = precision
     g = torch.Generator().manual_seed(13)
     W, F = case.kwargs["window_size"], case.kwargs["n_features"]
     n_big = 65536 + 37
