@@ -27,16 +27,16 @@ def build(force=False, verbose=True):
     """Compile the HIP kernels + C ABI into libmtadgat.so; returns the library path.
     One hipcc per stale translation unit (source or any header newer than its object), run concurrently,
     then one link step.  MTADGAT_EXTRA_FLAGS adds compiler flags (experiments)."""
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("MTADGAT_EXTRA_FLAGS", "").split()
+    stamp = os.path.join(OBJDIR, ".flags")
+    flags_now = " ".join(FLAGS + extra)
+    flags_same = (not os.path.isdir(OBJDIR) and not extra) or (os.path.exists(stamp) and open(stamp).read() == flags_now)
+    if not force and not _stale() and flags_same:
+        return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
-    stamp = os.path.join(OBJDIR, ".flags")
-    flags_now = " ".join(FLAGS + extra)
-    flags_same = os.path.exists(stamp) and open(stamp).read() == flags_now
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")

@@ -171,6 +171,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             u4 hw, mw, lw;
             auto pair = [&](const int pp) {
+#ifdef MTADGAT_X3_NOSPLIT           // timing experiment only (wrong results): what the kernel costs without the operand splits
+                hw[pp] = __builtin_bit_cast(unsigned, pp < 2 ? ra[2 * pp] : rb[2 * pp - 4]); mw[pp] = hw[pp]; lw[pp] = hw[pp];
+                return;
+#endif
                 const float v0 = pp < 2 ? ra[2 * pp] : rb[2 * pp - 4], v1 = pp < 2 ? ra[2 * pp + 1] : rb[2 * pp - 3];
                 const unsigned hh = pack_bf16(v0, v1);
                 const float r0 = v0 - __builtin_bit_cast(float, hh << 16), r1 = v1 - __builtin_bit_cast(float, hh & 0xffff0000u);
