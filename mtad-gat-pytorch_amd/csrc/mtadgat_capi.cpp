@@ -161,12 +161,11 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
-    } else if (m.precision == 2 && n >= 4096 && g.D >= 80 && !std::getenv("MTADGAT_GAT_FP32")) {
-        // large batches, long node vectors (feature layer: D = W = 100): split-bf16 operands for the projection -- fp32-class
-        // L' / R' on the bf16 matrix pipe, which runs beside the pair grid (the fp32 MFMA does not).  Measured at (W=100,
-        // F=55): feature layer 5.90 -> 5.12 ms; the temporal layer (D = 55: four 16-feature chunks for 56 features, and
-        // the larger pair-grid register block leaves no room for the pieces -- 19 spilled VGPRs) 7.44 -> 7.63 ms, so it
-        // stays on the fp32 MFMA
+    } else if (m.precision == 2 && n >= 4096 && !std::getenv("MTADGAT_GAT_FP32")) {
+        // large batches: split-bf16 operands for the projection -- fp32-class L' / R' on the bf16 matrix pipe, which runs
+        // beside the pair grid of the other waves (the fp32 MFMA does not: profiles/r02_mfma_valu_overlap.txt).  Measured at
+        // (W=100, F=55): feature layer 5.90 -> 5.09 ms, temporal layer 7.40 -> 6.94 ms (two weight chunks in registers; with
+        // four the temporal layer's larger pair-grid block spilled and lost)
         a.bf16 = 2; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w3_off);
     }

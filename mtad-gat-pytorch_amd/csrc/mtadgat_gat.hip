@@ -150,7 +150,10 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
 #ifndef MTADGAT_GAT_QB
 #define MTADGAT_GAT_QB 8
 #endif
-    constexpr int QB = X3 ? 4 : MTADGAT_GAT_QB;        // weight chunks held in registers per task batch
+#ifndef MTADGAT_GAT_QB3
+#define MTADGAT_GAT_QB3 2
+#endif
+    constexpr int QB = X3 ? MTADGAT_GAT_QB3 : MTADGAT_GAT_QB;       // weight chunks held in registers per task batch
     constexpr int NP = X3 ? 3 : 1;                     // 16-byte words per weight chunk and lane
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
