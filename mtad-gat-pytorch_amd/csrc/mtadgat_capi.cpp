@@ -240,7 +240,11 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         K_TRY(launch_gru16(a, s), "gru (16-window groups)");
         return 0;
     }
-    if (xp && g.has_xproj && g.xmode == 0) {
+    // large batch, split-bf16 operands: fp32-class results from the bf16 matrix pipe (k_gru X3 build), from 1.25 32-window
+    // groups per CU on (measured: 12 320 windows 10.5 ms against 13.1 ms for the hidden-tile-split kernel at 12 288; 8 192 windows 7.4 ms there)
+    const bool x3 = m.precision == 2 && !gates && (g.NCG == 4 || g.NCG == 5) && (n + 31) / 32 > 5L * cu_count() / 4 &&
+                    (g.Qxp16 == 1 || g.Qxp16 % 2 == 0);
+    if (!x3 && xp && g.has_xproj && g.xmode == 0) {
         // small batch: all steps' input products as one throughput GEMM, the recurrence keeps only its h part
         RowGemmArgs r{};
         r.X = x; r.ldx = ldx; r.Kvalid = g.in_dim; r.Q = g.xproj.Q;
@@ -265,9 +269,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.Qxp = g.Qxp16;
         a.bf16 = 1;
     }
-    if (m.precision == 2 && !gates && xmode != 3 && (g.NCG == 4 || g.NCG == 5) && (n + 31) / 32 > 2L * cu_count() &&
-        (g.Qxp16 == 1 || g.Qxp16 % 2 == 0)) {
-        // large batch, split-bf16 operands: fp32-class results from the bf16 matrix pipe (k_gru X3 build)
+    if (x3) {
         a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx3_off);
         a.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh3_off);
         a.whs = 2 * g.NCG + 2;

@@ -328,7 +328,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     {
         const long groups = (a.B + 31) / 32;
         const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
-        if (ncg >= 2 && groups <= 2L * n_cu && lds <= 64 * 1024) return launch_gru_split(a, ncg, xmode, fc, s);
+        if (!a.x3 && ncg >= 2 && groups <= 2L * n_cu && lds <= 64 * 1024) return launch_gru_split(a, ncg, xmode, fc, s);
     }
     // two groups per wave once that still gives every SIMD a wave
     const bool two = (a.B + 31) / 32 >= 8L * n_cu;

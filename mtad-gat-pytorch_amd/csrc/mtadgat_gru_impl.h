@@ -4,6 +4,10 @@
 #pragma once
 #include "mtadgat_device.h"
 
+#ifndef MTADGAT_X3_RING
+#define MTADGAT_X3_RING 2
+#endif
+
 namespace mtadgat {
 
 // ---------------------------------------------------------------------------
@@ -65,7 +69,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     // ring depth: 3 chunks of weights in flight (fp32: 36 MFMAs x 64 cycles ~ 2.3k cycles of cover).  A ring of 6 was
     // tried for the bf16 build, whose chunks are 8x shorter: no gain -- that build was bound by the input re-reads (XR)
     constexpr bool XR = BF && XMODE == 0 && QXC > 0;
-    constexpr int R = X3 ? 2 : 3;
+    constexpr int R = X3 ? MTADGAT_X3_RING : 3;
     constexpr int NP = X3 ? 3 : 1;                // operand pieces per weight word
     constexpr int WN = 3 * NP;                    // 16-byte words per chunk and lane: [gate][piece]
     constexpr int XW = X3 ? 2 : 1;                // registers of an input chunk: the two fp32 halves (X3) or the operand itself
