@@ -242,7 +242,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     }
     // large batch, split-bf16 operands: fp32-class results from the bf16 matrix pipe (k_gru X3 build), from 1.25 32-window
     // groups per CU on (measured: 12 320 windows 10.5 ms against 13.1 ms for the hidden-tile-split kernel at 12 288; 8 192 windows 7.4 ms there)
-    const bool x3 = m.precision == 2 && !gates && (g.NCG == 4 || g.NCG == 5) && (n + 31) / 32 > 5L * cu_count() / 4 &&
+    const bool x3 = m.precision == 2 && !gates && (n + 31) / 32 > 5L * cu_count() / 4 &&
                     (g.Qxp16 == 1 || g.Qxp16 % 2 == 0);
     if (!x3 && xp && g.has_xproj && g.xmode == 0) {
         // small batch: all steps' input products as one throughput GEMM, the recurrence keeps only its h part

@@ -6,7 +6,8 @@ namespace mtadgat {
 
 int launch_gru_big_f32(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
 int launch_gru_big_bf16(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
-int launch_gru_big_x3(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
+int launch_gru_big_x3_hi(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
+int launch_gru_big_x3_lo(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // GRU, hidden-tile split: a workgroup owns 32 windows, wave c the 32 hidden units of tile c (all three
@@ -334,7 +335,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     const bool two = (a.B + 31) / 32 >= 8L * n_cu;
     if (a.x3) {
         static const bool one = std::getenv("MTADGAT_X3_MW1") != nullptr;      // experiment: 32-window waves, two per SIMD
-        return launch_gru_big_x3(a, ncg, xmode, fc, two && !one, s);
+        return ncg >= 5 ? launch_gru_big_x3_hi(a, ncg, xmode, fc, two && !one, s) : launch_gru_big_x3_lo(a, ncg, xmode, fc, two && !one, s);
     }
     return a.bf16 ? launch_gru_big_bf16(a, ncg, xmode, fc, two, s) : launch_gru_big_f32(a, ncg, xmode, fc, two, s);
 }

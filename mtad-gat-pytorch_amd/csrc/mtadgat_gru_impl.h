@@ -541,12 +541,25 @@ inline int launch_gru_ncg(const GruArgs& a, int xmode, bool fc, bool two, hipStr
 }
 
 
-// split-bf16 build: the hidden sizes of the shipped configurations (tiles 4 and 5) only
+// split-bf16 build, in two translation units (hidden sizes up to 128 / up to 256)
+template <bool UPPER>
 inline int launch_gru_big_split(const GruArgs& a, int ncg, int xmode, bool fc, bool two, hipStream_t s) {
-    switch (ncg) {
-        case 4: return launch_gru_ncg<4, true, true>(a, xmode, fc, two, s);
-        case 5: return launch_gru_ncg<5, true, true>(a, xmode, fc, two, s);
-        default: return -2;
+    if constexpr (!UPPER) {
+        switch (ncg) {
+            case 1: return launch_gru_ncg<1, true, true>(a, xmode, fc, two, s);
+            case 2: return launch_gru_ncg<2, true, true>(a, xmode, fc, two, s);
+            case 3: return launch_gru_ncg<3, true, true>(a, xmode, fc, two, s);
+            case 4: return launch_gru_ncg<4, true, true>(a, xmode, fc, two, s);
+            default: return -2;
+        }
+    } else {
+        switch (ncg) {
+            case 5: return launch_gru_ncg<5, true, true>(a, xmode, fc, two, s);
+            case 6: return launch_gru_ncg<6, true, true>(a, xmode, fc, two, s);
+            case 7: return launch_gru_ncg<7, true, true>(a, xmode, fc, two, s);
+            case 8: return launch_gru_ncg<8, true, true>(a, xmode, fc, two, s);
+            default: return -2;
+        }
     }
 }
 
