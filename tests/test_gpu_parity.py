@@ -111,7 +111,7 @@ def test_ragged_batches_and_chunking(name, gpu_device):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "fp32_strict"])
-@pytest.mark.parametrize("name", ["msl", "syn_v2_embed"])
+@pytest.mark.parametrize("name", ["msl", "syn_v2_embed", "syn_v1_small"])
 def test_large_batch_kernels_match_small_batch_kernels(name, precision, gpu_device):
     """Batches above 16 k windows run the register-resident GRU (k_gru: by default its split-bf16 build -- three bf16
     pieces per operand on the bf16 matrix pipe --, with precision "fp32_strict" the fp32-MFMA build), smaller ones the
