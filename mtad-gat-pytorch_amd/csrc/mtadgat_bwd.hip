@@ -765,8 +765,11 @@ int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw,
 //     d a_k  = sum_ij d e_ij LeakyReLU(t) = (1+alpha)/2 sum d e t + (1-alpha)/2 sum d e |t|
 // One workgroup per window.  L, R are re-projected 32 columns at a time on the MFMA (un-scaled weight tiles)
 // exactly as in the forward; in the pair phase a lane owns one embedding column k (so d L and the d a sums
-// stay in registers), a half-wave one query row at a time, and the d R partial sums of all K keys live in
-// registers (the j loop is fully unrolled) until they are merged through LDS float atomics.
+// stay in registers), a wave one query row at a time -- 16 columns of the part per pass, its four 16-lane quarters take
+// the four quarters of the keys --, and the d R partial sums of a lane's keys live in registers (the j loop is fully
+// unrolled) until they are merged through LDS float atomics.  d e is read from memory where it is used (rows are
+// wave-uniform: broadcast loads that hit the L1); with it out of the LDS and a quarter of the key accumulators per
+// lane (128 registers), two workgroups (temporal layer; three for the feature layer) share a CU instead of one.
 // ---------------------------------------------------------------------------
 constexpr int GP_LLD = 34;
 
@@ -783,17 +786,17 @@ size_t gat_bwd_pair_lds(int K, int vld, int Ep) {
     const int Kp16 = (K + 15) & ~15;
     const int nj8 = pair_nj8(K);
     if (nj8 < 0) return (size_t)1 << 30;
-    const int KPD = 8 * nj8 + 4;
+    const int njq = (nj8 + 3) / 4;
     const int NTn = (K + 31) >> 5;
-    size_t f = (size_t)Kp16 * vld + (size_t)((K * KPD + 3) & ~3) + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)8 * nj8 * 32 + 8 * nj8 + 64;
+    size_t f = (size_t)Kp16 * vld + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)32 * njq * 32 + 32 * njq + 64;
     return f * sizeof(float);
 }
 
 template <int NJ8>
-__global__ __launch_bounds__(512) void k_gat_bwd_pair(const GatBwdPairArgs a) {
+__global__ __launch_bounds__(512, 4) void k_gat_bwd_pair(const GatBwdPairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KJ = 8 * NJ8;
-    constexpr int KPD = KJ + 4;
+    constexpr int NJQ = (NJ8 + 3) / 4;              // 8-key blocks per 16-lane quarter
+    constexpr int KJ = 32 * NJQ;                    // key slots (>= K; slots past K carry zeros)
     const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = nthr >> 6;
@@ -802,8 +805,7 @@ __global__ __launch_bounds__(512) void k_gat_bwd_pair(const GatBwdPairArgs a) {
     const int Kp16 = (K + 15) & ~15;
     const int NTn = (K + 31) >> 5;
     float* __restrict__ Vs = smem;
-    float* __restrict__ deS = Vs + Kp16 * vld;
-    float* __restrict__ Ls = deS + ((K * KPD + 3) & ~3);
+    float* __restrict__ Ls = Vs + Kp16 * vld;
     float* __restrict__ Rs = Ls + NTn * 32 * GP_LLD;
     float* __restrict__ NS = Rs + NTn * 32 * GP_LLD;
     float* __restrict__ cs = NS + KJ * 32;
@@ -829,26 +831,23 @@ __global__ __launch_bounds__(512) void k_gat_bwd_pair(const GatBwdPairArgs a) {
                 Vs[node * vld + col] = (node < K && col == D) ? 1.f : v;
             }
         }
-        const float* __restrict__ de = a.DE + win * (long)K * K;
-        for (int u = tid; u < K * KPD; u += nthr) {
-            const int r = u / KPD, j = u - r * KPD;
-            deS[u] = j < K ? de[(long)r * K + j] : 0.f;
-        }
         for (int u = tid; u < 2 * NTn * 32 * GP_LLD; u += nthr) Ls[u] = 0.f;      // Ls and Rs (rows >= K stay zero)
         for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
         if (tid < 64) daS[tid] = 0.f;
     }
-    __syncthreads();
-    for (int j = tid; j < KJ; j += nthr) {
+    const float* __restrict__ de = a.DE + win * (long)K * K;
+    for (int j = tid; j < KJ; j += nthr) {           // column sums of d e (coalesced over j)
         float s = 0.f;
-        for (int r = 0; r < K; ++r) s += deS[r * KPD + j];
+        if (j < K)
+            for (int r = 0; r < K; ++r) s += de[(long)r * K + j];
         cs[j] = s;
     }
+    __syncthreads();
 
     const int NTu = a.NTu, Q = a.Q;
     const int ntask = 2 * NTn;
-    const int k = lane & 31, half = lane >> 5;
-    const int rw = 2 * wave + half, NWK = 2 * NW;
+    const int k16 = lane & 15, quarter = lane >> 4;
+    const int j0 = 8 * NJQ * quarter;                // this quarter's keys: [j0, j0 + 8 NJQ)
     for (int part = 0; part < NTu; ++part) {
         // ---- MFMA phase: L, R columns [32 part, 32 part + 32) of all nodes
         for (int task = wave; task < ntask; task += NW) {
@@ -880,39 +879,53 @@ __global__ __launch_bounds__(512) void k_gat_bwd_pair(const GatBwdPairArgs a) {
             }
         }
         __syncthreads();
-        // ---- pair phase
-        {
+        // ---- pair phase: two passes of 16 columns
+        for (int cp = 0; cp < 2; ++cp) {
+            const int k = 16 * cp + k16;
             const int col = 32 * part + k;
             const float ak = a.avec[col];
             const float cl = ak * (1.f - a.alpha);
-            float Nacc[KJ];
+            float Nacc[8 * NJQ];
 #pragma unroll
-            for (int j = 0; j < KJ; ++j) Nacc[j] = 0.f;
+            for (int j = 0; j < 8 * NJQ; ++j) Nacc[j] = 0.f;
             float s1 = 0.f, s2 = 0.f;
-            for (int r = rw; r < K; r += NWK) {
+            const float* __restrict__ rsp = Rs + j0 * GP_LLD + k;
+            for (int r = wave; r < K; r += NW) {
                 const float L = Ls[r * GP_LLD + k];
-                const float* __restrict__ drow = deS + r * KPD;
+                const float* __restrict__ drow = de + (long)r * K + j0;
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // rows of K floats: dword aligned only
+                // the row's d e values of this quarter's keys, eight at a time, the next block requested before the current one
+                // is consumed (slots past K read on into the next row and are masked; the buffer is followed by other workspace
+                // regions).  sched_barrier keeps the blocks apart: all loads of the row hoisted together cost > 128 registers
+                f32x4u da = *reinterpret_cast<const f32x4u*>(drow), db = *reinterpret_cast<const f32x4u*>(drow + 4);
                 float Macc = 0.f;
 #pragma unroll
-                for (int jb = 0; jb < NJ8; ++jb) {
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(drow + 8 * jb);
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(drow + 8 * jb + 4);
+                for (int jb = 0; jb < NJQ; ++jb) {
+                    const f32x4u ca = da, cb = db;
+                    if (jb + 1 < NJQ) {
+                        da = *reinterpret_cast<const f32x4u*>(drow + 8 * jb + 8);
+                        db = *reinterpret_cast<const f32x4u*>(drow + 8 * jb + 12);
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int j = 8 * jb + u;
-                        const float dv = u < 4 ? d0[u & 3] : d1[u & 3];
-                        const float t = L + Rs[j * GP_LLD + k];
-                        const float mm = t > 0.f ? dv : 0.f;
+                        const float dvv = u < 4 ? ca[u & 3] : cb[u & 3];
+                        const float d = (j0 + j < K) ? dvv : 0.f;
+                        const float t = L + rsp[j * GP_LLD];
+                        const float mm = t > 0.f ? d : 0.f;
                         Macc += mm;
                         Nacc[j] += mm;
-                        s1 = __builtin_fmaf(dv, t, s1);
-                        s2 = __builtin_fmaf(dv, fabsf(t), s2);
+                        s1 = __builtin_fmaf(d, t, s1);
+                        s2 = __builtin_fmaf(d, fabsf(t), s2);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                a.DLR[(win * K + r) * (long)(2 * Ep) + col] = cl * Macc;
+                Macc += __shfl_xor(Macc, 16);
+                Macc += __shfl_xor(Macc, 32);
+                if (quarter == 0) a.DLR[(win * K + r) * (long)(2 * Ep) + col] = cl * Macc;
             }
 #pragma unroll
-            for (int j = 0; j < KJ; ++j) atomicAdd(&NS[j * 32 + k], Nacc[j]);
+            for (int j = 0; j < 8 * NJQ; ++j) atomicAdd(&NS[(j0 + j) * 32 + k], Nacc[j]);
             atomicAdd(&daS[k], s1);
             atomicAdd(&daS[32 + k], s2);
         }
