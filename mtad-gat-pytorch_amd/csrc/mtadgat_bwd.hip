@@ -848,7 +848,8 @@ __global__ __launch_bounds__(512, 4) void k_gat_bwd_pair(const GatBwdPairArgs a)
     const int ntask = 2 * NTn;
     const int k16 = lane & 15, quarter = lane >> 4;
     const int j0 = 8 * NJQ * quarter;                // this quarter's keys: [j0, j0 + 8 NJQ)
-    for (int part = 0; part < NTu; ++part) {
+    // the 32-column parts are independent: small batches spread them over gridDim.y workgroups per window
+    for (int part = blockIdx.y; part < NTu; part += gridDim.y) {
         // ---- MFMA phase: L, R columns [32 part, 32 part + 32) of all nodes
         for (int task = wave; task < ntask; task += NW) {
             const bool keyside = task >= NTn;
@@ -952,6 +953,9 @@ int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s
     const int nj8 = pair_nj8(a.K);
     if (nj8 < 0 || lds_bytes > 160 * 1024) return -2;
     const unsigned grid = (unsigned)a.nwin;
+    // few windows: one workgroup per (window, group of parts) so that the launch still covers the machine twice
+    const long want = (2L * cu_count() + a.nwin - 1) / a.nwin;
+    const unsigned split = (unsigned)(want < 1 ? 1 : (want > a.NTu ? a.NTu : want));
 #define GBP_CASE(N)                                                                                                    \
     if (nj8 == N) {                                                                                                    \
         if (lds_bytes > 64 * 1024) {                                                                                   \
@@ -959,7 +963,7 @@ int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
             if (e_ != hipSuccess) return (int)e_;                                                                      \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_gat_bwd_pair<N>), dim3(grid), dim3(512), lds_bytes, s, a);                               \
+        hipLaunchKernelGGL((k_gat_bwd_pair<N>), dim3(grid, split), dim3(512), lds_bytes, s, a);                        \
     }
     GBP_CASE(1) GBP_CASE(2) GBP_CASE(3) GBP_CASE(4) GBP_CASE(5) GBP_CASE(6) GBP_CASE(7) GBP_CASE(8) GBP_CASE(10) GBP_CASE(13) GBP_CASE(16)
 #undef GBP_CASE
