@@ -4,8 +4,18 @@
 #pragma once
 #include "mtadgat_device.h"
 
+// experiment: a workgroup barrier before every weight-chunk request keeps the four waves of a CU on the same chunk, so
+// that three of the four requests hit the vector L1
+#ifdef MTADGAT_X3_SYNC
+#define X3_CHUNK_SYNC() __builtin_amdgcn_s_barrier()
+#else
+#define X3_CHUNK_SYNC() ((void)0)
+#endif
 #ifndef MTADGAT_X3_RING
 #define MTADGAT_X3_RING 2
+#endif
+#ifndef MTADGAT_X3_RING1
+#define MTADGAT_X3_RING1 3
 #endif
 
 namespace mtadgat {
@@ -70,7 +80,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     // ring depth: 3 chunks of weights in flight (fp32: 36 MFMAs x 64 cycles ~ 2.3k cycles of cover).  A ring of 6 was
     // tried for the bf16 build, whose chunks are 8x shorter: no gain -- that build was bound by the input re-reads (XR)
     constexpr bool XR = BF && XMODE == 0 && QXC > 0;
-    constexpr int R = X3 ? MTADGAT_X3_RING : 3;
+    constexpr int R = X3 ? (MW == 1 ? MTADGAT_X3_RING1 : MTADGAT_X3_RING) : 3;
     constexpr int NP = X3 ? 3 : 1;                // operand pieces per weight word
     constexpr int WN = 3 * NP;                    // 16-byte words per chunk and lane: [gate][piece]
     constexpr int XW = X3 ? 2 : 1;                // registers of an input chunk: the two fp32 halves (X3) or the operand itself
@@ -253,6 +263,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                     for (int st = 0; st < R; ++st) {
                         stage(wr[st], xs0, ar[0], az[0], anx[0], xr[st][MW - 1][0], xr[st][MW - 1][XW - 1], xs1);
                         stage(wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
+                        X3_CHUNK_SYNC();
                         wload(wr[st]);
 #pragma unroll
                         for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, t, q0 + st + R);
@@ -313,6 +324,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                     } else {
                         mfma18(wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1]);
                     }
+                    X3_CHUNK_SYNC();
                     wload(wr[st]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -368,9 +380,14 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float hold = (t > 0) ? hn_s[w][c][r][lane] : 0.f;
+#ifdef MTADGAT_X3_NOGATE           // timing experiment only (wrong results): the step without the gate transcendentals
+                    const float rg = ar[w][r] * 0.01f, zg = az[w][r] * 0.01f;
+                    const float ng = (anx[w][r] + rg * anh[w][r]) * 0.01f;
+#else
                     const float rg = gate_sigmoid(ar[w][r]);
                     const float zg = gate_sigmoid(az[w][r]);
                     const float ng = gate_tanh(anx[w][r] + rg * anh[w][r]);
+#endif
                     ar[w][r] = __builtin_fmaf(zg, hold - ng, ng);          // (1 - z) n + z h
                 }
 #pragma unroll
