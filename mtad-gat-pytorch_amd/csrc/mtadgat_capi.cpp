@@ -276,6 +276,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.Qxp = g.Qxp16;
         a.bf16 = 1;
         a.x3 = 1;
+        a.scale = m.packed_dev + g.scale_off + 1;
     }
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
     a.Hend = hend; a.ldhe = ldhe;
@@ -498,16 +499,23 @@ int mtadgat_destroy(mtadgat_handle h) {
 // split-bf16 packs of the large-batch recurrences, derived on the device from the fp32 packs of the image
 static int run_split3(Model& m, hipStream_t s) {
     auto one = [&](const GruPlan& g) -> int {
+        // the layer's power-of-two weight scale (fp16 range of the recurrent pieces), from the largest weight, on the device
         const long outer_x = (long)(g.xmode == 1 ? m.W : 1) * g.NCG;
-        K_TRY(launch_split3(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, 3, s), "split-bf16 input weights");
-        K_TRY(launch_split3(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, s), "split-bf16 recurrent weights");
+        float* sc = m.packed_dev + g.scale_off;
+        HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
+        K_TRY(launch_absmax(m.packed_dev + g.wx_off, outer_x * g.Qxp * 3 * 256, sc, s), "weight range");
+        K_TRY(launch_absmax(m.packed_dev + g.wh_off, (long)g.NCG * (4 * g.NCG + 2) * 3 * 256, sc, s), "weight range");
+        K_TRY(launch_scale_from_max(sc, s), "weight scale");
+        K_TRY(launch_split3(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, 3, sc + 1, s), "split-bf16 input weights");
+        K_TRY(launch_split2h(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, sc + 1, s),
+              "split-fp16 recurrent weights");
         return 0;
     };
     for (const GruPlan& g : m.gru) { int rc = one(g); if (rc) return rc; }
     for (const GruPlan& g : m.rec) { int rc = one(g); if (rc) return rc; }
     for (const GatPlan* g : {&m.feat, &m.temp})
-        if (g->fused) K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, s), "split-bf16 projection weights");
-    K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, s),
+        if (g->fused) K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
+    K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, nullptr, s),
           "split-bf16 conv weights");
     return 0;
 }
@@ -684,7 +692,8 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     };
     auto one = [&](const GruPlan& g) {
         add(g.wx3_off, (size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 9 * 256);
-        add(g.wh3_off, (size_t)g.NCG * (2 * g.NCG + 2) * 9 * 256);
+        add(g.wh3_off, (size_t)g.NCG * (2 * g.NCG + 2) * 6 * 256 + 3 * 256);
+        add(g.scale_off, 4);
     };
     for (const GruPlan& g : m.gru) one(g);
     for (const GruPlan& g : m.rec) one(g);

@@ -109,6 +109,36 @@ __device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, f32x4& hi, 
     }
     hi = __builtin_bit_cast(f32x4, h); mid = __builtin_bit_cast(f32x4, m); lo = __builtin_bit_cast(f32x4, l);
 }
+// ---- two fp16 pieces: for operands of known range (the recurrent state, |h| <= 1; weights scaled by a power of two into
+// fp16's normal range): x = hi + lo to 2^-22 relative (or 2^-25 absolute, fp16's subnormal spacing), fp16 x fp16 products
+// are exact in fp32, and   w x ~= wh xh + wh xl + wl xh   is THREE v_mfma_f32_32x32x16_f16 per 16 features, with 4 bytes
+// per weight instead of 6 and a 5-instruction split per value pair instead of 11.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));       // v_cvt_pk_f16_f32, round to nearest even
+}
+__device__ __forceinline__ void split_pair_h(float v0, float v1, unsigned& hw, unsigned& lw) {
+    hw = pack_f16(v0, v1);
+    const f16x2 hh = __builtin_bit_cast(f16x2, hw);
+    lw = pack_f16(v0 - (float)hh[0], v1 - (float)hh[1]);
+}
+__device__ __forceinline__ void split2h(const f32x4 a, const f32x4 b, f32x4& hi, f32x4& lo) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        unsigned hw, lw;
+        split_pair_h(p < 2 ? a[2 * p] : b[2 * p - 4], p < 2 ? a[2 * p + 1] : b[2 * p - 3], hw, lw);
+        h[p] = hw; l[p] = lw;
+    }
+    hi = __builtin_bit_cast(f32x4, h); lo = __builtin_bit_cast(f32x4, l);
+}
+__device__ __forceinline__ f32x16 mfma_h(const f32x4 w, const f32x4 x, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+}
+
 // w: the three pieces of the weight word (hi, mid, lo); x likewise
 __device__ __forceinline__ f32x16 mfma_s3(const f32x4 (&w)[3], const f32x4 (&x)[3], f32x16 acc) {
     acc = mfma_bf(w[0], x[2], acc);

@@ -84,6 +84,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     constexpr int NP = X3 ? 3 : 1;                // operand pieces per weight word
     constexpr int WN = 3 * NP;                    // 16-byte words per chunk and lane: [gate][piece]
     constexpr int XW = X3 ? 2 : 1;                // registers of an input chunk: the two fp32 halves (X3) or the operand itself
+    constexpr int WNH = X3 ? 6 : WN;              // words of a recurrent chunk: X3 = two fp16 pieces per gate (|h| <= 1, scaled weights)
+    // X3: all weights of the layer carry the power-of-two factor S (fp16 range of the recurrent pieces): the
+    // accumulators hold S times the pre-activations
+    const float wS = X3 ? a.scale[0] : 1.f, wInvS = X3 ? a.scale[1] : 1.f;
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
     constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
@@ -112,10 +116,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
 #pragma unroll
         for (int j = 0; j < WN; ++j) dst[j] = p[64 * j];
         pwx += isx ? 64 * WN : 0;
-        pwh += isx ? 0 : 64 * WN;
+        pwh += isx ? 0 : 64 * WNH;                 // (X3: the three extra words fetched for a recurrent chunk are the next chunk's first)
         const bool ws = (ps + 1 == S);             // end of this tile's chunk sequence
         ps = ws ? 0 : ps + 1;
-        pwh += ws ? (a.whs - Qhe) * (64 * WN) : 0; // skip the unused all-padding chunks of the tile
+        pwh += ws ? (a.whs - Qhe) * (64 * WNH) : 0; // skip the unused all-padding chunks of the tile
         const bool wc = ws && (pc + 1 == NCG);     // end of the step
         pc = ws ? (wc ? 0 : pc + 1) : pc;
         pt = wc ? pt + 1 : pt;
@@ -178,35 +182,72 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             g0 = mfma_bf(wv[0], xs[0], g0); g1 = mfma_bf(wv[3], xs[0], g1); g2 = mfma_bf(wv[6], xs[0], g2);
         }
     };
-    // the six product terms in triples (one MFMA per gate), the four value pairs of the next operand's split between
-    // them; sched_barrier keeps the source order (the group-barrier solver gave up on whole stages)
-    auto stage = [&](const f32x4 (&wv)[WN], const f32x4 (&xs)[3], f32x16& g0, f32x16& g1, f32x16& g2, const f32x4 ra, const f32x4 rb,
-                     f32x4 (&xn)[3]) {
+    // the product terms in triples (one MFMA per gate), the four value pairs of the next operand's split between them;
+    // sched_barrier keeps the source order (the group-barrier solver gave up on whole stages).
+    // CUR3: the current item is an input chunk (three bf16 pieces, 6 terms) or a recurrent chunk (two fp16 pieces, 3 terms);
+    // NEXT: the item whose operand is split meanwhile -- 3 bf16 pieces, 2 fp16 pieces, or none (0)
+    auto stage = [&](auto cur3_tag, auto next_tag, const f32x4 (&wv)[WN], const f32x4 (&xs)[3], f32x16& g0, f32x16& g1, f32x16& g2,
+                     const f32x4 ra, const f32x4 rb, f32x4 (&xn)[3]) {
         if constexpr (X3) {
+            constexpr bool CUR3 = decltype(cur3_tag)::value;
+            constexpr int NEXT = decltype(next_tag)::value;
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
-            u4 hw, mw, lw;
+            u4 hw = {0, 0, 0, 0}, mw = {0, 0, 0, 0}, lw = {0, 0, 0, 0};
             auto pair = [&](const int pp) {
+                const float v0 = pp < 2 ? ra[2 * pp] : rb[2 * pp - 4], v1 = pp < 2 ? ra[2 * pp + 1] : rb[2 * pp - 3];
 #ifdef MTADGAT_X3_NOSPLIT           // timing experiment only (wrong results): what the kernel costs without the operand splits
-                hw[pp] = __builtin_bit_cast(unsigned, pp < 2 ? ra[2 * pp] : rb[2 * pp - 4]); mw[pp] = hw[pp]; lw[pp] = hw[pp];
+                hw[pp] = __builtin_bit_cast(unsigned, v0); mw[pp] = hw[pp]; lw[pp] = hw[pp];
                 return;
 #endif
-                const float v0 = pp < 2 ? ra[2 * pp] : rb[2 * pp - 4], v1 = pp < 2 ? ra[2 * pp + 1] : rb[2 * pp - 3];
-                const unsigned hh = pack_bf16(v0, v1);
-                const float r0 = v0 - __builtin_bit_cast(float, hh << 16), r1 = v1 - __builtin_bit_cast(float, hh & 0xffff0000u);
-                const unsigned mm = pack_bf16(r0, r1);
-                const float s0 = r0 - __builtin_bit_cast(float, mm << 16), s1 = r1 - __builtin_bit_cast(float, mm & 0xffff0000u);
-                hw[pp] = hh; mw[pp] = mm; lw[pp] = pack_bf16(s0, s1);
+                if constexpr (NEXT == 3) {
+                    const unsigned hh = pack_bf16(v0, v1);
+                    const float r0 = v0 - __builtin_bit_cast(float, hh << 16), r1 = v1 - __builtin_bit_cast(float, hh & 0xffff0000u);
+                    const unsigned mm = pack_bf16(r0, r1);
+                    const float s0 = r0 - __builtin_bit_cast(float, mm << 16), s1 = r1 - __builtin_bit_cast(float, mm & 0xffff0000u);
+                    hw[pp] = hh; mw[pp] = mm; lw[pp] = pack_bf16(s0, s1);
+                } else if constexpr (NEXT == 2) {
+                    unsigned hh, ll;
+                    split_pair_h(v0, v1, hh, ll);
+                    hw[pp] = hh; mw[pp] = ll;
+                }
             };
-            auto triple = [&](const int wi, const int xi) {
-                g0 = mfma_bf(wv[wi], xs[xi], g0); g1 = mfma_bf(wv[3 + wi], xs[xi], g1); g2 = mfma_bf(wv[6 + wi], xs[xi], g2);
-            };
-            triple(0, 2); __builtin_amdgcn_sched_barrier(0); pair(0); __builtin_amdgcn_sched_barrier(0);
-            triple(2, 0); __builtin_amdgcn_sched_barrier(0); pair(1); __builtin_amdgcn_sched_barrier(0);
-            triple(1, 1); __builtin_amdgcn_sched_barrier(0); pair(2); __builtin_amdgcn_sched_barrier(0);
-            triple(0, 1); __builtin_amdgcn_sched_barrier(0); pair(3); __builtin_amdgcn_sched_barrier(0);
-            triple(1, 0);
-            triple(0, 0);
-            xn[0] = __builtin_bit_cast(f32x4, hw); xn[1] = __builtin_bit_cast(f32x4, mw); xn[2] = __builtin_bit_cast(f32x4, lw);
+            if constexpr (CUR3) {
+                auto triple = [&](const int wi, const int xi) {
+                    g0 = mfma_bf(wv[wi], xs[xi], g0); g1 = mfma_bf(wv[3 + wi], xs[xi], g1); g2 = mfma_bf(wv[6 + wi], xs[xi], g2);
+                };
+                triple(0, 2); __builtin_amdgcn_sched_barrier(0); pair(0); __builtin_amdgcn_sched_barrier(0);
+                triple(2, 0); __builtin_amdgcn_sched_barrier(0); pair(1); __builtin_amdgcn_sched_barrier(0);
+                triple(1, 1); __builtin_amdgcn_sched_barrier(0); pair(2); __builtin_amdgcn_sched_barrier(0);
+                triple(0, 1); __builtin_amdgcn_sched_barrier(0); pair(3); __builtin_amdgcn_sched_barrier(0);
+                triple(1, 0);
+                triple(0, 0);
+            } else {
+                // recurrent chunk: words [gate][hi, lo]; terms w_h x_l, w_l x_h, w_h x_h
+                auto triple = [&](const int wi, const int xi) {
+                    g0 = mfma_h(wv[wi], xs[xi], g0); g1 = mfma_h(wv[2 + wi], xs[xi], g1); g2 = mfma_h(wv[4 + wi], xs[xi], g2);
+                };
+                triple(0, 1); __builtin_amdgcn_sched_barrier(0); pair(0); pair(1); __builtin_amdgcn_sched_barrier(0);
+                triple(1, 0); __builtin_amdgcn_sched_barrier(0); pair(2); pair(3); __builtin_amdgcn_sched_barrier(0);
+                triple(0, 0);
+            }
+            if constexpr (NEXT != 0) {
+                xn[0] = __builtin_bit_cast(f32x4, hw); xn[1] = __builtin_bit_cast(f32x4, mw); xn[2] = __builtin_bit_cast(f32x4, lw);
+            }
+        }
+    };
+    using T3 = std::true_type;
+    using T2 = std::false_type;
+    using N0 = std::integral_constant<int, 0>;
+    using N2 = std::integral_constant<int, 2>;
+    using N3 = std::integral_constant<int, 3>;
+    // one recurrent chunk, not pipelined (32-window waves): two fp16 pieces of h, three terms
+    auto gates_h = [&](const f32x4 (&wv)[WN], const f32x4 lo, const f32x4 hi, f32x16& g0, f32x16& g1, f32x16& g2) {
+        if constexpr (X3) {
+            f32x4 xh, xl;
+            split2h(lo, hi, xh, xl);
+            g0 = mfma_h(wv[0], xl, g0); g1 = mfma_h(wv[2], xl, g1); g2 = mfma_h(wv[4], xl, g2);
+            g0 = mfma_h(wv[1], xh, g0); g1 = mfma_h(wv[3], xh, g1); g2 = mfma_h(wv[5], xh, g2);
+            g0 = mfma_h(wv[0], xh, g0); g1 = mfma_h(wv[2], xh, g1); g2 = mfma_h(wv[4], xh, g2);
         }
     };
     auto hraw = [&](int w, int q, f32x4& lo, f32x4& hi) {        // h chunk q of group w: the two fp32 halves
@@ -238,10 +279,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                 for (int w = 0; w < MW; ++w)
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        ar[w][4 * m + s4] = b0[s4];
-                        az[w][4 * m + s4] = b1[s4];
-                        anx[w][4 * m + s4] = b2[s4];
-                        anh[w][4 * m + s4] = b3[s4];
+                        ar[w][4 * m + s4] = X3 ? b0[s4] * wS : b0[s4];
+                        az[w][4 * m + s4] = X3 ? b1[s4] * wS : b1[s4];
+                        anx[w][4 * m + s4] = X3 ? b2[s4] * wS : b2[s4];
+                        anh[w][4 * m + s4] = X3 ? b3[s4] * wS : b3[s4];
                     }
             }
             // ---- input part: W_i{r,z,n} x_t.  sched_barrier pins "MFMAs of chunk j, then the loads that
@@ -251,9 +292,9 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             if constexpr (PIPE && XMODE == 1) {
                 f32x4 lo, hi;
                 split3(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1], xs0[2]);
-                stage(wr[0], xs0, ar[0], az[0], anx[0], xr[0][MW - 1][0], xr[0][MW - 1][XW - 1], xs1);
+                stage(T3{}, N3{}, wr[0], xs0, ar[0], az[0], anx[0], xr[0][MW - 1][0], xr[0][MW - 1][XW - 1], xs1);
                 hraw(0, 0, lo, hi);
-                stage(wr[0], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], lo, hi, xs0);
+                stage(T3{}, N2{}, wr[0], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], lo, hi, xs0);
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
             } else if constexpr (PIPE) {
@@ -261,8 +302,8 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                 for (int q0 = 0; q0 < Qxp; q0 += R) {
 #pragma unroll
                     for (int st = 0; st < R; ++st) {
-                        stage(wr[st], xs0, ar[0], az[0], anx[0], xr[st][MW - 1][0], xr[st][MW - 1][XW - 1], xs1);
-                        stage(wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
+                        stage(T3{}, N3{}, wr[st], xs0, ar[0], az[0], anx[0], xr[st][MW - 1][0], xr[st][MW - 1][XW - 1], xs1);
+                        stage(T3{}, N3{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
                         X3_CHUNK_SYNC();
                         wload(wr[st]);
 #pragma unroll
@@ -273,7 +314,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                 {   // the last stage split a pad chunk: the first recurrent item instead
                     f32x4 lo, hi;
                     hraw(0, 0, lo, hi);
-                    split3(lo, hi, xs0[0], xs0[1], xs0[2]);
+                    split2h(lo, hi, xs0[0], xs0[1]);
                 }
             } else if (XMODE == 1) {
 #pragma unroll
@@ -317,12 +358,12 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                     const int st = (X0 + q) % R;
                     f32x4 lo, hi;
                     hraw(MW - 1, q, lo, hi);
-                    stage(wr[st], xs0, ar[0], az[0], anh[0], lo, hi, xs1);
+                    stage(T2{}, N2{}, wr[st], xs0, ar[0], az[0], anh[0], lo, hi, xs1);
                     if (q + 1 < Qhe) {
                         hraw(0, q + 1, lo, hi);
-                        stage(wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1], lo, hi, xs0);
+                        stage(T2{}, N2{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1], lo, hi, xs0);
                     } else {
-                        mfma18(wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1]);
+                        stage(T2{}, N0{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1], lo, hi, xs0);
                     }
                     X3_CHUNK_SYNC();
                     wload(wr[st]);
@@ -341,8 +382,8 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                         f32x4 lo, hi;
                         lo[0] = h[w][cq][e0 + 0]; lo[1] = h[w][cq][e0 + 1]; lo[2] = h[w][cq][e0 + 2]; lo[3] = h[w][cq][e0 + 3];
                         hi[0] = h[w][cq][e0 + 4]; hi[1] = h[w][cq][e0 + 5]; hi[2] = h[w][cq][e0 + 6]; hi[3] = h[w][cq][e0 + 7];
-                        if (X3) { hv[0] = lo; hv[XW - 1] = hi; }
-                        else hv[0] = cvt8(lo, hi);
+                        if (X3) { gates_h(wr[st], lo, hi, ar[w], az[w], anh[w]); continue; }
+                        hv[0] = cvt8(lo, hi);
                     } else {
                         const int cq = q >> 2, m = q & 3;
                         hv[0][0] = h[w][cq][4 * m + 0]; hv[0][1] = h[w][cq][4 * m + 1];
@@ -384,9 +425,9 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                     const float rg = ar[w][r] * 0.01f, zg = az[w][r] * 0.01f;
                     const float ng = (anx[w][r] + rg * anh[w][r]) * 0.01f;
 #else
-                    const float rg = gate_sigmoid(ar[w][r]);
-                    const float zg = gate_sigmoid(az[w][r]);
-                    const float ng = gate_tanh(anx[w][r] + rg * anh[w][r]);
+                    const float rg = gate_sigmoid(X3 ? ar[w][r] * wInvS : ar[w][r]);
+                    const float zg = gate_sigmoid(X3 ? az[w][r] * wInvS : az[w][r]);
+                    const float ng = gate_tanh(X3 ? (anx[w][r] + rg * anh[w][r]) * wInvS : anx[w][r] + rg * anh[w][r]);
 #endif
                     ar[w][r] = __builtin_fmaf(zg, hold - ng, ng);          // (1 - z) n + z h
                 }

@@ -215,7 +215,9 @@ struct GruArgs {
     int out_dim;
     float* Gates;        // training: (B*T, 4*Hp) r | z | n | q kept for the backward (k_gru_split only), or null
     int bf16;            // 1: Wx / Wh are bf16 packs (16-feature chunks): bf16 MFMA operands, fp32 accumulation and state
-    int x3;              // 1 (with bf16 = 1): split-bf16 packs, [gate][piece] words per chunk; k_gru (large batches) only
+    int x3;              // 1 (with bf16 = 1): split packs; k_gru (large batches) only.  Wx: three bf16 pieces per weight,
+                         // [gate][piece] words per chunk; Wh: two fp16 pieces, [gate][piece]; all weights scaled by S
+    const float* scale;  // x3: device pointer to [S, 1 / S] (a power of two chosen per layer at load time)
 };
 
 // small-batch recurrences (mtadgat_gru16.hip): 16 windows per workgroup, one wave per 16-unit hidden tile, weights in registers
@@ -312,7 +314,10 @@ int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t 
 long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
 int launch_fingerprint(const FingerprintArgs& a, int n_tensors, unsigned long long* out, hipStream_t s);
-int launch_split3(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, hipStream_t s);
+int launch_split3(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s);
+int launch_split2h(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s);
+int launch_absmax(const float* src, long n, float* sc, hipStream_t s);
+int launch_scale_from_max(float* sc, hipStream_t s);
 int launch_pack_gather(const float* flat, const int* gidx, float* img, long n, hipStream_t s);
 int launch_pack_gat(const PackGatArgs& a, hipStream_t s);
 int launch_pack_gru_bias(const float* flat, long bih, long bhh, int H, int Hp, float* b, float* bx, hipStream_t s);

@@ -186,7 +186,8 @@ std::string validate_and_plan(Model& m) {
         g.wx16_off = take((size_t)g.NCG * g.Qxp16 * 3 * 256);
         g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
         g.wx3_off = take((size_t)g.NCG * g.Qxp16 * 9 * 256);
-        g.wh3_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 9 * 256);
+        g.wh3_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 6 * 256 + 3 * 256);
+        g.scale_off = take(4);
         if (l == 0) {
             g.has_xproj = true;
             g.xproj.in_dim = g.in_dim; g.xproj.out_dim = 3 * g.Hp;
@@ -241,7 +242,8 @@ std::string validate_and_plan(Model& m) {
         g.wx16_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 3 * 256);
         g.wh16_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 3 * 256);
         g.wx3_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 9 * 256);
-        g.wh3_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 9 * 256);
+        g.wh3_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 6 * 256 + 3 * 256);
+        g.scale_off = take(4);
         if (l == 0) plan16(g);
     }
     {

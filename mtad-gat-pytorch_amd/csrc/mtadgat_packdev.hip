@@ -123,7 +123,50 @@ __global__ void k_pack_fold(const PackFoldArgs a) {
 // fp32 tile packs -> split-bf16 packs (mtadgat_device.h, "x3"): bf16 chunk qd of a tile pairs the fp32 chunks 2 qd and
 // 2 qd + 1 of the same lane (that IS the element order of the bf16 operand), each value becomes three bf16 pieces.
 // src [outer][Qs][G][64] f32x4, dst [outer][Qd][G][3 pieces][64] 16-byte words
-__global__ void k_split3(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n_outer, int Qs, int Qd, int G) {
+// largest |value| of a region, as float bits (non-negative floats order like unsigned integers)
+__global__ void k_absmax(const float* __restrict__ src, long n, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+// sc = [bits of max | S | 1 / S | 0]: S = the power of two that puts the largest weight into [2^13, 2^14) (fp16: 2^16 - 32 max)
+__global__ void k_scale_from_max(float* __restrict__ sc) {
+    const float m = __uint_as_float(reinterpret_cast<const unsigned*>(sc)[0]);
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e);        // m = f 2^e, f in [0.5, 1)
+    int sh = 14 - e;
+    sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    sc[1] = ldexpf(1.f, sh);
+    sc[2] = ldexpf(1.f, -sh);
+    sc[3] = 0.f;
+}
+
+// ... into two fp16 pieces of scale * value (mtadgat_device.h): dst [outer][Qd][G][2 pieces][64] words
+__global__ void k_split2h(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n_outer, int Qs, int Qd, int G, const float* __restrict__ scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = n_outer * Qd * G * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long r = idx >> 6;
+    const int g = (int)(r % G);
+    const long r2 = r / G;
+    const int qd = (int)(r2 % Qd);
+    const long o = r2 / Qd;
+    const float S = scale[0];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a = 2 * qd < Qs ? src[((o * Qs + 2 * qd) * G + g) * 64 + lane] : z;
+    f32x4 b = 2 * qd + 1 < Qs ? src[((o * Qs + 2 * qd + 1) * G + g) * 64 + lane] : z;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] *= S; b[e] *= S; }
+    f32x4 hi, lo;
+    split2h(a, b, hi, lo);
+    f32x4* __restrict__ d = dst + (((o * Qd + qd) * G + g) * 2) * 64 + lane;
+    d[0] = hi; d[64] = lo;
+}
+
+__global__ void k_split3(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n_outer, int Qs, int Qd, int G, const float* __restrict__ scale) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = n_outer * Qd * G * 64;
     if (idx >= total) return;
@@ -134,18 +177,43 @@ __global__ void k_split3(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
     const int qd = (int)(r2 % Qd);
     const long o = r2 / Qd;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 a = 2 * qd < Qs ? src[((o * Qs + 2 * qd) * G + g) * 64 + lane] : z;
-    const f32x4 b = 2 * qd + 1 < Qs ? src[((o * Qs + 2 * qd + 1) * G + g) * 64 + lane] : z;
+    f32x4 a = 2 * qd < Qs ? src[((o * Qs + 2 * qd) * G + g) * 64 + lane] : z;
+    f32x4 b = 2 * qd + 1 < Qs ? src[((o * Qs + 2 * qd + 1) * G + g) * 64 + lane] : z;
+    if (scale) {                               // a power of two: the pieces of S x are S times the pieces of x
+        const float S = scale[0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] *= S; b[e] *= S; }
+    }
     f32x4 hi, mid, lo;
     split3(a, b, hi, mid, lo);
     f32x4* __restrict__ d = dst + (((o * Qd + qd) * G + g) * 3) * 64 + lane;
     d[0] = hi; d[64] = mid; d[128] = lo;
 }
-int launch_split3(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, hipStream_t s) {
+int launch_split3(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s) {
     const long total = n_outer * Qd * G * 64;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_split3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
-                       reinterpret_cast<f32x4*>(dst), n_outer, Qs, Qd, G);
+                       reinterpret_cast<f32x4*>(dst), n_outer, Qs, Qd, G, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_split2h(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s) {
+    const long total = n_outer * Qd * G * 64;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_split2h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), n_outer, Qs, Qd, G, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+// sc[0] (as bits) = max |value| over the regions handed to launch_absmax since it was cleared; then sc[1] = S, sc[2] = 1 / S
+int launch_absmax(const float* src, long n, float* sc, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_absmax, dim3(64), dim3(256), 0, s, src, n, reinterpret_cast<unsigned*>(sc));
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_scale_from_max(float* sc, hipStream_t s) {
+    hipLaunchKernelGGL(k_scale_from_max, dim3(1), dim3(1), 0, s, sc);
     LAUNCH_CHECK();
     return 0;
 }
