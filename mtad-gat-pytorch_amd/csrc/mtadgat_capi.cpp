@@ -277,6 +277,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.bf16 = 1;
         a.x3 = 1;
         a.scale = m.packed_dev + g.scale_off + 1;
+        a.qb3 = g.qb3;
     }
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
     a.Hend = hend; a.ldhe = ldhe;
@@ -506,7 +507,7 @@ static int run_split3(Model& m, hipStream_t s) {
         K_TRY(launch_absmax(m.packed_dev + g.wx_off, outer_x * g.Qxp * 3 * 256, sc, s), "weight range");
         K_TRY(launch_absmax(m.packed_dev + g.wh_off, (long)g.NCG * (4 * g.NCG + 2) * 3 * 256, sc, s), "weight range");
         K_TRY(launch_scale_from_max(sc, s), "weight scale");
-        K_TRY(launch_split3(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, 3, sc + 1, s), "split-bf16 input weights");
+        K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, g.qb3, sc + 1, s), "split input weights");
         K_TRY(launch_split2h(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, sc + 1, s),
               "split-fp16 recurrent weights");
         return 0;

@@ -88,6 +88,9 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     // X3: all weights of the layer carry the power-of-two factor S (fp16 range of the recurrent pieces): the
     // accumulators hold S times the pre-activations
     const float wS = X3 ? a.scale[0] : 1.f, wInvS = X3 ? a.scale[1] : 1.f;
+    // X3: the first qb input chunks (the convolution's unbounded outputs) come as three bf16 pieces, the others (sigmoid
+    // outputs of the attention layers, a previous layer's or the encoder's state: all in [-1, 1]) as two fp16 pieces
+    const int qb = X3 ? a.qb3 : 0;
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
     constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
         const f32x4* __restrict__ p = (isx ? pwx : pwh) + lane;
 #pragma unroll
         for (int j = 0; j < WN; ++j) dst[j] = p[64 * j];
-        pwx += isx ? 64 * WN : 0;
+        pwx += isx ? (X3 ? (ps < qb ? 64 * WN : 64 * WNH) : 64 * WN) : 0;
         pwh += isx ? 0 : 64 * WNH;                 // (X3: the three extra words fetched for a recurrent chunk are the next chunk's first)
         const bool ws = (ps + 1 == S);             // end of this tile's chunk sequence
         ps = ws ? 0 : ps + 1;
@@ -291,19 +294,36 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             f32x4 xs0[3], xs1[3];                 // PIPE: split operands of the current / next item
             if constexpr (PIPE && XMODE == 1) {
                 f32x4 lo, hi;
-                split3(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1], xs0[2]);
-                stage(T3{}, N3{}, wr[0], xs0, ar[0], az[0], anx[0], xr[0][MW - 1][0], xr[0][MW - 1][XW - 1], xs1);
+                split2h(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1]);          // entries of the encoder's h_end: two fp16 pieces
+                stage(T2{}, N2{}, wr[0], xs0, ar[0], az[0], anx[0], xr[0][MW - 1][0], xr[0][MW - 1][XW - 1], xs1);
                 hraw(0, 0, lo, hi);
-                stage(T3{}, N2{}, wr[0], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], lo, hi, xs0);
+                stage(T2{}, N2{}, wr[0], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], lo, hi, xs0);
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
             } else if constexpr (PIPE) {
-                split3(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1], xs0[2]);
-                for (int q0 = 0; q0 < Qxp; q0 += R) {
+                if (qb > 0) split3(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1], xs0[2]);
+                else split2h(xr[0][0][0], xr[0][0][XW - 1], xs0[0], xs0[1]);
+                int q0 = 0;
+                for (; q0 < qb; q0 += R) {             // three-piece chunks (qb is a multiple of R)
 #pragma unroll
                     for (int st = 0; st < R; ++st) {
                         stage(T3{}, N3{}, wr[st], xs0, ar[0], az[0], anx[0], xr[st][MW - 1][0], xr[st][MW - 1][XW - 1], xs1);
-                        stage(T3{}, N3{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
+                        if (st == R - 1 && q0 + R >= qb)   // the next chunk is the first two-piece one
+                            stage(T3{}, N2{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
+                        else
+                            stage(T3{}, N3{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
+                        X3_CHUNK_SYNC();
+                        wload(wr[st]);
+#pragma unroll
+                        for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, t, q0 + st + R);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                for (; q0 < Qxp; q0 += R) {            // two-piece chunks
+#pragma unroll
+                    for (int st = 0; st < R; ++st) {
+                        stage(T2{}, N2{}, wr[st], xs0, ar[0], az[0], anx[0], xr[st][MW - 1][0], xr[st][MW - 1][XW - 1], xs1);
+                        stage(T2{}, N2{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
                         X3_CHUNK_SYNC();
                         wload(wr[st]);
 #pragma unroll
@@ -318,7 +338,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                 }
             } else if (XMODE == 1) {
 #pragma unroll
-                for (int w = 0; w < MW; ++w) gates3(wr[0], xr[0][w], ar[w], az[w], anx[w]);
+                for (int w = 0; w < MW; ++w) {
+                    if constexpr (X3) gates_h(wr[0], xr[0][w][0], xr[0][w][XW - 1], ar[w], az[w], anx[w]);
+                    else gates3(wr[0], xr[0][w], ar[w], az[w], anx[w]);
+                }
                 wload(wr[0]);
                 __builtin_amdgcn_sched_barrier(0);
             } else if (XR) {
@@ -341,7 +364,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
 #pragma unroll
                     for (int st = 0; st < R; ++st) {
 #pragma unroll
-                        for (int w = 0; w < MW; ++w) gates3(wr[st], xr[st][w], ar[w], az[w], anx[w]);
+                        for (int w = 0; w < MW; ++w) {
+                            if (X3 && q0 + st >= qb) gates_h(wr[st], xr[st][w][0], xr[st][w][XW - 1], ar[w], az[w], anx[w]);
+                            else gates3(wr[st], xr[st][w], ar[w], az[w], anx[w]);
+                        }
                         wload(wr[st]);
 #pragma unroll
                         for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, t, q0 + st + R);

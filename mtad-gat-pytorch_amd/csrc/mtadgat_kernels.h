@@ -218,6 +218,7 @@ struct GruArgs {
     int x3;              // 1 (with bf16 = 1): split packs; k_gru (large batches) only.  Wx: three bf16 pieces per weight,
                          // [gate][piece] words per chunk; Wh: two fp16 pieces, [gate][piece]; all weights scaled by S
     const float* scale;  // x3: device pointer to [S, 1 / S] (a power of two chosen per layer at load time)
+    int qb3;             // x3: leading input chunks on three bf16 pieces (9 words); the others on two fp16 pieces (6 words)
 };
 
 // small-batch recurrences (mtadgat_gru16.hip): 16 windows per workgroup, one wave per 16-unit hidden tile, weights in registers
@@ -315,6 +316,7 @@ long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
 int launch_fingerprint(const FingerprintArgs& a, int n_tensors, unsigned long long* out, hipStream_t s);
 int launch_split3(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s);
+int launch_split_x(const float* src, float* dst, long n_outer, int Qs, int Qd, int qb, const float* scale, hipStream_t s);
 int launch_split2h(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s);
 int launch_absmax(const float* src, long n, float* sc, hipStream_t s);
 int launch_scale_from_max(float* sc, hipStream_t s);

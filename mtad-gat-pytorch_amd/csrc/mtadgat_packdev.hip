@@ -166,6 +166,46 @@ __global__ void k_split2h(const f32x4* __restrict__ src, f32x4* __restrict__ dst
     d[0] = hi; d[64] = lo;
 }
 
+// input-part weights of a recurrent layer, three gates per chunk: chunks below qb as three bf16 pieces (9 words), the
+// others as two fp16 pieces (6 words), all of S * W
+__global__ void k_split_x(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n_outer, int Qs, int Qd, int qb, const float* __restrict__ scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = n_outer * Qd * 3 * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long r = idx >> 6;
+    const int g = (int)(r % 3);
+    const long r2 = r / 3;
+    const int qd = (int)(r2 % Qd);
+    const long o = r2 / Qd;
+    const float S = scale[0];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a = 2 * qd < Qs ? src[((o * Qs + 2 * qd) * 3 + g) * 64 + lane] : z;
+    f32x4 b = 2 * qd + 1 < Qs ? src[((o * Qs + 2 * qd + 1) * 3 + g) * 64 + lane] : z;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] *= S; b[e] *= S; }
+    const long wtot = (long)qb * 9 + (long)(Qd - qb) * 6;               // words per outer block
+    if (qd < qb) {
+        f32x4 hi, mid, lo;
+        split3(a, b, hi, mid, lo);
+        f32x4* __restrict__ d = dst + (o * wtot + (long)qd * 9 + g * 3) * 64 + lane;
+        d[0] = hi; d[64] = mid; d[128] = lo;
+    } else {
+        f32x4 hi, lo;
+        split2h(a, b, hi, lo);
+        f32x4* __restrict__ d = dst + (o * wtot + (long)qb * 9 + (long)(qd - qb) * 6 + g * 2) * 64 + lane;
+        d[0] = hi; d[64] = lo;
+    }
+}
+int launch_split_x(const float* src, float* dst, long n_outer, int Qs, int Qd, int qb, const float* scale, hipStream_t s) {
+    const long total = n_outer * Qd * 3 * 64;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_split_x, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), n_outer, Qs, Qd, qb, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void k_split3(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n_outer, int Qs, int Qd, int G, const float* __restrict__ scale) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = n_outer * Qd * G * 64;
