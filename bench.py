@@ -73,6 +73,21 @@ def algorithmic_flops(kw):
     }
 
 
+def split_issue_factor(kw):
+    """k_gru in the default fp32 arithmetic: bf16 / fp16 MFMA MACs issued per algorithmic MAC (GRU layer + decoder together).
+    Input chunks of 16 features that touch the convolution's channels go as three bf16 pieces (6 MFMA terms), all other
+    chunks -- attention outputs, recurrent state, the decoder's folded input -- as two fp16 pieces (3 terms); chunk and
+    tile padding included."""
+    F, W, H, Hr = kw["n_features"], kw["window_size"], kw["gru_hid_dim"], kw["recon_hid_dim"]
+    up = lambda a, b: -(-a // b) * b      # noqa: E731
+    qx = up(-(-(3 * F) // 16), 6)                       # packed input chunks (whole ring turns)
+    qb = min(qx, up(-(-F // 16), 2))
+    qh = lambda h: -(-h // 16)              # noqa: E731
+    issued = (up(H, 32) * 16 * (6 * qb + 3 * (qx - qb) + 3 * qh(H)) + up(Hr, 32) * 16 * (3 * 1 + 3 * qh(Hr))) * 3 * W
+    alg = (3 * H * (3 * F + H) + 3 * Hr * (3 + Hr)) * W
+    return issued / alg
+
+
 def _reference_module():
     """The unmodified reference MTAD_GAT class, if its tree is on this host (never on the GPU box)."""
     ref = os.environ.get("MTADGAT_REFERENCE", "/root/reference")
@@ -356,7 +371,7 @@ def main():
                     tot[fam] = (ms, n, fl)
                     tf = fl * B * args.steps / (ms * 1e-3) / 1e12
                     # matrix-pipe ceiling of this family in this mode (see the roofline note below)
-                    pk = (BF16_MFMA_PEAK_TFLOPS / 6.0 if (args.precision == "fp32" and fam == "k_gru") else
+                    pk = (BF16_MFMA_PEAK_TFLOPS / split_issue_factor(kw) if (args.precision == "fp32" and fam == "k_gru") else
                           BF16_MFMA_PEAK_TFLOPS if (args.precision == "bf16" and fam != "k_rowgemm(fc)") else FP32_MFMA_PEAK_TFLOPS)
                     fams[fam] = {"ms_per_step": round(ms / args.steps, 3), "launches": int(n),
                                  "alg_mfma_gflop_per_launch": round(fl * B * args.steps / n / 1e9, 3),
@@ -385,10 +400,12 @@ def main():
             # bf16 MFMAs (split-bf16 operands), i.e. 1/6 of the dense bf16 peak per algorithmic FLOP; bf16 -> the bf16 peak.
             # k_gat's matrix work is fp32 MFMA in both fp32 modes.
             split = args.precision == "fp32" and dom == "k_gru"
-            peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else (BF16_MFMA_PEAK_TFLOPS / 6.0 if split else FP32_MFMA_PEAK_TFLOPS)
+            sf = split_issue_factor(kw)
+            peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else (BF16_MFMA_PEAK_TFLOPS / sf if split else FP32_MFMA_PEAK_TFLOPS)
             note = ("v_mfma_f32_32x32x16_bf16 peak" if args.precision == "bf16" else
-                    "split-bf16 operands: six v_mfma_f32_32x32x16_bf16 per fp32 product -> ceiling = dense bf16 peak / 6 = 416.7 TFLOP/s "
-                    "of algorithmic FLOPs (the fp32 MFMA peak is 157.3)" if split else "v_mfma_f32_32x32x2_f32 (exact f32) peak")
+                    f"split operands: every fp32 product is 3 (two fp16 pieces) or 6 (three bf16 pieces) 16-bit MFMA terms -- {sf:.2f} MFMA "
+                    f"MACs issued per algorithmic MAC incl. padding -> ceiling = dense bf16/fp16 peak / {sf:.2f} = {BF16_MFMA_PEAK_TFLOPS / sf:.0f} "
+                    "TFLOP/s of algorithmic FLOPs (the fp32 MFMA peak is 157.3)" if split else "v_mfma_f32_32x32x2_f32 (exact f32) peak")
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
                                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                                "traffic_source": tsrc,

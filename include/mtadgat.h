@@ -137,9 +137,11 @@ int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, voi
 /* Arithmetic of the inference entry points (forward / forward_series / stage calls):
  *   0 (default of a new handle)  fp32 operands on the exact fp32 MFMA: <= 1e-5 of the reference's float32 forward
  *   2            fp32 results, the products of the large-batch kernels (k_gru above 16 384 windows, the attention
- *                projection above 4 096) formed from split-bf16 operands: every fp32 operand is the exact sum of three
- *                bf16 pieces, six bf16 MFMAs with fp32 accumulation per product -- within ~2e-7 of mode 0, same 1e-5
- *                gate, 2.7x less matrix-pipe time on the pipe that runs beside the VALU (the Python module's default).
+ *                projection above 4 096) formed from split 16-bit operands: every fp32 operand is the exact sum of three
+ *                bf16 pieces (six MFMA terms with fp32 accumulation per product) or, where its range is bounded by
+ *                construction -- recurrent state, attention outputs, weights scaled by a per-layer power of two --, of
+ *                two fp16 pieces (three terms): within ~2e-7 of mode 0, same 1e-5 gate, 2.7-5x less matrix-pipe time
+ *                on the pipe that runs beside the VALU (the Python module's default).
  *                The split weight packs are derived on the device at every load; switching needs no reload.
  *   1            bf16 MFMA operands (weights packed to bf16 once per load_weights, activations rounded on the
  *                way into the matrix unit), fp32 accumulation, fp32 recurrent state / gates / softmax:
