@@ -658,6 +658,7 @@ int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64
         a.tiles_out = m.packed_dev + g.wx_off; a.fold_out = g.has16 ? m.packed_dev + g.fold_off : nullptr;
         K_TRY(launch_pack_fold(a, s), "decoder input fold");
     }
+    { int rc = run_split3(m, s); if (rc) return rc; }      // the split packs follow the fp32 packs they are derived from
     m.bf16_packed = false;
     return 0;
 }

@@ -135,6 +135,9 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     for (int w = 0; w < MW; ++w) xbase[w] = (XMODE == 0) ? a.X + winc[w] * T * a.ldx + 4 * g : a.X + winc[w] * a.ldx;
     auto loadx_t = [&](int w, int t, int q) -> f32x4 {
         const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
+#ifdef MTADGAT_X3_HOTX              // timing experiment only (wrong results): every step re-reads the rows of step 0 (cache resident)
+        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase[w] + 8 * qq);
+#endif
         if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase[w] + (long)t * a.ldx + 8 * qq);
         const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
         f32x4 v;

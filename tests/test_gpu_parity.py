@@ -135,6 +135,35 @@ def test_large_batch_kernels_match_small_batch_kernels(name, precision, gpu_devi
     assert (r_big[19000:19300] - r_small).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e4])
+def test_split_operand_kernels_track_the_fp32_mfma_kernels_at_any_input_scale(scale, gpu_device):
+    """The default arithmetic of large batches splits operands into 16-bit pieces: three bf16 pieces (fp32's exponent range)
+    where magnitudes are unbounded -- the window values and the convolution's outputs --, two fp16 pieces only where the
+    range is bounded by construction (recurrent state, attention outputs; weights scaled per layer).  Inputs far outside
+    [0, 1] (un-normalised series) must therefore still reproduce the fp32-MFMA kernels, and weights of unusual magnitude
+    too."""
+    case = Case("msl")
+    model = case.build_model().to(gpu_device)
+    g = torch.Generator().manual_seed(17)
+    W, F = case.kwargs["window_size"], case.kwargs["n_features"]
+    x = (torch.rand(20000, W, F, generator=g) * scale).to(gpu_device)
+    with torch.no_grad():
+        outs = {}
+        for wmul in (1.0, 0.23):                       # also: smaller recurrent weights (another power-of-two weight scale)
+            for p in (model.gru.gru.weight_hh_l0, model.recon_model.decoder.rnn.weight_hh_l0):
+                p.mul_(wmul)
+            for precision in ("fp32", "fp32_strict"):
+                model.precision = precision
+                outs[(wmul, precision)] = model(x)
+            pa, ra = outs[(wmul, "fp32")]
+            pb, rb = outs[(wmul, "fp32_strict")]
+            assert torch.isfinite(pa).all() and torch.isfinite(ra).all()
+            # un-normalised inputs drive the pre-activations to ~1e4, where fp32 itself resolves 1e-3: any two summation
+            # orders differ by ~1e-3 in the few units whose large terms cancel
+            tol = (2e-6 if scale <= 1.0 else 5e-3) * max(1.0, rb.abs().max().item())
+            assert (pa - pb).abs().max().item() <= tol and (ra - rb).abs().max().item() <= tol, (scale, wmul)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "fp32_strict"])
 @pytest.mark.parametrize("name", ["msl", "syn_v2_embed"])
 def test_full_machine_batch_matches(name, precision, gpu_device):
