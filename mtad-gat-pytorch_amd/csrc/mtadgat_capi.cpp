@@ -72,7 +72,8 @@ struct XSource {
     int64_t start0 = 0, stride = 1;
 };
 
-int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s) {
+int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s,
+             unsigned* vmax = nullptr) {
     Scope sc(m, S_CONV, s);
     ConvArgs a{};
     if (src.gather) {
@@ -104,6 +105,10 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
     a.bias = m.packed_dev + m.conv_b_off;
     a.NT = m.convNT;
     a.XC = xc; a.XCT = xct; a.Wpad = m.Wp; a.HCAT = hcat; a.Dp = m.Dp; a.Y = y;
+    if (vmax) {
+        HIP_TRY(hipMemsetAsync(vmax, 0, sizeof(unsigned), s));
+        a.vmax = vmax;
+    }
     K_TRY(launch_conv(a, s), "conv");
     return 0;
 }
@@ -151,7 +156,8 @@ bool use_fused(const GatPlan& g) { return g.fused; }
 
 // fused layer: V rows (n*K, ldv) -> out, nothing but V read from / out written to HBM
 int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, int64_t n, float* out, long so_w, long so_i,
-                  long so_d, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0) {
+                  long so_d, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0,
+                  const unsigned* vmax = nullptr) {
     Scope sc(m, S_ATTEND, s);
     GatArgs a{};
     a.V = v; a.ldv = ldv; a.vt = vt; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.lr_floats = g.f_lr;
@@ -168,6 +174,10 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
         // four the temporal layer's larger pair-grid block spilled and lost)
         a.bf16 = 2; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w3_off);
+        // two fp16 pieces instead when the convolution that produced the node values recorded a maximum below 2^15
+        a.vmax = vmax;
+        a.Wp2 = reinterpret_cast<const f32x4*>(m.packed_dev + g.w2h_off);
+        a.scale2 = m.packed_dev + g.gscale_off + 1;
     }
     a.bias = m.packed_dev + g.bias_off;
     a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
@@ -515,7 +525,14 @@ static int run_split3(Model& m, hipStream_t s) {
     for (const GruPlan& g : m.gru) { int rc = one(g); if (rc) return rc; }
     for (const GruPlan& g : m.rec) { int rc = one(g); if (rc) return rc; }
     for (const GatPlan* g : {&m.feat, &m.temp})
-        if (g->fused) K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
+        if (g->fused) {
+            K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
+            float* sc = m.packed_dev + g->gscale_off;
+            HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
+            K_TRY(launch_absmax(m.packed_dev + g->w_off, (long)g->NT * g->Q * 256, sc, s), "projection weight range");
+            K_TRY(launch_scale_from_max(sc, s), "projection weight scale");
+            K_TRY(launch_split2h(m.packed_dev + g->w_off, m.packed_dev + g->w2h_off, g->NT, g->Q, g->Q16, 1, sc + 1, s), "split-fp16 projection weights");
+        }
     K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, nullptr, s),
           "split-bf16 conv weights");
     return 0;
@@ -702,6 +719,10 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     add(m.conv_w3_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
     add(m.feat.w3_off, (size_t)m.feat.NT * m.feat.Q16 * 3 * 256);
     add(m.temp.w3_off, (size_t)m.temp.NT * m.temp.Q16 * 3 * 256);
+    for (const GatPlan* g : {&m.feat, &m.temp}) {
+        add(g->w2h_off, (size_t)g->NT * g->Q16 * 2 * 256);
+        add(g->gscale_off, 4);
+    }
     return n;
 }
 
@@ -761,9 +782,10 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
         if (use_fused(m.temp) && use_fused(m.feat)) {
             // fused front: conv writes only h_cat[:, :F]; each layer's workgroup stages its window from
             // there (the feature layer transposes on the way into LDS) -- no xc / xc^T / L' / R' in HBM
-            if ((rc = run_conv(m, src, c0, n, nullptr, nullptr, hcat, nullptr, s))) return rc;
-            if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s))) return rc;
-            if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s))) return rc;
+            unsigned* vmax = reinterpret_cast<unsigned*>(ws + o.vmax);
+            if ((rc = run_conv(m, src, c0, n, nullptr, nullptr, hcat, nullptr, s, vmax))) return rc;
+            if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, nullptr, nullptr, 0, vmax))) return rc;
+            if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, nullptr, nullptr, 0, vmax))) return rc;
         } else {
             if ((rc = run_conv(m, src, c0, n, xc, xct, hcat, nullptr, s))) return rc;
             // temporal layer: nodes = time steps, rows of xc

@@ -179,15 +179,24 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     // that ends the previous VALU phase, for part 0 before the window is staged -- so the L2 round trip is
     // not on the critical path of the MFMA phase.  (The projection bias is row D of the packed weights,
     // multiplied by a constant-one column of Vs: no separate bias loads.)
+    // X3: when the node values are known to fit fp16 (the producing convolution recorded their maximum), two fp16 pieces
+    // per operand and three MFMA terms instead of three bf16 pieces and six; the weights then carry the layer's power of two
+    bool useh = false;
+    if constexpr (X3) useh = a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f;
+    const int npw = X3 ? (useh ? 2 : 3) : 1;           // words per weight chunk and lane
+    const f32x4* __restrict__ Wbase = (X3 && useh) ? a.Wp2 : a.Wp;
     f32x4 w[QB][NP];
+    auto wfetch = [&](const f32x4* __restrict__ wp, int u, int q) {
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+            if (pc < npw) w[u][pc] = wp[((long)q * npw + pc) * 64];
+    };
     auto prefetch = [&](int part) {
         if (wave < ntask) {
             const int wtile = wave >= NTn ? a.NT_L + part : part;
-            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * (64 * NP) + lane;
+            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * npw) + lane;
 #pragma unroll
-            for (int u = 0; u < QB; ++u)
-#pragma unroll
-                for (int pc = 0; pc < NP; ++pc) w[u][pc] = wp[((long)(u < Q ? u : Q - 1) * NP + pc) * 64];
+            for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
         }
     };
 
@@ -286,12 +295,10 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
             const int wtile = keyside ? a.NT_L + part : part;
             const int node = nt * 32 + i;
             const float* __restrict__ vrow = Vs + (node < K ? node : K - 1) * vld;
-            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * (64 * NP) + lane;
+            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * npw) + lane;
             if (task != wave) {                    // more tiles than waves: later tasks pay their own round trip
 #pragma unroll
-                for (int u = 0; u < QB; ++u)
-#pragma unroll
-                    for (int pc = 0; pc < NP; ++pc) w[u][pc] = wp[((long)(u < Q ? u : Q - 1) * NP + pc) * 64];
+                for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
             }
             f32x16 o;
 #pragma unroll
@@ -309,9 +316,17 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
                             if constexpr (X3) {
                                 // (a clamped upper half would carry real values here: its weights are zero, but the three
                                 // pieces of a wrong value are still finite -- nothing to mask)
-                                f32x4 xs[3];
-                                split3(lo, hi, xs[0], xs[1], xs[2]);
-                                o = mfma_s3(w[u], xs, o);
+                                if (useh) {
+                                    f32x4 xh, xl;
+                                    split2h(lo, hi, xh, xl);
+                                    o = mfma_h(w[u][0], xl, o);
+                                    o = mfma_h(w[u][1], xh, o);
+                                    o = mfma_h(w[u][0], xh, o);
+                                } else {
+                                    f32x4 xs[3];
+                                    split3(lo, hi, xs[0], xs[1], xs[2]);
+                                    o = mfma_s3(w[u], xs, o);
+                                }
                             } else {
                                 o = mfma_bf(w[u][0], cvt8(lo, hi), o);
                             }
@@ -320,11 +335,13 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
                             o = mfma4(w[u][0], xv, o);
                         }
                         // the chunk QB further on replaces this one as soon as it has been issued
-                        if (qb + QB + u < Q) {
-#pragma unroll
-                            for (int pc = 0; pc < NP; ++pc) w[u][pc] = wp[((long)(qb + QB + u) * NP + pc) * 64];
-                        }
+                        if (qb + QB + u < Q) wfetch(wp, u, qb + QB + u);
                     }
+            }
+            if (X3 && useh) {                      // the fp16 weights carry S
+                const float inv = a.scale2[1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] *= inv;
             }
             if (node < K) {
                 float* __restrict__ dst = (keyside ? Rs : Ls) + node * GAT_LLD + 4 * g;

@@ -33,6 +33,8 @@ struct GatPlan {
     int Q16 = 0;            // bf16 build of the fused projection: 16-feature chunks incl. the bias row
     size_t w16_off = 0;
     size_t w3_off = 0;      // split-bf16 pack [tile][Q16][piece][64] of the fused projection, derived on the device
+    size_t w2h_off = 0;     // two fp16 pieces of S * W, [tile][Q16][2][64]; gscale_off: [bits of max |W|, S, 1 / S, 0]
+    size_t gscale_off = 0;
 };
 
 struct LinPlan {
@@ -177,6 +179,7 @@ struct Workspace {
     size_t xc, xct, lct, rtt, lcf, rtf, hcat, hend, seq0, seq1, fc0, fc1, rseq0, rseq1, xp, total;
     bool has_xp;         // room for the pre-projected GRU input (batches the hidden-tile-split kernel serves)
     bool rec16;          // room for the decoder's pre-projected input and state sequence (k_gru16)
+    size_t vmax;         // one word: bits of the largest convolution output of the chunk (range guard of the fp16 operand pieces)
 };
 
 // activations kept between the training forward and the backward (caller-owned "tape"), offsets in floats

@@ -59,6 +59,7 @@ struct ConvArgs {
     int W, F, Fp, taps, pad;
     int Fq;              // channel count the MFMA chunks run over: Fp (fp32 build), F rounded up to 16 (bf16 build)
     int bf16;            // 1: Wp is the bf16 pack (k_conv_lds only)
+    unsigned* vmax;      // k_conv_lds: bits of the largest output written so far (atomic max), or null
     int x_bf16;          // 1: X holds bfloat16 (read directly by k_conv_lds; no fp32 copy of the input exists)
     const f32x4* Wp;     // packed (F x taps*Fq), NT tiles, Q = taps*Fq/8 (bf16: /16)
     const float* bias;   // NT*32
@@ -97,7 +98,12 @@ struct GatArgs {
     int vld;             // LDS row stride of the staged V rows
     int lr_floats;       // LDS floats reserved for L' / R' (and the aliased softmax rows) ahead of the V rows
     const f32x4* Wp;     // packed projection tiles [2*NT_L][Q][64]: query-side tiles then key-side tiles
-    int bf16;            // 1: Wp is the bf16 pack, Q counts 16-feature chunks
+    int bf16;            // 1: Wp is the bf16 pack, Q counts 16-feature chunks; 2: split pack (three bf16 pieces per weight)
+    // bf16 == 2 and the node values are known to fit fp16 (vmax: bits of the largest |value| the producing convolution
+    // wrote, < 2^15): two fp16 pieces instead -- Wp2 = [tile][Q][2 pieces][64] of S * W, scale2 = [S, 1 / S]
+    const unsigned* vmax;
+    const f32x4* Wp2;
+    const float* scale2;
     const float* pbias;  // projection bias, 2*NT_L*32
     int NT_L, Q, PT, P8;
     const float* bias;   // (K, K) attention bias or null

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
         return v;
     };
     auto mm = [&](const f32x4 w, const f32x4 x, f32x16 acc) -> f32x16 { return BF ? mfma_bf(w, x, acc) : mfma4(w, x, acc); };
+    float vmx = 0.f;                      // largest output of this lane (outputs are >= 0: ReLU)
     for (int n0 = 0; n0 < a.NT; n0 += NTB) {
         f32x16 acc[NTB];
 #pragma unroll
@@ -407,6 +408,8 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) v[s4] = fmaxf(acc[nb][4 * m + s4] + bv[s4], 0.f);
                 if (row < R) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) vmx = (col + s4 < a.F) ? fmaxf(vmx, v[s4]) : vmx;
                     if (a.HCAT) {   // rows of h_cat are 16-byte aligned: one store per 4 channels
                         float* hp = a.HCAT + row * a.Dp + col;
                         if (col + 3 < a.F) {
@@ -429,6 +432,13 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
                 }
             }
         }
+    }
+    if (a.vmax) {
+        // range of the node values for the attention layers' fp16 operand pieces: one atomic per wave at most, and only
+        // while the maximum still grows
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmx = fmaxf(vmx, __shfl_xor(vmx, off));
+        if (lane == 0 && !(vmx <= __uint_as_float(*a.vmax))) atomicMax(a.vmax, __float_as_uint(vmx));     // (NaN: recorded, disables the fp16 path)
     }
 }
 
@@ -502,10 +512,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
             hipLaunchKernelGGL((k_conv_lds<2, false>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
         else
             hipLaunchKernelGGL((k_conv_lds<1, false>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
-    } else if (a.NT >= 2)
-        hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_conv<1>, dim3(grid), dim3(64), 0, s, a);
+    } else {
+        // the straight-from-memory kernel does not record the output range: mark it unknown (a NaN pattern)
+        if (a.vmax && hipMemsetAsync(a.vmax, 0xFF, sizeof(unsigned), s) != hipSuccess) return -3;
+        if (a.NT >= 2)
+            hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(64), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_conv<1>, dim3(grid), dim3(64), 0, s, a);
+    }
     LAUNCH_CHECK();
     return 0;
 }

@@ -155,6 +155,8 @@ std::string validate_and_plan(Model& m) {
         g.Q16 = g.fused ? (D + 1 + 15) / 16 : 0;
         g.w16_off = take((size_t)g.NT * g.Q16 * 256);
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
+        g.w2h_off = take((size_t)g.NT * g.Q16 * 2 * 256);
+        g.gscale_off = take(4);
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
@@ -390,6 +392,7 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     ws.rseq1 = take((m.rec.size() > 2 || (m.rec.size() > 1 && m.cfg.out_dim > 4)) ? N * m.W * m.rec[0].Hp : 0);
     ws.has_xp = m.gru[0].has_xproj && n <= 16384;          // 64 windows per CU x 256 CUs: above that k_gru streams x itself
     ws.xp = take((ws.has_xp || rec16) ? N * m.W * 3 * std::max(m.gru[0].Hp, m.rec[0].Hp) : 0);
+    ws.vmax = take(64);
     ws.total = off;
 }
 
