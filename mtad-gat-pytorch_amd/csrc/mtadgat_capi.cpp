@@ -219,7 +219,7 @@ bool use_g1(int64_t n) {
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
 int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx, int kx, int64_t n, float* hend,
                   long ldhe, float* seq, const LinPlan* fc, float* yfc, float* ylast, hipStream_t s, float* gates = nullptr,
-                  float* xp = nullptr, bool g16 = false) {
+                  float* xp = nullptr, bool g16 = false, const unsigned* vmax = nullptr) {
     Scope sc(m, slot, s);
     int xmode = g.xmode;
     if (g16) {
@@ -288,6 +288,10 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.x3 = 1;
         a.scale = m.packed_dev + g.scale_off + 1;
         a.qb3 = g.qb3;
+        if (vmax && g.wx2_off && g.qb3 > 0) {
+            a.vmax = vmax;
+            a.Wx2 = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx2_off);
+        }
     }
     a.Hp = g.Hp; a.H = g.H; a.T = m.W; a.B = n;
     a.Hend = hend; a.ldhe = ldhe;
@@ -311,7 +315,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
 
 // hcat is the internal (n*W, Dp) buffer: 16-byte aligned rows whose pad columns are zero (the kernels read them unguarded)
 int run_gru_stack(Model& m, const float* hcat, long ldx, int64_t n, float* hend, long ldhe, float* ws,
-                  const Workspace& o, hipStream_t s) {
+                  const Workspace& o, hipStream_t s, const unsigned* vmax = nullptr) {
     const int L = (int)m.gru.size();
     const float* x = hcat;
     long ld = ldx;
@@ -321,7 +325,8 @@ int run_gru_stack(Model& m, const float* hcat, long ldx, int64_t n, float* hend,
         float* seq = last ? nullptr : ws + ((l & 1) ? o.seq1 : o.seq0);
         const bool g16 = use_g16(m, m.gru, n) && o.has_xp;
         float* xp = (l == 0 && o.has_xp && (g16 || n <= gru_split_max_windows())) ? ws + o.xp : nullptr;
-        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s, nullptr, xp, g16);
+        int rc = run_gru_layer(m, S_GRU, m.gru[l], x, ld, kx, n, last ? hend : nullptr, ldhe, seq, nullptr, nullptr, nullptr, s, nullptr, xp, g16,
+                               l == 0 ? vmax : nullptr);
         if (rc) return rc;
         x = seq; ld = m.gru[l].Hp; kx = m.gru[l].H;      // sequence buffers hold all Hp columns, padding lanes are exact zeros
     }
@@ -518,6 +523,8 @@ static int run_split3(Model& m, hipStream_t s) {
         K_TRY(launch_absmax(m.packed_dev + g.wh_off, (long)g.NCG * (4 * g.NCG + 2) * 3 * 256, sc, s), "weight range");
         K_TRY(launch_scale_from_max(sc, s), "weight scale");
         K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, g.qb3, sc + 1, s), "split input weights");
+        if (g.wx2_off && g.qb3 > 0)
+            K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx2_off, outer_x, g.Qxp, g.Qxp16, 0, sc + 1, s), "split input weights (fp16)");
         K_TRY(launch_split2h(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, sc + 1, s),
               "split-fp16 recurrent weights");
         return 0;
@@ -713,6 +720,7 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
         add(g.wx3_off, (size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 9 * 256);
         add(g.wh3_off, (size_t)g.NCG * (2 * g.NCG + 2) * 6 * 256 + 3 * 256);
         add(g.scale_off, 4);
+        if (g.wx2_off) add(g.wx2_off, (size_t)g.NCG * g.Qxp16 * 6 * 256 + 3 * 256);
     };
     for (const GruPlan& g : m.gru) one(g);
     for (const GruPlan& g : m.rec) one(g);
@@ -795,7 +803,8 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
         }
         float* hend = ws + o.hend;
         const long ldh = m.gru.back().Hp;
-        if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s))) return rc;
+        if ((rc = run_gru_stack(m, hcat, m.Dp, n, hend, ldh, ws, o, s,
+                                (use_fused(m.temp) && use_fused(m.feat)) ? reinterpret_cast<const unsigned*>(ws + o.vmax) : nullptr))) return rc;
         if (hend_out)
             K_TRY(launch_copy2d(hend, ldh, hend_out + c0 * m.cfg.gru_hid_dim, m.cfg.gru_hid_dim, n, m.cfg.gru_hid_dim, s),
                   "h_end copy");

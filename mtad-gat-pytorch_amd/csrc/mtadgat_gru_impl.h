@@ -90,7 +90,10 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     const float wS = X3 ? a.scale[0] : 1.f, wInvS = X3 ? a.scale[1] : 1.f;
     // X3: the first qb input chunks (the convolution's unbounded outputs) come as three bf16 pieces, the others (sigmoid
     // outputs of the attention layers, a previous layer's or the encoder's state: all in [-1, 1]) as two fp16 pieces
-    const int qb = X3 ? a.qb3 : 0;
+    // (when the producing convolution recorded an output range that fits fp16, all input chunks go as two pieces: Wx2)
+    const bool xh = X3 && a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f;
+    const int qb = X3 ? (xh ? 0 : a.qb3) : 0;
+    const f32x4* __restrict__ Wx0 = (X3 && xh) ? a.Wx2 : a.Wx;
     constexpr int ROT = (XMODE == 1) ? (1 + Qhe) % R : Qhe % R;   // ring phase advance per hidden tile
     constexpr int Qf = 4 * NCG - (BF ? 0 : DROP); // fp32 8-feature chunks of h used by the per-step Linear (always fp32)
     const int S = Qxp + Qhe;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     // prefetch cursor: wave-uniform running pointers into the two packed streams (they stay in SGPRs; the
     // per-lane part of every weight address is the constant lane*16 bytes), advanced by one chunk per fetch
     int pc = 0, ps = 0, pt = 0;
-    const f32x4* __restrict__ pwx = a.Wx;          // next input-part chunk to fetch
+    const f32x4* __restrict__ pwx = Wx0;           // next input-part chunk to fetch
     const f32x4* __restrict__ pwh = a.Wh;          // next recurrent-part chunk to fetch
     auto wload = [&](f32x4 (&dst)[WN]) {
         const bool isx = ps < Qxp;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
         pt = wc ? pt + 1 : pt;
         pwh = wc ? a.Wh : pwh;
         // input-part weights: per step for the decoder ([t][c][Qxp], contiguous), shared by all steps otherwise
-        pwx = wc ? ((XMODE == 0 || pt >= T) ? a.Wx : pwx) : pwx;
+        pwx = wc ? ((XMODE == 0 || pt >= T) ? Wx0 : pwx) : pwx;
     };
     const float* xbase[MW];
 #pragma unroll

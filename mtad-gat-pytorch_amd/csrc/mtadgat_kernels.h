@@ -225,6 +225,8 @@ struct GruArgs {
                          // [gate][piece] words per chunk; Wh: two fp16 pieces, [gate][piece]; all weights scaled by S
     const float* scale;  // x3: device pointer to [S, 1 / S] (a power of two chosen per layer at load time)
     int qb3;             // x3: leading input chunks on three bf16 pieces (9 words); the others on two fp16 pieces (6 words)
+    const unsigned* vmax; // x3, layer 0: bits of the largest value the producing convolution wrote, or null (unknown)
+    const f32x4* Wx2;    // x3: the input pack with ALL chunks on two fp16 pieces (used when *vmax < 2^15)
 };
 
 // small-batch recurrences (mtadgat_gru16.hip): 16 windows per workgroup, one wave per 16-unit hidden tile, weights in registers

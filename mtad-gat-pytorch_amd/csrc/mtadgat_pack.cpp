@@ -193,6 +193,7 @@ std::string validate_and_plan(Model& m) {
         // layer 0 reads h_cat = [conv output (relu: unbounded) | h_feat | h_temp (sigmoids)]: the chunks that touch the
         // first F features keep three bf16 pieces; later layers read a previous layer's state, |h| <= 1
         g.qb3 = l == 0 ? std::min(g.Qxp16, round_up((m.F + 15) / 16, 2)) : 0;
+        if (l == 0) g.wx2_off = take((size_t)g.NCG * g.Qxp16 * 6 * 256 + 3 * 256);
         if (l == 0) {
             g.has_xproj = true;
             g.xproj.in_dim = g.in_dim; g.xproj.out_dim = 3 * g.Hp;
