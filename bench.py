@@ -75,13 +75,15 @@ def algorithmic_flops(kw):
 
 def split_issue_factor(kw):
     """k_gru in the default fp32 arithmetic: bf16 / fp16 MFMA MACs issued per algorithmic MAC (GRU layer + decoder together).
-    Input chunks of 16 features that touch the convolution's channels go as three bf16 pieces (6 MFMA terms), all other
-    chunks -- attention outputs, recurrent state, the decoder's folded input -- as two fp16 pieces (3 terms); chunk and
-    tile padding included."""
+    Every chunk of 16 features goes as two fp16 pieces (3 MFMA terms per product) -- the recurrent state, the attention
+    outputs and the decoder's input by construction, the convolution's channels because their recorded range allows
+    it (three bf16 pieces, 6 terms, otherwise); chunk and tile padding included."""
     F, W, H, Hr = kw["n_features"], kw["window_size"], kw["gru_hid_dim"], kw["recon_hid_dim"]
     up = lambda a, b: -(-a // b) * b      # noqa: E731
     qx = up(-(-(3 * F) // 16), 6)                       # packed input chunks (whole ring turns)
-    qb = min(qx, up(-(-F // 16), 2))
+    # this workload's convolution outputs stay far below 2^15 (inputs in [0, 1)): the device-side range guard puts the
+    # convolution's channels on two fp16 pieces as well; un-normalised series would keep qb = ceil(F / 16) chunks on bf16
+    qb = 0
     qh = lambda h: -(-h // 16)              # noqa: E731
     issued = (up(H, 32) * 16 * (6 * qb + 3 * (qx - qb) + 3 * qh(H)) + up(Hr, 32) * 16 * (3 * 1 + 3 * qh(Hr))) * 3 * W
     alg = (3 * H * (3 * F + H) + 3 * Hr * (3 + Hr)) * W
@@ -403,7 +405,7 @@ def main():
             sf = split_issue_factor(kw)
             peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else (BF16_MFMA_PEAK_TFLOPS / sf if split else FP32_MFMA_PEAK_TFLOPS)
             note = ("v_mfma_f32_32x32x16_bf16 peak" if args.precision == "bf16" else
-                    f"split operands: every fp32 product is 3 (two fp16 pieces) or 6 (three bf16 pieces) 16-bit MFMA terms -- {sf:.2f} MFMA "
+                    f"split operands: every fp32 product is 3 16-bit MFMA terms (two fp16 pieces per operand) -- {sf:.2f} MFMA "
                     f"MACs issued per algorithmic MAC incl. padding -> ceiling = dense bf16/fp16 peak / {sf:.2f} = {BF16_MFMA_PEAK_TFLOPS / sf:.0f} "
                     "TFLOP/s of algorithmic FLOPs (the fp32 MFMA peak is 157.3)" if split else "v_mfma_f32_32x32x2_f32 (exact f32) peak")
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
