@@ -496,6 +496,29 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
             for (int grp = 0; grp < ngrp; ++grp) {
                 const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 16 * grp + 4 * kb);
                 const float* __restrict__ vk = Vs + (pass * 64 + 16 * grp + 4 * kb) * vld;
+                if (X3 && useh) {
+                    // two fp16 pieces of the attention weights (in [0, 1 / (1 - p)]) and of the node values (below 2^15): the
+                    // four keys of a lane are one v_mfma_f32_16x16x16_f16 operand, three terms per product -- on the pipe
+                    // that runs beside the other waves' pair grids (the fp32 form below does not)
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                    unsigned h0, l0, h1, l1;
+                    split_pair_h(bq[0], bq[1], h0, l0);
+                    split_pair_h(bq[2], bq[3], h1, l1);
+                    const f16x4 bhh = __builtin_bit_cast(f16x4, u2{h0, h1}), bll = __builtin_bit_cast(f16x4, u2{l0, l1});
+#pragma unroll
+                    for (int dt = 0; dt < DTMAX; ++dt)
+                        if (dt < DT) {
+                            unsigned a0, c0, a1, c1;
+                            split_pair_h(vk[dcol[dt]], vk[vld + dcol[dt]], a0, c0);
+                            split_pair_h(vk[2 * vld + dcol[dt]], vk[3 * vld + dcol[dt]], a1, c1);
+                            const f16x4 ahh = __builtin_bit_cast(f16x4, u2{a0, a1}), all_ = __builtin_bit_cast(f16x4, u2{c0, c1});
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahh, bll, o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(all_, bhh, o[dt], 0, 0, 0);
+                            o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahh, bhh, o[dt], 0, 0, 0);
+                        }
+                    continue;
+                }
 #pragma unroll
                 for (int dt = 0; dt < DTMAX; ++dt)
                     if (dt < DT) {
