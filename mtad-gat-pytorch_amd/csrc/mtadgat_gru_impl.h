@@ -450,6 +450,29 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             // every lane reads and writes only its own slots -> no cross-lane hazard
 #pragma unroll
             for (int w = 0; w < MW; ++w) {
+                if constexpr (X3) {
+                    // two values per instruction where the ISA has a packed form (v_pk_mul / add / fma_f32): the wave's VALU
+                    // issue is what bounds this build.  Same arithmetic as gate_sigmoid / gate_tanh with the power-of-two
+                    // weight scale folded into the exponent constants, without their clamps (exp2 saturates to 0 / inf and
+                    // 1 / (1 + inf) = 0: the limits come out right without them)
+                    const float cs = -1.4426950408889634f * wInvS, ct = 2.8853900817779268f * wInvS;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 hold = {(t > 0) ? hn_s[w][c][r][lane] : 0.f, (t > 0) ? hn_s[w][c][r + 1][lane] : 0.f};
+                        const f32x2 av = {ar[w][r], ar[w][r + 1]}, zv = {az[w][r], az[w][r + 1]};
+                        const f32x2 xv = {anx[w][r], anx[w][r + 1]}, hv = {anh[w][r], anh[w][r + 1]};
+                        const f32x2 ea = av * cs, ez = zv * cs;
+                        const f32x2 da = f32x2{__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])} + 1.0f;
+                        const f32x2 dz = f32x2{__builtin_amdgcn_exp2f(ez[0]), __builtin_amdgcn_exp2f(ez[1])} + 1.0f;
+                        const f32x2 rg = {__builtin_amdgcn_rcpf(da[0]), __builtin_amdgcn_rcpf(da[1])};
+                        const f32x2 zg = {__builtin_amdgcn_rcpf(dz[0]), __builtin_amdgcn_rcpf(dz[1])};
+                        const f32x2 en = (xv + rg * hv) * ct;
+                        const f32x2 dn = f32x2{__builtin_amdgcn_exp2f(en[0]), __builtin_amdgcn_exp2f(en[1])} + 1.0f;
+                        const f32x2 ng = f32x2{__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])} * -2.0f + 1.0f;
+                        const f32x2 hn = zg * (hold - ng) + ng;
+                        ar[w][r] = hn[0]; ar[w][r + 1] = hn[1];
+                    }
+                } else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float hold = (t > 0) ? hn_s[w][c][r][lane] : 0.f;
