@@ -450,7 +450,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             // every lane reads and writes only its own slots -> no cross-lane hazard
 #pragma unroll
             for (int w = 0; w < MW; ++w) {
-                if constexpr (X3) {
+                if constexpr (X3 || BF) {
                     // two values per instruction where the ISA has a packed form (v_pk_mul / add / fma_f32): the wave's VALU
                     // issue is what bounds this build.  Same arithmetic as gate_sigmoid / gate_tanh with the power-of-two
                     // weight scale folded into the exponent constants, without their clamps (exp2 saturates to 0 / inf and
