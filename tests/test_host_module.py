@@ -152,6 +152,12 @@ def test_create_validates_and_plans_without_a_gpu():
     assert 60_000 < lib.mtadgat_workspace_bytes(h, 65536) / 65536 < 80_000
     chunk = lib.mtadgat_chunk_windows(h)
     assert lib.mtadgat_workspace_bytes(h, 10 * chunk) == lib.mtadgat_workspace_bytes(h, chunk)
+    # arithmetic switch: 0 fp32 MFMA, 1 bf16 operands, 2 fp32 through split 16-bit operands; anything else is refused
+    for mode, ok in ((0, True), (1, True), (2, True), (3, False), (-1, False)):
+        assert (lib.mtadgat_set_precision(h, mode) == 0) == ok
+    assert lib.mtadgat_set_precision(h, 0) == 0
+    # the device-side re-pack needs an earlier load on a GPU: refused here with an error code, nothing is touched
+    assert lib.mtadgat_update_weights_device(h, None, 0, None) != 0
     # forward before load_weights: an error code, not a crash, and nothing touches the device
     rc = lib.mtadgat_forward(h, None, 4, None, None, None, None, 0, None)
     assert rc == -4 and b"load_weights" in lib.mtadgat_last_error()
