@@ -126,6 +126,11 @@ int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64
  * that autograd's version counters do not see (p.data.mul_(), nn.init.*_(p.data)). */
 int mtadgat_params_fingerprint(const void* const* tensors_dev, const int64_t* n_elements, int n_tensors, uint64_t* out_dev, void* stream);
 
+/* Host-only self check of the gather table behind mtadgat_update_weights_device (needs no GPU): packs `params_host`
+ * with the host packer, derives the table, and returns the number of image positions the table would fill with a value
+ * different from the host packer's (0 = consistent; negative = error).  *n_gathered: positions the table covers. */
+int64_t mtadgat_selfcheck_gather_table(mtadgat_handle h, const mtadgat_params* params_host, int64_t* n_gathered);
+
 /* Diagnostic: copies the packed weight image (mtadgat_packed_floats floats) to host memory after synchronising
  * `stream` -- the tests compare the device-side re-pack with the host packer through it. */
 int64_t mtadgat_packed_floats(mtadgat_handle h);

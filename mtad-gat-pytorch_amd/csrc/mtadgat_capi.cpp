@@ -734,6 +734,59 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     return n;
 }
 
+/* Host-only self check of the device-side re-pack's gather table (no GPU needed): packs `p` with the host packer, builds
+ * the table and counts the image positions whose table entry does not reproduce the packed value from the flat
+ * parameter buffer.  *n_gathered receives the number of positions the table covers.  Returns the mismatch count (0 =
+ * consistent), or a negative error code. */
+int64_t mtadgat_selfcheck_gather_table(mtadgat_handle h, const mtadgat_params* p, int64_t* n_gathered) {
+    if (!h || !p) return fail(MTADGAT_ERR_INVALID, "null argument");
+    Model& m = h->m;
+    const int keep_prec = m.precision;
+    m.precision = 0;
+    std::vector<float> img;
+    std::string err = pack_weights(m, *p, img);
+    if (err.empty()) err = build_device_tables(m);
+    m.precision = keep_prec;
+    if (!err.empty()) return fail(MTADGAT_ERR_UNSUPPORTED, err);
+    const DevTables& t = m.dt;
+    // the flat parameter buffer in the field order of mtadgat_params
+    std::vector<float> flat((size_t)t.fo.total);
+    auto put = [&](int64_t off, const float* src, int64_t n) { std::memcpy(flat.data() + off, src, (size_t)n * sizeof(float)); };
+    const mtadgat_config& c = m.cfg;
+    put(t.fo.conv_w, p->conv_weight, (int64_t)m.F * m.F * m.taps); put(t.fo.conv_b, p->conv_bias, m.F);
+    for (int which = 0; which < 2; ++which) {
+        const GatPlan& g = which == 0 ? m.feat : m.temp;
+        const int lin_in = c.use_gatv2 ? 2 * g.D : g.D;
+        put(t.fo.lin_w[which], which == 0 ? p->feat_lin_weight : p->temp_lin_weight, (int64_t)g.E * lin_in);
+        put(t.fo.lin_b[which], which == 0 ? p->feat_lin_bias : p->temp_lin_bias, g.E);
+        put(t.fo.a[which], which == 0 ? p->feat_a : p->temp_a, c.use_gatv2 ? g.E : 2 * g.E);
+        put(t.fo.bias[which], which == 0 ? p->feat_bias : p->temp_bias, (int64_t)g.K * g.K);
+    }
+    for (size_t l = 0; l < m.gru.size(); ++l) {
+        const int in = m.gru[l].in_dim, H = m.gru[l].H;
+        put(t.fo.gru_wih[l], p->gru_w_ih[l], (int64_t)3 * H * in); put(t.fo.gru_whh[l], p->gru_w_hh[l], (int64_t)3 * H * H);
+        put(t.fo.gru_bih[l], p->gru_b_ih[l], 3 * H); put(t.fo.gru_bhh[l], p->gru_b_hh[l], 3 * H);
+    }
+    for (size_t i = 0; i < m.fc.size(); ++i) {
+        put(t.fo.fc_w[i], p->fc_weight[i], (int64_t)m.fc[i].out_dim * m.fc[i].in_dim); put(t.fo.fc_b[i], p->fc_bias[i], m.fc[i].out_dim);
+    }
+    for (size_t l = 0; l < m.rec.size(); ++l) {
+        const int in = m.rec[l].in_dim, H = m.rec[l].H;
+        put(t.fo.rec_wih[l], p->rec_w_ih[l], (int64_t)3 * H * in); put(t.fo.rec_whh[l], p->rec_w_hh[l], (int64_t)3 * H * H);
+        put(t.fo.rec_bih[l], p->rec_b_ih[l], 3 * H); put(t.fo.rec_bhh[l], p->rec_b_hh[l], 3 * H);
+    }
+    put(t.fo.rec_fc_w, p->rec_fc_weight, (int64_t)c.out_dim * c.recon_hid_dim); put(t.fo.rec_fc_b, p->rec_fc_bias, c.out_dim);
+    int64_t bad = 0, cov = 0;
+    for (size_t i = 0; i < m.packed_floats; ++i) {
+        const int g = t.gidx[i];
+        if (g < 0) continue;
+        ++cov;
+        if (std::memcmp(&img[i], &flat[(size_t)g], sizeof(float)) != 0) ++bad;
+    }
+    if (n_gathered) *n_gathered = cov;
+    return bad;
+}
+
 int64_t mtadgat_packed_floats(mtadgat_handle h) { return h ? (int64_t)h->m.packed_floats : 0; }
 int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, void* stream) {
     if (!h || !dst_host) return fail(MTADGAT_ERR_INVALID, "null argument");

@@ -168,3 +168,60 @@ def test_create_validates_and_plans_without_a_gpu():
         assert lib.mtadgat_create(ctypes.byref(_cfg(**bad)), ctypes.byref(h)) == -2, bad
         assert len(lib.mtadgat_last_error()) > 0
     assert lib.mtadgat_create(None, ctypes.byref(h)) == -1
+
+
+_GATHER_CONFIGS = {
+    "msl_shape": dict(n_features=55, window_size=100, out_dim=1, kernel_size=7, gru_hid_dim=150, forecast_n_layers=3,
+                      forecast_hid_dim=150, recon_hid_dim=150),
+    "gat_v1_stacked": dict(n_features=7, window_size=12, out_dim=7, kernel_size=3, use_gatv2=False, feat_gat_embed_dim=5,
+                           time_gat_embed_dim=6, gru_n_layers=2, gru_hid_dim=20, forecast_n_layers=2, forecast_hid_dim=24,
+                           recon_n_layers=2, recon_hid_dim=18),
+    "wide_hidden": dict(n_features=6, window_size=12, out_dim=2, kernel_size=3, gru_hid_dim=200, recon_hid_dim=180,
+                        forecast_n_layers=1, forecast_hid_dim=8),
+    "many_nodes": dict(n_features=5, window_size=140, out_dim=5, kernel_size=3, gru_hid_dim=16, recon_hid_dim=16,
+                       forecast_n_layers=1, forecast_hid_dim=8),
+}
+
+
+@pytest.mark.parametrize("name", list(_GATHER_CONFIGS))
+def test_device_repack_gather_table_is_consistent_with_the_host_packer(name):
+    """The device-side re-pack copies parameters into the tile image through an index table that is harvested from
+    the host packer (run over parameters whose values are their own indices).  Host-only self check of that table:
+    every position it covers must reproduce what the host packer put there, for real parameter values."""
+    import _native
+    import torch
+    from mtad_gat import MTAD_GAT
+    torch.manual_seed(3)
+    model = MTAD_GAT(**_GATHER_CONFIGS[name])
+    lib = _native.load_library()
+    lib.mtadgat_selfcheck_gather_table.restype = ctypes.c_int64
+    h = ctypes.c_void_p()
+    assert lib.mtadgat_create(ctypes.byref(_native.Config(**model._native_cfg)), ctypes.byref(h)) == 0
+    sd = {k: v.detach().float().contiguous() for k, v in model.state_dict().items()}
+    cfg = model._native_cfg
+    p = _native.Params()
+    ptr = lambda key: ctypes.c_void_p(sd[key].data_ptr())      # noqa: E731
+    p.conv_weight, p.conv_bias = ptr("conv.conv.weight"), ptr("conv.conv.bias")
+    p.feat_lin_weight, p.feat_lin_bias = ptr("feature_gat.lin.weight"), ptr("feature_gat.lin.bias")
+    p.feat_a, p.feat_bias = ptr("feature_gat.a"), ptr("feature_gat.bias")
+    p.temp_lin_weight, p.temp_lin_bias = ptr("temporal_gat.lin.weight"), ptr("temporal_gat.lin.bias")
+    p.temp_a, p.temp_bias = ptr("temporal_gat.a"), ptr("temporal_gat.bias")
+    for l in range(cfg["gru_n_layers"]):
+        p.gru_w_ih[l], p.gru_w_hh[l] = ptr(f"gru.gru.weight_ih_l{l}").value, ptr(f"gru.gru.weight_hh_l{l}").value
+        p.gru_b_ih[l], p.gru_b_hh[l] = ptr(f"gru.gru.bias_ih_l{l}").value, ptr(f"gru.gru.bias_hh_l{l}").value
+    for i in range(cfg["forecast_n_linear"]):
+        p.fc_weight[i] = ptr(f"forecasting_model.layers.{i}.weight").value
+        p.fc_bias[i] = ptr(f"forecasting_model.layers.{i}.bias").value
+    for l in range(cfg["recon_n_layers"]):
+        pre = "recon_model.decoder.rnn."
+        p.rec_w_ih[l], p.rec_w_hh[l] = ptr(f"{pre}weight_ih_l{l}").value, ptr(f"{pre}weight_hh_l{l}").value
+        p.rec_b_ih[l], p.rec_b_hh[l] = ptr(f"{pre}bias_ih_l{l}").value, ptr(f"{pre}bias_hh_l{l}").value
+    p.rec_fc_weight, p.rec_fc_bias = ptr("recon_model.fc.weight"), ptr("recon_model.fc.bias")
+    covered = ctypes.c_int64(0)
+    bad = lib.mtadgat_selfcheck_gather_table(h, ctypes.byref(p), ctypes.byref(covered))
+    assert bad == 0, (name, bad, lib.mtadgat_last_error())
+    # the recurrent layers, the convolution and the heads are plain copies (the attention projections are computed
+    # regions, filled by their own kernels)
+    n_copied = sum(v.numel() for k, v in sd.items() if not k.startswith(("feature_gat", "temporal_gat")))
+    assert covered.value >= n_copied
+    assert lib.mtadgat_destroy(h) == 0
