@@ -309,6 +309,18 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         K_TRY(launch_gru_train(a, g.NCG, xmode, fc != nullptr, s), "gru (training)");
         return 0;
     }
+    // chunk-major recurrence (k_gru_cm): 32 windows per wave, the weight stream shared by a workgroup's waves through LDS.
+    // It needs two-piece (fp16) input operands: the decoder's and stacked layers' inputs always are; layer 0's when the
+    // convolution's recorded range allows -- decided on the device: both kernels are launched, each returns at once when
+    // the launch is the other's.  From one workgroup (128 windows) per CU on.
+    if (x3 && m.gru_kernel != 1 && gru_cm_supported(g.NCG, xmode, fc != nullptr, fc ? fc->out_dim : 0) &&
+        (xmode == 1 || g.wxq_off != 0) && (xmode == 1 ? g.Qxp16 == 1 : (a.vmax != nullptr || g.qb3 == 0)) &&
+        (hend == nullptr || ldhe >= g.Hp) && m.W <= 512 && (m.gru_kernel >= 2 || n >= 96L * cu_count())) {
+        a.Wxq = xmode == 1 ? a.Wx : reinterpret_cast<const f32x4*>(m.packed_dev + g.wxq_off);
+        K_TRY(launch_gru_cm(a, g.NCG, xmode, fc != nullptr, m.gru_kernel == 3 ? 0 : 1, s), "gru (chunk-major)");
+        if (a.vmax == nullptr) return 0;
+        a.skip_xh = 1;
+    }
     K_TRY(launch_gru(a, g.NCG, xmode, fc != nullptr, s), "gru");
     return 0;
 }
@@ -527,6 +539,9 @@ static int run_split3(Model& m, hipStream_t s) {
             K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx2_off, outer_x, g.Qxp, g.Qxp16, 0, sc + 1, s), "split input weights (fp16)");
         K_TRY(launch_split2h(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, sc + 1, s),
               "split-fp16 recurrent weights");
+        if (g.wxq_off)       // chunk-major copy of the two-piece input pack (k_gru_cm)
+            K_TRY(launch_reorder_xq(m.packed_dev + ((g.wx2_off && g.qb3 > 0) ? g.wx2_off : g.wx3_off), m.packed_dev + g.wxq_off, g.NCG, g.Qxp16, s),
+                  "chunk-major input weights");
         return 0;
     };
     for (const GruPlan& g : m.gru) { int rc = one(g); if (rc) return rc; }
@@ -721,6 +736,7 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
         add(g.wh3_off, (size_t)g.NCG * (2 * g.NCG + 2) * 6 * 256 + 3 * 256);
         add(g.scale_off, 4);
         if (g.wx2_off) add(g.wx2_off, (size_t)g.NCG * g.Qxp16 * 6 * 256 + 3 * 256);
+        if (g.wxq_off) add(g.wxq_off, (size_t)g.NCG * g.Qxp16 * 6 * 256 + 3 * 256);
     };
     for (const GruPlan& g : m.gru) one(g);
     for (const GruPlan& g : m.rec) one(g);
@@ -808,6 +824,14 @@ int mtadgat_set_precision(mtadgat_handle h, int mode) {
 /* 1 when the bf16 weight streams are present in the packed image (they are packed by mtadgat_load_weights only
  * while precision 1 is selected: call set_precision before load_weights, or load again after switching) */
 int mtadgat_bf16_ready(mtadgat_handle h) { return (h && h->m.have_weights && h->m.bf16_packed) ? 1 : 0; }
+
+/* Testing / measurement hook: "gru_kernel" = 0 automatic choice of the large-batch recurrence kernel, 1 tile-major (k_gru),
+ * 2 chunk-major (k_gru_cm) wherever it applies, 3 its direct-load cross-check build (when compiled in) */
+int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
+    if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
+    if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
+    return fail(MTADGAT_ERR_INVALID, "unknown option or value");
+}
 
 int64_t mtadgat_chunk_windows(mtadgat_handle h) { return h ? h->m.chunk : 0; }
 int mtadgat_set_chunk_windows(mtadgat_handle h, int64_t w) {

@@ -62,6 +62,8 @@ template <int NCG, int XMODE, bool FC, int DROP, int MW, bool BF = false, int QX
 __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3) ? 2 : 1)) void k_gru(const GruArgs a) {
     static_assert(!X3 || (BF && QXC == 0), "split-bf16 build uses the bf16 chunk geometry");
     extern __shared__ __attribute__((aligned(16))) float hn_dyn[];
+    // the chunk-major kernel (mtadgat_gru_cm.hip) serves this launch when the input range allows two-piece operands
+    if (X3 && a.skip_xh && a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f) return;
     constexpr int WPB = MW == 2 ? 4 : 1;
     const int lane = threadIdx.x & 63;
     const int wv = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

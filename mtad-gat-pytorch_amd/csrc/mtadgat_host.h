@@ -61,6 +61,7 @@ struct GruPlan {
     // split-bf16 packs of the large-batch kernel (three bf16 pieces per weight, derived on the device from the fp32 packs)
     size_t wx3_off = 0, wh3_off = 0;   // wx3: three bf16 pieces of S * W_ih; wh3: TWO fp16 pieces of S * W_hh, [gate][piece] words (+ 3 words of slack)
     size_t wx2_off = 0;                // the input pack with all chunks on two fp16 pieces (layer 0, when the conv's range allows)
+    size_t wxq_off = 0;                // row-input layers: the two-piece input pack in [chunk][tile][gate][piece] order (k_gru_cm)
     int qb3 = 0;                       // leading input chunks (of 16) kept on three bf16 pieces: the convolution's channels, rounded to 2
     size_t scale_off = 0;              // [bits of max |W| of the layer, S, 1 / S, 0]: S = the power of two that puts it into [2^13, 2^14)
     // one-window-per-workgroup recurrence (k_gru1 / k_gru1_bwd): [waves][16 * g1_ksm(H)][64], a lane's weights for all hidden indices
@@ -169,6 +170,7 @@ struct Model {
     bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
+    int gru_kernel = 0;              // large-batch recurrence: 0 automatic, 1 tile-major k_gru, 2 chunk-major k_gru_cm (testing hook: mtadgat_set_option)
     DevTables dt;
     // profiling
     bool profile = false;

@@ -227,6 +227,10 @@ struct GruArgs {
     int qb3;             // x3: leading input chunks on three bf16 pieces (9 words); the others on two fp16 pieces (6 words)
     const unsigned* vmax; // x3, layer 0: bits of the largest value the producing convolution wrote, or null (unknown)
     const f32x4* Wx2;    // x3: the input pack with ALL chunks on two fp16 pieces (used when *vmax < 2^15)
+    // chunk-major recurrence (k_gru_cm, mtadgat_gru_cm.hip): the two-piece input pack re-ordered [chunk][tile][gate][piece]
+    // (the decoder's per-step pack already is one contiguous block per step)
+    const f32x4* Wxq;
+    int skip_xh;         // k_gru: return at once when *vmax < 2^15 (k_gru_cm serves that case)
 };
 
 // small-batch recurrences (mtadgat_gru16.hip): 16 windows per workgroup, one wave per 16-unit hidden tile, weights in registers
@@ -320,6 +324,9 @@ int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int 
                     float alpha, hipStream_t s);
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
+bool gru_cm_supported(int ncg, int xmode, bool fc, int out_dim);
+int launch_gru_cm(const GruArgs& a, int ncg, int xmode, bool fc, int wmode, hipStream_t s);
+int launch_reorder_xq(const float* src, float* dst, int ncg, int Qd, hipStream_t s);
 long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);
 int launch_fingerprint(const FingerprintArgs& a, int n_tensors, unsigned long long* out, hipStream_t s);

@@ -194,6 +194,7 @@ std::string validate_and_plan(Model& m) {
         // first F features keep three bf16 pieces; later layers read a previous layer's state, |h| <= 1
         g.qb3 = l == 0 ? std::min(g.Qxp16, round_up((m.F + 15) / 16, 2)) : 0;
         if (l == 0) g.wx2_off = take((size_t)g.NCG * g.Qxp16 * 6 * 256 + 3 * 256);
+        g.wxq_off = take((size_t)g.NCG * g.Qxp16 * 6 * 256 + 3 * 256);
         if (l == 0) {
             g.has_xproj = true;
             g.xproj.in_dim = g.in_dim; g.xproj.out_dim = 3 * g.Hp;
@@ -250,6 +251,7 @@ std::string validate_and_plan(Model& m) {
         g.wx3_off = take((size_t)(g.xmode == 1 ? m.W : 1) * g.NCG * g.Qxp16 * 9 * 256);
         g.wh3_off = take((size_t)g.NCG * (2 * g.NCG + 2) * 6 * 256 + 3 * 256);
         g.scale_off = take(4);
+        if (g.xmode == 0) g.wxq_off = take((size_t)g.NCG * g.Qxp16 * 6 * 256 + 3 * 256);
         if (l == 0) plan16(g);
     }
     {
