@@ -161,8 +161,7 @@ int mtadgat_bf16_ready(mtadgat_handle h);
 
 /* Testing / measurement hook (not needed for normal use).  "gru_kernel": which kernel runs the large-batch recurrences
  * (GRULayer.forward modules.py:235-238, the decoder modules.py:276-283) in precision mode 2:
- *   0 automatic (default), 1 the tile-major kernel at every batch size, 2 the chunk-major kernel wherever it applies,
- *   3 its direct-load cross-check build (only in developer builds of the library; an error otherwise when launched). */
+ *   0 automatic (default), 1 the tile-major kernel at every batch size, 2 the chunk-major kernel wherever it applies. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
 
 /* Bytes of device scratch forward() needs for a batch of `batch` windows

@@ -250,9 +250,19 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         K_TRY(launch_gru16(a, s), "gru (16-window groups)");
         return 0;
     }
+    // chunk-major recurrence (k_gru_cm): 32 windows per wave, the weight stream shared by a workgroup's waves through LDS.
+    // It needs two-piece (fp16) input operands: the decoder's and stacked layers' inputs always are; layer 0's when the
+    // convolution's recorded range allows -- decided on the device: both kernels are launched, each returns at once when
+    // the launch is the other's.  Measured against the kernels it replaces (MSL shape, GRU layer + decoder): 12 288 windows
+    // 5.9 -> 4.0 ms, 32 768: 7.3 -> 4.4, 65 536: 12.0 -> 9.1; from CM_MIN_WINDOWS on.
+    const bool cm_fit = m.precision == 2 && !gates && gru_cm_supported(g.NCG, g.xmode, fc != nullptr, fc ? fc->out_dim : 0) &&
+                        (g.Qxp16 == 1 || g.Qxp16 % 2 == 0) &&
+                        (g.xmode == 1 ? g.Qxp16 == 1 : (g.wxq_off != 0 && g.Qx >= 3 && ((vmax && g.wx2_off && g.qb3 > 0) || g.qb3 == 0))) &&
+                        (hend == nullptr || ldhe >= g.Hp) && m.W <= 512;
+    const bool use_cm = cm_fit && m.gru_kernel != 1 && (m.gru_kernel == 2 || n >= CM_MIN_WINDOWS);
     // large batch, split-bf16 operands: fp32-class results from the bf16 matrix pipe (k_gru X3 build), from 1.25 32-window
     // groups per CU on (measured: 12 320 windows 10.5 ms against 13.1 ms for the hidden-tile-split kernel at 12 288; 8 192 windows 7.4 ms there)
-    const bool x3 = m.precision == 2 && !gates && (n + 31) / 32 > 5L * cu_count() / 4 &&
+    const bool x3 = m.precision == 2 && !gates && ((n + 31) / 32 > 5L * cu_count() / 4 || use_cm) &&
                     (g.Qxp16 == 1 || g.Qxp16 % 2 == 0);
     if (!x3 && xp && g.has_xproj && g.xmode == 0) {
         // small batch: all steps' input products as one throughput GEMM, the recurrence keeps only its h part
@@ -309,15 +319,9 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         K_TRY(launch_gru_train(a, g.NCG, xmode, fc != nullptr, s), "gru (training)");
         return 0;
     }
-    // chunk-major recurrence (k_gru_cm): 32 windows per wave, the weight stream shared by a workgroup's waves through LDS.
-    // It needs two-piece (fp16) input operands: the decoder's and stacked layers' inputs always are; layer 0's when the
-    // convolution's recorded range allows -- decided on the device: both kernels are launched, each returns at once when
-    // the launch is the other's.  From one workgroup (128 windows) per CU on.
-    if (x3 && m.gru_kernel != 1 && gru_cm_supported(g.NCG, xmode, fc != nullptr, fc ? fc->out_dim : 0) &&
-        (xmode == 1 || g.wxq_off != 0) && (xmode == 1 ? g.Qxp16 == 1 : (a.vmax != nullptr || g.qb3 == 0)) &&
-        (hend == nullptr || ldhe >= g.Hp) && m.W <= 512 && (m.gru_kernel >= 2 || n >= 96L * cu_count())) {
+    if (use_cm) {
         a.Wxq = xmode == 1 ? a.Wx : reinterpret_cast<const f32x4*>(m.packed_dev + g.wxq_off);
-        K_TRY(launch_gru_cm(a, g.NCG, xmode, fc != nullptr, m.gru_kernel == 3 ? 0 : 1, s), "gru (chunk-major)");
+        K_TRY(launch_gru_cm(a, g.NCG, xmode, fc != nullptr, s), "gru (chunk-major)");
         if (a.vmax == nullptr) return 0;
         a.skip_xh = 1;
     }
@@ -826,10 +830,10 @@ int mtadgat_set_precision(mtadgat_handle h, int mode) {
 int mtadgat_bf16_ready(mtadgat_handle h) { return (h && h->m.have_weights && h->m.bf16_packed) ? 1 : 0; }
 
 /* Testing / measurement hook: "gru_kernel" = 0 automatic choice of the large-batch recurrence kernel, 1 tile-major (k_gru),
- * 2 chunk-major (k_gru_cm) wherever it applies, 3 its direct-load cross-check build (when compiled in) */
+ * 2 chunk-major (k_gru_cm) wherever it applies */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
-    if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
+    if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 2) { h->m.gru_kernel = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
 
