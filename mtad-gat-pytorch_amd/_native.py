@@ -10,7 +10,7 @@ import os
 import torch  # must be imported before the library: both bind libamdhip64.so.7, torch's copy wins
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get("MTADGAT_LIB") or os.path.join(_HERE, "libmtadgat.so")      # MTADGAT_LIB: A/B builds of the library
+_LIB_PATH = os.path.join(_HERE, "libmtadgat.so")
 MAX_LAYERS = 8
 PROFILE_SLOTS = 6
 
@@ -244,7 +244,7 @@ class Engine:
     def update_weights_device(self, sd, device):
         """Re-pack from parameters that live on `device` without leaving it (after an optimizer step).  False when the
         library declines (no earlier host-side load, bf16 image, ...): the caller then uses load_weights."""
-        if self._keep is None or os.environ.get("MTADGAT_HOST_PACK"):
+        if self._keep is None:
             return False
         flat = torch.cat([sd[k].detach().reshape(-1).to(torch.float32) for k in self.flat_keys()])
         if flat.device != device:

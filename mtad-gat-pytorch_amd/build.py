@@ -26,9 +26,9 @@ def _stale():
 def build(force=False, verbose=True):
     """Compile the HIP kernels + C ABI into libmtadgat.so; returns the library path.
     One hipcc per stale translation unit (source or any header newer than its object), run concurrently,
-    then one link step.  MTADGAT_EXTRA_FLAGS adds compiler flags (experiments)."""
+    then one link step.  (Developer variants of single translation units: profiles/build_variants.sh.)"""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("MTADGAT_EXTRA_FLAGS", "").split()
+    extra = []
     stamp = os.path.join(OBJDIR, ".flags")
     flags_now = " ".join(FLAGS + extra)
     flags_same = (not os.path.isdir(OBJDIR) and not extra) or (os.path.exists(stamp) and open(stamp).read() == flags_now)

@@ -1,7 +1,7 @@
 // Backward kernels of the MTAD-GAT hot path (training step, reference training.py:106-127: loss.backward()
 // through MTAD_GAT.forward) + launchers.  gfx950, wave64, fp32.
 //
-//   k_wgrad / k_wgrad_reduce   every weight / bias gradient: dW = A^T B over all (window, step) rows, split over
+//   k_wgrad_lds / k_wgrad_reduce   every weight / bias gradient: dW = A^T B over all (window, step) rows, split over
 //                              row slabs, deterministic two-stage sum, scattered into the reference's parameter layout
 //   k_gru_bwd                  back-propagation through time of a GRU layer (GRULayer / RNNDecoder, modules.py:235-257)
 //   k_gat_bwd_att / _pair      backward of a graph-attention layer (modules.py:65-95, :166-193), per window
@@ -13,140 +13,7 @@
 namespace mtadgat {
 
 // ---------------------------------------------------------------------------
-// wgrad: P[slab][m][n] = sum_{rows of the slab} A[row][m] * B[row][n].
-// MFMA with the data rows as the contraction index: for v_mfma_f32_32x32x2_f32 lane (c = lane & 31,
-// kk = lane >> 5) supplies A[row][m = c] and B[row][n = c] of row r + 4 kk + s for the s-th of four
-// instructions -- 8 rows per group, one dword per operand and lane, coalesced 128-byte row segments.
-// A wave owns a 2 x 2 block of 32 x 32 output tiles; every load is unconditional from a clamped address and
-// masked afterwards (a guarded load would cost one memory round trip per group).
-// ---------------------------------------------------------------------------
-template <int BMODE>
-__global__ __launch_bounds__(64) void k_wgrad(const WgradArgs a) {
-    const int lane = threadIdx.x;
-    const int c = lane & 31, kk = lane >> 5;
-    const int Nb = (a.Np + 63) >> 6;
-    const int mb = blockIdx.x / Nb, nb = blockIdx.x - mb * Nb;
-    const int slab = blockIdx.y;
-    const long rbeg = (long)slab * a.rows_per_slab;
-    const long rend = rbeg + a.rows_per_slab < a.R ? rbeg + a.rows_per_slab : a.R;
-    const int T = a.T > 0 ? a.T : 1;
-
-    int mcol[2], ncol[2], mc[2], nc[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        mcol[u] = 64 * mb + 32 * u + c;
-        ncol[u] = 64 * nb + 32 * u + c;
-        mc[u] = mcol[u] < a.M ? mcol[u] : a.M - 1;
-        nc[u] = ncol[u] < a.N ? ncol[u] : a.N - 1;
-    }
-    // conv im2col: column n = tap * F + ch
-    int tapn[2] = {0, 0}, chn[2] = {0, 0};
-    if (BMODE == 1) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            tapn[u] = nc[u] / a.F;
-            chn[u] = nc[u] - tapn[u] * a.F;
-        }
-    }
-    const bool need_t = (BMODE == 1) || a.bshift;
-    int ts[4];                                        // step index within the window of this lane's 4 rows
-#pragma unroll
-    for (int s = 0; s < 4; ++s) ts[s] = need_t ? (int)((rbeg + 4 * kk + s) % T) : 0;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-
-    auto load = [&](long r0, float (&av)[2][4], float (&bv)[2][4]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const long row = r0 + 4 * kk + s;
-            const bool rok = row < rend;
-            const long rowc = rok ? row : a.R - 1;
-            const int t = ts[s];
-            // A
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float v = a.A[rowc * a.lda + mc[u]];
-                av[u][s] = (rok && mcol[u] < a.M) ? v : 0.f;
-            }
-            // B
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float v;
-                bool ok = rok && ncol[u] < a.N;
-                if (BMODE == 1) {
-                    const int tt = t + tapn[u] - a.pad;
-                    const bool tin = tt >= 0 && tt < T;
-                    long xr = rowc + tapn[u] - a.pad;
-                    xr = xr < 0 ? 0 : (xr < a.R ? xr : a.R - 1);
-                    v = a.B[xr * a.F + chn[u]];
-                    ok = ok && tin;
-                } else {
-                    // bshift: the row of the previous step (h_{t-1} next to the gradients of step t), zero at t = 0
-                    long br = rowc - (a.bshift ? 1 : 0);
-                    br = br < 0 ? 0 : br;
-                    v = a.B[br * a.ldb + nc[u]];
-                    ok = ok && !(a.bshift && t == 0);
-                }
-                v = ok ? v : 0.f;
-                bv[u][s] = (rok && ncol[u] == a.N) ? 1.f : v;            // the all-ones column: bias gradients
-            }
-        }
-    };
-    auto advance = [&]() {
-        if (need_t) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                int t = ts[s] + 8;
-                while (t >= T) t -= T;
-                ts[s] = t;
-            }
-        }
-    };
-
-    float a0[2][4], b0[2][4], a1[2][4], b1[2][4];
-    if (rbeg < rend) {
-        load(rbeg, a0, b0);
-        for (long r = rbeg; r < rend; r += 8) {
-            advance();
-            load(r + 8, a1, b1);                      // rows past the slab come back masked to zero
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[x][s], b0[y][s], acc[x][y], 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { a0[u][s] = a1[u][s]; b0[u][s] = b1[u][s]; }
-        }
-    }
-    float* __restrict__ P = a.P + (long)slab * a.Mp * a.Np;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-            const int m0 = 64 * mb + 32 * x, n = 64 * nb + 32 * y + c;
-            if (m0 < a.Mp && n < a.Np) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int m = m0 + (q & 3) + 8 * (q >> 2) + 4 * kk;
-                    P[(long)m * a.Np + n] = acc[x][y][q];
-                }
-            }
-        }
-}
-
-
-// ---------------------------------------------------------------------------
-// wgrad, LDS-tiled (the one used): a workgroup of 4 waves owns a 128 x 128 block of d W (wave (wm, wn): 64 x 64 =
+// wgrad: P[slab][m][n] = sum_{rows of the slab} A[row][m] * B[row][n], LDS-tiled: a workgroup of 4 waves owns a 128 x 128 block of d W (wave (wm, wn): 64 x 64 =
 // 2 x 2 MFMA tiles) and walks its row slab 16 rows at a time.  The 16 x 128 pieces of A and B are staged in LDS
 // by all 256 threads (coalesced dword loads, unconditional from clamped addresses, masked afterwards; the loader
 // modes -- im2col for the convolution, previous-step rows, the all-ones bias column -- are applied here), double
@@ -330,14 +197,7 @@ __global__ void k_wgrad_reduce(const WgradReduceArgs a) {
 
 int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     if (a.R <= 0 || a.M <= 0 || a.N <= 0) return 0;
-    static const bool direct = std::getenv("MTADGAT_WGRAD_DIRECT") != nullptr;      // first version, kept for A/B
-    if (direct) {
-        const dim3 grid((unsigned)(((a.Mp + 63) / 64) * ((a.Np + 63) / 64)), (unsigned)a.nslab);
-        if (a.bmode == 1)
-            hipLaunchKernelGGL(k_wgrad<1>, grid, dim3(64), 0, s, a);
-        else
-            hipLaunchKernelGGL(k_wgrad<0>, grid, dim3(64), 0, s, a);
-    } else {
+    {
         const dim3 grid((unsigned)(((a.Mp + 127) / 128) * ((a.Np + 127) / 128)), (unsigned)a.nslab);
         const bool vec = a.bmode == 0 && (a.lda & 3) == 0 && (a.ldb & 3) == 0 && a.lda >= 4 && a.ldb >= 4 &&
                          (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;

@@ -94,14 +94,8 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
         a.bf16 = 1; a.Fq = m.Fp16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w16_off);
     }
-    // split-bf16 operands (default fp32 arithmetic of large batches): same geometry, fp32-class results
-    // (measured 3.36 vs 3.37 ms at the flagship shape: the convolution is bound by its staging and stores, not by the matrix
-    // pipe -- kept behind a switch)
-    static const bool conv_x3 = std::getenv("MTADGAT_CONV_X3") != nullptr;
-    if (conv_x3 && m.precision == 2 && !src.x_bf16 && n >= 4096 && (size_t)(32 + m.taps - 1) * (m.Fp16 + 4) * sizeof(float) <= 20 * 1024) {
-        a.bf16 = 2; a.Fq = m.Fp16;
-        a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w3_off);
-    }
+    // (split-bf16 operands were tried for the convolution as well: 3.36 vs 3.37 ms at the flagship shape -- it is bound by its
+    // staging and stores, not by the matrix pipe; the fp32 MFMA build stays)
     a.bias = m.packed_dev + m.conv_b_off;
     a.NT = m.convNT;
     a.XC = xc; a.XCT = xct; a.Wpad = m.Wp; a.HCAT = hcat; a.Dp = m.Dp; a.Y = y;
@@ -129,7 +123,7 @@ int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nro
 int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, const float* v, int ldv, int64_t n, float* out,
                long so_w, long so_i, long so_d, hipStream_t s) {
     Scope sc(m, S_ATTEND, s);
-    if (g.K <= 512 && g.D <= 512 && !std::getenv("MTADGAT_OLD_ATTEND")) {
+    if (g.K <= 512 && g.D <= 512) {
         // LDS-tiled pair grid of the fused kernel over the HBM-resident projections (BASELINE config 4 shapes)
         K_TRY(launch_gat_wide(lc, rt, g.ldl, g.rt_rows, g.Kp, g.PT, g.P8, m.packed_dev + g.bias_off, v, ldv, g.D, g.K, out, so_w,
                               so_i, so_d, n, m.cfg.use_gatv2 ? 0 : 1, m.cfg.alpha, s),
@@ -167,7 +161,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
-    } else if (m.precision == 2 && n >= 4096 && !std::getenv("MTADGAT_GAT_FP32")) {
+    } else if (m.precision == 2 && n >= 4096) {
         // large batches: split-bf16 operands for the projection -- fp32-class L' / R' on the bf16 matrix pipe, which runs
         // beside the pair grid of the other waves (the fp32 MFMA does not: profiles/r02_mfma_valu_overlap.txt).  Measured at
         // (W=100, F=55): feature layer 5.90 -> 5.09 ms, temporal layer 7.40 -> 6.94 ms (two weight chunks in registers; with
@@ -204,16 +198,14 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 // (inference in the bf16 mode uses k_gru1 up to 1024 windows -- faster there than the bf16 build of the throughput
 // kernels, and exact; the training step keeps the bf16 recurrences it was asked for)
 bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n, bool training = false) {
-    static const bool off = std::getenv("MTADGAT_NO_GRU16") != nullptr;
-    if (off || stack.size() != 1 || !stack[0].has16) return false;
+    if (stack.size() != 1 || !stack[0].has16) return false;
     if (m.precision == 1) return !training && n <= 1024;
     return n <= G16_MAX_WINDOWS;
 }
 
 // ... and below G1_MAX_WINDOWS a workgroup takes one window at a time
 bool use_g1(int64_t n) {
-    static const bool off = std::getenv("MTADGAT_NO_GRU1") != nullptr;
-    return !off && n <= G1_MAX_WINDOWS;
+    return n <= G1_MAX_WINDOWS;
 }
 
 // one GRU layer.  x: rows (n*T, ldx) for xmode 0, hin (n, ldx) for xmode 1
@@ -559,8 +551,6 @@ static int run_split3(Model& m, hipStream_t s) {
             K_TRY(launch_scale_from_max(sc, s), "projection weight scale");
             K_TRY(launch_split2h(m.packed_dev + g->w_off, m.packed_dev + g->w2h_off, g->NT, g->Q, g->Q16, 1, sc + 1, s), "split-fp16 projection weights");
         }
-    K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, nullptr, s),
-          "split-bf16 conv weights");
     return 0;
 }
 
@@ -604,7 +594,6 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream
     HIP_TRY(hipMemcpyAsync(m.packed_dev, m.staging_pinned, m.packed_floats * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(m.upload_ev, s));
     { int rc = run_split3(m, s); if (rc) return rc; }
-    if (std::getenv("MTADGAT_SYNC_UPLOAD")) HIP_TRY(hipStreamSynchronize(s));      // debugging aid
     m.have_weights = true;
     return 0;
 }
@@ -744,7 +733,6 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     };
     for (const GruPlan& g : m.gru) one(g);
     for (const GruPlan& g : m.rec) one(g);
-    add(m.conv_w3_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
     add(m.feat.w3_off, (size_t)m.feat.NT * m.feat.Q16 * 3 * 256);
     add(m.temp.w3_off, (size_t)m.temp.NT * m.temp.Q16 * 3 * 256);
     for (const GatPlan* g : {&m.feat, &m.temp}) {

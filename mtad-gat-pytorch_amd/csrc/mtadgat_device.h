@@ -92,10 +92,6 @@ __device__ __forceinline__ f32x16 mfma_bf(const f32x4 w, const f32x4 x, f32x16 a
 // are exact in fp32 and the accumulation is the same fp32 accumulation, so the result differs from the fp32 MFMA's by
 // a few 2^-24 per product.  Weights are split once per load (k_split3), activations where they are consumed.
 __device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, f32x4& hi, f32x4& mid, f32x4& lo) {
-#ifdef MTADGAT_X3_NOSPLIT           // timing experiment only (wrong results)
-    hi = a; mid = b; lo = a;
-    return;
-#endif
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     u4 h, m, l;
 #pragma unroll

@@ -334,8 +334,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     // two groups per wave once that still gives every SIMD a wave
     const bool two = (a.B + 31) / 32 >= 8L * n_cu;
     if (a.x3) {
-        static const bool one = std::getenv("MTADGAT_X3_MW1") != nullptr;      // experiment: 32-window waves, two per SIMD
-        return ncg >= 5 ? launch_gru_big_x3_hi(a, ncg, xmode, fc, two && !one, s) : launch_gru_big_x3_lo(a, ncg, xmode, fc, two && !one, s);
+        return ncg >= 5 ? launch_gru_big_x3_hi(a, ncg, xmode, fc, two, s) : launch_gru_big_x3_lo(a, ncg, xmode, fc, two, s);
     }
     return a.bf16 ? launch_gru_big_bf16(a, ncg, xmode, fc, two, s) : launch_gru_big_f32(a, ncg, xmode, fc, two, s);
 }

@@ -4,19 +4,6 @@
 #pragma once
 #include "mtadgat_device.h"
 
-// experiment: a workgroup barrier before every weight-chunk request keeps the four waves of a CU on the same chunk, so
-// that three of the four requests hit the vector L1
-#ifdef MTADGAT_X3_SYNC
-#define X3_CHUNK_SYNC() __builtin_amdgcn_s_barrier()
-#else
-#define X3_CHUNK_SYNC() ((void)0)
-#endif
-#ifndef MTADGAT_X3_RING
-#define MTADGAT_X3_RING 2
-#endif
-#ifndef MTADGAT_X3_RING1
-#define MTADGAT_X3_RING1 3
-#endif
 
 namespace mtadgat {
 
@@ -82,7 +69,7 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     // ring depth: 3 chunks of weights in flight (fp32: 36 MFMAs x 64 cycles ~ 2.3k cycles of cover).  A ring of 6 was
     // tried for the bf16 build, whose chunks are 8x shorter: no gain -- that build was bound by the input re-reads (XR)
     constexpr bool XR = BF && XMODE == 0 && QXC > 0;
-    constexpr int R = X3 ? (MW == 1 ? MTADGAT_X3_RING1 : MTADGAT_X3_RING) : 3;
+    constexpr int R = X3 ? (MW == 1 ? 3 : 2) : 3;
     constexpr int NP = X3 ? 3 : 1;                // operand pieces per weight word
     constexpr int WN = 3 * NP;                    // 16-byte words per chunk and lane: [gate][piece]
     constexpr int XW = X3 ? 2 : 1;                // registers of an input chunk: the two fp32 halves (X3) or the operand itself
@@ -140,9 +127,6 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
     for (int w = 0; w < MW; ++w) xbase[w] = (XMODE == 0) ? a.X + winc[w] * T * a.ldx + 4 * g : a.X + winc[w] * a.ldx;
     auto loadx_t = [&](int w, int t, int q) -> f32x4 {
         const int qq = q < Qx ? q : Qx - 1;       // padded chunks re-read the last real one (their weights are zero)
-#ifdef MTADGAT_X3_HOTX              // timing experiment only (wrong results): every step re-reads the rows of step 0 (cache resident)
-        if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase[w] + 8 * qq);
-#endif
         if (XMODE == 0) return *reinterpret_cast<const f32x4*>(xbase[w] + (long)t * a.ldx + 8 * qq);
         const int k0 = a.m0[t] + 8 * qq + 4 * g, kmax = (int)a.ldx - 1;     // stay inside the (zero padded) row
         f32x4 v;
@@ -206,10 +190,6 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
             u4 hw = {0, 0, 0, 0}, mw = {0, 0, 0, 0}, lw = {0, 0, 0, 0};
             auto pair = [&](const int pp) {
                 const float v0 = pp < 2 ? ra[2 * pp] : rb[2 * pp - 4], v1 = pp < 2 ? ra[2 * pp + 1] : rb[2 * pp - 3];
-#ifdef MTADGAT_X3_NOSPLIT           // timing experiment only (wrong results): what the kernel costs without the operand splits
-                hw[pp] = __builtin_bit_cast(unsigned, v0); mw[pp] = hw[pp]; lw[pp] = hw[pp];
-                return;
-#endif
                 if constexpr (NEXT == 3) {
                     const unsigned hh = pack_bf16(v0, v1);
                     const float r0 = v0 - __builtin_bit_cast(float, hh << 16), r1 = v1 - __builtin_bit_cast(float, hh & 0xffff0000u);
@@ -320,7 +300,6 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                             stage(T3{}, N2{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
                         else
                             stage(T3{}, N3{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
-                        X3_CHUNK_SYNC();
                         wload(wr[st]);
 #pragma unroll
                         for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, t, q0 + st + R);
@@ -332,7 +311,6 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                     for (int st = 0; st < R; ++st) {
                         stage(T2{}, N2{}, wr[st], xs0, ar[0], az[0], anx[0], xr[st][MW - 1][0], xr[st][MW - 1][XW - 1], xs1);
                         stage(T2{}, N2{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anx[MW - 1], xr[(st + 1) % R][0][0], xr[(st + 1) % R][0][XW - 1], xs0);
-                        X3_CHUNK_SYNC();
                         wload(wr[st]);
 #pragma unroll
                         for (int w = 0; w < MW; ++w) loadxq(xr[st][w], w, t, q0 + st + R);
@@ -399,7 +377,6 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
                     } else {
                         stage(T2{}, N0{}, wr[st], xs1, ar[MW - 1], az[MW - 1], anh[MW - 1], lo, hi, xs0);
                     }
-                    X3_CHUNK_SYNC();
                     wload(wr[st]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -478,14 +455,9 @@ __global__ __launch_bounds__((MW == 2 ? 256 : 64), ((NCG <= 6 && MW == 1 && !X3)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float hold = (t > 0) ? hn_s[w][c][r][lane] : 0.f;
-#ifdef MTADGAT_X3_NOGATE           // timing experiment only (wrong results): the step without the gate transcendentals
-                    const float rg = ar[w][r] * 0.01f, zg = az[w][r] * 0.01f;
-                    const float ng = (anx[w][r] + rg * anh[w][r]) * 0.01f;
-#else
                     const float rg = gate_sigmoid(X3 ? ar[w][r] * wInvS : ar[w][r]);
                     const float zg = gate_sigmoid(X3 ? az[w][r] * wInvS : az[w][r]);
                     const float ng = gate_tanh(X3 ? (anx[w][r] + rg * anh[w][r]) * wInvS : anx[w][r] + rg * anh[w][r]);
-#endif
                     ar[w][r] = __builtin_fmaf(zg, hold - ng, ng);          // (1 - z) n + z h
                 }
 #pragma unroll
@@ -621,8 +593,7 @@ inline int launch_gru_mode(const GruArgs& a, bool fc, int drop, hipStream_t s) {
         hipLaunchKernelGGL((k_gru<NCG, 0, false, DR, 2, true, QX>), dim3(grid), dim3(64 * WPB), lds, s, a);            \
     }
     if constexpr (BF && !X3 && XMODE == 0 && MW == 2 && NCG <= 5) {
-        static const bool stream_x = std::getenv("MTADGAT_GRU_STREAM_X") != nullptr;      // A/B switch
-        if (!fc && !stream_x && (a.Qxp == 6 || a.Qxp == 12)) {
+        if (!fc && (a.Qxp == 6 || a.Qxp == 12)) {
             if (a.Qxp == 6) { if (drop == 0) GRU_LAUNCH_XR(0, 6) else GRU_LAUNCH_XR(1, 6) }
             else { if (drop == 0) GRU_LAUNCH_XR(0, 12) else GRU_LAUNCH_XR(1, 12) }
             LAUNCH_CHECK();

@@ -155,7 +155,6 @@ struct Model {
     int Fp16 = 0;                    // bf16 conv build: channels padded to 16
     size_t conv_w16_off = 0;
     size_t conv_wf16_off = 0;        // fp32 tiles in the 16-channel geometry (source of the split-bf16 pack)
-    size_t conv_w3_off = 0;          // split-bf16 pack [tile][chunk][piece][64], derived on the device
     GatPlan feat, temp;
     std::vector<GruPlan> gru, rec;
     std::vector<LinPlan> fc;

@@ -490,7 +490,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)((R + 31) / 32);
     const size_t lds = (size_t)(32 + a.taps - 1) * (a.Fq + 4) * sizeof(float);
     if ((a.bf16 || a.x_bf16) && lds > 20 * 1024) return -2;
-    static const size_t lds_max = std::getenv("MTADGAT_CONV_LDS_MAX") ? (size_t)atol(std::getenv("MTADGAT_CONV_LDS_MAX")) : 20 * 1024;
+    constexpr size_t lds_max = 20 * 1024;
     if (lds <= lds_max || a.bf16 || a.x_bf16) {       // >= 8 waves per CU keep their tile in LDS
         if (lds > 64 * 1024) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_lds<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -498,12 +498,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         }
         const unsigned wpb = (grid >= 4096 && 4 * lds <= 64 * 1024) ? 4 : 1;     // waves per workgroup
         const unsigned g4 = (grid + wpb - 1) / wpb;
-        if (a.bf16 == 2) {         // split-bf16 operands
-            if (a.NT >= 2)
-                hipLaunchKernelGGL((k_conv_lds<2, true, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
-            else
-                hipLaunchKernelGGL((k_conv_lds<1, true, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
-        } else if (a.bf16) {
+        if (a.bf16) {
             if (a.NT >= 2)
                 hipLaunchKernelGGL((k_conv_lds<2, true>), dim3(g4), dim3(64 * wpb), wpb * lds, s, a);
             else

@@ -113,7 +113,6 @@ std::string validate_and_plan(Model& m) {
         m.Fp16 = round_up(m.F, 16);
         m.conv_w16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 256);
         m.conv_wf16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 8) * 256);
-        m.conv_w3_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
     }
     // GAT layers
     auto plan_gat = [&](GatPlan& g, int K, int D, int E) {
@@ -801,18 +800,9 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
         }
     }
     };
-    if (std::getenv("MTADGAT_PACK_TIMING")) {
-        auto tm = [&](const char* n, auto&& f) {
-            auto t0 = std::chrono::steady_clock::now();
-            f();
-            fprintf(stderr, "[pack] %s %.3f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        };
-        tm("conv+feat", job_conv_feat); tm("temp+gru", job_temp_gru); tm("heads", job_heads); tm("bwd", job_bwd);
-    } else {
-        std::thread t1(job_conv_feat), t2(job_temp_gru), t3(job_heads);
-        job_bwd();
-        t1.join(); t2.join(); t3.join();
-    }
+    std::thread t1(job_conv_feat), t2(job_temp_gru), t3(job_heads);
+    job_bwd();
+    t1.join(); t2.join(); t3.join();
     m.bf16_packed = (m.precision == 1);
     return "";
 }

@@ -237,6 +237,10 @@ class MTAD_GAT(nn.Module):
             # `nn.init.*_(p.data)`) are seen.  False: trust (data_ptr, _version) only -- no sync per call;
             # call refresh_weights() after such edits.
             object.__setattr__(self, "check_weight_contents", True)
+        if "device_repack" not in self.__dict__:
+            # True: after the first load, changed fp32 weights (an optimizer step) are re-packed on the GPU
+            # (mtadgat_update_weights_device); False: every load goes through the host packer
+            object.__setattr__(self, "device_repack", True)
 
     def __getstate__(self):
         d = self.__dict__.copy()
@@ -287,7 +291,7 @@ class MTAD_GAT(nn.Module):
         mode = 1 if bf16 else (0 if self.precision == "fp32_strict" else 2)
         self._engine.set_precision(mode)
         if key != self._weights_key or (bf16 and not self._engine.bf16_ready()):
-            self._engine.load_weights(self.state_dict(), device)
+            self._engine.load_weights(self.state_dict(), device, allow_device_pack=self.device_repack)
             object.__setattr__(self, "_weights_key", key)
         return self._engine
 

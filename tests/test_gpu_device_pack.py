@@ -73,12 +73,9 @@ def test_training_loop_on_device_packed_weights_tracks_the_host_packed_loop(gpu_
     kw = dict(CONFIGS["odd_shapes"], dropout=0.0)
 
     def run(host_pack):
-        if host_pack:
-            monkeypatch.setenv("MTADGAT_HOST_PACK", "1")
-        else:
-            monkeypatch.delenv("MTADGAT_HOST_PACK", raising=False)
         torch.manual_seed(0)
         m = MTAD_GAT(**kw).to(gpu_device).train()
+        m.device_repack = not host_pack
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
         g = torch.Generator().manual_seed(5)
         x = torch.rand(48, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
