@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- sliding windows/s through the MI355X HIP path of MTAD_GAT.forward.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode infer|train]
 
 A "step" is one full `MTAD_GAT.forward` (conv -> feature-GAT || temporal-GAT -> GRU ->
 forecasting + reconstruction heads; reference mtad_gat.py:64-79) over one batch of
@@ -22,9 +22,15 @@ Also in the line:
                    kind "reference") when that tree exists on this host, else the oracle port of it
                    (oracle/, kind "port"), timed on this host's cores on a bounded sample, N=1 / rank 0 only.
   sub           -- outside the timed region, N=1 only: `batch256` (the reference Predictor's fixed batch,
-                   prediction.py:31: latency of one forward), `train_step` (BASELINE config 3 shape: SMD
-                   F=38, out=38, batch 256 -- forward + loss + backward + Adam, training.py:106-127) and
-                   `smap_bf16_b4096` (config 2); each names the code path that ran.
+                   prediction.py:31: latency of one forward), `fp32_strict_b65536` (the flagship workload on the
+                   fp32-MFMA kernels only), `train_step` (BASELINE config 3 shape: SMD F=38, out=38, batch 256 --
+                   forward + loss + backward + Adam, training.py:106-127), `smap_bf16_b4096` (config 2, shipped
+                   SMAP weights) and `config4_f512_w256` (config 4, batch 8192); each names the code path that ran.
+
+--mode train times the data-parallel TRAINING step instead (BASELINE config 5's exchange step: sharding.dp_training_step =
+forward + global-batch RMSE losses through a 4-scalar all-reduce + backward + one flat gradient all-reduce on RCCL + Adam;
+reference training.py:106-127) at the MSL shape, `--batch` windows per GPU (default 8192); the two collectives are timed
+separately with HIP events on the stream they run on.  Works at N = 1 (the collectives are skipped).
 """
 import argparse
 import json
@@ -46,9 +52,9 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T fp32 lane-ops/s
 
 
-def load_msl_state_dict():
-    """Shipped MSL checkpoint (reference output/MSL/27062021_111641/model.pt) as stored in the golden fixture."""
-    z = np.load(os.path.join(ROOT, "tests", "golden", "msl.npz"))
+def load_msl_state_dict(name="msl"):
+    """Shipped MSL (or SMAP / SMD) checkpoint of the reference (output/<DATASET>/<id>/model.pt) as stored in the golden fixture."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     meta = json.loads(bytes(z["meta"]).decode())
     sd = {k[len("sd/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
     return sd, meta["kwargs"]
@@ -73,21 +79,34 @@ def algorithmic_flops(kw):
     }
 
 
-def split_issue_factor(kw):
-    """k_gru in the default fp32 arithmetic: bf16 / fp16 MFMA MACs issued per algorithmic MAC (GRU layer + decoder together).
-    Every chunk of 16 features goes as two fp16 pieces (3 MFMA terms per product) -- the recurrent state, the attention
-    outputs and the decoder's input by construction, the convolution's channels because their recorded range allows
-    it (three bf16 pieces, 6 terms, otherwise); chunk and tile padding included."""
+def split_issue_factor(kw, two_piece_x=True):
+    """The recurrence kernels in the default fp32 arithmetic: 16-bit MFMA MACs issued per algorithmic MAC (GRU layer +
+    decoder together).  Every operand goes as two fp16 pieces (3 MFMA terms per product) -- the recurrent state, the
+    attention outputs and the decoder's input by construction, the convolution's channels when their recorded range allows it
+    (`two_piece_x`, read back from the engine: mtadgat_last_conv_max; three bf16 pieces = 6 terms for those chunks otherwise,
+    on the tile-major kernel).  Chunk (16 features) and tile (32 hidden units) padding included; the chunk-major kernel
+    (k_gru_cm) skips all-padding chunks."""
     F, W, H, Hr = kw["n_features"], kw["window_size"], kw["gru_hid_dim"], kw["recon_hid_dim"]
     up = lambda a, b: -(-a // b) * b      # noqa: E731
-    qx = up(-(-(3 * F) // 16), 6)                       # packed input chunks (whole ring turns)
-    # this workload's convolution outputs stay far below 2^15 (inputs in [0, 1)): the device-side range guard puts the
-    # convolution's channels on two fp16 pieces as well; un-normalised series would keep qb = ceil(F / 16) chunks on bf16
-    qb = 0
-    qh = lambda h: -(-h // 16)              # noqa: E731
+    qx = -(-(3 * F) // 16)                              # 16-feature input chunks with non-zero weights
+    qb = 0 if two_piece_x else -(-F // 16)
+    qh = lambda h: up(h, 32) // 16          # noqa: E731
     issued = (up(H, 32) * 16 * (6 * qb + 3 * (qx - qb) + 3 * qh(H)) + up(Hr, 32) * 16 * (3 * 1 + 3 * qh(Hr))) * 3 * W
     alg = (3 * H * (3 * F + H) + 3 * Hr * (3 + Hr)) * W
     return issued / alg
+
+
+def kernel_sources_sha16():
+    """Content hash of the kernel sources: profiles/collect.sh stamps the PMC traffic file with it, bench.py refuses a file
+    whose stamp differs (the snapshot on the GPU box has no .git to ask)."""
+    import hashlib
+    d = os.path.join(ROOT, "mtad-gat-pytorch_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _reference_module():
@@ -198,6 +217,13 @@ def sub_records(model, kw, dev, args_precision="fp32"):
         torch.cuda.synchronize(dev)
         prof = eng.profile_read()
         eng.profile_enable(False)
+        model.precision = "fp32_strict"
+        model._sync_engine(dev)
+        ts = _timed(lambda: model(xb), dev, 3, warm=1)
+        out["fp32_strict_b65536"] = {
+            "ms": round(1e3 * ts, 3), "windows_per_s": round(65536 / ts, 1),
+            "what": "the flagship workload with precision='fp32_strict': v_mfma_f32_32x32x2_f32 / fp32 VALU only (no split 16-bit "
+                    "operands anywhere) -- the exact-fp32 figure next to the headline"}
         model.precision = "auto"
         fl = algorithmic_flops(kw)
         ms_gru = (prof["gru"][0] + prof["recon"][0]) / 3
@@ -259,17 +285,109 @@ def sub_records(model, kw, dev, args_precision="fp32"):
                          "grad_path": getattr(m3, "grad_path", "hip"),
                          "what": "SMD shape (F=38, W=100, out=38), batch 256, dropout 0.3: forward + RMSE losses + backward + Adam "
                                  "(training.py:106-127), fp32"}
-    # BASELINE config 2: SMAP shape F=25, batch 4096, bf16 I/O
-    kw2 = dict(kw, n_features=25, out_dim=1)
-    torch.manual_seed(0)
-    m2 = MTAD_GAT(**kw2).to(dev).eval()
+    # BASELINE config 2: SMAP (F=25), batch 4096, bf16 I/O, shipped SMAP weights
+    try:
+        sd2, kw2 = load_msl_state_dict("smap")
+        m2 = MTAD_GAT(**kw2)
+        m2.load_state_dict(sd2)
+        w2 = "shipped SMAP checkpoint"
+    except Exception:
+        kw2 = dict(kw, n_features=25, out_dim=1)
+        torch.manual_seed(0)
+        m2 = MTAD_GAT(**kw2)
+        w2 = "random-init weights (fixture tests/golden/smap.npz not found)"
+    m2 = m2.to(dev).eval()
     m2.check_weight_contents = False
     x2 = torch.rand(4096, kw2["window_size"], 25, generator=g).to(dev).to(torch.bfloat16)
     with torch.no_grad():
         t = _timed(lambda: m2(x2), dev, 10)
     out["smap_bf16_b4096"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(4096 / t, 1),
-                              "what": "SMAP shape (F=25), batch 4096, bf16 in / bf16 out, random-init weights"}
+                              "what": f"SMAP shape (F=25), batch 4096, bf16 in / bf16 out, {w2}"}
+    del m2, x2
+    # BASELINE config 4: synthetic F=512, W=256, out=512, H=150, batch 8192 (chunked by the library), fp32, random init
+    try:
+        kw4 = dict(kw, n_features=512, window_size=256, out_dim=512)
+        torch.manual_seed(0)
+        m4 = MTAD_GAT(**kw4).to(dev).eval()
+        m4.check_weight_contents = False
+        x4 = torch.rand(8192, 256, 512, device=dev)
+        with torch.no_grad():
+            e4 = m4._sync_engine(dev)
+            m4(x4[:256])
+            t4 = _timed(lambda: m4(x4), dev, 2, warm=1)
+            e4.profile_enable(True)
+            m4(x4)
+            torch.cuda.synchronize(dev)
+            p4 = e4.profile_read()
+            e4.profile_enable(False)
+        fl4 = algorithmic_flops(kw4)
+        km = {k: round(v[0], 2) for k, v in p4.items() if v[1]}
+        dom4 = max(km, key=km.get)
+        tf4 = fl4[dom4] * 8192 / (km[dom4] * 1e-3) / 1e12
+        out["config4_f512_w256"] = {
+            "ms": round(1e3 * t4, 2), "windows_per_s": round(8192 / t4, 1), "chunk_windows": int(e4.chunk_windows()),
+            "kernel_ms": km,
+            "roofline": {"kernel": dom4, "bound": "mfma", "achieved": round(tf4, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf4 / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "note": "largest launch family of this shape by time; algorithmic matrix FLOPs of that family / its time vs the fp32 MFMA peak "
+                                 "(wide attention layers run the un-fused fp32 path: projections through HBM, k_gat_wide)"},
+            "what": "BASELINE config 4: F=512, W=256, out_dim=512, H=150, 8192 windows per call (processed in chunks of chunk_windows), "
+                    "fp32, random-init weights"}
+        del m4, x4
+    except Exception as e:
+        out["config4_f512_w256"] = {"error": repr(e)}
     return out
+
+
+def train_mode(args, model, kw, dev, world, rank):
+    """The exchange step of the path (BASELINE config 5): sharding.dp_training_step over this rank's shard of the global batch."""
+    import torch.distributed as dist
+    from sharding import dp_training_step, max_over_ranks
+    B = args.batch
+    model.train()
+    model.precision = "auto"
+    model.check_weight_contents = False          # optimizer steps bump the parameters' version counters
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(4321 + rank)
+    x = torch.rand(B, kw["window_size"], kw["n_features"], generator=g).to(dev)
+    y = torch.rand(B, 1, kw["n_features"], generator=g).to(dev)
+    tdims = [0] if kw["out_dim"] == 1 else None     # MSL / SMAP: target dimension 0 (reference utils.py:46-49)
+    timings = {}
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        dp_training_step(model, x, y, opt, target_dims=tdims)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rm = dp_training_step(model, x, y, opt, target_dims=tdims, timings=timings)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    ar = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timings.items()}
+    if rank == 0:
+        n_par = sum(p.numel() for p in model.parameters())
+        res = {
+            "metric": "training windows/sec (W=100,F=55), data-parallel step", "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MSL-shaped windows W=100 F=55 out_dim=1, training step = MTAD_GAT.forward (train mode, dropout 0.3) + "
+                                   "global-batch RMSE losses + backward + Adam (reference training.py:106-127), shipped MSL checkpoint as the start point",
+                       "windows_per_gpu_per_step": B, "parallelism": f"dp{world}: windows sharded; 4-scalar SSE all-reduce + one flat "
+                                                                      f"{4 * n_par} B gradient all-reduce per step (RCCL)"},
+            "exchange_ms_per_step": {"stats_allreduce": round(ar.get("stats_events", 0.0), 4), "grad_allreduce": round(ar.get("grad_events", 0.0), 4),
+                                     "note": "HIP events around the two collectives on the stream they are enqueued on; 0 at one GPU (skipped)"},
+            "grad_path": getattr(model, "grad_path", None), "loss_rmse": [round(float(v), 6) for v in rm],
+        }
+        print(json.dumps(res))
 
 
 def main():
@@ -277,7 +395,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="windows per GPU per step")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: MTAD_GAT.forward (the headline metric); train: the data-parallel training step (BASELINE config 5's exchange step)")
+    ap.add_argument("--batch", type=int, default=0, help="windows per GPU per step (default 65536, train mode 8192)")
     ap.add_argument("--chunk", type=int, default=0, help="windows per internal chunk (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -286,6 +406,8 @@ def main():
                     help="arithmetic of the timed region: fp32 (the headline, <= 1e-5 parity: fp32 accumulation, products of the "
                          "large-batch kernels from split-bf16 operands), fp32_strict (fp32 MFMA only) or bf16 MFMA operands (<= 2e-2)")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 65536 if args.mode == "infer" else 8192
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -306,6 +428,12 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model.precision = args.precision
+
+    if args.mode == "train":
+        train_mode(args, model, kw, dev, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # this rank's shard of the job: contiguous block of windows, independent of the others
     B = args.batch
@@ -350,7 +478,11 @@ def main():
             "metric": "sliding windows/sec (W=100,F=55)", "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.precision != "bf16" else "bf16 operands / f32 accumulate", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {"fp32": "f32 (2xf16 split operands on the 16-bit MFMA pipe in the large-batch recurrences and attention projections, "
+                              "f32 accumulate / state / gates / softmax; small batches: f32 MFMA)",
+                      "fp32_strict": "f32 (f32 MFMA / f32 VALU only)", "bf16": "bf16 operands, f32 accumulate"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": "MSL-shaped sliding windows W=100 F=55 out_dim=1, full MTAD_GAT.forward "
                                    "(conv + feature-GAT + temporal-GAT + GRU + forecasting/reconstruction heads), "
                                    "weights = shipped MSL checkpoint, x ~ U[0,1) seed 1234+rank, eval mode",
@@ -359,61 +491,82 @@ def main():
         if prof:
             flops = algorithmic_flops(kw)
             valu = valu_lane_ops(kw)
-            # launch families by kernel template: the GRU layer and the reconstruction decoder are two
-            # launches of the same kernel (k_gru), the two attention layers two launches of k_gat
+            # which arithmetic the range guard chose on the device (read back, not assumed)
+            conv_max = eng.last_conv_max(B, dev)
+            two_piece = 0.0 < conv_max < 32768.0
+            sf = split_issue_factor(kw, two_piece)
+            # launch families by kernel template: the GRU layer and the reconstruction decoder are two launches of the same
+            # kernel (k_gru_cm from 4 097 windows per chunk on, k_gru below), the two attention layers two launches of k_gat
             groups = {"k_conv": ["conv"], "k_gat": ["proj", "attend"], "k_gru": ["gru", "recon"], "k_rowgemm(fc)": ["fc"]}
-            fams = {}
-            tot = {}
+            fams, tot = {}, {}
             for fam, slots in groups.items():
                 ms = sum(prof[s_][0] for s_ in slots)
                 n = sum(prof[s_][1] for s_ in slots)
                 fl = sum(flops[s_] for s_ in slots)
                 vl = sum(valu.get(s_, 0) for s_ in slots)
-                if n:
-                    tot[fam] = (ms, n, fl)
-                    tf = fl * B * args.steps / (ms * 1e-3) / 1e12
-                    # matrix-pipe ceiling of this family in this mode (see the roofline note below)
-                    pk = (BF16_MFMA_PEAK_TFLOPS / split_issue_factor(kw) if (args.precision == "fp32" and fam == "k_gru") else
-                          BF16_MFMA_PEAK_TFLOPS if (args.precision == "bf16" and fam != "k_rowgemm(fc)") else FP32_MFMA_PEAK_TFLOPS)
-                    fams[fam] = {"ms_per_step": round(ms / args.steps, 3), "launches": int(n),
-                                 "alg_mfma_gflop_per_launch": round(fl * B * args.steps / n / 1e9, 3),
-                                 "mfma_tflops": round(tf, 2), "mfma_peak_tflops": round(pk, 1), "mfma_frac": round(tf / pk, 4)}
-                    if vl:
-                        tl = vl * B * args.steps / (ms * 1e-3) / 1e12
-                        fams[fam]["alg_valu_glaneops_per_launch"] = round(vl * B * args.steps / n / 1e9, 3)
-                        fams[fam]["valu_tlaneops"] = round(tl, 2)
-                        fams[fam]["valu_frac"] = round(tl / VALU_PEAK_TLANEOPS, 4)
+                if not n:
+                    continue
+                tot[fam] = (ms, n, fl)
+                tf = fl * B * args.steps / (ms * 1e-3) / 1e12
+                split = args.precision == "fp32" and fam == "k_gru"
+                pk = BF16_MFMA_PEAK_TFLOPS if (split or (args.precision == "bf16" and fam != "k_rowgemm(fc)")) else FP32_MFMA_PEAK_TFLOPS
+                fams[fam] = {"ms_per_step": round(ms / args.steps, 3), "launches": int(n),
+                             "alg_mfma_gflop_per_launch": round(fl * B * args.steps / n / 1e9, 3),
+                             "mfma_tflops": round(tf, 2), "mfma_peak_tflops": round(pk, 1), "mfma_alg_frac": round(tf / pk, 4)}
+                if split:
+                    fams[fam]["mfma_issued_per_alg_mac"] = round(sf, 3)
+                    fams[fam]["mfma_issued_frac"] = round(tf * sf / pk, 4)
+                if vl:
+                    tl = vl * B * args.steps / (ms * 1e-3) / 1e12
+                    fams[fam]["alg_valu_glaneops_per_launch"] = round(vl * B * args.steps / n / 1e9, 3)
+                    fams[fam]["valu_tlaneops"] = round(tl, 2)
+                    fams[fam]["valu_frac"] = round(tl / VALU_PEAK_TLANEOPS, 4)
             res["kernels"] = fams
-            dom = max(fams, key=lambda k: fams[k]["ms_per_step"])
-            ms_dom, n_dom, fl_dom = tot[dom]
-            ach = fl_dom * B * args.steps / (ms_dom * 1e-3) / 1e12
-            # HBM bytes per launch: NOT measured in this run (PMC counters need their own rocprofv3 pass,
-            # profiles/collect.sh); taken from the newest committed PMC summary and scaled to this batch
-            traffic, tsrc = None, None
+            res["range_guard"] = {"conv_max": conv_max, "two_fp16_pieces_everywhere": bool(two_piece),
+                                  "note": "largest convolution output of the last step, read back from the engine: below 2^15 every operand of the "
+                                          "recurrences / attention projections went as two fp16 pieces"}
+            # HBM bytes per window and family: NOT measured in this run (PMC counters need their own rocprofv3 passes,
+            # profiles/collect.sh); taken from the newest committed PMC summary -- only if it was collected on these very
+            # kernel sources (content hash), otherwise reported as null
+            traffic_pw, tsrc = {}, "no PMC summary collected on these kernel sources (profiles/*_traffic.json stamp differs or is absent)"
             try:
                 cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
                 tj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
-                if dom in tj["bytes_per_window"]:
-                    traffic = int(tj["bytes_per_window"][dom] * B * args.steps / n_dom)
-                    tsrc = f"profiles/{cands[-1]} (rocprofv3 --pmc pass, {tj.get('git', 'unknown commit')}), scaled to this batch; not measured in this run"
+                if tj.get("csrc_sha16") == kernel_sources_sha16():
+                    traffic_pw = tj["bytes_per_window"]
+                    tsrc = f"profiles/{cands[-1]} (rocprofv3 --pmc passes on the same kernel sources, FETCH_SIZE doubled per MI355X_MICROARCH.md), scaled to this batch; not measured in this run"
             except Exception:
                 pass
-            # ceiling of the dominant kernel: fp32_strict -> the fp32 MFMA peak; fp32 -> k_gru forms every product from six
-            # bf16 MFMAs (split-bf16 operands), i.e. 1/6 of the dense bf16 peak per algorithmic FLOP; bf16 -> the bf16 peak.
-            # k_gat's matrix work is fp32 MFMA in both fp32 modes.
-            split = args.precision == "fp32" and dom == "k_gru"
-            sf = split_issue_factor(kw)
-            peak = BF16_MFMA_PEAK_TFLOPS if args.precision == "bf16" else (BF16_MFMA_PEAK_TFLOPS / sf if split else FP32_MFMA_PEAK_TFLOPS)
-            note = ("v_mfma_f32_32x32x16_bf16 peak" if args.precision == "bf16" else
-                    f"split operands: every fp32 product is 3 16-bit MFMA terms (two fp16 pieces per operand) -- {sf:.2f} MFMA "
-                    f"MACs issued per algorithmic MAC incl. padding -> ceiling = dense bf16/fp16 peak / {sf:.2f} = {BF16_MFMA_PEAK_TFLOPS / sf:.0f} "
-                    "TFLOP/s of algorithmic FLOPs (the fp32 MFMA peak is 157.3)" if split else "v_mfma_f32_32x32x2_f32 (exact f32) peak")
-            res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1),
-                               "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                               "traffic_source": tsrc,
-                               "avg_launch_ms": round(ms_dom / n_dom, 3),
-                               "alg_flop_per_window": fl_dom,
-                               "note": note + "; algorithmic FLOPs exclude tile padding"}
+
+            def traffic_of(fam, n_launch):
+                key = {"k_conv": "k_conv", "k_gat": "k_gat", "k_gru": "k_gru", "k_rowgemm(fc)": "k_rowgemm"}[fam]
+                return int(traffic_pw[key] * B * args.steps / n_launch) if key in traffic_pw else None
+
+            dom = max(fams, key=lambda k: fams[k]["ms_per_step"])
+            ms_g, n_g, fl_g = tot["k_gru"]
+            ach = fl_g * B * args.steps / (ms_g * 1e-3) / 1e12
+            pk_g = fams["k_gru"]["mfma_peak_tflops"]
+            roof_gru = {"kernel": "k_gru (GRU layer + reconstruction decoder: k_gru_cm above 4 096 windows per chunk)", "bound": "mfma",
+                        "achieved": round(ach, 2), "peak": pk_g, "unit": "TFLOP/s", "frac": round(ach / pk_g, 4),
+                        "alg_frac": round(ach / pk_g, 4),
+                        "issued_frac": round(ach * (sf if args.precision == "fp32" else 1.0) / pk_g, 4),
+                        "traffic": traffic_of("k_gru", n_g), "traffic_source": tsrc, "avg_launch_ms": round(ms_g / n_g, 3),
+                        "alg_flop_per_window": fl_g,
+                        "note": ("peak = dense 16-bit MFMA peak of MI355X_MICROARCH.md; alg_frac = algorithmic FLOPs (no padding, one MAC per "
+                                 f"weight and window) / time / peak; issued_frac = alg_frac x {sf:.2f} MFMA MACs issued per algorithmic MAC (three "
+                                 "16-bit terms per fp32 product, 16-feature chunk and 32-unit tile padding) = share of the matrix pipe's time the "
+                                 "kernel keeps it busy") if args.precision == "fp32" else "algorithmic FLOPs / time vs the peak of the MFMA type used"}
+            # `roofline`: the matrix-pipe kernel of the path (the recurrences: most FLOPs, the kernel VERDICT names).  The
+            # attention family is bound by the vector ALU -- a roofline the contract has no name for -- and gets its own object.
+            roof_gru["largest_family_by_time"] = dom
+            res["roofline"] = roof_gru
+            ms_a, n_a, _ = tot["k_gat"]
+            res["roofline_valu"] = {"kernel": "k_gat (temporal + feature attention layer)", "bound": "valu",
+                                    "achieved": fams["k_gat"]["valu_tlaneops"], "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-op/s",
+                                    "frac": fams["k_gat"]["valu_frac"], "traffic": traffic_of("k_gat", n_a), "traffic_source": tsrc,
+                                    "avg_launch_ms": round(ms_a / n_a, 3),
+                                    "note": "bound by neither HBM nor the matrix pipe but by the vector ALU: 2 lane-operations per (query, key, "
+                                            "embedding column) element of the GATv2 score (add, |.|-accumulate) at 64 lanes/clk/CU"}
         gbs = value * alg_bytes / 1e9
         res["hbm"] = {"alg_bytes_per_window": alg_bytes, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(gbs / HBM_PEAK_GBS / world, 5),

@@ -163,6 +163,10 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  * (GRULayer.forward modules.py:235-238, the decoder modules.py:276-283) in precision mode 2:
  *   0 automatic (default), 1 the tile-major kernel at every batch size, 2 the chunk-major kernel wherever it applies. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
+/* Diagnostics for bench.py: the largest convolution output of the last forward() that used workspace `ws` (its last
+ * chunk; synchronises `stream`).  Below 2^15 the large-batch kernels used two fp16 pieces per operand, otherwise three
+ * bf16 pieces for the convolution's channels (device-side range guard). */
+int mtadgat_last_conv_max(mtadgat_handle h, const void* ws_dev, int64_t batch, float* out_host, void* stream);
 
 /* Bytes of device scratch forward() needs for a batch of `batch` windows
  * (intermediates of at most mtadgat_chunk_windows() windows are live at once). */

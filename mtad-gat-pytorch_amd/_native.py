@@ -68,6 +68,8 @@ def load_library():
     lib.mtadgat_workspace_bytes.argtypes = [vp, i64]
     lib.mtadgat_workspace_bytes.restype = sz
     lib.mtadgat_set_precision.argtypes = [vp, ctypes.c_int]
+    lib.mtadgat_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int]
+    lib.mtadgat_last_conv_max.argtypes = [vp, vp, i64, ctypes.POINTER(ctypes.c_float), vp]
     lib.mtadgat_bf16_ready.argtypes = [vp]
     lib.mtadgat_chunk_windows.argtypes = [vp]
     lib.mtadgat_chunk_windows.restype = i64
@@ -346,6 +348,25 @@ class Engine:
 
     def bf16_ready(self):
         return bool(self.lib.mtadgat_bf16_ready(self.handle))
+
+    def set_option(self, name, value):
+        """Testing / measurement hook (include/mtadgat.h): e.g. ("gru_kernel", 0 automatic | 1 tile-major | 2 chunk-major)."""
+        _check(self.lib.mtadgat_set_option(self.handle, name.encode(), int(value)), "set_option")
+
+    def last_conv_max(self, batch, device):
+        """Largest convolution output of the last forward of `batch` windows (range guard of the fp16 operand pieces);
+        synchronises the current stream."""
+        if self._ws is None:
+            return 0.0
+        out = ctypes.c_float(0.0)
+        with torch.cuda.device(device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _check(self.lib.mtadgat_last_conv_max(self.handle, ctypes.c_void_p(self._ws.data_ptr()), int(batch), ctypes.byref(out), stream),
+                   "last_conv_max")
+        return float(out.value)
+
+    def chunk_windows(self):
+        return int(self.lib.mtadgat_chunk_windows(self.handle))
 
     def set_chunk_windows(self, n):
         _check(self.lib.mtadgat_set_chunk_windows(self.handle, int(n)), "set_chunk_windows")

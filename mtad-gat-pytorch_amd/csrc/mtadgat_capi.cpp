@@ -825,6 +825,18 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
 
+/* Largest value the convolution wrote during the last forward() on this workspace (of its last chunk), read back after
+ * the stream has drained: below 2^15 the large-batch kernels formed their products from two fp16 pieces per operand, above
+ * from three bf16 pieces (the device-side range guard).  0 when the forward did not record it (un-fused attention path). */
+int mtadgat_last_conv_max(mtadgat_handle h, const void* ws, int64_t batch, float* out_host, void* stream) {
+    if (!h || !ws || !out_host || batch <= 0) return fail(MTADGAT_ERR_INVALID, "null argument");
+    Workspace o;
+    plan_workspace(h->m, std::min<int64_t>(batch, h->m.chunk), o);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(out_host, static_cast<const float*>(ws) + o.vmax, sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int64_t mtadgat_chunk_windows(mtadgat_handle h) { return h ? h->m.chunk : 0; }
 int mtadgat_set_chunk_windows(mtadgat_handle h, int64_t w) {
     if (!h || w < 1) return fail(MTADGAT_ERR_INVALID, "chunk must be >= 1");

@@ -19,6 +19,23 @@ def shard_range(n_total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _staged(t: torch.Tensor) -> bool:
+    """gloo moves host memory: device tensors go through a host copy (two processes sharing one GPU in the tests, where RCCL
+    refuses a second rank on the same device); RCCL ("nccl") takes device tensors as they are."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_(t: torch.Tensor, op=None) -> torch.Tensor:
+    op = dist.ReduceOp.SUM if op is None else op
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def max_over_ranks(seconds: float, device=None) -> float:
     """Slowest rank's time (the job's time); identity when not running distributed."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -42,7 +59,7 @@ def gather_windows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
 
 
-def dp_training_step(model, x, y, optimizer, target_dims=None):
+def dp_training_step(model, x, y, optimizer, target_dims=None, timings=None):
     """One data-parallel optimisation step with the semantics of a single process seeing the
     global batch (reference training.py:106-127: loss = sqrt(MSE(y, preds)) + sqrt(MSE(x, recons))).
 
@@ -52,18 +69,22 @@ def dp_training_step(model, x, y, optimizer, target_dims=None):
     SSE_f / (2 RMSE_f N_f) + SSE_r / (2 RMSE_r N_r) whose gradients sum over ranks to the global
     gradient, then sum-all-reduce one flat gradient bucket (RCCL over xGMI on the GPUs; the bucket
     is ~1.7 MB, latency-class).  Returns (forecast_rmse, recon_rmse) of the global batch.
+
+    `timings`: optional dict; on a GPU the two exchanges are bracketed with events on the stream they run on and the pairs
+    appended to timings["stats_events"] / timings["grad_events"] (no synchronisation here: read them after the step).
     """
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     optimizer.zero_grad()
     if distributed and x.device.type == "cuda":
         # one dropout stream for the logical batch: rank 0's seed, this shard's first global window index (equal
         # shards up to one window, see shard_range) -> the masks of the single-process step over the whole batch
-        meta = torch.zeros(2, dtype=torch.int64, device=x.device)
+        cdev = torch.device("cpu") if dist.get_backend() == "gloo" else x.device
+        meta = torch.zeros(2, dtype=torch.int64, device=cdev)
         if dist.get_rank() == 0:
             meta[0] = int(torch.randint(0, 2 ** 62, (1,)).item())
         dist.broadcast(meta, src=0)
-        counts = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(dist.get_world_size())]
-        dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+        counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(dist.get_world_size())]
+        dist.all_gather(counts, torch.tensor([x.shape[0]], dtype=torch.int64, device=cdev))
         first = int(sum(int(c.item()) for c in counts[: dist.get_rank()]))
         object.__setattr__(model, "dropout_stream", (int(meta[0].item()), first))
     try:
@@ -83,8 +104,17 @@ def dp_training_step(model, x, y, optimizer, target_dims=None):
     sse_r = ((xt - recons) ** 2).sum()
     stats = torch.stack([sse_f.detach(), torch.tensor(float(preds.numel()), device=x.device),
                          sse_r.detach(), torch.tensor(float(recons.numel()), device=x.device)]).double()
+    def _timed(key, fn):
+        if timings is None or x.device.type != "cuda":
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        timings.setdefault(key, []).append((e0, e1))
+
     if distributed:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        _timed("stats_events", lambda: all_reduce_(stats))
     rmse_f = torch.sqrt(stats[0] / stats[1]).to(sse_f.dtype)
     rmse_r = torch.sqrt(stats[2] / stats[3]).to(sse_r.dtype)
     surrogate = sse_f / (2.0 * rmse_f * stats[1].to(sse_f.dtype)) + sse_r / (2.0 * rmse_r * stats[3].to(sse_r.dtype))
@@ -92,7 +122,7 @@ def dp_training_step(model, x, y, optimizer, target_dims=None):
     if distributed:
         params = [p for p in model.parameters() if p.grad is not None]
         flat = torch.cat([p.grad.reshape(-1) for p in params])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        _timed("grad_events", lambda: all_reduce_(flat))
         off = 0
         for p in params:
             n = p.numel()

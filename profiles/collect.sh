@@ -1,8 +1,8 @@
 #!/bin/bash
-# Regenerates the files under profiles/ on a GPU box:  bash profiles/collect.sh r02 <git rev>
+# Regenerates the files under profiles/ on a GPU box:  bash profiles/collect.sh r03 <git rev>
 # (rocprofv3 passes are separate: --kernel-trace --stats, then one --pmc pass per counter group).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REV=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG

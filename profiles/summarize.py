@@ -81,7 +81,20 @@ traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes),
                      "sums over the 2 forward passes of that run, divided by 2*65536 windows",
            "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 / windows; FETCH_SIZE doubled per MI355X_MICROARCH.md "
                       "(gfx950 counts 64 B per 128-B read request)",
-           "git": rev, "bytes_per_window": {}, "raw_KiB_per_forward": {}}
+           "git": rev, "csrc_sha16": None, "bytes_per_window": {}, "raw_KiB_per_forward": {}}
+# stamp with the content hash of the kernel sources this was collected on (bench.py only trusts a file whose stamp matches)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    import hashlib
+    _c = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mtad-gat-pytorch_amd", "csrc")
+    _h = hashlib.sha256()
+    for _f in sorted(os.listdir(_c)):
+        if _f.endswith((".hip", ".h", ".cpp")):
+            _h.update(_f.encode())
+            _h.update(open(os.path.join(_c, _f), "rb").read())
+    traffic["csrc_sha16"] = _h.hexdigest()[:16]
+except Exception:
+    pass
 with open(os.path.join(d, f"{tag}_pmc_summary.txt"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc <counters> (one pass per group), MI355X; per-dispatch averages.\n"
             "# FETCH_SIZE / WRITE_SIZE in KiB as reported (passes at --batch 65536, i.e. the large-batch kernels); SQ pass at --batch 65536.\n"

@@ -198,3 +198,82 @@ def test_two_processes_share_the_gpu_and_run_the_hip_forward(tmp_path, gpu_devic
     assert res["t"] == 2.0 and res["lib"].endswith("libmtadgat.so")
     gate(res["p"], case.preds, case.preds64, what="2-rank preds")
     gate(res["r"], case.recons, case.recons64, what="2-rank recons")
+
+
+def _dropout_free(case):
+    """The case's parameters in a model built with dropout 0 (the shard step and the whole-batch step then see the same
+    network; with dropout on, the mask stream is a function of the global row index and is covered by the CPU tests)."""
+    from mtad_gat import MTAD_GAT
+    model = MTAD_GAT(**dict(case.kwargs, dropout=0.0))
+    model.load_state_dict(case.state_dict())
+    return model
+
+
+def _two_rank_train_worker(rank, world, port, backend, out_path):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "mtad-gat-pytorch_amd"), root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import Case
+    from sharding import dp_training_step, shard_range
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dev = torch.device("cuda", 0)                              # both ranks share the box's one GPU
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                                 # RCCL refuses a second rank on the same device here, if it does
+        torch.cuda.synchronize(dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = Case("syn_v2_embed")
+    model = _dropout_free(case).to(dev).train()
+    g = torch.Generator().manual_seed(11)
+    y = torch.rand(case.x.shape[0], 1, case.kwargs["n_features"], generator=g)
+    lo, hi = shard_range(case.x.shape[0], rank, world)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    tim = {}
+    rm = dp_training_step(model, case.x[lo:hi].to(dev), y[lo:hi].to(dev), opt, target_dims=list(range(case.kwargs["out_dim"])), timings=tim)
+    torch.cuda.synchronize(dev)
+    assert model.grad_path == "hip"
+    dist.barrier()
+    if rank == 0:
+        torch.save(dict(rm=rm, grads=[p.grad.detach().cpu() for p in model.parameters()], backend=dist.get_backend(),
+                        timed=sorted(tim)), out_path)
+    dist.destroy_process_group()
+
+
+def test_two_process_training_step_equals_the_global_batch_step(tmp_path, gpu_device):
+    """sharding.dp_training_step in two processes (both on this box's one GPU, the HIP training step in each): the summed
+    shard gradients and the global RMSEs equal the single-process step over the whole batch (reference loss,
+    training.py:122-126).  Transport: RCCL when it accepts two ranks on one device, gloo (host-staged) otherwise -- which
+    one ran is asserted on, not hidden."""
+    import warnings
+    from sharding import dp_training_step
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "train.pt")
+    used = "nccl"
+    try:
+        mp.spawn(_two_rank_train_worker, args=(2, port, "nccl", out), nprocs=2, join=True)
+    except Exception as e:      # RCCL: "Duplicate GPU detected" -- a one-GPU box cannot host a two-rank RCCL communicator
+        warnings.warn(f"RCCL with two ranks on one GPU is not possible here ({type(e).__name__}: {str(e)[-200:]}); gloo carries the exchange")
+        used = "gloo"
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_two_rank_train_worker, args=(2, port, "gloo", out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["backend"] == used and res["timed"] == ["grad_events", "stats_events"]
+    case = Case("syn_v2_embed")
+    model = _dropout_free(case).to(gpu_device).train()
+    g = torch.Generator().manual_seed(11)
+    y = torch.rand(case.x.shape[0], 1, case.kwargs["n_features"], generator=g)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    rm = dp_training_step(model, case.x.to(gpu_device), y.to(gpu_device), opt, target_dims=list(range(case.kwargs["out_dim"])))
+    assert abs(rm[0] - res["rm"][0]) <= 1e-6 and abs(rm[1] - res["rm"][1]) <= 1e-6
+    for (n, p), gsh in zip(model.named_parameters(), res["grads"]):
+        ref = p.grad.detach().cpu()
+        assert (gsh - ref).abs().max().item() <= 1e-6 + 1e-5 * ref.abs().max().item(), (n, used)
