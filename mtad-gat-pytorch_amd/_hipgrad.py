@@ -7,6 +7,8 @@ attention layers beyond 128 nodes) and inputs that themselves require a gradient
 package's torch-op algebra (`_torchpath.py`) with autograd; `MTAD_GAT.grad_path` says which path the last
 differentiable call took ("hip" / "torch-ops: <reason>").
 """
+import warnings
+
 import torch
 
 import _torchpath
@@ -75,6 +77,9 @@ class _HipStep(torch.autograd.Function):
         return (None, None, None, None, None, *out)
 
 
+_warned = set()      # reasons already reported (one warning per reason and process)
+
+
 def forward(model, eng, x):
     """(preds, recons) with autograd history when grad is enabled; dropout active iff model.training."""
     why = None
@@ -83,7 +88,16 @@ def forward(model, eng, x):
     elif x.requires_grad and torch.is_grad_enabled():
         why = "the input requires a gradient (the HIP backward produces parameter gradients only)"
     if why is not None:
+        # Not silent: the torch-op route materialises the (b, K, K, 2E) attention tensors and runs MIOpen's GRU -- a caller
+        # who expects the HIP training step must learn that this configuration does not have one.
         object.__setattr__(model, "grad_path", "torch-ops: " + why)
+        if getattr(model, "strict_hip_training", False):
+            raise RuntimeError("MTAD_GAT.strict_hip_training is set and this training step cannot run on the HIP kernels: " + why)
+        if why not in _warned:
+            _warned.add(why)
+            warnings.warn("MTAD_GAT training step on the GPU runs through torch ops (autograd), not the HIP backward: " + why +
+                          ".  The inference forward of this configuration is unaffected.  Set model.strict_hip_training = True "
+                          "to make this an error.", RuntimeWarning, stacklevel=3)
         return _torchpath.forward(model, x.float())
     object.__setattr__(model, "grad_path", "hip")
     p = float(model.dropout_p) if model.training else 0.0

@@ -57,12 +57,20 @@ def anomaly_scores(preds, recons, values, window_size, target_dims=None, gamma=1
     (prediction.py:72-91, before the optional per-dimension scaling).  Returns (global (n,), per_dim (n, d))."""
     lib = _lib()
     n, d = preds.shape
+    if values.ndim != 2 or values.shape[0] < window_size + n:
+        raise ValueError(f"values must hold at least window_size + n = {window_size + n} rows (the series the {n} windows were cut "
+                         f"from), got shape {tuple(values.shape)}")
+    if recons.shape[0] != n or recons.shape[-1] != d:
+        raise ValueError(f"recons {tuple(recons.shape)} does not match preds {tuple(preds.shape)}")
     actual = values[window_size:window_size + n].float().contiguous()
     dims = None
     if target_dims is not None:
         dims = torch.tensor([target_dims] if isinstance(target_dims, int) else list(target_dims), dtype=torch.int32, device=preds.device)
         if dims.numel() != d:
             raise RuntimeError("target_dims do not match the model's out_dim")
+        tl = [target_dims] if isinstance(target_dims, int) else list(target_dims)
+        if min(tl) < 0 or max(tl) >= actual.shape[1]:
+            raise ValueError(f"target_dims {tl} outside the series' {actual.shape[1]} columns")
     elif actual.shape[1] != d:
         raise RuntimeError("out_dim differs from the number of features: pass target_dims")
     p, r = preds.float().contiguous(), recons.float().contiguous()
@@ -93,6 +101,7 @@ def find_epsilon(errors, reg_level=1):
         _check(lib.mtadgat_eval_epsilon_table(e.data_ptr(), n, eps.ctypes.data_as(_c_double_p), len(zs), 49, scratch.data_ptr(), tab,
                                               _stream(e)), "eval_epsilon_table")
     best, max_score = None, -10000000
+    mean64, sd64 = np.float64(mean), np.float64(sd)
     for k in range(len(zs)):
         ps, ps2, pc, dil = tab[4 * k], tab[4 * k + 1], tab[4 * k + 2], tab[4 * k + 3]
         if dil > 0:
@@ -100,15 +109,19 @@ def find_epsilon(errors, reg_level=1):
                 pm = ps / pc
                 psd = math.sqrt(max(ps2 / pc - pm * pm, 0.0))
             else:
-                pm = psd = float("nan")
-            mean_perc_decrease = (mean - pm) / mean
-            sd_perc_decrease = (sd - psd) / sd
-            denom = 1 if reg_level == 0 else (dil if reg_level == 1 else dil ** 2)
-            score = (mean_perc_decrease + sd_perc_decrease) / denom
+                pm = psd = float("nan")         # np.mean / np.std of an empty pruned set
+            # numpy float64 arithmetic as in the reference: constant scores (sd == 0) or a zero mean give nan / inf here,
+            # not ZeroDivisionError; a nan score fails the comparison below and the z is skipped (eval_methods.py:220-231)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                mean_perc_decrease = (mean64 - np.float64(pm)) / mean64
+                sd_perc_decrease = (sd64 - np.float64(psd)) / sd64
+                denom = 1 if reg_level == 0 else (dil if reg_level == 1 else dil ** 2)
+                score = float((mean_perc_decrease + sd_perc_decrease) / denom)
             # `>=`: among equal scores the reference keeps the last z.  Two z with the same pruned set have the same
             # score exactly in the reference; here their float64 sums come from atomics in varying order, so
             # "equal" is taken with a 1e-9 relative margin.
-            if score >= max_score - 1e-9 * abs(max_score) and dil < n * 0.5:
+            at_least = score >= max_score or (math.isfinite(max_score) and score >= max_score - 1e-9 * abs(max_score))
+            if at_least and dil < n * 0.5:
                 max_score, best = max(score, max_score), float(eps[k])
     if best is None:
         best = float(e.max().item())

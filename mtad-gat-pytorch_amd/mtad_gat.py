@@ -15,9 +15,16 @@ exactly as with the reference classes (`modules.py:5-311`).  Their `forward`
 methods call the corresponding stage entry point of the native library.
 
 Device contract.  Tensors on the GPU ('cuda' = HIP on PyTorch-ROCm) always run the
-HIP kernels -- forward, and (when gradients are wanted) the HIP backward behind a
-`torch.autograd.Function` -- and raise if `libmtadgat.so` is missing: there is no
-fallback for GPU tensors.  A model and input left on the CPU (the reference's
+HIP kernels in inference (no grad) and raise if `libmtadgat.so` is missing: there is no
+fallback for the inference forward of GPU tensors.  When gradients are wanted, the HIP
+training step (forward that keeps a tape + HIP backward behind a `torch.autograd.Function`)
+runs for the configurations it covers: GATv2 attention, one GRU layer and one decoder
+layer, attention layers of at most 128 nodes (window_size, n_features <= 128), parameter
+gradients only.  Outside of that (use_gatv2=False, stacked recurrences, wider layers, an
+input that requires a gradient) the step is evaluated by torch ops on the GPU
+(`_torchpath.py`, autograd): `model.grad_path` names the route and the reason, a
+RuntimeWarning is raised once per reason, and `model.strict_hip_training = True` turns it
+into an error.  A model and input left on the CPU (the reference's
 `--use_cuda False` / no-GPU branch, predict.py:122, training.py:60; BASELINE config 1)
 are evaluated by the package's own torch-op algebra (`_torchpath.py`), chosen by the
 caller through the tensors' device.
@@ -235,7 +242,8 @@ class MTAD_GAT(nn.Module):
             # True: every GPU call fingerprints the parameter *contents* (one small reduction + a host
             # sync), so in-place edits that bypass autograd's version counter (`p.data.mul_()`,
             # `nn.init.*_(p.data)`) are seen.  False: trust (data_ptr, _version) only -- no sync per call;
-            # call refresh_weights() after such edits.
+            # call refresh_weights() after such edits.  While the model is in train() mode the fingerprint is skipped
+            # (optimizers bump the version counter; one host sync less per training step) unless this is "always".
             object.__setattr__(self, "check_weight_contents", True)
         if "device_repack" not in self.__dict__:
             # True: after the first load, changed fp32 weights (an optimizer step) are re-packed on the GPU
@@ -283,7 +291,7 @@ class MTAD_GAT(nn.Module):
             object.__setattr__(self, "_engine", _native.Engine(self._native_cfg, device))
             object.__setattr__(self, "_weights_key", None)
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
-        if self.check_weight_contents:
+        if self.check_weight_contents == "always" or (self.check_weight_contents and not self.training):
             if all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
                 key = key + (self._engine.fingerprint(params, device),)
             else:

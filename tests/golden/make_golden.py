@@ -5,6 +5,7 @@ Run in the build container (where /root/reference exists):
 
     python -B tests/golden/make_golden.py            # the small per-stage fixtures
     python -B tests/golden/make_golden.py --wide     # >= 256-window fixtures (outputs only) + C1 statistics
+    python -B tests/golden/make_golden.py --grads    # gradients of the training loss, held by the reference
 
 It imports the *unmodified* reference modules (`/root/reference/mtad_gat.py`,
 `modules.py`), runs `MTAD_GAT.forward` on CPU in eval mode on seeded inputs and
@@ -194,8 +195,125 @@ def main():
                       % (INIT_SEED, INIT_SEED + 1)))
 
 
+# ---- gradients of the training step, held by the reference (training.py:106-127) ------------------------------------
+# (case name, shipped checkpoint, batch, variant, target_dims): batches chosen so that the library's training step runs
+# its window-per-workgroup recurrence kernels (<= 1792 windows), its 16-window-group kernels (<= 4096) and its
+# hidden-tile-split kernels (above).  Variant "eval": model.eval() with autograd on -- the deterministic function.
+# Variant "masks": model.train(), the library's counter-based dropout masks (tests/helpers.py restates the hash) injected
+# into the reference's own dropout calls (torch.dropout in the attention layers, F.dropout behind nn.Dropout).
+GRAD_CASES = [
+    ("grads_msl_eval", "msl", 32, "eval", [0]),
+    ("grads_msl_masks", "msl", 32, "masks", [0]),
+    ("grads_smd_eval", "smd_1_1", 33, "eval", None),
+    ("grads_smd_masks", "smd_1_1", 33, "masks", None),
+    ("grads_msl_b2000_masks", "msl", 2000, "masks", [0]),
+    ("grads_msl_b4100_eval", "msl", 4100, "eval", [0]),
+]
+GRAD_XY_SEED = 777
+GRAD_CHUNK = 250
+GRAD_DROP_SEED = (0x5EED << 32) | 0x1234ABCD      # both seed words in use
+
+
+class _InjectedDropout:
+    """While active, the reference's dropout calls take their keep-masks from a queue (in call order: feature attention,
+    temporal attention, the forecasting head's hidden layers) instead of torch's generator."""
+
+    def __init__(self, masks, p):
+        self.queue = [masks["feat"], masks["temp"]] + list(masks["fc"])
+        self.scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+        self.p = p
+
+    def _apply(self, inp, p, train):
+        assert train and abs(p - self.p) < 1e-12 and self.queue, "unexpected dropout call in the reference forward"
+        m = self.queue.pop(0).to(inp.dtype)
+        assert m.shape == inp.shape, (tuple(m.shape), tuple(inp.shape))
+        return inp * (m * float(self.scale))
+
+    def __enter__(self):
+        import torch.nn.functional as Fn
+        self._saved = (torch.dropout, Fn.dropout)
+        torch.dropout = lambda inp, p, train: self._apply(inp, p, train)
+        Fn.dropout = lambda inp, p=0.5, training=True, inplace=False: self._apply(inp, p, training)
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as Fn
+        torch.dropout, Fn.dropout = self._saved
+        assert exc[0] is not None or not self.queue, "the reference made fewer dropout calls than there are masks"
+
+
+def main_grads():
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import dropout_masks_like_the_library, grad_case_inputs, training_loss
+    torch.set_num_threads(os.cpu_count())
+    for name, ckpt, batch, variant, target_dims in GRAD_CASES:
+        if os.path.exists(os.path.join(HERE, name + ".npz")) and "--force" not in sys.argv:
+            print(f"{name}: exists (use --force to regenerate)")
+            continue
+        rel, dims = SHIPPED[ckpt]
+        kwargs = dict(SHIPPED_KW, **dims)
+        sd = torch.load(os.path.join(REF, rel), map_location="cpu")
+        x, y = grad_case_inputs(kwargs, batch, GRAD_XY_SEED)
+        masks = dropout_masks_like_the_library(kwargs, batch, GRAD_DROP_SEED) if variant == "masks" else None
+        res = {}
+        for dt in (torch.float32, torch.float64):
+            model = RefMTAD(**kwargs).to(dt)
+            model.load_state_dict({k: v.to(dt) for k, v in sd.items()})
+            model.train() if variant == "masks" else model.eval()
+            if batch <= GRAD_CHUNK:
+                if masks is not None:
+                    with _InjectedDropout(masks, kwargs["dropout"]):
+                        preds, recons = model(x.to(dt))
+                else:
+                    preds, recons = model(x.to(dt))
+                inj = None
+            else:
+                # the (b, W, W, 2F) attention tensors of the reference do not fit the host at this batch: the same model
+                # and the same loss over the whole batch, with the forward of GRAD_CHUNK-window slices re-computed in
+                # backward (torch.utils.checkpoint) -- no algebra of ours between the reference's forward and its loss
+                from torch.utils.checkpoint import checkpoint
+                inj = _InjectedDropout(masks, kwargs["dropout"]).__enter__() if masks is not None else None
+
+                def run(xi, lo, hi):
+                    if inj is not None:
+                        inj.queue = [masks["feat"][lo:hi], masks["temp"][lo:hi]] + [m[lo:hi] for m in masks["fc"]]
+                    return model(xi)
+
+                outs = [checkpoint(run, x[lo:lo + GRAD_CHUNK].to(dt), lo, min(lo + GRAD_CHUNK, batch), use_reentrant=False)
+                        for lo in range(0, batch, GRAD_CHUNK)]
+                preds, recons = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+            fl, rl = training_loss(preds, recons, x.to(dt), y.to(dt), target_dims)
+            (fl + rl).backward()          # training.py:124-126
+            if inj is not None:
+                inj.queue = []
+                inj.__exit__(None, None, None)
+            res[dt] = dict(grads={n: p.grad.detach() for n, p in model.named_parameters()}, preds=preds.detach(),
+                           recons=recons.detach(), loss=(float(fl), float(rl)))
+        r32, r64 = res[torch.float32], res[torch.float64]
+        out = {"g/" + n: g.numpy() for n, g in r32["grads"].items()}
+        worst = 0.0
+        for n, g in r32["grads"].items():
+            noise = float((g.double() - r64["grads"][n]).abs().max())
+            out["n/" + n] = np.float64(noise)
+            worst = max(worst, noise / (1e-5 + 1e-4 * float(g.abs().max())))
+        out["preds_head"] = r32["preds"][:64].numpy()
+        out["recons_head"] = r32["recons"][:8].numpy()
+        out["loss"] = np.array(r64["loss"], np.float64)
+        meta = dict(name=name, kwargs=kwargs, batch=batch, variant=variant, target_dims=target_dims, weights_from=ckpt,
+                    xy_seed=GRAD_XY_SEED, drop_seed=GRAD_DROP_SEED if variant == "masks" else None,
+                    xy_sha256=hashlib.sha256(x.numpy().tobytes() + y.numpy().tobytes()).hexdigest(),
+                    sd_sha256=sd_digest(sd), torch=torch.__version__)
+        out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: b={batch} {variant} loss64=({r64['loss'][0]:.6f}, {r64['loss'][1]:.6f}) loss32=({r32['loss'][0]:.6f}, "
+              f"{r32['loss'][1]:.6f}) reference's own fp32 noise = {worst:.3f} x the test gate -> {os.path.getsize(path)/1e6:.2f} MB", flush=True)
+
+
 if __name__ == "__main__":
-    if "--wide" in sys.argv:
+    if "--grads" in sys.argv:
+        main_grads()
+    elif "--wide" in sys.argv:
         main_wide()
     else:
         main()

@@ -107,3 +107,84 @@ class WideCase:
 
     def state_dict(self):
         return self.base.state_dict()
+
+
+# ---- the library's counter-based dropout, restated (csrc/mtadgat_device.h: mix32 / drop_window_key / drop_keep;
+# stream numbers csrc/mtadgat_kernels.h: DROP_FEAT = 1, DROP_TEMP = 2, DROP_FC0 = 16).  The reference draws its masks from
+# torch's generator (modules.py:90, :189, :310); to hold the reference's gradients WITH dropout as a fixture, the fixture
+# generator injects these masks into the unmodified reference and the GPU test runs the kernels with the same seed.
+def _mix32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7FEB352D); x ^= x >> np.uint32(15); x *= np.uint32(0x846CA68B); x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_keep_mask(seed, stream, p, n_windows, n_per_window, window0=0):
+    """float32 (n_windows, n_per_window) of 0/1: element e of window w is kept iff the library's hash says so."""
+    if p <= 0.0:
+        return np.ones((n_windows, n_per_window), np.float32)
+    t = p * 4294967296.0
+    thresh = np.uint32(4294967295 if t >= 4294967295.0 else max(int(t), 1))
+    w = np.arange(window0, window0 + n_windows, dtype=np.uint64)
+    lo, hi = (w & np.uint64(0xFFFFFFFF)).astype(np.uint32), (w >> np.uint64(32)).astype(np.uint32)
+    seed_lo, seed_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        h = _mix32(lo ^ seed_lo)
+        h = _mix32(h + hi * np.uint32(0x9E3779B9) + seed_hi + np.uint32((stream * 0x85EBCA6B) & 0xFFFFFFFF))
+        e = np.arange(n_per_window, dtype=np.uint32) * np.uint32(0x9E3779B1) + np.uint32(0x7F4A7C15)
+        keep = _mix32(h[:, None] ^ e[None, :]) >= thresh
+    return keep.astype(np.float32)
+
+
+def dropout_masks_like_the_library(kwargs, batch, seed, window0=0):
+    """{"feat": (b,F,F), "temp": (b,W,W), "fc": [(b,hid)] * hidden layers} -- the layout of Engine.dropout_masks."""
+    p, F_, W_ = kwargs["dropout"], kwargs["n_features"], kwargs["window_size"]
+    hid, nh = kwargs["forecast_hid_dim"], kwargs["forecast_n_layers"]
+    return {"feat": torch.from_numpy(dropout_keep_mask(seed, 1, p, batch, F_ * F_, window0)).reshape(batch, F_, F_),
+            "temp": torch.from_numpy(dropout_keep_mask(seed, 2, p, batch, W_ * W_, window0)).reshape(batch, W_, W_),
+            "fc": [torch.from_numpy(dropout_keep_mask(seed, 16 + i, p, batch, hid, window0)) for i in range(nh)]}
+
+
+GRAD_CASES = ["grads_msl_eval", "grads_msl_masks", "grads_smd_eval", "grads_smd_masks", "grads_msl_b2000_masks", "grads_msl_b4100_eval"]
+
+
+class GradCase:
+    """Reference-held gradients of the training loss (tests/golden/make_golden.py --grads): every parameter's gradient from
+    the unmodified reference model on CPU (float32), the per-parameter rounding noise of that computation (max |g32 - g64|
+    against the same model in float64), the outputs at a few windows.  Inputs are regenerated from the recorded seeds and
+    checked against their sha-256; weights come from the shipped checkpoint's small fixture."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.name = name
+        self.meta = json.loads(bytes(z["meta"]).decode())
+        self.kwargs = self.meta["kwargs"]
+        self.base = Case(self.meta["weights_from"])
+        self.grads = {k[len("g/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g/")}
+        self.noise = {k[len("n/"):]: float(z[k]) for k in z.files if k.startswith("n/")}
+        self.preds_head = torch.from_numpy(z["preds_head"])
+        self.recons_head = torch.from_numpy(z["recons_head"])
+        self.loss = [float(v) for v in z["loss"]]
+        self.x, self.y = grad_case_inputs(self.kwargs, self.meta["batch"], self.meta["xy_seed"])
+        assert hashlib.sha256(self.x.numpy().tobytes() + self.y.numpy().tobytes()).hexdigest() == self.meta["xy_sha256"], \
+            "torch.rand no longer reproduces the fixture's inputs"
+
+
+def grad_case_inputs(kwargs, batch, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, kwargs["window_size"], kwargs["n_features"], generator=g)
+    y = torch.rand(batch, 1, kwargs["n_features"], generator=g)
+    return x, y
+
+
+def training_loss(preds, recons, x, y, target_dims):
+    """reference training.py:113-124, verbatim in meaning: returns (forecast_loss, recon_loss)."""
+    if target_dims is not None:
+        x = x[:, :, target_dims]
+        y = y[:, :, target_dims].squeeze(-1)
+    if preds.ndim == 3:
+        preds = preds.squeeze(1)
+    if y.ndim == 3:
+        y = y.squeeze(1)
+    mse = torch.nn.MSELoss()
+    return torch.sqrt(mse(y, preds)), torch.sqrt(mse(x, recons))

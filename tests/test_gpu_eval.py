@@ -78,3 +78,31 @@ def test_point_adjust_edge_cases_against_the_oracle(gpu_device):
         for reg in (0, 1, 2):
             a, b = ev.find_epsilon(torch.from_numpy(e.astype(np.float32)).to(gpu_device), reg), eo.find_epsilon(e.astype(np.float32), reg)
             assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (trial, reg, a, b)
+
+
+def test_find_epsilon_degenerate_scores(gpu_device):
+    """sd == 0 / mean == 0: numpy semantics of the reference (nan / inf scores), not ZeroDivisionError."""
+    import warnings
+    import evaluation as ev
+    e = np.zeros(4000, np.float32)
+    e[100], e[2000] = 3.0, -3.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cases = [np.full(500, 0.25, np.float32), np.zeros(300, np.float32), e]
+        for c in cases:
+            for reg in (0, 1, 2):
+                got = ev.find_epsilon(torch.from_numpy(c).to(gpu_device), reg_level=reg)
+                ref = eo.find_epsilon(c, reg_level=reg)
+                assert abs(got - ref) <= 1e-6 * max(1.0, abs(ref)), (got, ref, reg)
+
+
+def test_anomaly_scores_rejects_mismatched_inputs(gpu_device):
+    import evaluation as ev
+    preds = torch.zeros(10, 1, device=gpu_device)
+    recons = torch.zeros(10, 1, device=gpu_device)
+    with pytest.raises(ValueError):
+        ev.anomaly_scores(preds, recons, torch.zeros(105, 3, device=gpu_device), 100, target_dims=[1])     # series too short
+    with pytest.raises(ValueError):
+        ev.anomaly_scores(preds, recons, torch.zeros(110, 3, device=gpu_device), 100, target_dims=[3])     # column 3 of 3
+    with pytest.raises(ValueError):
+        ev.anomaly_scores(preds, torch.zeros(9, 1, device=gpu_device), torch.zeros(110, 3, device=gpu_device), 100, target_dims=[1])

@@ -63,3 +63,16 @@ def test_point_adjust_equals_the_reference_state_machine():
         p, l = eo.point_adjust(score, label, thr)
         assert np.array_equal(p, p_ref) and abs(l - l_ref) <= 1e-12, trial
         assert np.allclose(eo.confusion(p, label), ref.calc_point2point(p_ref, label.astype(np.int64)), rtol=0, atol=1e-12)
+
+
+def test_find_epsilon_degenerate_scores_follow_numpy_semantics():
+    """Constant training scores: sd = 0, every z gives epsilon = mean, every point is 'anomalous', the pruned set is empty and
+    the reference's score is nan (eval_methods.py:197-231) -> no z is accepted and the threshold is max(e_s)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert eo.find_epsilon(np.full(500, 0.25), reg_level=1) == 0.25
+        assert eo.find_epsilon(np.zeros(300), reg_level=0) == 0.0
+        e = np.zeros(4000)
+        e[100], e[2000] = 3.0, -3.0                      # zero mean, non-zero sd: a division by zero mean (inf), not an exception
+        assert np.isfinite(eo.find_epsilon(e, reg_level=1))

@@ -108,3 +108,29 @@ def test_data_parallel_step_equals_global_batch(tmp_path):
     assert abs(res["rmse"][0] - float(fl)) <= 1e-6 and abs(res["rmse"][1] - float(rl)) <= 1e-6
     for n, prm in m.named_parameters():
         assert (prm.grad - res["grads"][n]).abs().max().item() <= 2e-6, n
+
+
+@pytest.mark.parametrize("name", ["grads_msl_eval", "grads_msl_masks", "grads_smd_eval", "grads_smd_masks"])
+def test_torch_op_algebra_matches_the_reference_held_gradients(name):
+    """_torchpath.forward (the CPU route of the training step and the other side of tests/test_gpu_backward.py) against
+    the gradients the reference itself produced (tests/golden/make_golden.py --grads; loss as training.py:113-126)."""
+    import _torchpath
+    from helpers import GradCase, dropout_masks_like_the_library, training_loss
+    from mtad_gat import MTAD_GAT
+    c = GradCase(name)
+    m = MTAD_GAT(**c.kwargs)
+    m.load_state_dict(c.base.state_dict())
+    masks = None
+    if c.meta["variant"] == "masks":
+        m.train()
+        masks = dropout_masks_like_the_library(c.kwargs, c.meta["batch"], c.meta["drop_seed"])
+    else:
+        m.eval()
+    p, r = _torchpath.forward(m, c.x, masks)
+    fl, rl = training_loss(p, r, c.x, c.y, c.meta["target_dims"])
+    assert abs(fl.item() - c.loss[0]) <= 1e-5 and abs(rl.item() - c.loss[1]) <= 1e-5
+    (fl + rl).backward()
+    for n, prm in m.named_parameters():
+        ref = c.grads[n]
+        d = (prm.grad - ref).abs().max().item()
+        assert d <= 1e-5 + 1e-4 * ref.abs().max().item() + c.noise[n], (n, d)
