@@ -47,34 +47,12 @@ __device__ __forceinline__ void gat_load(f32x2 (&l)[IBL], f32x2 (&r)[JPL], const
 }
 
 // The two instructions per pair are written as (volatile) inline asm: left to itself the compiler packs
-// the column pair into v_pk_add_f32 (no faster) and schedules all sums of a step
+// the column pair into v_pk_add_f32 (no faster -- neither its form with shuffles nor, round 3, a hand-placed
+// v_pk_add_f32 on the 8-byte words as loaded, 3 instructions per 2 pair-columns: 10.91 -> 10.82 ms, the pair grid is
+// not bound by VALU issue alone) and schedules all sums of a step
 // ahead of their uses, which costs > 100 VGPRs of temporaries and spills the accumulators.
-#ifndef MTADGAT_GAT_PK
-#define MTADGAT_GAT_PK 0
-#endif
 template <int IBL, int JPL, bool NEG>
 __device__ __forceinline__ void gat_step(float (&acc)[IBL][JPL], const f32x2 (&l)[IBL], const f32x2 (&r)[JPL]) {
-#if MTADGAT_GAT_PK
-    // the sums of a column pair in one packed add (operands are the 8-byte LDS words as loaded), the two |.|-accumulates
-    // single: 3 VALU instructions per 2 pair-columns; same order of accumulation as the single-add form
-#pragma unroll
-    for (int ii = 0; ii < IBL; ++ii) {
-        f32x2 t[JPL];
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(t[jj]) : "v"(l[ii]), "v"(r[jj]));
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) {
-            const float t0 = t[jj][0], t1 = t[jj][1];
-            if (NEG) {
-                asm volatile("v_sub_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t0));
-                asm volatile("v_sub_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t1));
-            } else {
-                asm volatile("v_add_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t0));
-                asm volatile("v_add_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t1));
-            }
-        }
-    }
-#else
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -94,7 +72,6 @@ __device__ __forceinline__ void gat_step(float (&acc)[IBL][JPL], const f32x2 (&l
                     asm volatile("v_add_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t[jj]));
             }
         }
-#endif
 }
 
 // one 8-column k tile; on entry set A holds columns 0,1 of the tile (loads possibly still in flight),
