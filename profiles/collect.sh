@@ -16,6 +16,8 @@ rm -rf /tmp/ktb && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/
 cp "$(find /tmp/ktb -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bf16.csv"
 rm -rf /tmp/ktt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt -- python "$ROOT/profiles/train_step.py" 256 > "$OUT/train_step_256.txt" 2> /dev/null
 cp "$(find /tmp/ktt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_train256.csv"
+rm -rf /tmp/ktt8 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt8 -- python "$ROOT/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_bench_line.json" 2> /dev/null
+cp "$(find /tmp/ktt8 -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_train8192.csv"
 rm -rf /tmp/ktf && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -- python "$ROOT/profiles/forward_small.py" 256 > "$OUT/forward_256.txt" 2> /dev/null
 cp "$(find /tmp/ktf -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_fwd256.csv"
 # 2. HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) and the SQ group
