@@ -72,10 +72,12 @@ struct XSource {
     int64_t start0 = 0, stride = 1;
 };
 
+// geo (optional): the rows are cut into `geo_W`-row windows instead of the model's W-row ones (run_conv_shared)
 int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s,
-             unsigned* vmax = nullptr) {
+             unsigned* vmax = nullptr, int64_t geo_W = 0, bool keep_vmax = false) {
     Scope sc(m, S_CONV, s);
     ConvArgs a{};
+    const int64_t Wk = geo_W ? geo_W : m.W;
     if (src.gather) {
         a.X = src.x; a.gather = 1;
         a.starts = src.starts ? reinterpret_cast<const long*>(src.starts + c0) : nullptr;
@@ -86,7 +88,7 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
         a.X = src.x + c0 * (int64_t)m.W * m.F;
     }
     a.x_bf16 = src.x_bf16;
-    a.B = n; a.W = m.W; a.F = m.F; a.Fp = m.Fp; a.taps = m.taps; a.pad = m.pad;
+    a.B = n; a.W = (int)Wk; a.F = m.F; a.Fp = m.Fp; a.taps = m.taps; a.pad = m.pad;
     a.Fq = m.Fp;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w_off);
     // bf16 operand build: inference forward only (hcat / y outputs), when the LDS-staged kernel applies
@@ -100,10 +102,36 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
     a.NT = m.convNT;
     a.XC = xc; a.XCT = xct; a.Wpad = m.Wp; a.HCAT = hcat; a.Dp = m.Dp; a.Y = y;
     if (vmax) {
-        HIP_TRY(hipMemsetAsync(vmax, 0, sizeof(unsigned), s));
+        if (!keep_vmax) HIP_TRY(hipMemsetAsync(vmax, 0, sizeof(unsigned), s));
         a.vmax = vmax;
     }
     K_TRY(launch_conv(a, s), "conv");
+    return 0;
+}
+
+// The convolution of n stride-1 windows of a series without computing a shared row more than once (SURVEY section 8f row 3:
+// interior rows are shared by up to W windows; the per-window zero padding, modules.py:14,20, makes the first / last `pad`
+// rows of every window its own).  Three launches of the SAME kernel -- so every value equals the per-window launch's, bit
+// for bit: the segment as one (n + W - 1)-row window, the windows' first and last 2 pad rows as 2 pad-row windows -- and a
+// copy that places the rows into h_cat.  Applies when the LDS-staged kernel does (it records the output range).
+bool conv_shared_applies(const Model& m, const XSource& src, int64_t n) {
+    if (!src.gather || src.starts || src.stride != 1 || n < 1024 || m.precision == 1 || src.x_bf16) return false;   // (the bf16 build writes h_cat only)
+    if (m.taps != 2 * m.pad + 1 || m.pad < 1 || m.W < 4 * m.pad) return false;
+    const int Fq = m.precision == 1 ? m.Fp16 : m.Fp;
+    return (size_t)(32 + m.taps - 1) * (Fq + 4) * sizeof(float) <= 20 * 1024;
+}
+int run_conv_shared(Model& m, const XSource& src, int64_t c0, int64_t n, float* hcat, float* cf, float* el, float* er, hipStream_t s,
+                    unsigned* vmax) {
+    int rc;
+    XSource seg = src;
+    seg.start0 = src.start0 + c0; seg.stride = 1;
+    const int64_t L = n + m.W - 1, EW = 2 * m.pad;
+    if ((rc = run_conv(m, seg, 0, 1, cf, nullptr, nullptr, nullptr, s, vmax, L))) return rc;
+    if ((rc = run_conv(m, seg, 0, n, el, nullptr, nullptr, nullptr, s, vmax, EW, true))) return rc;
+    seg.start0 += m.W - EW;
+    if ((rc = run_conv(m, seg, 0, n, er, nullptr, nullptr, nullptr, s, vmax, EW, true))) return rc;
+    Scope sc(m, S_CONV, s);
+    K_TRY(launch_conv_scatter(cf, el, er, hcat, n, m.W, m.F, m.Fp, m.Dp, m.pad, s), "conv row placement");
     return 0;
 }
 
@@ -831,7 +859,8 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
 int mtadgat_last_conv_max(mtadgat_handle h, const void* ws, int64_t batch, float* out_host, void* stream) {
     if (!h || !ws || !out_host || batch <= 0) return fail(MTADGAT_ERR_INVALID, "null argument");
     Workspace o;
-    plan_workspace(h->m, std::min<int64_t>(batch, h->m.chunk), o);
+    const int64_t tail = batch % h->m.chunk;                  // the layout of the call's last chunk (each chunk has its own plan)
+    plan_workspace(h->m, batch <= h->m.chunk ? batch : (tail ? tail : h->m.chunk), o);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(out_host, static_cast<const float*>(ws) + o.vmax, sizeof(float), hipMemcpyDeviceToHost));
     return 0;
@@ -844,11 +873,21 @@ int mtadgat_set_chunk_windows(mtadgat_handle h, int64_t w) {
     return 0;
 }
 
+// Every chunk is planned for its own number of windows (a short last chunk gets the small-batch kernels and their
+// buffers, not the layout of a full chunk): the workspace must hold the larger of the two plans.
+static size_t workspace_floats(const Model& m, int64_t batch) {
+    Workspace o;
+    plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
+    size_t need = o.total;
+    if (batch > m.chunk && batch % m.chunk != 0) {
+        plan_workspace(m, batch % m.chunk, o);
+        need = std::max(need, o.total);
+    }
+    return need;
+}
 size_t mtadgat_workspace_bytes(mtadgat_handle h, int64_t batch) {
     if (!h || batch <= 0) return 0;
-    Workspace o;
-    plan_workspace(h->m, std::min<int64_t>(batch, h->m.chunk), o);
-    return o.total * sizeof(float);
+    return workspace_floats(h->m, batch) * sizeof(float);
 }
 
 static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, float* preds, float* recons, float* recons_last,
@@ -864,7 +903,7 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
     for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
         const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
         Workspace o;
-        plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
+        plan_workspace(m, n, o);
         float* xc = ws + o.xc;
         float* xct = ws + o.xct;
         float* hcat = ws + o.hcat;
@@ -872,7 +911,9 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
             // fused front: conv writes only h_cat[:, :F]; each layer's workgroup stages its window from
             // there (the feature layer transposes on the way into LDS) -- no xc / xc^T / L' / R' in HBM
             unsigned* vmax = reinterpret_cast<unsigned*>(ws + o.vmax);
-            if ((rc = run_conv(m, src, c0, n, nullptr, nullptr, hcat, nullptr, s, vmax))) return rc;
+            if (conv_shared_applies(m, src, n)) {
+                if ((rc = run_conv_shared(m, src, c0, n, hcat, ws + o.cf, ws + o.el, ws + o.er, s, vmax))) return rc;
+            } else if ((rc = run_conv(m, src, c0, n, nullptr, nullptr, hcat, nullptr, s, vmax))) return rc;
             if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, nullptr, nullptr, 0, vmax))) return rc;
             if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, nullptr, nullptr, 0, vmax))) return rc;
         } else {

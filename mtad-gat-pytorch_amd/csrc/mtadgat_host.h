@@ -183,6 +183,7 @@ struct Workspace {
     bool has_xp;         // room for the pre-projected GRU input (batches the hidden-tile-split kernel serves)
     bool rec16;          // room for the decoder's pre-projected input and state sequence (k_gru16)
     size_t vmax;         // one word: bits of the largest convolution output of the chunk (range guard of the fp16 operand pieces)
+    size_t cf, el, er;   // convolution rows shared by stride-1 windows of a series (run_conv_shared): segment rows, edge rows
 };
 
 // activations kept between the training forward and the backward (caller-owned "tape"), offsets in floats

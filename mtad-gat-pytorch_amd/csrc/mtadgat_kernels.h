@@ -364,6 +364,8 @@ int launch_dxc(const float* hcat, const float* dhcat, long ldh, const float* dvt
 // keep-mask (1 / 0) of a dropout stream: mask[w*n + idx] for windows win0 + w (test hook)
 int launch_dropmask(const DropArgs& d, unsigned stream, long nwin, long n_per_win, float* mask, hipStream_t s);
 int launch_copy2d(const float* src, long lds, float* dst, long ldd, long R, int ncols, hipStream_t s);
+int launch_conv_scatter(const float* cf, const float* el, const float* er, float* hcat, long n, int W, int F, int Fp, int Dp, int pad,
+                        hipStream_t s);
 int launch_transpose_win(const float* src, long lds, float* dst, long ldd, long B, int R, int C, hipStream_t s);
 
 }  // namespace mtadgat

@@ -452,6 +452,34 @@ __global__ void k_copy2d(const float* __restrict__ src, long lds, float* __restr
         dst[r * ldd + c] = src[r * lds + c];
     }
 }
+// Stride-1 windows of one series share their convolution rows (reference quirk: the zero padding is
+// per WINDOW, modules.py:14,20): row t of window w equals the row s_w + t of the convolution over the whole segment
+// unless a tap leaves the window, i.e. for the first / last `pad` rows.  CF: convolution of the segment as one long
+// window; EL / ER: of the windows' first / last EW = 2 pad rows as EW-row windows (their first / last pad rows are the
+// edge rows).  This kernel places the rows into h_cat[:, :F] and zeroes the row's alignment padding.
+__global__ void k_conv_scatter(const float* __restrict__ CF, const float* __restrict__ EL, const float* __restrict__ ER, float* __restrict__ HCAT,
+                               long n, int W, int F, int Fp, int Dp, int pad, int EW) {
+    const int G4 = (F + 3) >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * W * G4) return;
+    const long row = idx / G4;
+    const int c = (int)(idx - row * G4) * 4;
+    const long w = row / W;
+    const int t = (int)(row - w * W);
+    const float* __restrict__ src = t < pad ? EL + (w * EW + t) * (long)Fp
+                                  : (t >= W - pad ? ER + (w * EW + (t - (W - EW))) * (long)Fp : CF + (w + t) * (long)Fp);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);          // rows are Fp floats apart (F rounded up to 8): aligned, in range
+    float* __restrict__ dst = HCAT + row * Dp + c;
+    if (c + 3 < F) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < F) dst[e] = v[e];
+    }
+    if (c == 0)
+        for (int k = 3 * F; k < Dp; ++k) HCAT[row * Dp + k] = 0.f;
+}
 // transpose per window: src (B, R, C) with row stride lds -> dst (B, C, R) with row stride ldd
 __global__ void k_transpose_win(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, long B, int R,
                                 int C) {
@@ -523,6 +551,14 @@ int launch_copy2d(const float* src, long lds, float* dst, long ldd, long R, int 
     const long total = R * ncols;
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_copy2d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, lds, dst, ldd, R, ncols);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_conv_scatter(const float* cf, const float* el, const float* er, float* hcat, long n, int W, int F, int Fp, int Dp, int pad,
+                        hipStream_t s) {
+    const long total = n * W * ((F + 3) >> 2);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_conv_scatter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cf, el, er, hcat, n, W, F, Fp, Dp, pad, 2 * pad);
     LAUNCH_CHECK();
     return 0;
 }

@@ -290,3 +290,24 @@ def test_bf16_operand_mode_within_2e_2(name, gpu_device):
     n = x.shape[0]
     assert (pbig[:n].cpu() - case.preds).abs().max().item() <= 2e-2 and (rbig[:n].cpu() - case.recons).abs().max().item() <= 2e-2
     assert (pa.float().cpu() - case.preds).abs().max().item() <= 3e-2 and (ra.float().cpu() - case.recons).abs().max().item() <= 3e-2
+
+
+def test_short_last_chunk_is_planned_for_its_own_size(gpu_device):
+    """A batch of one chunk + a few windows: the short last chunk runs exactly what a call with only those windows runs
+    (small-batch recurrence kernels and their buffers), not the full chunk's layout -- a 65 537-window call used to spend
+    6 ms on its 1-window tail."""
+    a = Case("smap")
+    model = a.build_model().to(gpu_device)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2000 + 5, a.kwargs["window_size"], a.kwargs["n_features"], generator=g).to(gpu_device)
+    with torch.no_grad():
+        eng = model._sync_engine(gpu_device)
+        keep = eng.chunk_windows()
+        try:
+            p1, r1 = model(x[:2000])
+            p2, r2 = model(x[2000:])
+            eng.set_chunk_windows(2000)
+            p, r = model(x)
+        finally:
+            eng.set_chunk_windows(keep)
+    assert torch.equal(p, torch.cat([p1, p2])) and torch.equal(r, torch.cat([r1, r2]))

@@ -109,3 +109,36 @@ def test_forward_series_on_a_wide_model(gpu_device):
         p0, r0 = model(x)
         p1, r1 = model.forward_series(series)
     assert torch.equal(p0, p1) and torch.equal(r0, r1)
+
+
+def test_shared_convolution_rows_of_stride_one_windows_are_bit_equal(gpu_device):
+    """From 1 024 stride-1 windows on, the series path computes every convolution row once (segment rows + the per-window
+    edge rows) instead of once per window: outputs bit-equal to the materialised-window forward,
+    in the default and the strict fp32 arithmetic, for a kernel size of 7 (MSL checkpoint) and of 3."""
+    from mtad_gat import MTAD_GAT
+    case = Case("msl")
+    model = case.build_model().to(gpu_device)
+    w, F = case.kwargs["window_size"], case.kwargs["n_features"]
+    g = torch.Generator().manual_seed(5)
+    series = torch.rand(w + 1300, F, generator=g).to(gpu_device)
+    torch.manual_seed(4)
+    small = MTAD_GAT(n_features=11, window_size=24, out_dim=2, kernel_size=3, gru_hid_dim=40, recon_hid_dim=40).to(gpu_device).eval()
+    series_s = torch.rand(24 + 2100, 11, device=gpu_device)
+    with torch.no_grad():
+        for m, sr, ww in ((model, series, w), (small, series_s, 24)):
+            n = sr.shape[0] - ww + 1
+            x = torch.stack([sr[i:i + ww] for i in range(n)])
+            for prec in ("fp32", "fp32_strict"):
+                m.precision = prec
+                p0, r0 = m(x)
+                p1, r1 = m.forward_series(sr)
+                assert torch.equal(p0, p1) and torch.equal(r0, r1), (prec, ww)
+                p2, r2 = m.forward_series(sr, start=3, stride=1, count=1100)          # a segment that does not start at row 0
+                p3, r3 = m(x[3:1103])           # (the same batch size: the recurrence kernels are chosen by it)
+                assert torch.equal(p3, p2) and torch.equal(r3, r2), (prec, ww)
+            m.precision = "auto"
+        # score_series (windows 0 .. N - W, one forward each) over the same segment
+        preds, last = model.score_series(series)
+        xw = torch.stack([series[i:i + w] for i in range(series.shape[0] - w + 1)])
+        pw, rw = model(xw)
+        assert torch.equal(preds, pw[:-1]) and torch.equal(last, rw[1:, -1, :])
