@@ -652,8 +652,10 @@ size_t gat_bwd_pair_lds(int K, int vld, int Ep) {
     return f * sizeof(float);
 }
 
+// (from 80 keys on -- NJ8 >= 10: 32 key accumulators per lane -- the 128-register budget of two workgroups per CU spills 27 / 81
+// registers; those instantiations take the 256-register budget and one workgroup per CU)
 template <int NJ8>
-__global__ __launch_bounds__(512, 4) void k_gat_bwd_pair(const GatBwdPairArgs a) {
+__global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const GatBwdPairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NJQ = (NJ8 + 3) / 4;              // 8-key blocks per 16-lane quarter
     constexpr int KJ = 32 * NJQ;                    // key slots (>= K; slots past K carry zeros)
