@@ -161,7 +161,8 @@ int mtadgat_bf16_ready(mtadgat_handle h);
 
 /* Testing / measurement hook (not needed for normal use).  "gru_kernel": which kernel runs the large-batch recurrences
  * (GRULayer.forward modules.py:235-238, the decoder modules.py:276-283) in precision mode 2:
- *   0 automatic (default), 1 the tile-major kernel at every batch size, 2 the chunk-major kernel wherever it applies. */
+ *   0 automatic (default), 1 the tile-major kernel at every batch size, 2 the chunk-major kernel wherever it applies,
+ *   3 the hidden-tile-split kernel on split operands wherever it applies. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
 /* Diagnostics for bench.py: the largest convolution output of the last forward() that used workspace `ws` (its last
  * chunk; synchronises `stream`).  Below 2^15 the large-batch kernels used two fp16 pieces per operand, otherwise three

@@ -350,7 +350,7 @@ class Engine:
         return bool(self.lib.mtadgat_bf16_ready(self.handle))
 
     def set_option(self, name, value):
-        """Testing / measurement hook (include/mtadgat.h): e.g. ("gru_kernel", 0 automatic | 1 tile-major | 2 chunk-major)."""
+        """Testing / measurement hook (include/mtadgat.h): e.g. ("gru_kernel", 0 automatic | 1 tile-major | 2 chunk-major | 3 hidden-tile split on split operands)."""
         _check(self.lib.mtadgat_set_option(self.handle, name.encode(), int(value)), "set_option")
 
     def last_conv_max(self, batch, device):

@@ -228,6 +228,9 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n, bool training = false) {
     if (stack.size() != 1 || !stack[0].has16) return false;
     if (m.precision == 1) return !training && n <= 1024;
+    // inference in the split-operand arithmetic: from SPLIT3_MIN_WINDOWS on the hidden-tile-split kernel's split-operand build
+    // is the faster one (run_gru_layer); the measurement hook can force it at any size
+    if (m.precision == 2 && !training && (m.gru_kernel == 3 || (m.gru_kernel == 0 && n >= SPLIT3_MIN_WINDOWS))) return false;
     return n <= G16_MAX_WINDOWS;
 }
 
@@ -279,10 +282,13 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
                         (g.Qxp16 == 1 || g.Qxp16 % 2 == 0) &&
                         (g.xmode == 1 ? g.Qxp16 == 1 : (g.wxq_off != 0 && g.Qx >= 3 && ((vmax && g.wx2_off && g.qb3 > 0) || g.qb3 == 0))) &&
                         (hend == nullptr || ldhe >= g.Hp) && m.W <= 512;
-    const bool use_cm = cm_fit && m.gru_kernel != 1 && (m.gru_kernel == 2 || n >= CM_MIN_WINDOWS);
+    // ... and between CM_MIN_WINDOWS and SPLIT3_MAX_WINDOWS the split-operand build of the hidden-tile-split kernel (same
+    // packs, same range guard): there a 32-window wave per SIMD is a latency chain, five waves per 32 windows are not
+    const bool use_sp = cm_fit && g.NCG >= 2 && (m.gru_kernel == 3 || (m.gru_kernel == 0 && n >= SPLIT3_MIN_WINDOWS && n <= SPLIT3_MAX_WINDOWS));
+    const bool use_cm = cm_fit && !use_sp && m.gru_kernel != 1 && m.gru_kernel != 3 && (m.gru_kernel == 2 || n >= CM_MIN_WINDOWS);
     // large batch, split-bf16 operands: fp32-class results from the bf16 matrix pipe (k_gru X3 build), from 1.25 32-window
     // groups per CU on (measured: 12 320 windows 10.5 ms against 13.1 ms for the hidden-tile-split kernel at 12 288; 8 192 windows 7.4 ms there)
-    const bool x3 = m.precision == 2 && !gates && ((n + 31) / 32 > 5L * cu_count() / 4 || use_cm) &&
+    const bool x3 = m.precision == 2 && !gates && ((n + 31) / 32 > 5L * cu_count() / 4 || use_cm || use_sp) &&
                     (g.Qxp16 == 1 || g.Qxp16 % 2 == 0);
     if (!x3 && xp && g.has_xproj && g.xmode == 0) {
         // small batch: all steps' input products as one throughput GEMM, the recurrence keeps only its h part
@@ -339,7 +345,15 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         K_TRY(launch_gru_train(a, g.NCG, xmode, fc != nullptr, s), "gru (training)");
         return 0;
     }
-    if (use_cm) {
+    if (use_sp) {
+        a.Wxq = (xmode == 0 && a.Wx2) ? a.Wx2 : a.Wx;         // the two-piece input pack in [tile][chunk] order
+        const size_t lds = ((size_t)g.NCG * 1024 + (fc ? (size_t)g.NCG * fc->out_dim * 32 : 0)) * sizeof(float);
+        if (lds <= 64 * 1024) {
+            K_TRY(launch_gru_split_x3(a, g.NCG, xmode, fc != nullptr, s), "gru (hidden-tile split, split operands)");
+            if (a.vmax == nullptr) return 0;
+            a.skip_xh = 1;
+        }
+    } else if (use_cm) {
         a.Wxq = xmode == 1 ? a.Wx : reinterpret_cast<const f32x4*>(m.packed_dev + g.wxq_off);
         K_TRY(launch_gru_cm(a, g.NCG, xmode, fc != nullptr, s), "gru (chunk-major)");
         if (a.vmax == nullptr) return 0;
@@ -846,10 +860,10 @@ int mtadgat_set_precision(mtadgat_handle h, int mode) {
 int mtadgat_bf16_ready(mtadgat_handle h) { return (h && h->m.have_weights && h->m.bf16_packed) ? 1 : 0; }
 
 /* Testing / measurement hook: "gru_kernel" = 0 automatic choice of the large-batch recurrence kernel, 1 tile-major (k_gru),
- * 2 chunk-major (k_gru_cm) wherever it applies */
+ * 2 chunk-major (k_gru_cm) wherever it applies, 3 hidden-tile split on split operands (k_gru_split X3H) wherever it applies */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
-    if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 2) { h->m.gru_kernel = value; return 0; }
+    if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
 

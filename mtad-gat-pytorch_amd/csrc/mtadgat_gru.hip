@@ -25,8 +25,18 @@ int launch_gru_big_x3_lo(const GruArgs& a, int ncg, int xmode, bool fc, bool two
 // whole number of ring turns for any hidden size, which keeps NCG and H run-time values.
 // ---------------------------------------------------------------------------
 // SAVE (training): the gate activations r, z, n and q = W_hn h + b_hn of every step go to a.Gates for the backward.
-template <int XMODE, bool FC, bool SAVE = false, bool BF = false>
-__global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const GruArgs a) {
+// X3H (with BF's 16-feature chunk geometry): split operands, two fp16 pieces per value -- weights from the [gate][piece]
+// packs scaled by S (six words per chunk), x_t split where it is consumed, h_t split ONCE per step by the wave that
+// publishes its tile (hs holds the two pieces of every chunk), nine v_mfma_f32_32x32x16_f16 per chunk on the 16-bit pipe:
+// fp32-class results (mtadgat_device.h) at a fifth of the fp32 MFMA time.  The mid-size batches' recurrence: a
+// 32-window wave of k_gru_cm is a latency chain (one round of it takes 4 ms however few windows it holds), five waves
+// per 32 windows are five times the SIMDs.  Needs |x| < 2^15 (recorded by the convolution; otherwise the launch returns
+// at once and the caller's three-piece kernel serves it).
+template <int XMODE, bool FC, bool SAVE = false, bool BF = false, bool X3H = false>
+__global__ __launch_bounds__(512, (X3H || XMODE == 3 ? 2 : 3)) void k_gru_split(const GruArgs a) {
+    static_assert(!X3H || (BF && XMODE != 3), "split operands: 16-feature chunks, in-kernel input part");
+    if (X3H && a.vmax != nullptr && !(__uint_as_float(*a.vmax) < 32768.f)) return;
+    if (!X3H && a.skip_xh && a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f) return;
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     const int lane = threadIdx.x & 63;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -47,18 +57,21 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
     // Running wave-uniform pointers, advanced by adds and scalar selects only (a branch inside the chunk
     // loops makes the compiler drain the ring with s_waitcnt vmcnt(0)); the h stream of a tile ends in
     // two all-zero chunks, so the padded chunks need no special case.
-    const f32x4* __restrict__ whc = a.Wh + (long)c * a.whs * 192;
-    const f32x4* __restrict__ wx0 = a.Wx + (long)c * Qxp * 192;
-    const long wxskip = (XMODE == 0) ? 0 : (long)(NCG - 1) * Qxp * 192;    // decoder input weights are [t][c][Qxp]
+    constexpr int NWD = X3H ? 6 : 3;               // 1-KiB words per chunk: [gate] or [gate][piece]
+    constexpr int CST = 64 * NWD;                  // chunk stride in float4
+    const f32x4* __restrict__ whc = a.Wh + (long)c * a.whs * CST;
+    const f32x4* __restrict__ wx0 = (X3H ? a.Wxq : a.Wx) + (long)c * Qxp * CST;
+    const long wxskip = (XMODE == 0) ? 0 : (long)(NCG - 1) * Qxp * CST;    // decoder input weights are [t][c][Qxp]
     int ps_ = 0, pt = 0;
     const f32x4* __restrict__ pwx = wx0;
     const f32x4* __restrict__ pwh = whc;
-    auto wload = [&](f32x4 (&dst)[3]) {
+    auto wload = [&](f32x4 (&dst)[NWD]) {
         const bool isx = ps_ < Qxp;
         const f32x4* __restrict__ p = (isx ? pwx : pwh) + lane;
-        dst[0] = p[0]; dst[1] = p[64]; dst[2] = p[128];
-        pwx += isx ? 192 : 0;
-        pwh += isx ? 0 : 192;
+#pragma unroll
+        for (int k = 0; k < NWD; ++k) dst[k] = p[64 * k];
+        pwx += isx ? CST : 0;
+        pwh += isx ? 0 : CST;
         const bool ws = ps_ + 1 == S3;             // end of the step
         ps_ = ws ? 0 : ps_ + 1;
         pt = ws ? pt + 1 : pt;
@@ -76,7 +89,9 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
         v[2] = xbase[min(k0 + 2, kmax)]; v[3] = xbase[min(k0 + 3, kmax)];
         return v;
     };
-    auto hread = [&](int q) -> f32x4 { return hs[(q < Qhe ? q : Qhe - 1) * 64 + lane]; };   // padding: any finite chunk
+    // (X3H: chunk q is the pair hs[2q], hs[2q + 1] = its hi and lo pieces)
+    auto hread = [&](int q) -> f32x4 { return hs[(q < Qhe ? q : Qhe - 1) * (X3H ? 128 : 64) + lane]; };   // padding: any finite chunk
+    auto hread_lo = [&](int q) -> f32x4 { return hs[(q < Qhe ? q : Qhe - 1) * 128 + 64 + lane]; };
     // XMODE 3: the input products W_i{r,z,n} x_t + b of all steps were computed beforehand by one throughput GEMM
     // (k_rowgemm over the b*T rows): X = (B*T, 3*Hp) [r | z | n]; a step starts from this tile's 3 x 16 values.
     // At small batches the recurrence is a latency chain -- the input chunks are half of its MFMAs.
@@ -94,21 +109,41 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
     for (int r = 0; r < 16; ++r) hown[r] = 0.f;
     // hs: h_{t-1} as MFMA B operands -- fp32 build [NCG][4][64] float4 (F-layout chunks), bf16 build [NCG][2][64]
     // 16-byte containers of 8 bf16 (converted once by the publishing wave)
-    constexpr int HSC = BF ? 2 : 4;
+    constexpr int HSC = (BF && !X3H) ? 2 : 4;
 #pragma unroll
     for (int m = 0; m < HSC; ++m) hs[(c * HSC + m) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto loadxq = [&](int t, int q) -> f32x4 {
+    const float wS = X3H ? a.scale[0] : 1.f, wInvS = X3H ? a.scale[1] : 1.f;
+    f32x4 xr2[3];                                  // X3H: second raw half of the ring's input chunks
+    auto loadxq = [&](int t, int q, f32x4& second) -> f32x4 {
         if (!BF) return loadx_t(t, q);
+        if (X3H) {
+            second = XMODE == 1 ? f32x4{0.f, 0.f, 0.f, 0.f} : loadx_t(t, 2 * q + 1);
+            return XMODE == 1 ? loadx_t(t, q) : loadx_t(t, 2 * q);
+        }
         if (XMODE == 1) return cvt8(loadx_t(t, q), f32x4{0.f, 0.f, 0.f, 0.f});
         return cvt8(loadx_t(t, 2 * q), loadx_t(t, 2 * q + 1));
     };
-    f32x4 wr[3][3], xr[3];
+    // one chunk into the three gate accumulators
+    auto mmx = [&](const f32x4 (&w)[NWD], const f32x4 x, const f32x4 x2, f32x16& g0, f32x16& g1, f32x16& g2, const bool is_h) {
+        if constexpr (X3H) {
+            f32x4 bh, bl;
+            if (is_h) { bh = x; bl = x2; }         // pieces published by the tile's owner
+            else split2h(x, x2, bh, bl);
+            g0 = mfma_h(w[0], bl, g0); g1 = mfma_h(w[2], bl, g1); g2 = mfma_h(w[4], bl, g2);
+            g0 = mfma_h(w[1], bh, g0); g1 = mfma_h(w[3], bh, g1); g2 = mfma_h(w[5], bh, g2);
+            g0 = mfma_h(w[0], bh, g0); g1 = mfma_h(w[2], bh, g1); g2 = mfma_h(w[4], bh, g2);
+        } else {
+            f32x4 w3[3] = {w[0], w[1], w[2]};
+            mfma_x3<BF>(w3, x, g0, g1, g2);
+        }
+    };
+    f32x4 wr[3][NWD], xr[3];
     wload(wr[0]); wload(wr[1]); wload(wr[2]);
     if (XMODE == 3) {
         loadxp(0);
     } else {
 #pragma unroll
-        for (int st = 0; st < 3; ++st) xr[st] = loadxq(0, st);
+        for (int st = 0; st < 3; ++st) xr[st] = loadxq(0, st, xr2[st]);
     }
     __syncthreads();
 
@@ -131,37 +166,40 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + a.Hp + col);
                 const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias + 2 * a.Hp + col);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    ar[4 * m + s4] = b0[s4];
-                    az[4 * m + s4] = b1[s4];
-                    anx[4 * m + s4] = b2[s4];
-                    anh[4 * m + s4] = b3[s4];
+                for (int s4 = 0; s4 < 4; ++s4) {            // (X3H: the accumulators hold S x the pre-activations)
+                    ar[4 * m + s4] = b0[s4] * wS;
+                    az[4 * m + s4] = b1[s4] * wS;
+                    anx[4 * m + s4] = b2[s4] * wS;
+                    anh[4 * m + s4] = b3[s4] * wS;
                 }
             }
         }
         // chunk q of h_{t-1} is requested one chunk ahead of its MFMAs (LDS latency under the previous group)
-        f32x4 hv = hread(0);
+        f32x4 hv = hread(0), hv2 = hv;
+        if constexpr (X3H) hv2 = hread_lo(0);
         int qh = 0;                                // next h chunk to consume
         if (XMODE == 1) {
             // first ring turn: the single x chunk, then h chunks 0 and 1
-            mfma_x3<BF>(wr[0], xr[0], ar, az, anx);
+            mmx(wr[0], xr[0], xr2[0], ar, az, anx, false);
             wload(wr[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 1; st < 3; ++st) {
                 const f32x4 hn = hread(qh + 1);
-                mfma_x3<BF>(wr[st], hv, ar, az, anh);
+                f32x4 hn2 = hn;
+                if constexpr (X3H) hn2 = hread_lo(qh + 1);
+                mmx(wr[st], hv, hv2, ar, az, anh, true);
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
-                hv = hn; ++qh;
+                hv = hn; hv2 = hn2; ++qh;
             }
         } else {
             for (int q0 = 0; q0 < Qxp; q0 += 3) {
 #pragma unroll
                 for (int st = 0; st < 3; ++st) {
-                    mfma_x3<BF>(wr[st], xr[st], ar, az, anx);
+                    mmx(wr[st], xr[st], xr2[st], ar, az, anx, false);
                     wload(wr[st]);
-                    xr[st] = loadxq(t, q0 + st + 3);
+                    xr[st] = loadxq(t, q0 + st + 3, xr2[st]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -170,10 +208,12 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
 #pragma unroll
             for (int st = 0; st < 3; ++st) {
                 const f32x4 hn = hread(qh + st + 1);
-                mfma_x3<BF>(wr[st], hv, ar, az, anh);
+                f32x4 hn2 = hn;
+                if constexpr (X3H) hn2 = hread_lo(qh + st + 1);
+                mmx(wr[st], hv, hv2, ar, az, anh, true);
                 wload(wr[st]);
                 __builtin_amdgcn_sched_barrier(0);
-                hv = hn;
+                hv = hn; hv2 = hn2;
             }
             qh += 3;
         };
@@ -189,12 +229,13 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
                 loadxp(tn);
             } else {
 #pragma unroll
-                for (int st = 0; st < 3; ++st) xr[st] = loadxq(tn, st);
+                for (int st = 0; st < 3; ++st) xr[st] = loadxq(tn, st, xr2[st]);
             }
         }
         // ---- gates (reference GRULayer / RNNDecoder: torch.nn.GRU equations, r|z|n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if constexpr (X3H) { ar[r] *= wInvS; az[r] *= wInvS; anx[r] *= wInvS; anh[r] *= wInvS; }
             const float rg = gate_sigmoid(ar[r]);
             const float zg = gate_sigmoid(az[r]);
             const float ng = gate_tanh(anx[r] + rg * anh[r]);
@@ -220,7 +261,13 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
             hvv[m][0] = hown[4 * m + 0]; hvv[m][1] = hown[4 * m + 1]; hvv[m][2] = hown[4 * m + 2]; hvv[m][3] = hown[4 * m + 3];
         }
         __syncthreads();                           // B: every wave is done reading h_{t-1}
-        if (BF) {
+        if (X3H) {
+            f32x4 ph, pl;
+            split2h(hvv[0], hvv[1], ph, pl);
+            hs[(2 * c + 0) * 128 + lane] = ph; hs[(2 * c + 0) * 128 + 64 + lane] = pl;
+            split2h(hvv[2], hvv[3], ph, pl);
+            hs[(2 * c + 1) * 128 + lane] = ph; hs[(2 * c + 1) * 128 + 64 + lane] = pl;
+        } else if (BF) {
             hs[(c * 2 + 0) * 64 + lane] = cvt8(hvv[0], hvv[1]);
             hs[(c * 2 + 1) * 64 + lane] = cvt8(hvv[2], hvv[3]);
         } else {
@@ -280,15 +327,22 @@ __global__ __launch_bounds__(512, (XMODE == 3 ? 2 : 3)) void k_gru_split(const G
     }
 }
 
+template <int XM, bool F>
+static void launch_split_x3(const GruArgs& a, unsigned grid, int ncg, size_t lds, hipStream_t s) {
+    if constexpr (XM != 3) hipLaunchKernelGGL((k_gru_split<XM, F, false, true, true>), dim3(grid), dim3(64 * ncg), lds, s, a);
+}
+
 static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
     const unsigned grid = (unsigned)((a.B + 31) / 32);
     const size_t lds = ((size_t)ncg * 1024 + (fc ? (size_t)ncg * a.out_dim * 32 : 0)) * sizeof(float);
     if (lds > 64 * 1024) return -2;
     const int xm = xmode == 3 ? 3 : (xmode == 0 ? 0 : (a.Qxp == 1 ? 1 : 2));
     const bool save = a.Gates != nullptr;
+    if (a.x3 && (xm == 3 || save || a.Wxq == nullptr || a.scale == nullptr)) return -2;
 #define SPLIT_CASE(XM, F)                                                                                        \
     if (xm == XM && fc == F) {                                                                                   \
-        if (a.bf16 && !save) hipLaunchKernelGGL((k_gru_split<XM, F, false, true>), dim3(grid), dim3(64 * ncg), lds, s, a); \
+        if (a.x3) launch_split_x3<XM, F>(a, grid, ncg, lds, s);                                                  \
+        else if (a.bf16 && !save) hipLaunchKernelGGL((k_gru_split<XM, F, false, true>), dim3(grid), dim3(64 * ncg), lds, s, a); \
         else if (a.bf16) hipLaunchKernelGGL((k_gru_split<XM, F, true, true>), dim3(grid), dim3(64 * ncg), lds, s, a);      \
         else if (save) hipLaunchKernelGGL((k_gru_split<XM, F, true>), dim3(grid), dim3(64 * ncg), lds, s, a);    \
         else hipLaunchKernelGGL((k_gru_split<XM, F, false>), dim3(grid), dim3(64 * ncg), lds, s, a);             \
@@ -307,6 +361,16 @@ int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t 
     if (xmode == 3 && (a.ldx & 3) != 0) return -2;
     if (xmode != 0 && xmode != 3 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
     if (ncg < 1) return -2;
+    return launch_gru_split(a, ncg, xmode, fc, s);
+}
+
+// split-operand (two fp16 pieces) build of the hidden-tile-split kernel: a.x3 = 1, a.Wh the [gate][piece] pack, a.Wxq the
+// two-piece input pack in [tile][chunk] order, a.Qxp in 16-feature chunks (a multiple of 3, or 1 for the decoder)
+int launch_gru_split_x3(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
+    if (a.B <= 0) return 0;
+    if (!a.x3 || ncg < 1 || xmode == 3) return -2;
+    if (xmode == 0 && ((a.ldx & 3) != 0 || a.Qxp % 3 != 0)) return -2;
+    if (xmode != 0 && a.Qxp != 1 && a.Qxp % 3 != 0) return -2;
     return launch_gru_split(a, ncg, xmode, fc, s);
 }
 

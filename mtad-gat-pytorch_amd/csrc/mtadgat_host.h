@@ -68,7 +68,10 @@ struct GruPlan {
     size_t g1_off = 0, g1T_off = 0;
 };
 constexpr int64_t G16_MAX_WINDOWS = 4096;      // 16 windows per workgroup x 256 CUs: beyond that the throughput kernels take over
-constexpr int64_t CM_MIN_WINDOWS = 4097;      // k_gru_cm (chunk-major recurrence, 128 windows per workgroup) from here on
+constexpr int64_t CM_MIN_WINDOWS = 4097;
+// ... of which the hidden-tile-split kernel's split-operand build takes the lower band: five waves per 32 windows instead of
+// one, a round of 8 192 windows (one workgroup per CU) in ~1.2 ms (GRU + decoder) against the 4 ms of a k_gru_cm round
+constexpr int64_t SPLIT3_MIN_WINDOWS = 2561, SPLIT3_MAX_WINDOWS = 8192;      // k_gru_cm (chunk-major recurrence, 128 windows per workgroup) from here on
 constexpr int64_t G1_MAX_WINDOWS = 1792;       // up to 7 windows per CU one after the other; beyond that 16-window groups pay
 
 // ---- backward (training) plans -------------------------------------------------------------------------

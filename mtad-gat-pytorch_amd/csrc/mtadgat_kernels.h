@@ -326,6 +326,7 @@ int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
 bool gru_cm_supported(int ncg, int xmode, bool fc, int out_dim);
 int launch_gru_cm(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
+int launch_gru_split_x3(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_reorder_xq(const float* src, float* dst, int ncg, int Qd, hipStream_t s);
 long gru_split_max_windows();
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s);

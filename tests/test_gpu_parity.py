@@ -311,3 +311,38 @@ def test_short_last_chunk_is_planned_for_its_own_size(gpu_device):
         finally:
             eng.set_chunk_windows(keep)
     assert torch.equal(p, torch.cat([p1, p2])) and torch.equal(r, torch.cat([r1, r2]))
+
+
+@pytest.mark.parametrize("n_mid", [3000, 8192])
+@pytest.mark.parametrize("name", ["msl", "smd_1_1", "syn_v2_embed", "syn_v1_small"])
+def test_mid_size_batches_match(name, n_mid, gpu_device):
+    """2 561 - 8 192 windows: the hidden-tile-split recurrence on split operands (two fp16 pieces per value, one workgroup
+    of NCG waves per 32 windows) -- fixture windows embedded in such a batch match the reference, the batch agrees with the
+    same windows run as a small batch (16-window-group / window-per-workgroup kernels) and, forced through the engine's
+    measurement hook, with the chunk-major and the tile-major kernels."""
+    case = Case(name)
+    model = case.build_model().to(gpu_device)
+    g = torch.Generator().manual_seed(19)
+    W, F = case.kwargs["window_size"], case.kwargs["n_features"]
+    x = torch.rand(n_mid, W, F, generator=g)
+    n = case.x.shape[0]
+    x[100:100 + n] = case.x
+    x = x.to(gpu_device)
+    with torch.no_grad():
+        p_mid, r_mid = model(x)
+        p_small, r_small = model(x[1000:1300].contiguous())
+        eng = model._sync_engine(gpu_device)
+        outs = {}
+        try:
+            for k in (1, 2, 3):
+                eng.set_option("gru_kernel", k)
+                outs[k] = model(x)
+        finally:
+            eng.set_option("gru_kernel", 0)
+    gate(p_mid[100:100 + n], case.preds, case.preds64, what=f"preds in a {n_mid}-window batch")
+    gate(r_mid[100:100 + n], case.recons, case.recons64, what=f"recons in a {n_mid}-window batch")
+    assert (p_mid[1000:1300] - p_small).abs().max().item() <= 2e-6
+    assert (r_mid[1000:1300] - r_small).abs().max().item() <= 2e-6
+    assert torch.equal(outs[3][0], p_mid) and torch.equal(outs[3][1], r_mid)       # the automatic choice in this band
+    for k in (1, 2):
+        assert (outs[k][0] - p_mid).abs().max().item() <= 2e-6 and (outs[k][1] - r_mid).abs().max().item() <= 2e-6, k
