@@ -496,7 +496,7 @@ def main():
             two_piece = 0.0 < conv_max < 32768.0
             sf = split_issue_factor(kw, two_piece)
             # launch families by kernel template: the GRU layer and the reconstruction decoder are two launches of the same
-            # kernel (k_gru_cm from 4 097 windows per chunk on, k_gru below), the two attention layers two launches of k_gat
+            # kernel (k_gru_cm above 8 192 windows per chunk; the hidden-tile-split kernel on split operands from 2 561), the two attention layers two launches of k_gat
             groups = {"k_conv": ["conv"], "k_gat": ["proj", "attend"], "k_gru": ["gru", "recon"], "k_rowgemm(fc)": ["fc"]}
             fams, tot = {}, {}
             for fam, slots in groups.items():
@@ -546,7 +546,7 @@ def main():
             ms_g, n_g, fl_g = tot["k_gru"]
             ach = fl_g * B * args.steps / (ms_g * 1e-3) / 1e12
             pk_g = fams["k_gru"]["mfma_peak_tflops"]
-            roof_gru = {"kernel": "k_gru (GRU layer + reconstruction decoder: k_gru_cm above 4 096 windows per chunk)", "bound": "mfma",
+            roof_gru = {"kernel": "k_gru (GRU layer + reconstruction decoder: k_gru_cm above 8 192 windows per chunk)", "bound": "mfma",
                         "achieved": round(ach, 2), "peak": pk_g, "unit": "TFLOP/s", "frac": round(ach / pk_g, 4),
                         "alg_frac": round(ach / pk_g, 4),
                         "issued_frac": round(ach * (sf if args.precision == "fp32" else 1.0) / pk_g, 4),
