@@ -2,7 +2,7 @@
 activations the backward needs in a tape, dropout inside the kernels) and the HIP backward
 (`mtadgat_forward_train` / `mtadgat_backward`, include/mtadgat.h).
 
-Configurations without a HIP backward (`Engine.backward_supported()` false: GAT v1, stacked GRU layers,
+Configurations without a HIP backward (`Engine.backward_supported()` false: stacked GRU / decoder layers,
 attention layers beyond 128 nodes) and inputs that themselves require a gradient are evaluated by the
 package's torch-op algebra (`_torchpath.py`) with autograd; `MTAD_GAT.grad_path` says which path the last
 differentiable call took ("hip" / "torch-ops: <reason>").

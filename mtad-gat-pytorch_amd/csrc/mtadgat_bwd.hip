@@ -618,6 +618,150 @@ int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw,
 }
 
 // ---------------------------------------------------------------------------
+// graph attention backward, part 2 for GAT (v1) scores  e_ij = LeakyReLU(s_ij),  s_ij = c_i + d_j,
+//     c_i = a1 . (W v_i + b),  d_j = a2 . (W v_j + b)          (reference modules.py:80-83 / :180-183)
+// Everything below d s_ij = d e_ij [s_ij > 0 ? 1 : alpha] is linear in the node vectors, so no projected embedding is ever
+// formed: with u1 = W^T a1, u2 = W^T a2 (k_gat_v1_prep, once per call), d c_i = sum_j d s_ij and d d_j = sum_i d s_ij,
+//     d v_i += d c_i u1 + d d_i u2
+//     per window:  p1 = sum_i d c_i v_i,  p2 = sum_j d d_j v_j,  sc = sum d c,  sd = sum d d      (k_gat_bwd_v1)
+//     over the batch (k_sum_rows) P1, P2, SC, SD, then (k_gat_v1_finish)
+//     d W = a1 (x) P1 + a2 (x) P2,   d b = a1 SC + a2 SD,   d a1 = W P1 + b SC,   d a2 = W P2 + b SD.
+// ---------------------------------------------------------------------------
+__global__ void k_gat_v1_prep(const float* __restrict__ Wm, const float* __restrict__ bv, const float* __restrict__ av, int E, int D,
+                              float* __restrict__ u) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < D) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int e = 0; e < E; ++e) {
+            const float w = Wm[(long)e * D + d];
+            s1 += av[e] * w;
+            s2 += av[E + e] * w;
+        }
+        u[d] = s1; u[D + d] = s2;
+    } else if (d == D || d == D + 1) {
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) s += av[(d - D) * E + e] * bv[e];
+        u[2 * D + (d - D)] = s;
+    }
+}
+
+// one workgroup (256 threads) per window.  LDS: Vs [K][D + 1] | cq[K] | dk[K] | dc[K] | dd[K]
+__global__ __launch_bounds__(256) void k_gat_bwd_v1(const float* __restrict__ V, int ldv, int D, int K, int vt, const float* __restrict__ u,
+                                                    const float* __restrict__ DE, float alpha, float* __restrict__ DV, int lddv,
+                                                    float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long win = blockIdx.x;
+    const int ld = D + 1;
+    float* __restrict__ Vs = sm;
+    float* __restrict__ cq = Vs + K * ld;
+    float* __restrict__ dk = cq + K;
+    float* __restrict__ dc = dk + K;
+    float* __restrict__ dd = dc + K;
+    {
+        const float* __restrict__ vsrc = V + win * (long)(vt ? D : K) * ldv;
+        if (!vt) {
+            for (int x = tid; x < K * D; x += 256) { const int node = x / D, col = x - node * D; Vs[node * ld + col] = vsrc[(long)node * ldv + col]; }
+        } else {
+            for (int x = tid; x < K * D; x += 256) { const int col = x / K, node = x - col * K; Vs[node * ld + col] = vsrc[(long)col * ldv + node]; }
+        }
+        for (int x = tid; x < 2 * K; x += 256) dc[x] = 0.f;      // dc and dd
+    }
+    __syncthreads();
+    for (int i = tid; i < K; i += 256) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int col = 0; col < D; ++col) { const float v = Vs[i * ld + col]; s1 += u[col] * v; s2 += u[D + col] * v; }
+        cq[i] = s1 + u[2 * D]; dk[i] = s2 + u[2 * D + 1];
+    }
+    __syncthreads();
+    // d s: a wave per query row (lanes over the keys): row sums by a wave reduction, column sums kept per lane
+    const float* __restrict__ de = DE + win * (long)K * K;
+    float colacc[2] = {0.f, 0.f};                  // keys lane, lane + 64  (K <= 128)
+    for (int i = wave; i < K; i += 4) {
+        const float ci = cq[i];
+        float rs = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = lane + 64 * h;
+            if (j < K) {
+                const float sij = ci + dk[j];
+                const float ds = de[(long)i * K + j] * (sij > 0.f ? 1.f : alpha);
+                rs += ds; colacc[h] += ds;
+            }
+        }
+        rs = wave_sum(rs);
+        if (lane == 0) dc[i] = rs;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (lane + 64 * h < K) atomicAdd(&dd[lane + 64 * h], colacc[h]);
+    __syncthreads();
+    for (int x = tid; x < K * D; x += 256) {
+        const int node = x / D, col = x - node * D;
+        DV[(win * K + node) * (long)lddv + col] += dc[node] * u[col] + dd[node] * u[D + col];
+    }
+    float* __restrict__ po = part + win * (long)(2 * D + 2);
+    for (int col = tid; col < D; col += 256) {
+        float p1 = 0.f, p2 = 0.f;
+        for (int i = 0; i < K; ++i) { const float v = Vs[i * ld + col]; p1 += dc[i] * v; p2 += dd[i] * v; }
+        po[col] = p1; po[D + col] = p2;
+    }
+    if (tid == 255) {
+        float sc = 0.f, sd = 0.f;
+        for (int i = 0; i < K; ++i) { sc += dc[i]; sd += dd[i]; }
+        po[2 * D] = sc; po[2 * D + 1] = sd;
+    }
+}
+
+// P = [P1 (D) | P2 (D) | SC | SD] summed over the batch; gradients accumulate into the flat buffer
+__global__ void k_gat_v1_finish(const float* __restrict__ P, const float* __restrict__ Wm, const float* __restrict__ bv,
+                                const float* __restrict__ av, int E, int D, float* __restrict__ gW, float* __restrict__ gb,
+                                float* __restrict__ ga) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)E * D) {
+        const int e = (int)(idx / D), d = (int)(idx - (long)e * D);
+        gW[idx] += av[e] * P[d] + av[E + e] * P[D + d];
+    }
+    if (idx < E) {
+        const int e = (int)idx;
+        const float sc = P[2 * D], sd = P[2 * D + 1];
+        gb[e] += av[e] * sc + av[E + e] * sd;
+        float s1 = 0.f, s2 = 0.f;
+        for (int d = 0; d < D; ++d) { const float w = Wm[(long)e * D + d]; s1 += w * P[d]; s2 += w * P[D + d]; }
+        ga[e] += s1 + bv[e] * sc;
+        ga[E + e] += s2 + bv[e] * sd;
+    }
+}
+
+size_t gat_bwd_v1_lds(int K, int D) { return ((size_t)K * (D + 1) + 4 * (size_t)K) * sizeof(float); }
+
+int launch_gat_v1_prep(const float* Wm, const float* bv, const float* av, int E, int D, float* u, hipStream_t s) {
+    hipLaunchKernelGGL(k_gat_v1_prep, dim3((unsigned)((D + 2 + 255) / 256)), dim3(256), 0, s, Wm, bv, av, E, D, u);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_gat_bwd_v1(const float* V, int ldv, int D, int K, int vt, const float* u, const float* DE, float alpha, float* DV, int lddv,
+                      float* part, long nwin, hipStream_t s) {
+    if (nwin <= 0) return 0;
+    if (K > 128) return -2;
+    const size_t lds = gat_bwd_v1_lds(K, D);
+    if (lds > 64 * 1024) {
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_v1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e_ != hipSuccess) return (int)e_;
+    }
+    hipLaunchKernelGGL(k_gat_bwd_v1, dim3((unsigned)nwin), dim3(256), lds, s, V, ldv, D, K, vt, u, DE, alpha, DV, lddv, part);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_gat_v1_finish(const float* P, const float* Wm, const float* bv, const float* av, int E, int D, float* gW, float* gb, float* ga,
+                         hipStream_t s) {
+    const long total = (long)E * D;
+    hipLaunchKernelGGL(k_gat_v1_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, P, Wm, bv, av, E, D, gW, gb, ga);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // graph attention backward, part 2 (GATv2 scores e_ij = sum_k a_k LeakyReLU(L_ik + R_jk), L = W_l v + b,
 // R = W_r v; modules.py:74-77 / :174-177).  With t = L_ik + R_jk and g = [t > 0]:
 //     d L_ik = a_k (1 - alpha) sum_j d e_ij g         (the alpha part vanishes: sum_j d e_ij = 0, softmax rows)

@@ -1433,6 +1433,23 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         aa.DE = de; aa.DV = dv; aa.lddv = lddv; aa.nwin = n;
         aa.drop = drop; aa.drop_stream = which == 0 ? DROP_FEAT : DROP_TEMP;
         K_TRY(launch_gat_bwd_att(aa, gp.f_IBL, gp.f_JPL, gp.f_RJ, gp.f_nw, gb.att_lds, s), "attention backward (scores)");
+        if (!m.cfg.use_gatv2) {
+            // GAT (v1) scores: linear in the node vectors below d s (mtadgat_bwd.hip)
+            const int E = gp.E, D = gp.D, PV = 2 * D + 2;
+            float* u = ws + w.v1s + (size_t)which * 2 * (2 * std::max(m.F, m.W) + 2);
+            float* P = u + (2 * std::max(m.F, m.W) + 2);
+            const float* Wm = m.packed_dev + gb.w1_off;
+            const float* bv = m.packed_dev + gb.b1_off;
+            const float* av = m.packed_dev + gb.a_off;
+            K_TRY(launch_gat_v1_prep(Wm, bv, av, E, D, u, s), "attention backward (v1 vectors)");
+            K_TRY(launch_gat_bwd_v1(hcat, m.Dp, D, K, aa.vt, u, de, m.cfg.alpha, dv, lddv, dlr, n, s), "attention backward (v1 scores)");
+            HIP_TRY(hipMemsetAsync(P, 0, (size_t)PV * sizeof(float), s));
+            K_TRY(launch_sum_rows(dlr, PV, n, PV, ws + w.sums, P, s), "attention backward (v1 sums)");
+            K_TRY(launch_gat_v1_finish(P, Wm, bv, av, E, D, grads + gl.lin_w[which], grads + gl.lin_b[which], grads + gl.a[which], s),
+                  "attention parameter gradients (v1)");
+            K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
+            continue;
+        }
         GatBwdPairArgs pa{};
         pa.V = hcat; pa.ldv = m.Dp; pa.D = gp.D; pa.K = K; pa.vt = aa.vt; pa.vld = gp.f_vld;
         pa.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + gb.wu_off);

@@ -95,6 +95,8 @@ struct GatBwdPlan {
     LinTPlan lrT;                   // d V += [dL | dR] [W_l ; W_r]
     WgradPlan wg;                   // lin.weight / lin.bias
     size_t att_lds = 0, pair_lds = 0;
+    // GAT (v1): plain copies of lin.weight (E x D), lin.bias (E), a (2E) for the score backward
+    size_t w1_off = 0, b1_off = 0;
 };
 struct GruBwdPlan {
     size_t whT_off = 0;             // W_hh^T tiles for k_gru_bwd
@@ -197,6 +199,7 @@ struct Tape {
 // scratch of the backward
 struct BwdWorkspace {
     size_t da, dhcat, dhdec, dhend, dz0, dz1, de_f, de_t, dv_f, dv_t, dlr_f, dlr_t, dap_f, dap_t, dpre, wpart, sums, total;
+    size_t v1s;          // GAT (v1): [u1 | u2 | k1 k2] and the batch sums [P1 | P2 | SC SD] of the two layers
     size_t wpart_floats;
 };
 

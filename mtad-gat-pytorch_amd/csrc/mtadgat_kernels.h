@@ -355,6 +355,13 @@ int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s);
 // dst[n] += sum_r src[r*ld + n]  (n < N), two-stage through `scratch` (>= sum_rows_scratch(R, N) floats)
 size_t sum_rows_scratch(long R, int N);
 int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, float* dst, hipStream_t s);
+// GAT (v1) score backward (mtadgat_bwd.hip)
+size_t gat_bwd_v1_lds(int K, int D);
+int launch_gat_v1_prep(const float* Wm, const float* bv, const float* av, int E, int D, float* u, hipStream_t s);
+int launch_gat_bwd_v1(const float* V, int ldv, int D, int K, int vt, const float* u, const float* DE, float alpha, float* DV, int lddv,
+                      float* part, long nwin, hipStream_t s);
+int launch_gat_v1_finish(const float* P, const float* Wm, const float* bv, const float* av, int E, int D, float* gW, float* gb, float* ga,
+                         hipStream_t s);
 // decoder input of the reference (modules.py:279) materialised: X[(b*T + t)*ldx + j] = hend[b*ldh + (t*H + j) / T]
 int launch_xdec(const float* hend, long ldh, int H, int T, long B, float* X, long ldx, hipStream_t s);
 // and its adjoint: dhend[b*ldh + m] += sum over the flat positions f = t*H + j with f / T == m of dX[(b*T + t)*ldx + j]

@@ -306,19 +306,27 @@ std::string validate_and_plan(Model& m) {
         gl.total = go;
 
         b.supported = true;
-        if (!c.use_gatv2) { b.supported = false; b.why = "GAT (v1) attention"; }
-        else if (!m.feat.fused || !m.temp.fused) { b.supported = false; b.why = "graph-attention layers beyond the fused kernel (more than 128 nodes / features)"; }
+        if (!m.feat.fused || !m.temp.fused) { b.supported = false; b.why = "graph-attention layers beyond the fused kernel (more than 128 nodes / features)"; }
         else if (c.gru_n_layers != 1 || c.recon_n_layers != 1) { b.supported = false; b.why = "stacked GRU / decoder layers"; }
         if (b.supported) {
             for (int which = 0; which < 2; ++which) {
                 const GatPlan& g = which == 0 ? m.feat : m.temp;
                 GatBwdPlan& gb = b.gat[which];
                 gb.Ep = round_up(g.E, 32); gb.NTu = gb.Ep / 32;
+                gb.att_lds = gat_bwd_att_lds(g.K, g.D, g.f_vld, (g.K + 15) / 16);
+                if (!c.use_gatv2) {
+                    // GAT (v1): the score backward is linear in the node vectors (mtadgat_bwd.hip): plain parameter copies
+                    gb.w1_off = take((size_t)g.E * g.D);
+                    gb.b1_off = take((size_t)g.E);
+                    gb.a_off = take((size_t)2 * g.E);
+                    gb.pair_lds = gat_bwd_v1_lds(g.K, g.D);
+                    if (gb.att_lds > 160 * 1024 || gb.pair_lds > 160 * 1024) { b.supported = false; b.why = "attention backward tiles exceed the LDS"; }
+                    continue;
+                }
                 gb.wu_off = take((size_t)2 * gb.NTu * g.Q * 256);
                 gb.a_off = take((size_t)gb.Ep);
                 lint(gb.lrT, 2 * gb.Ep, g.D);
                 wg(gb.wg, 2 * gb.Ep, g.D, true);
-                gb.att_lds = gat_bwd_att_lds(g.K, g.D, g.f_vld, (g.K + 15) / 16);
                 gb.pair_lds = gat_bwd_pair_lds(g.K, g.f_vld, gb.Ep);
                 if (gb.att_lds > 160 * 1024 || gb.pair_lds > 160 * 1024) { b.supported = false; b.why = "attention backward tiles exceed the LDS"; }
             }
@@ -473,15 +481,19 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
     auto need = [&](const WgradPlan& p, long R) { wp = std::max(wp, (size_t)wgrad_slabs(R, p.Mp, p.Np) * p.Mp * p.Np); };
     const long RW = (long)n * m.W;
     need(b.conv_wg, RW);
-    need(b.gat[0].wg, (long)n * m.F);
-    need(b.gat[1].wg, RW);
+    if (m.cfg.use_gatv2) {
+        need(b.gat[0].wg, (long)n * m.F);
+        need(b.gat[1].wg, RW);
+    }
     need(b.gru.wg_ih, RW); need(b.gru.wg_hh, RW);
     need(b.rec.wg_ih, RW); need(b.rec.wg_hh, RW);
     need(b.recfc_wg, RW);
     for (const WgradPlan& p : b.fc_wg) need(p, (long)n);
     w.wpart_floats = wp;
     w.wpart = take(wp);
-    const size_t smax = std::max((size_t)m.W * m.W, std::max((size_t)m.F * m.F, (size_t)std::max(b.gat[0].Ep, b.gat[1].Ep)));
+    const size_t pv = 2 * (size_t)std::max(m.F, m.W) + 2;             // GAT (v1): per-window partials [p1 | p2 | sc sd]
+    w.v1s = take(4 * pv);
+    const size_t smax = std::max(std::max((size_t)m.W * m.W, pv), std::max((size_t)m.F * m.F, (size_t)std::max(b.gat[0].Ep, b.gat[1].Ep)));
     w.sums = take(sum_rows_scratch(n, (int)smax));
     w.total = off;
 }
@@ -746,6 +758,12 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
             const float* lb = which == 0 ? p.feat_lin_bias : p.temp_lin_bias;
             const float* av = which == 0 ? p.feat_a : p.temp_a;
             const int E = g.E, D = g.D, Ep = gb.Ep;
+            if (!c.use_gatv2) {
+                for (size_t i = 0; i < (size_t)E * D; ++i) out[gb.w1_off + i] = lw[i];
+                for (int e = 0; e < E; ++e) out[gb.b1_off + e] = lb[e];
+                for (int e = 0; e < 2 * E; ++e) out[gb.a_off + e] = av[e];
+                continue;
+            }
             pack_tiles(out.data() + gb.wu_off, 2 * gb.NTu, g.Q, [&](int n, int k) -> float {
                 const int side = n / Ep, e = n % Ep;
                 if (e >= E) return 0.f;

@@ -23,6 +23,11 @@ CONFIGS = {
                        forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 40),
     "smd_shape": (dict(n_features=38, window_size=100, out_dim=38, kernel_size=7, gru_hid_dim=150, forecast_n_layers=3,
                        forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 33),
+    # GAT (v1) scoring (reference modules.py:80-83 / :180-183): LeakyReLU(a1 . Wx_i + a2 . Wx_j), custom embedding dims
+    "v1_small": (dict(n_features=7, window_size=12, out_dim=7, kernel_size=3, use_gatv2=False, feat_gat_embed_dim=5, time_gat_embed_dim=6,
+                      gru_hid_dim=20, forecast_n_layers=2, forecast_hid_dim=24, recon_hid_dim=18, dropout=0.2, alpha=0.2), 37),
+    "v1_msl_shape": (dict(n_features=25, window_size=100, out_dim=1, kernel_size=7, use_gatv2=False, gru_hid_dim=150, forecast_n_layers=3,
+                          forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 20),
     "wide_nodes": (dict(n_features=70, window_size=120, out_dim=5, kernel_size=3, gru_hid_dim=64, forecast_n_layers=1,
                         forecast_hid_dim=32, recon_hid_dim=96, dropout=0.1, alpha=0.2), 9),
 }
@@ -118,7 +123,7 @@ def test_gradients_match_autograd_above_the_small_batch_kernels(name, gpu_device
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape"])
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape"])
 def test_gradients_match_autograd_with_dropout(name, gpu_device):
     """train(): dropout inside the kernels; the same keep-masks (exported by the library) injected into the
     torch-op algebra must give the same outputs and gradients."""
