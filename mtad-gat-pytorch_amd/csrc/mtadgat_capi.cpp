@@ -288,8 +288,15 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     const bool use_cm = cm_fit && !use_sp && m.gru_kernel != 1 && m.gru_kernel != 3 && (m.gru_kernel == 2 || n >= CM_MIN_WINDOWS);
     // large batch, split-bf16 operands: fp32-class results from the bf16 matrix pipe (k_gru X3 build), from 1.25 32-window
     // groups per CU on (measured: 12 320 windows 10.5 ms against 13.1 ms for the hidden-tile-split kernel at 12 288; 8 192 windows 7.4 ms there)
+    // training forward (gates kept for the backward): the same split-operand build of the hidden-tile-split kernel from
+    // SPLIT3_MIN_WINDOWS on -- the input part in the kernel (no pre-projection GEMM on the fp32 pipe), any per-step Linear
+    const bool sp_train = gates != nullptr && m.precision == 2 && g.NCG >= 2 && m.gru_kernel != 1 && n >= SPLIT3_MIN_WINDOWS &&
+                          (g.Qxp16 == 1 || g.Qxp16 % 6 == 0) &&
+                          (g.xmode == 1 ? g.Qxp16 == 1 : ((vmax && g.wx2_off && g.qb3 > 0) || g.qb3 == 0)) && (hend == nullptr || ldhe >= g.Hp) &&
+                          ((size_t)g.NCG * 1024 + (fc ? (size_t)g.NCG * fc->out_dim * 32 : 0)) * sizeof(float) <= 64 * 1024;
     const bool x3 = m.precision == 2 && !gates && ((n + 31) / 32 > 5L * cu_count() / 4 || use_cm || use_sp) &&
                     (g.Qxp16 == 1 || g.Qxp16 % 2 == 0);
+    if (sp_train) xp = nullptr;
     if (!x3 && xp && g.has_xproj && g.xmode == 0) {
         // small batch: all steps' input products as one throughput GEMM, the recurrence keeps only its h part
         RowGemmArgs r{};
@@ -342,6 +349,18 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
     }
     if (gates) {     // training forward: keep the gate activations of every step
         a.Gates = gates;
+        if (sp_train) {
+            GruArgs a3 = a;
+            a3.Wh = reinterpret_cast<const f32x4*>(m.packed_dev + g.wh3_off);
+            a3.whs = 2 * g.NCG + 2; a3.Qxp = g.Qxp16; a3.bf16 = 1; a3.x3 = 1;
+            a3.scale = m.packed_dev + g.scale_off + 1;
+            const bool guard = xmode == 0 && g.qb3 > 0;              // layer 0: the convolution's channels need the recorded range
+            a3.vmax = guard ? vmax : nullptr;
+            a3.Wxq = reinterpret_cast<const f32x4*>(m.packed_dev + (guard ? g.wx2_off : g.wx3_off));
+            K_TRY(launch_gru_split_x3(a3, g.NCG, xmode, fc != nullptr, s), "gru (training, split operands)");
+            if (!guard) return 0;
+            a.vmax = vmax; a.skip_xh = 1;                            // the fp32 kernel serves the launch when the range is too large
+        }
         K_TRY(launch_gru_train(a, g.NCG, xmode, fc != nullptr, s), "gru (training)");
         return 0;
     }
@@ -1247,13 +1266,14 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     float* hcat = T + t.hcat;
     XSource src;
     src.x = x;
-    if ((rc = run_conv(m, src, 0, n, nullptr, T + t.xct, hcat, nullptr, s))) return rc;
+    unsigned* vmax = reinterpret_cast<unsigned*>(T + t.vmax);
+    if ((rc = run_conv(m, src, 0, n, nullptr, T + t.xct, hcat, nullptr, s, vmax))) return rc;
     if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
     if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
     const GruPlan& g = m.gru[0];
     float* hend = T + t.hend;
     if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g, T + t.xp,
-                            use_g16(m, m.gru, n, true)))) return rc;
+                            use_g16(m, m.gru, n, true), vmax))) return rc;
     // forecasting head: ReLU + dropout on the hidden layers (modules.py:307-311), activations kept
     {
         Scope sc(m, S_FC, s);

@@ -329,7 +329,10 @@ __global__ __launch_bounds__(512, (X3H || XMODE == 3 ? 2 : 3)) void k_gru_split(
 
 template <int XM, bool F>
 static void launch_split_x3(const GruArgs& a, unsigned grid, int ncg, size_t lds, hipStream_t s) {
-    if constexpr (XM != 3) hipLaunchKernelGGL((k_gru_split<XM, F, false, true, true>), dim3(grid), dim3(64 * ncg), lds, s, a);
+    if constexpr (XM != 3) {
+        if (a.Gates) hipLaunchKernelGGL((k_gru_split<XM, F, true, true, true>), dim3(grid), dim3(64 * ncg), lds, s, a);
+        else hipLaunchKernelGGL((k_gru_split<XM, F, false, true, true>), dim3(grid), dim3(64 * ncg), lds, s, a);
+    }
 }
 
 static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s) {
@@ -338,7 +341,7 @@ static int launch_gru_split(const GruArgs& a, int ncg, int xmode, bool fc, hipSt
     if (lds > 64 * 1024) return -2;
     const int xm = xmode == 3 ? 3 : (xmode == 0 ? 0 : (a.Qxp == 1 ? 1 : 2));
     const bool save = a.Gates != nullptr;
-    if (a.x3 && (xm == 3 || save || a.Wxq == nullptr || a.scale == nullptr)) return -2;
+    if (a.x3 && (xm == 3 || a.Wxq == nullptr || a.scale == nullptr)) return -2;
 #define SPLIT_CASE(XM, F)                                                                                        \
     if (xm == XM && fc == F) {                                                                                   \
         if (a.x3) launch_split_x3<XM, F>(a, grid, ncg, lds, s);                                                  \

@@ -194,6 +194,7 @@ struct Workspace {
 // activations kept between the training forward and the backward (caller-owned "tape"), offsets in floats
 struct Tape {
     size_t hcat, xct, att_f, att_t, hend, gates_g, seq_g, gates_d, seq_d, xdec, xp, total;
+    size_t vmax;         // one word: bits of the largest convolution output (range guard of the split-operand recurrences)
     std::vector<size_t> fc_act;     // outputs of the hidden forecasting layers (after ReLU + dropout)
 };
 // scratch of the backward

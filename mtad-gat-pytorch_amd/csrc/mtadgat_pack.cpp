@@ -444,6 +444,7 @@ void plan_tape(const Model& m, int64_t n, Tape& t) {
     t.xp = take(N * m.W * 3 * std::max(g.Hp, r.Hp));
     t.fc_act.clear();
     for (size_t i = 0; i + 1 < m.fc.size(); ++i) t.fc_act.push_back(take(N * (size_t)m.fc[i].NT * 32));
+    t.vmax = take(64);
     t.total = off;
 }
 
