@@ -235,9 +235,12 @@ class MTAD_GAT(nn.Module):
             # (bf16 MFMA operands, fp32 accumulation / state / softmax, <= 2e-2), "auto" = bf16 exactly when the
             # caller hands over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
             object.__setattr__(self, "precision", "auto")
-        if "bf16_train_min_batch" not in self.__dict__:
-            # training steps below this many windows run in fp32 even when bf16 is requested (see forward)
-            object.__setattr__(self, "bf16_train_min_batch", 4097)
+        if "bf16_training_recurrences" not in self.__dict__:
+            # False (default): a training step always runs the fp32 step (split-operand / small-batch recurrences), also
+            # when bf16 is requested -- it is the faster one at every batch size (batch 256: 3.2 vs 8.5 ms, 8 192: 46.7 vs
+            # 47.9 ms) and the more accurate one.  True: the four recurrences of the step on bf16 MFMA operands (the
+            # arithmetic of BASELINE's "bf16 train loop" configuration)
+            object.__setattr__(self, "bf16_training_recurrences", False)
         if "check_weight_contents" not in self.__dict__:
             # True: every GPU call fingerprints the parameter *contents* (one small reduction + a host
             # sync), so in-place edits that bypass autograd's version counter (`p.data.mul_()`,
@@ -362,9 +365,9 @@ class MTAD_GAT(nn.Module):
             preds, recons = _torchpath.forward(self, x.float())
             return (preds.to(x.dtype), recons.to(x.dtype)) if x.dtype != torch.float32 else (preds, recons)
         grad_step = self.training or self._wants_grad(x)
-        # training steps of up to 4096 windows: the fp32 16-window-group recurrences with device-side re-packing are
-        # faster than the bf16 build of the throughput kernels, so a bf16 request is served in fp32 there
-        bf16 = self._use_bf16(x) and not (grad_step and x.shape[0] < self.bf16_train_min_batch)
+        # a training step computes in fp32 whatever the request (faster and more accurate than the bf16 recurrence kernels at
+        # every batch size, see bf16_training_recurrences); bf16 tensors are still answered in bf16
+        bf16 = self._use_bf16(x) and (not grad_step or self.bf16_training_recurrences)
         eng = self._sync_engine(x.device, bf16)
         if grad_step:
             # training step (Trainer.fit, training.py:100-130) or any call that will be differentiated:

@@ -248,13 +248,14 @@ def test_backward_stage_diagnostics(gpu_device):
 
 @pytest.mark.parametrize("name", ["odd_shapes", "smd_shape"])
 def test_bf16_training_step_tracks_the_fp32_step(name, gpu_device):
-    """precision = "bf16" in train(): the four recurrences (GRU layer and decoder, forward and BPTT) run on bf16 MFMA
-    operands with fp32 accumulation / state / gate arithmetic (BASELINE config 3: bf16 train loop); everything else
-    is fp32.  Outputs stay within the bf16 inference gate (2e-2); every parameter gradient stays within a few
+    """precision = "bf16" in train() with model.bf16_training_recurrences = True (opt-in; by default a bf16 request trains on
+    the fp32 step, which is faster and more accurate): the four recurrences (GRU layer and decoder, forward and BPTT) run on
+    bf16 MFMA operands with fp32 accumulation / state / gate arithmetic (BASELINE config 3: bf16 train loop); everything
+    else is fp32.  Outputs stay within the bf16 inference gate (2e-2); every parameter gradient stays within a few
     percent of the fp32 step's in norm; a few Adam steps still learn."""
     kw, b = CONFIGS[name]
     model = _model(kw, gpu_device).train()
-    model.bf16_train_min_batch = 0        # by default steps of <= 4096 windows are served by the (faster) fp32 small-batch kernels
+    model.bf16_training_recurrences = True
     g = torch.Generator().manual_seed(14)
     x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
     y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
@@ -270,6 +271,10 @@ def test_bf16_training_step_tracks_the_fp32_step(name, gpu_device):
         return pr.detach(), rc.detach(), {n: p.grad.clone() for n, p in model.named_parameters()}
 
     p32, r32, g32 = step("fp32")
+    model.bf16_training_recurrences = False
+    pd, rd, gd = step("bf16")                                 # default: the bf16 request trains on the fp32 step
+    assert torch.equal(pd, p32) and torch.equal(rd, r32) and all(torch.equal(gd[n], g32[n]) for n in g32)
+    model.bf16_training_recurrences = True
     p16, r16, g16 = step("bf16")
     assert (p16 - p32).abs().max().item() <= 2e-2 and (r16 - r32).abs().max().item() <= 2e-2
     assert not torch.equal(r16, r32)
