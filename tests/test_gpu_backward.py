@@ -273,7 +273,8 @@ def test_bf16_training_step_tracks_the_fp32_step(name, gpu_device):
     p32, r32, g32 = step("fp32")
     model.bf16_training_recurrences = False
     pd, rd, gd = step("bf16")                                 # default: the bf16 request trains on the fp32 step
-    assert torch.equal(pd, p32) and torch.equal(rd, r32) and all(torch.equal(gd[n], g32[n]) for n in g32)
+    assert torch.equal(pd, p32) and torch.equal(rd, r32)      # (the backward sums through float atomics: not bit-reproducible)
+    assert all((gd[n] - g32[n]).abs().max().item() <= 1e-6 + 1e-5 * g32[n].abs().max().item() for n in g32)
     model.bf16_training_recurrences = True
     p16, r16, g16 = step("bf16")
     assert (p16 - p32).abs().max().item() <= 2e-2 and (r16 - r32).abs().max().item() <= 2e-2
