@@ -150,40 +150,45 @@ def point_adjust_counts(score, label, thresholds, compare_f32=False, max_segment
     return out
 
 
-def _point2point(tp, tn, fp, fn):
-    precision = tp / (tp + fp + 0.00001)
-    recall = tp / (tp + fn + 0.00001)
-    f1 = 2 * precision * recall / (precision + recall + 0.00001)
-    return f1, precision, recall, tp, tn, fp, fn
+def _scores_from_counts(tp, tn, fp, fn):
+    """F1 / precision / recall with the reference's 1e-5 guards (eval_methods.py:6-21)."""
+    prec = tp / (tp + fp + 0.00001)
+    rec = tp / (tp + fn + 0.00001)
+    return 2 * prec * rec / (prec + rec + 0.00001), prec, rec
+
+
+def _result(counts, threshold, **extra):
+    f1, prec, rec = _scores_from_counts(counts[0], counts[1], counts[2], counts[3])
+    out = {"f1": f1, "precision": prec, "recall": rec, "TP": counts[0], "TN": counts[1], "FP": counts[2], "FN": counts[3],
+           "threshold": threshold, "latency": counts[4] / (counts[5] + 1e-4)}
+    out.update(extra)
+    return out
 
 
 def epsilon_eval(train_scores, test_scores, test_labels, reg_level=1):
-    """eval_methods.py:164-186."""
-    best_epsilon = find_epsilon(train_scores, reg_level)
+    """Threshold from the training scores (find_epsilon), point-adjusted metrics on the test scores (eval_methods.py:164-186)."""
+    eps = find_epsilon(train_scores, reg_level)
     if test_labels is None:
-        return {"threshold": best_epsilon, "reg_level": reg_level}
-    c = point_adjust_counts(test_scores, test_labels, [best_epsilon])[0]
-    p_t = _point2point(c[0], c[1], c[2], c[3])
-    return {"f1": p_t[0], "precision": p_t[1], "recall": p_t[2], "TP": p_t[3], "TN": p_t[4], "FP": p_t[5], "FN": p_t[6],
-            "threshold": best_epsilon, "latency": c[4] / (c[5] + 1e-4), "reg_level": reg_level}
+        return {"threshold": eps, "reg_level": reg_level}
+    return _result(point_adjust_counts(test_scores, test_labels, [eps])[0], eps, reg_level=reg_level)
 
 
 def bf_search(score, label, start, end=None, step_num=1, display_freq=1, verbose=False):
     """Best-F1 threshold sweep (eval_methods.py:117-158): all thresholds evaluated by one kernel launch."""
     if step_num is None or end is None:
-        end = start
-        step_num = 1
-    search_step, search_range, search_lower_bound = step_num, end - start, start
-    threshold = search_lower_bound
-    thrs = []
-    for _ in range(search_step):                       # the reference accumulates the threshold in a Python float
-        threshold += search_range / float(search_step)
-        thrs.append(threshold)
-    counts = point_adjust_counts(score, label, thrs, compare_f32=True)      # float32 array > Python float: a float32 comparison
-    m, m_t, m_l = (-1.0, -1.0, -1.0), 0.0, 0
-    for thr, c in zip(thrs, counts):
-        target = _point2point(c[0], c[1], c[2], c[3])
-        if target[0] > m[0]:
-            m_t, m, m_l = thr, target, c[4] / (c[5] + 1e-4)
-    return {"f1": m[0], "precision": m[1], "recall": m[2], "TP": m[3], "TN": m[4], "FP": m[5], "FN": m[6], "threshold": m_t,
-            "latency": m_l}
+        end, step_num = start, 1
+    # the reference walks the thresholds by repeated addition in a Python float: the same sums, so the same thresholds
+    increment = (end - start) / float(step_num)
+    grid, at = [], start
+    for _ in range(step_num):
+        at += increment
+        grid.append(at)
+    table = point_adjust_counts(score, label, grid, compare_f32=True)      # float32 array > Python float: a float32 comparison
+    best_row, best_thr, best_f1 = None, 0.0, -1.0
+    for thr, row in zip(grid, table):
+        f1 = _scores_from_counts(row[0], row[1], row[2], row[3])[0]
+        if f1 > best_f1:                               # strict: the first of equal F1 values wins, as in the reference
+            best_row, best_thr, best_f1 = row, thr, f1
+    if best_row is None:
+        return {"f1": -1.0, "precision": -1.0, "recall": -1.0, "TP": -1.0, "TN": -1.0, "FP": -1.0, "FN": -1.0, "threshold": 0.0, "latency": 0}
+    return _result(best_row, best_thr)
