@@ -82,3 +82,51 @@ def test_unsupported_shapes_fail_loudly(gpu_device):
     model = MTAD_GAT(n_features=4, window_size=10, out_dim=1, gru_hid_dim=300).eval().to(gpu_device)
     with pytest.raises(RuntimeError, match="hidden"):
         model(torch.rand(1, 10, 4, device=gpu_device))
+
+
+def _random_shapes(count, seed):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(count):
+        F = rnd.choice([3, 5, 9, 13, 21, 38, 55, 64])
+        W = rnd.choice([8, 17, 30, 64, 100, 120])
+        out.append(dict(n_features=F, window_size=W, out_dim=rnd.choice([1, min(F, 4), F]), kernel_size=rnd.choice([3, 5, 7]),
+                        use_gatv2=rnd.random() < 0.75, gru_n_layers=rnd.choice([1, 1, 2]), gru_hid_dim=rnd.choice([33, 40, 64, 96, 100, 128, 150, 160]),
+                        forecast_n_layers=rnd.choice([1, 3]), forecast_hid_dim=rnd.choice([24, 150]), recon_n_layers=rnd.choice([1, 1, 2]),
+                        recon_hid_dim=rnd.choice([35, 44, 70, 100, 150]), alpha=0.2))
+    return out
+
+
+@pytest.mark.parametrize("idx", list(range(10)))
+def test_recurrence_kernel_bands_on_random_shapes(idx, gpu_device):
+    """Random model shapes through every band of the batch-size dispatch of the default arithmetic -- 3 000 windows
+    (hidden-tile split on split operands), 8 192 (its largest batch), 9 000 (chunk-major), also as stride-1 windows of a series
+    (shared convolution rows) -- against precision = "fp32_strict" (fp32-MFMA kernels, themselves pinned to the oracle at
+    small batches by the tests above): <= 2e-6 of the output scale, and the first windows against the oracle."""
+    from mtad_gat import MTAD_GAT
+    kw = _random_shapes(10, 77)[idx]
+    torch.manual_seed(100 + idx)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+    W, F = kw["window_size"], kw["n_features"]
+    series = torch.rand(W + 9000 - 1, F)
+    with torch.no_grad():
+        x_head = torch.stack([series[i:i + W] for i in range(6)])
+        p_ref, r_ref = oracle.forward(x_head, model.state_dict(), alpha=kw["alpha"])
+        m = model.to(gpu_device)
+        sd = series.to(gpu_device)
+        for n in (3000, 8192, 9000):
+            x = torch.stack([sd[i:i + W] for i in range(n)])
+            m.precision = "fp32_strict"
+            ps, rs = m(x)
+            m.precision = "fp32"
+            pd, rd = m(x)
+            pser, rser = m.forward_series(sd, start=0, stride=1, count=n)
+            tol = 2e-6 * max(1.0, rs.abs().max().item(), ps.abs().max().item())
+            assert (pd - ps).abs().max().item() <= tol and (rd - rs).abs().max().item() <= tol, (kw, n)
+            assert torch.equal(pser, pd) and torch.equal(rser, rd), (kw, n)
+            gate(pd[:6], p_ref, what=f"preds, {n} windows")
+            gate(rd[:6], r_ref, what=f"recons, {n} windows")
