@@ -262,6 +262,10 @@ int mtadgat_backward(mtadgat_handle h, const float* x_dev, int64_t batch, int64_
  * (floats) of the tape / backward-workspace regions (order: see mtadgat_capi.cpp). */
 int mtadgat_dropout_masks(mtadgat_handle h, int64_t batch, int64_t window0, float dropout_p, uint64_t seed,
                           float* mask_feat_dev, float* mask_temp_dev, float* mask_fc_dev, void* stream);
+/* ... and of nn.GRU's dropout between stacked layers (reference modules.py:233, :253; training only): mask_gru
+ * (gru_n_layers - 1, batch, W, gru_hid_dim), mask_rec (recon_n_layers - 1, batch, W, recon_hid_dim); either may be NULL. */
+int mtadgat_dropout_masks_rnn(mtadgat_handle h, int64_t batch, int64_t window0, float dropout_p, uint64_t seed, float* mask_gru,
+                              float* mask_rec, void* stream);
 int mtadgat_train_layout(mtadgat_handle h, int64_t batch, int64_t* offsets_out, int max_n);
 
 /* ---- anomaly-score post-processing on the device (callers' data path) ------

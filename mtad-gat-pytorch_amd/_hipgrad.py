@@ -2,8 +2,7 @@
 activations the backward needs in a tape, dropout inside the kernels) and the HIP backward
 (`mtadgat_forward_train` / `mtadgat_backward`, include/mtadgat.h).
 
-Configurations without a HIP backward (`Engine.backward_supported()` false: stacked GRU / decoder layers,
-attention layers beyond 128 nodes) and inputs that themselves require a gradient are evaluated by the
+Configurations without a HIP backward (`Engine.backward_supported()` false: attention layers beyond 128 nodes) and inputs that themselves require a gradient are evaluated by the
 package's torch-op algebra (`_torchpath.py`) with autograd; `MTAD_GAT.grad_path` says which path the last
 differentiable call took ("hip" / "torch-ops: <reason>").
 """
@@ -24,10 +23,12 @@ def param_order(model):
     names = ["conv.conv.weight", "conv.conv.bias"]
     for g in ("feature_gat", "temporal_gat"):
         names += [f"{g}.lin.weight", f"{g}.lin.bias", f"{g}.a", f"{g}.bias"]
-    names += [f"gru.gru.{k}_l0" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    for l in range(model.gru.gru.num_layers):
+        names += [f"gru.gru.{k}_l{l}" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     for i in range(len(model.forecasting_model.layers)):
         names += [f"forecasting_model.layers.{i}.weight", f"forecasting_model.layers.{i}.bias"]
-    names += [f"recon_model.decoder.rnn.{k}_l0" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    for l in range(model.recon_model.decoder.rnn.num_layers):
+        names += [f"recon_model.decoder.rnn.{k}_l{l}" for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
     names += ["recon_model.fc.weight", "recon_model.fc.bias"]
     named = dict(model.named_parameters())
     return [named[n] for n in names]

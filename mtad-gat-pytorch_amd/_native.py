@@ -94,6 +94,7 @@ def load_library():
     lib.mtadgat_forward_train.argtypes = [vp, vp, i64, i64, f32, u64, vp, vp, vp, sz, vp]
     lib.mtadgat_backward.argtypes = [vp, vp, i64, i64, f32, u64, vp, vp, vp, sz, vp, vp, sz, vp]
     lib.mtadgat_dropout_masks.argtypes = [vp, i64, i64, f32, u64, vp, vp, vp, vp]
+    lib.mtadgat_dropout_masks_rnn.argtypes = [vp, i64, i64, f32, u64, vp, vp, vp]
     lib.mtadgat_profile_enable.argtypes = [vp, ctypes.c_int]
     lib.mtadgat_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     lib.mtadgat_profile_name.argtypes = [ctypes.c_int]
@@ -160,7 +161,7 @@ class Engine:
 
     def grad_layout(self):
         """[offsets] of the flat gradient buffer in the field order of mtadgat_params, total floats."""
-        n = 14 + 2 * self.cfg.forecast_n_linear + 6
+        n = 10 + 4 * self.cfg.gru_n_layers + 2 * self.cfg.forecast_n_linear + 4 * self.cfg.recon_n_layers + 2
         offs = (ctypes.c_int64 * n)()
         got = self.lib.mtadgat_grad_offsets(self.handle, offs, n)
         if got != n:
@@ -227,7 +228,16 @@ class Engine:
         mfc = torch.empty((max(nh, 1), batch, c.forecast_hid_dim), dtype=torch.float32, device=device)
         self._call(self.lib.mtadgat_dropout_masks, "dropout_masks", device, batch, int(window0), float(p), int(seed),
                    _dev_ptr(mf, "mask"), _dev_ptr(mt, "mask"), _dev_ptr(mfc, "mask"))
-        return {"feat": mf, "temp": mt, "fc": [mfc[i] for i in range(nh)]}
+        out = {"feat": mf, "temp": mt, "fc": [mfc[i] for i in range(nh)]}
+        lg, ld = c.gru_n_layers - 1, c.recon_n_layers - 1
+        if lg > 0 or ld > 0:      # nn.GRU's dropout between stacked layers
+            mg = torch.empty((max(lg, 1), batch, c.window_size, c.gru_hid_dim), dtype=torch.float32, device=device)
+            mr = torch.empty((max(ld, 1), batch, c.window_size, c.recon_hid_dim), dtype=torch.float32, device=device)
+            self._call(self.lib.mtadgat_dropout_masks_rnn, "dropout_masks_rnn", device, batch, int(window0), float(p), int(seed),
+                       _dev_ptr(mg, "mask") if lg > 0 else None, _dev_ptr(mr, "mask") if ld > 0 else None)
+            out["gru"] = [mg[i] for i in range(lg)]
+            out["rec"] = [mr[i] for i in range(ld)]
+        return out
 
     # -- weights ------------------------------------------------------------------------------
     def flat_keys(self):

@@ -19,7 +19,8 @@ Dropout follows the reference: on the two attention matrices (modules.py:90, :18
 forecasting layers (modules.py:310) and between stacked GRU layers (modules.py:233, :253, inside
 nn.GRU); masks come from torch's generator in the reference's order of consumption, so a seeded CPU run
 reproduces the reference's masks exactly.  `masks` (optional) injects explicit keep-masks instead:
-{"feat": (b,F,F), "temp": (b,W,W), "fc": [(b,hid), ...]} of 0/1 floats, scaled by 1/(1-p) here.
+{"feat": (b,F,F), "temp": (b,W,W), "fc": [(b,hid), ...]} of 0/1 floats, scaled by 1/(1-p) here; with stacked recurrences also
+"gru" / "rec": [(b,W,H), ...] for nn.GRU's dropout between the layers.
 """
 import torch
 import torch.nn.functional as F
@@ -70,7 +71,24 @@ def temporal_gat_stage(model, xc, training=False, mask=None):
     return graph_attention(xc, model.temporal_gat, training, mask)
 
 
-def gru_stage(model, h_cat):
+def _layered_gru(rnn, x, masks):
+    """nn.GRU evaluated layer by layer (single-layer aten::gru calls on the module's own parameters), with the given keep-masks
+    (b, W, H) applied -- scaled by 1 / (1 - p) -- to the outputs of every layer but the last: nn.GRU's inter-layer dropout
+    (reference modules.py:233 / :253) with the masks made explicit.  Returns the last layer's state sequence."""
+    p = rnn.dropout
+    out = x
+    for l in range(rnn.num_layers):
+        w = [getattr(rnn, f"{k}_l{l}") for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        h0 = out.new_zeros(1, out.shape[0], rnn.hidden_size)
+        out, _ = torch._VF.gru(out, h0, w, True, 1, 0.0, False, False, True)
+        if l + 1 < rnn.num_layers:
+            out = out * masks[l] * (1.0 / (1.0 - p))
+    return out
+
+
+def gru_stage(model, h_cat, masks=None):
+    if masks:
+        return _layered_gru(model.gru.gru, h_cat, masks)[:, -1, :]
     _, h = model.gru.gru(h_cat)                                 # nn.GRU: h0 = 0, inter-layer dropout in train()
     return h[-1]
 
@@ -83,10 +101,13 @@ def forecast_stage(model, h_end, training=False, masks=None):
     return layers[-1](y)
 
 
-def recon_stage(model, h_end):
+def recon_stage(model, h_end, masks=None):
     w = model.recon_model.window_size
     rep = h_end.repeat_interleave(w, dim=1).view(h_end.shape[0], w, h_end.shape[1])     # the reference's decoder input (modules.py:279)
-    dec, _ = model.recon_model.decoder.rnn(rep)
+    if masks:
+        dec = _layered_gru(model.recon_model.decoder.rnn, rep, masks)
+    else:
+        dec, _ = model.recon_model.decoder.rnn(rep)
     return model.recon_model.fc(dec)
 
 
@@ -97,9 +118,9 @@ def forward(model, x, masks=None):
     xc = conv_stage(model, x)
     h_feat = feature_gat_stage(model, xc, training, masks.get("feat"))
     h_temp = temporal_gat_stage(model, xc, training, masks.get("temp"))
-    h_end = gru_stage(model, torch.cat([xc, h_feat, h_temp], dim=2))
+    h_end = gru_stage(model, torch.cat([xc, h_feat, h_temp], dim=2), masks.get("gru"))
     preds = forecast_stage(model, h_end, training, masks.get("fc"))
-    recons = recon_stage(model, h_end)
+    recons = recon_stage(model, h_end, masks.get("rec"))
     return preds, recons
 
 

@@ -1051,6 +1051,30 @@ __global__ void k_dropmask(const DropArgs d, unsigned stream, long nwin, long n,
     const unsigned key = drop_window_key(d, stream, w);
     mask[idx] = (d.thresh == 0 || drop_keep(key, e, d.thresh)) ? 1.f : 0.f;
 }
+// y[row][j] = x[row][j] * keep(window, t * H + j) / (1 - p): the dropout nn.GRU applies to the outputs of every stacked layer
+// but the last (reference modules.py:233 / :253, training only); the same map is its own adjoint (src = dst allowed)
+__global__ void k_seq_dropout(const float* __restrict__ src, float* __restrict__ dst, long nwin, int T, int H, int ld, const DropArgs d,
+                              unsigned stream) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nwin * T * ld) return;
+    const long row = idx / ld;
+    const int j = (int)(idx - row * ld);
+    const long w = row / T;
+    const int t = (int)(row - w * T);
+    float v = 0.f;
+    if (j < H) {
+        v = src[idx];
+        if (d.thresh) v = drop_keep(drop_window_key(d, stream, w), (unsigned)(t * H + j), d.thresh) ? v * d.keep_scale : 0.f;
+    }
+    dst[idx] = v;
+}
+int launch_seq_dropout(const float* src, float* dst, long nwin, int T, int H, int ld, const DropArgs& d, unsigned stream, hipStream_t s) {
+    const long total = nwin * T * ld;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_seq_dropout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, nwin, T, H, ld, d, stream);
+    LAUNCH_CHECK();
+    return 0;
+}
 int launch_dropmask(const DropArgs& d, unsigned stream, long nwin, long n_per_win, float* mask, hipStream_t s) {
     const long total = nwin * n_per_win;
     if (total <= 0) return 0;

@@ -1223,10 +1223,11 @@ int64_t mtadgat_grad_floats(mtadgat_handle h) { return h ? h->m.bw.gl.total : 0;
 int mtadgat_grad_offsets(mtadgat_handle h, int64_t* out, int max_n) {
     if (!h || !out) return fail(MTADGAT_ERR_INVALID, "null argument");
     const GradLayout& g = h->m.bw.gl;
-    std::vector<int64_t> v = {g.conv_w, g.conv_b, g.lin_w[0], g.lin_b[0], g.a[0], g.bias[0], g.lin_w[1], g.lin_b[1], g.a[1], g.bias[1],
-                              g.gru_wih, g.gru_whh, g.gru_bih, g.gru_bhh};
+    std::vector<int64_t> v = {g.conv_w, g.conv_b, g.lin_w[0], g.lin_b[0], g.a[0], g.bias[0], g.lin_w[1], g.lin_b[1], g.a[1], g.bias[1]};
+    for (size_t l = 0; l < g.gru_wih.size(); ++l) v.insert(v.end(), {g.gru_wih[l], g.gru_whh[l], g.gru_bih[l], g.gru_bhh[l]});
     for (size_t i = 0; i < g.fc_w.size(); ++i) { v.push_back(g.fc_w[i]); v.push_back(g.fc_b[i]); }
-    v.insert(v.end(), {g.rec_wih, g.rec_whh, g.rec_bih, g.rec_bhh, g.rec_fc_w, g.rec_fc_b});
+    for (size_t l = 0; l < g.rec_wih.size(); ++l) v.insert(v.end(), {g.rec_wih[l], g.rec_whh[l], g.rec_bih[l], g.rec_bhh[l]});
+    v.insert(v.end(), {g.rec_fc_w, g.rec_fc_b});
     if ((int)v.size() > max_n) return fail(MTADGAT_ERR_INVALID, "offset array too small");
     for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
     return (int)v.size();
@@ -1270,10 +1271,29 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     if ((rc = run_conv(m, src, 0, n, nullptr, T + t.xct, hcat, nullptr, s, vmax))) return rc;
     if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
     if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
-    const GruPlan& g = m.gru[0];
+    // GRU stack (modules.py:235-238): every layer keeps its gates and states; between stacked layers nn.GRU's dropout
+    // (training only; reference modules.py:232-233): the dropped sequence is what the next layer reads and is kept as well
+    const int Lg = (int)m.gru.size(), Ld = (int)m.rec.size();
+    const GruPlan& g = m.gru.back();                 // the layer that produces h_end
     float* hend = T + t.hend;
-    if ((rc = run_gru_layer(m, S_GRU, g, hcat, m.Dp, 3 * F, n, hend, g.Hp, T + t.seq_g, nullptr, nullptr, nullptr, s, T + t.gates_g, T + t.xp,
-                            use_g16(m, m.gru, n, true), vmax))) return rc;
+    {
+        const float* xin = hcat;
+        long ldin = m.Dp;
+        int kx = 3 * F;
+        for (int l = 0; l < Lg; ++l) {
+            const GruPlan& gl_ = m.gru[l];
+            const bool last = l == Lg - 1;
+            float* seq = T + (l == 0 ? t.seq_g : t.seq_gu[l - 1]);
+            float* gates = T + (l == 0 ? t.gates_g : t.gates_gu[l - 1]);
+            if ((rc = run_gru_layer(m, S_GRU, gl_, xin, ldin, kx, n, last ? hend : nullptr, gl_.Hp, seq, nullptr, nullptr, nullptr, s, gates,
+                                    l == 0 ? T + t.xp : nullptr, l == 0 && use_g16(m, m.gru, n, true), l == 0 ? vmax : nullptr))) return rc;
+            if (!last) {
+                float* dr = T + t.drop_g[l];
+                K_TRY(launch_seq_dropout(seq, dr, n, W, gl_.H, gl_.Hp, drop, DROP_GRU0 + (unsigned)l, s), "gru inter-layer dropout");
+                xin = dr; ldin = gl_.Hp; kx = gl_.H;
+            }
+        }
+    }
     // forecasting head: ReLU + dropout on the hidden layers (modules.py:307-311), activations kept
     {
         Scope sc(m, S_FC, s);
@@ -1304,7 +1324,7 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     }
     // reconstruction decoder, all steps kept
     const GruPlan& r = m.rec[0];
-    if (use_g16(m, m.rec, n, true)) {
+    if (Ld == 1 && use_g16(m, m.rec, n, true)) {
         if ((rc = run_gru_layer(m, S_RECON, r, hend, g.Hp, m.cfg.gru_hid_dim, n, nullptr, 0, T + t.seq_d, nullptr, nullptr, nullptr, s, T + t.gates_d,
                                 T + t.xp, true))) return rc;
         Scope sc(m, S_RECON, s);
@@ -1317,8 +1337,26 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
         a.vec_store = (p.out_dim % 4 == 0 && aligned16(recons)) ? 1 : 0;
         a.R = n * (int64_t)W; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
         K_TRY(launch_rowgemm(a, s), "reconstruction Linear (training)");
-    } else if ((rc = run_gru_layer(m, S_RECON, r, hend, g.Hp, m.cfg.gru_hid_dim, n, nullptr, 0, T + t.seq_d, &m.rec_fc, recons, nullptr, s, T + t.gates_d)))
-        return rc;
+    } else {
+        // layer 0 reads the repeated h_end (modules.py:279), the layers above the (dropped-out) states of the one below; the
+        // per-step Linear (modules.py:282) rides in the last layer
+        const float* xin = hend;
+        long ldin = g.Hp;
+        int kx = m.cfg.gru_hid_dim;
+        for (int l = 0; l < Ld; ++l) {
+            const GruPlan& rl = m.rec[l];
+            const bool last = l == Ld - 1;
+            float* seq = T + (l == 0 ? t.seq_d : t.seq_du[l - 1]);
+            float* gates = T + (l == 0 ? t.gates_d : t.gates_du[l - 1]);
+            if ((rc = run_gru_layer(m, S_RECON, rl, xin, ldin, kx, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr, last ? recons : nullptr, nullptr, s,
+                                    gates))) return rc;
+            if (!last) {
+                float* dr = T + t.drop_d[l];
+                K_TRY(launch_seq_dropout(seq, dr, n, W, rl.H, rl.Hp, drop, DROP_REC0 + (unsigned)l, s), "decoder inter-layer dropout");
+                xin = dr; ldin = rl.Hp; kx = rl.H;
+            }
+        }
+    }
     K_TRY(launch_xdec(hend, g.Hp, m.cfg.gru_hid_dim, W, n, T + t.xdec, g.Hp, s), "decoder input");
     return 0;
 }
@@ -1346,8 +1384,9 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
     const int64_t n = batch;
     const long RW = (long)n * W;
     const DropArgs drop = make_drop(dropout_p, seed, window0);
-    const GruPlan& g = m.gru[0];
-    const GruPlan& r = m.rec[0];
+    const int Lg = (int)m.gru.size(), Ld = (int)m.rec.size();
+    const GruPlan& g = m.gru.back();                 // the layer that produced h_end (all GRU layers share the hidden size)
+    const GruPlan& r = m.rec.back();                 // the decoder layer under the per-step Linear
     const float* hcat = T + t.hcat;
     const float* hend = T + t.hend;
     float* wpart = ws + w.wpart;
@@ -1371,68 +1410,82 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
             dy = y; lddy = ldy;
         }
     }
-    // ---- 2. reconstruction model (modules.py:276-283): per-step Linear, decoder GRU, decoder input
+    // One recurrence layer backward: BPTT (gate gradients of every step into `da`) and the layer's weight gradients.
+    // dhseq: gradient of every state (nullptr: none); dhend_: of the last state only (nullptr: none); xin: the rows the layer read.
     float* da = ws + w.da;
+    auto layer_bwd = [&](const GruPlan& q, const GruBwdPlan& qb, bool small, const float* gates, const float* seq, const float* dhseq,
+                         const float* dhend_, const float* xin, long ldxin, int64_t o_wih, int64_t o_whh, int64_t o_bih, int64_t o_bhh,
+                         const char* what) -> int {
+        if (small) {
+            Gru16BwdArgs ga{};
+            ga.Gates = gates; ga.Seq = seq; ga.DHseq = dhseq; ga.lddh = q.Hp; ga.DHend = dhend_; ga.ldde = q.Hp;
+            ga.W16T = m.packed_dev + q.g16T_off; ga.DA = da; ga.Hp = q.Hp; ga.KS = q.KS16; ga.NT16 = q.NT16; ga.T = W; ga.B = n; ga.H = q.H;
+            if (use_g1(n)) {
+                ga.W16T = m.packed_dev + q.g1T_off;
+                K_TRY(launch_gru1_bwd(ga, s), what);
+            } else
+                K_TRY(launch_gru16_bwd(ga, s), what);
+        } else {
+            GruBwdArgs ga{};
+            ga.Gates = gates; ga.Seq = seq; ga.DHseq = dhseq; ga.lddh = q.Hp; ga.DHend = dhend_; ga.ldde = q.Hp;
+            ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + qb.whT_off);
+            ga.DA = da; ga.Hp = q.Hp; ga.H = q.H; ga.T = W; ga.NCG = q.NCG; ga.B = n;
+            if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + qb.whT16_off); }
+            K_TRY(launch_gru_bwd(ga, s), what);
+        }
+        int rc2;
+        WgradIn hh;
+        hh.A = da + q.Hp; hh.lda = 4L * q.Hp; hh.bshift = 1; hh.B = seq; hh.ldb = q.Hp; hh.R = RW; hh.T = W;
+        if ((rc2 = run_wgrad(m, qb.wg_hh, hh, wpart, grads + o_whh, grads + o_bhh, s))) return rc2;
+        WgradIn ih;
+        ih.A = da; ih.lda = 4L * q.Hp; ih.B = xin; ih.ldb = ldxin; ih.R = RW; ih.T = W;
+        return run_wgrad(m, qb.wg_ih, ih, wpart, grads + o_wih, grads + o_bih, s);
+    };
+    // ---- 2. reconstruction model (modules.py:276-283): per-step Linear, decoder layers from the top, decoder input
     float* dhdec = ws + w.dhdec;
     {
+        const float* seq_top = T + (Ld == 1 ? t.seq_d : t.seq_du[Ld - 2]);
         if ((rc = run_rowgemm_T(m, b.recfcT, d_recons, od, RW, dhdec, r.Hp, r.Hp, false, nullptr, 0, 1.f, s))) return rc;
         WgradIn in;
-        in.A = d_recons; in.lda = od; in.B = T + t.seq_d; in.ldb = r.Hp; in.R = RW; in.T = W;
+        in.A = d_recons; in.lda = od; in.B = seq_top; in.ldb = r.Hp; in.R = RW; in.T = W;
         if ((rc = run_wgrad(m, b.recfc_wg, in, wpart, grads + gl.rec_fc_w, grads + gl.rec_fc_b, s))) return rc;
-        if (use_g16(m, m.rec, n, true)) {
-            Gru16BwdArgs ga{};
-            ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
-            ga.W16T = m.packed_dev + r.g16T_off; ga.DA = da; ga.Hp = r.Hp; ga.KS = r.KS16; ga.NT16 = r.NT16; ga.T = W; ga.B = n; ga.H = r.H;
-            if (use_g1(n)) {
-                ga.W16T = m.packed_dev + r.g1T_off;
-                K_TRY(launch_gru1_bwd(ga, s), "decoder backward (window per workgroup)");
-            } else
-            K_TRY(launch_gru16_bwd(ga, s), "decoder backward (16-window groups)");
-        } else {
-        GruBwdArgs ga{};
-        ga.Gates = T + t.gates_d; ga.Seq = T + t.seq_d; ga.DHseq = dhdec; ga.lddh = r.Hp; ga.DHend = nullptr;
-        ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.rec.whT_off);
-        ga.DA = da; ga.Hp = r.Hp; ga.H = r.H; ga.T = W; ga.NCG = r.NCG; ga.B = n;
-        if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.rec.whT16_off); }
-        K_TRY(launch_gru_bwd(ga, s), "decoder backward");
+        for (int l = Ld - 1; l >= 0; --l) {
+            const GruPlan& q = m.rec[l];
+            const float* gates = T + (l == 0 ? t.gates_d : t.gates_du[l - 1]);
+            const float* seq = T + (l == 0 ? t.seq_d : t.seq_du[l - 1]);
+            const float* xin = l == 0 ? T + t.xdec : T + t.drop_d[l - 1];
+            const long ldxin = l == 0 ? m.gru.back().Hp : m.rec[l - 1].Hp;
+            if ((rc = layer_bwd(q, b.rec[l], Ld == 1 && use_g16(m, m.rec, n, true), gates, seq, dhdec, nullptr, xin, ldxin, gl.rec_wih[l],
+                                gl.rec_whh[l], gl.rec_bih[l], gl.rec_bhh[l], "decoder backward"))) return rc;
+            if (l > 0) {
+                // d (dropped states of the layer below), then through the dropout: the gradient of that layer's states
+                const GruPlan& lo = m.rec[l - 1];
+                if ((rc = run_rowgemm_T(m, b.rec[l].wihT, da, 4L * q.Hp, RW, dhdec, lo.Hp, lo.Hp, false, nullptr, 0, 1.f, s))) return rc;
+                K_TRY(launch_seq_dropout(dhdec, dhdec, n, W, lo.H, lo.Hp, drop, DROP_REC0 + (unsigned)(l - 1), s), "decoder inter-layer dropout (adjoint)");
+            } else {
+                // d (decoder input) -> d h_end through the repeat_interleave / view of modules.py:279
+                if ((rc = run_rowgemm_T(m, b.rec[0].wihT, da, 4L * q.Hp, RW, dhdec, g.Hp, g.Hp, false, nullptr, 0, 1.f, s))) return rc;
+                K_TRY(launch_xdec_bwd(dhdec, g.Hp, m.cfg.gru_hid_dim, W, n, dhend, g.Hp, s), "decoder input adjoint");
+            }
         }
-        WgradIn hh;
-        hh.A = da + r.Hp; hh.lda = 4L * r.Hp; hh.bshift = 1; hh.B = T + t.seq_d; hh.ldb = r.Hp; hh.R = RW; hh.T = W;
-        if ((rc = run_wgrad(m, b.rec.wg_hh, hh, wpart, grads + gl.rec_whh, grads + gl.rec_bhh, s))) return rc;
-        WgradIn ih;
-        ih.A = da; ih.lda = 4L * r.Hp; ih.B = T + t.xdec; ih.ldb = g.Hp; ih.R = RW; ih.T = W;
-        if ((rc = run_wgrad(m, b.rec.wg_ih, ih, wpart, grads + gl.rec_wih, grads + gl.rec_bih, s))) return rc;
-        // d (decoder input) -> d h_end through the repeat_interleave / view of modules.py:279
-        if ((rc = run_rowgemm_T(m, b.rec.wihT, da, 4L * r.Hp, RW, dhdec, g.Hp, g.Hp, false, nullptr, 0, 1.f, s))) return rc;
-        K_TRY(launch_xdec_bwd(dhdec, g.Hp, m.cfg.gru_hid_dim, W, n, dhend, g.Hp, s), "decoder input adjoint");
     }
-    // ---- 3. GRU layer (modules.py:235-238)
+    // ---- 3. GRU layers from the top (modules.py:235-238): the last one receives d h_end, the others the gradient of their states
     float* dhcat = ws + w.dhcat;
-    {
-        if (use_g16(m, m.gru, n, true)) {
-            Gru16BwdArgs ga{};
-            ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
-            ga.W16T = m.packed_dev + g.g16T_off; ga.DA = da; ga.Hp = g.Hp; ga.KS = g.KS16; ga.NT16 = g.NT16; ga.T = W; ga.B = n; ga.H = g.H;
-            if (use_g1(n)) {
-                ga.W16T = m.packed_dev + g.g1T_off;
-                K_TRY(launch_gru1_bwd(ga, s), "gru backward (window per workgroup)");
-            } else
-            K_TRY(launch_gru16_bwd(ga, s), "gru backward (16-window groups)");
-        } else {
-        GruBwdArgs ga{};
-        ga.Gates = T + t.gates_g; ga.Seq = T + t.seq_g; ga.DHseq = nullptr; ga.DHend = dhend; ga.ldde = g.Hp;
-        ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.gru.whT_off);
-        ga.DA = da; ga.Hp = g.Hp; ga.H = g.H; ga.T = W; ga.NCG = g.NCG; ga.B = n;
-        if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + b.gru.whT16_off); }
-        K_TRY(launch_gru_bwd(ga, s), "gru backward");
-        }
-        WgradIn hh;
-        hh.A = da + g.Hp; hh.lda = 4L * g.Hp; hh.bshift = 1; hh.B = T + t.seq_g; hh.ldb = g.Hp; hh.R = RW; hh.T = W;
-        if ((rc = run_wgrad(m, b.gru.wg_hh, hh, wpart, grads + gl.gru_whh, grads + gl.gru_bhh, s))) return rc;
-        WgradIn ih;
-        ih.A = da; ih.lda = 4L * g.Hp; ih.B = hcat; ih.ldb = m.Dp; ih.R = RW; ih.T = W;
-        if ((rc = run_wgrad(m, b.gru.wg_ih, ih, wpart, grads + gl.gru_wih, grads + gl.gru_bih, s))) return rc;
-        if ((rc = run_rowgemm_T(m, b.gru.wihT, da, 4L * g.Hp, RW, dhcat, m.Dp, m.Dp, false, nullptr, 0, 1.f, s))) return rc;
+    for (int l = Lg - 1; l >= 0; --l) {
+        const GruPlan& q = m.gru[l];
+        const float* gates = T + (l == 0 ? t.gates_g : t.gates_gu[l - 1]);
+        const float* seq = T + (l == 0 ? t.seq_g : t.seq_gu[l - 1]);
+        const float* xin = l == 0 ? hcat : T + t.drop_g[l - 1];
+        const long ldxin = l == 0 ? m.Dp : m.gru[l - 1].Hp;
+        const bool top = l == Lg - 1;
+        if ((rc = layer_bwd(q, b.gru[l], Lg == 1 && use_g16(m, m.gru, n, true), gates, seq, top ? nullptr : dhdec, top ? dhend : nullptr, xin, ldxin,
+                            gl.gru_wih[l], gl.gru_whh[l], gl.gru_bih[l], gl.gru_bhh[l], "gru backward"))) return rc;
+        if (l > 0) {
+            const GruPlan& lo = m.gru[l - 1];
+            if ((rc = run_rowgemm_T(m, b.gru[l].wihT, da, 4L * q.Hp, RW, dhdec, lo.Hp, lo.Hp, false, nullptr, 0, 1.f, s))) return rc;
+            K_TRY(launch_seq_dropout(dhdec, dhdec, n, W, lo.H, lo.Hp, drop, DROP_GRU0 + (unsigned)(l - 1), s), "gru inter-layer dropout (adjoint)");
+        } else if ((rc = run_rowgemm_T(m, b.gru[0].wihT, da, 4L * q.Hp, RW, dhcat, m.Dp, m.Dp, false, nullptr, 0, 1.f, s)))
+            return rc;
     }
     // ---- 4. the two graph-attention layers (modules.py:65-95, :166-193)
     for (int which = 1; which >= 0; --which) {
@@ -1494,6 +1547,24 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         in.A = dpre; in.lda = m.Fp; in.B = x; in.bmode = 1; in.R = RW; in.T = W;
         if ((rc = run_wgrad(m, b.conv_wg, in, wpart, grads + gl.conv_w, grads + gl.conv_b, s))) return rc;
     }
+    return 0;
+}
+
+/* The keep-masks of nn.GRU's dropout between stacked layers (reference modules.py:233 / :253): mask_gru (gru_n_layers - 1, batch, W, H),
+ * mask_rec (recon_n_layers - 1, batch, W, recon_hid_dim); either may be NULL */
+int mtadgat_dropout_masks_rnn(mtadgat_handle h, int64_t batch, int64_t window0, float dropout_p, uint64_t seed, float* mask_gru,
+                              float* mask_rec, void* stream) {
+    if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");
+    if (batch <= 0) return 0;
+    Model& m = h->m;
+    hipStream_t s = (hipStream_t)stream;
+    const DropArgs drop = make_drop(dropout_p, seed, window0);
+    if (mask_gru)
+        for (size_t l = 0; l + 1 < m.gru.size(); ++l)
+            K_TRY(launch_dropmask(drop, DROP_GRU0 + (unsigned)l, batch, (long)m.W * m.gru[l].H, mask_gru + l * (size_t)batch * m.W * m.gru[l].H, s), "dropout mask");
+    if (mask_rec)
+        for (size_t l = 0; l + 1 < m.rec.size(); ++l)
+            K_TRY(launch_dropmask(drop, DROP_REC0 + (unsigned)l, batch, (long)m.W * m.rec[l].H, mask_rec + l * (size_t)batch * m.W * m.rec[l].H, s), "dropout mask");
     return 0;
 }
 

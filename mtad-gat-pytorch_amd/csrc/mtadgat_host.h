@@ -107,16 +107,17 @@ struct GruBwdPlan {
 struct GradLayout {                 // offsets (floats) into the flat gradient buffer, reference parameter shapes
     int64_t conv_w = 0, conv_b = 0;
     int64_t lin_w[2] = {0, 0}, lin_b[2] = {0, 0}, a[2] = {0, 0}, bias[2] = {0, 0};   // [0] feature, [1] temporal
-    int64_t gru_wih = 0, gru_whh = 0, gru_bih = 0, gru_bhh = 0;
+    std::vector<int64_t> gru_wih, gru_whh, gru_bih, gru_bhh;      // per GRU layer
     std::vector<int64_t> fc_w, fc_b;
-    int64_t rec_wih = 0, rec_whh = 0, rec_bih = 0, rec_bhh = 0, rec_fc_w = 0, rec_fc_b = 0;
+    std::vector<int64_t> rec_wih, rec_whh, rec_bih, rec_bhh;      // per decoder layer
+    int64_t rec_fc_w = 0, rec_fc_b = 0;
     int64_t total = 0;
 };
 struct BwdPlan {
     bool supported = false;
     std::string why;                // reason when not supported
     GatBwdPlan gat[2];              // [0] feature, [1] temporal
-    GruBwdPlan gru, rec;
+    std::vector<GruBwdPlan> gru, rec;   // per layer
     std::vector<LinTPlan> fcT;
     std::vector<WgradPlan> fc_wg;
     LinTPlan recfcT;                // d h_t (decoder) = d recons_t W_fc
@@ -195,6 +196,9 @@ struct Workspace {
 struct Tape {
     size_t hcat, xct, att_f, att_t, hend, gates_g, seq_g, gates_d, seq_d, xdec, xp, total;
     size_t vmax;         // one word: bits of the largest convolution output (range guard of the split-operand recurrences)
+    // stacked recurrences: gates / state sequences of the layers above the first, and the (dropped-out) state sequences
+    // that feed them (nn.GRU's inter-layer dropout, modules.py:233 / :253)
+    std::vector<size_t> gates_gu, seq_gu, drop_g, gates_du, seq_du, drop_d;
     std::vector<size_t> fc_act;     // outputs of the hidden forecasting layers (after ReLU + dropout)
 };
 // scratch of the backward

@@ -40,7 +40,7 @@ struct RowGemmArgs {
 };
 
 // dropout streams (one per dropout site of the reference: modules.py:90, :189, :310)
-enum { DROP_FEAT = 1, DROP_TEMP = 2, DROP_FC0 = 16 };
+enum { DROP_FEAT = 1, DROP_TEMP = 2, DROP_FC0 = 16, DROP_GRU0 = 64, DROP_REC0 = 96 };    // GRU0 / REC0 + l: between stacked layers l and l + 1
 
 struct DropArgs {
     unsigned thresh, seed_lo, seed_hi;   // P(drop) = thresh / 2^32; thresh == 0: no dropout
@@ -371,6 +371,8 @@ int launch_dxc(const float* hcat, const float* dhcat, long ldh, const float* dvt
                long B, int T, int F, float* dpre, long ldp, hipStream_t s);
 // keep-mask (1 / 0) of a dropout stream: mask[w*n + idx] for windows win0 + w (test hook)
 int launch_dropmask(const DropArgs& d, unsigned stream, long nwin, long n_per_win, float* mask, hipStream_t s);
+// nn.GRU's dropout between stacked layers on a (nwin * T, ld) state sequence (columns >= H are written as zero); also its adjoint
+int launch_seq_dropout(const float* src, float* dst, long nwin, int T, int H, int ld, const DropArgs& d, unsigned stream, hipStream_t s);
 int launch_copy2d(const float* src, long lds, float* dst, long ldd, long R, int ncols, hipStream_t s);
 int launch_conv_scatter(const float* cf, const float* el, const float* er, float* hcat, long n, int W, int F, int Fp, int Dp, int pad,
                         hipStream_t s);

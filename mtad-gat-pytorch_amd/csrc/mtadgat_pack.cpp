@@ -290,24 +290,25 @@ std::string validate_and_plan(Model& m) {
             gl.lin_w[which] = gtake((int64_t)g.E * lin_in); gl.lin_b[which] = gtake(g.E);
             gl.a[which] = gtake(c.use_gatv2 ? g.E : 2 * g.E); gl.bias[which] = gtake((int64_t)g.K * g.K);
         }
+        gl.gru_wih.clear(); gl.gru_whh.clear(); gl.gru_bih.clear(); gl.gru_bhh.clear();
         for (int l = 0; l < c.gru_n_layers; ++l) {
             const int in = m.gru[l].in_dim, H = m.gru[l].H;
-            const int64_t a0 = gtake((int64_t)3 * H * in), a1 = gtake((int64_t)3 * H * H), a2 = gtake(3 * H), a3 = gtake(3 * H);
-            if (l == 0) { gl.gru_wih = a0; gl.gru_whh = a1; gl.gru_bih = a2; gl.gru_bhh = a3; }
+            gl.gru_wih.push_back(gtake((int64_t)3 * H * in)); gl.gru_whh.push_back(gtake((int64_t)3 * H * H));
+            gl.gru_bih.push_back(gtake(3 * H)); gl.gru_bhh.push_back(gtake(3 * H));
         }
         gl.fc_w.clear(); gl.fc_b.clear();
         for (const LinPlan& p : m.fc) { gl.fc_w.push_back(gtake((int64_t)p.out_dim * p.in_dim)); gl.fc_b.push_back(gtake(p.out_dim)); }
+        gl.rec_wih.clear(); gl.rec_whh.clear(); gl.rec_bih.clear(); gl.rec_bhh.clear();
         for (int l = 0; l < c.recon_n_layers; ++l) {
             const int in = m.rec[l].in_dim, H = m.rec[l].H;
-            const int64_t a0 = gtake((int64_t)3 * H * in), a1 = gtake((int64_t)3 * H * H), a2 = gtake(3 * H), a3 = gtake(3 * H);
-            if (l == 0) { gl.rec_wih = a0; gl.rec_whh = a1; gl.rec_bih = a2; gl.rec_bhh = a3; }
+            gl.rec_wih.push_back(gtake((int64_t)3 * H * in)); gl.rec_whh.push_back(gtake((int64_t)3 * H * H));
+            gl.rec_bih.push_back(gtake(3 * H)); gl.rec_bhh.push_back(gtake(3 * H));
         }
         gl.rec_fc_w = gtake((int64_t)c.out_dim * c.recon_hid_dim); gl.rec_fc_b = gtake(c.out_dim);
         gl.total = go;
 
         b.supported = true;
         if (!m.feat.fused || !m.temp.fused) { b.supported = false; b.why = "graph-attention layers beyond the fused kernel (more than 128 nodes / features)"; }
-        else if (c.gru_n_layers != 1 || c.recon_n_layers != 1) { b.supported = false; b.why = "stacked GRU / decoder layers"; }
         if (b.supported) {
             for (int which = 0; which < 2; ++which) {
                 const GatPlan& g = which == 0 ? m.feat : m.temp;
@@ -337,8 +338,10 @@ std::string validate_and_plan(Model& m) {
                 wg(gb.wg_ih, 3 * g.Hp, g.in_dim, true);
                 wg(gb.wg_hh, 3 * g.Hp, g.H, true);
             };
-            gru_b(b.gru, m.gru[0]);
-            gru_b(b.rec, m.rec[0]);
+            b.gru.assign(m.gru.size(), GruBwdPlan());
+            b.rec.assign(m.rec.size(), GruBwdPlan());
+            for (size_t l = 0; l < m.gru.size(); ++l) gru_b(b.gru[l], m.gru[l]);
+            for (size_t l = 0; l < m.rec.size(); ++l) gru_b(b.rec[l], m.rec[l]);
             b.fcT.assign(m.fc.size(), LinTPlan());
             b.fc_wg.assign(m.fc.size(), WgradPlan());
             for (size_t i = 0; i < m.fc.size(); ++i) {
@@ -445,6 +448,17 @@ void plan_tape(const Model& m, int64_t n, Tape& t) {
     t.fc_act.clear();
     for (size_t i = 0; i + 1 < m.fc.size(); ++i) t.fc_act.push_back(take(N * (size_t)m.fc[i].NT * 32));
     t.vmax = take(64);
+    t.gates_gu.clear(); t.seq_gu.clear(); t.drop_g.clear(); t.gates_du.clear(); t.seq_du.clear(); t.drop_d.clear();
+    for (size_t l = 1; l < m.gru.size(); ++l) {
+        t.drop_g.push_back(take(N * m.W * m.gru[l - 1].Hp));
+        t.gates_gu.push_back(take(N * m.W * 4 * m.gru[l].Hp));
+        t.seq_gu.push_back(take(N * m.W * m.gru[l].Hp));
+    }
+    for (size_t l = 1; l < m.rec.size(); ++l) {
+        t.drop_d.push_back(take(N * m.W * m.rec[l - 1].Hp));
+        t.gates_du.push_back(take(N * m.W * 4 * m.rec[l].Hp));
+        t.seq_du.push_back(take(N * m.W * m.rec[l].Hp));
+    }
     t.total = off;
 }
 
@@ -459,7 +473,9 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
     const GruPlan& g = m.gru[0];
     const GruPlan& r = m.rec[0];
     const BwdPlan& b = m.bw;
-    const size_t hpmax = std::max(g.Hp, r.Hp);
+    size_t hpmax = std::max(g.Hp, r.Hp);
+    for (const GruPlan& q : m.gru) hpmax = std::max(hpmax, (size_t)q.Hp);
+    for (const GruPlan& q : m.rec) hpmax = std::max(hpmax, (size_t)q.Hp);
     w.da = take(N * m.W * 4 * hpmax);
     w.dhcat = take(N * m.W * m.Dp);
     w.dhdec = take(N * m.W * hpmax);
@@ -486,8 +502,8 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
         need(b.gat[0].wg, (long)n * m.F);
         need(b.gat[1].wg, RW);
     }
-    need(b.gru.wg_ih, RW); need(b.gru.wg_hh, RW);
-    need(b.rec.wg_ih, RW); need(b.rec.wg_hh, RW);
+    for (const GruBwdPlan& gp : b.gru) { need(gp.wg_ih, RW); need(gp.wg_hh, RW); }
+    for (const GruBwdPlan& gp : b.rec) { need(gp.wg_ih, RW); need(gp.wg_hh, RW); }
     need(b.recfc_wg, RW);
     for (const WgradPlan& p : b.fc_wg) need(p, (long)n);
     w.wpart_floats = wp;
@@ -800,8 +816,8 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
             maps(gb.wg_hh, [&](int r) { const int blk = r / Hp, u = r % Hp; return u < H ? (blk * H + u) * H : -1; }, ident,
                  [&](int r) { const int blk = r / Hp, u = r % Hp; return u < H ? blk * H + u : -1; });
         };
-        gru_pack(b.gru, m.gru[0], p.gru_w_ih[0], p.gru_w_hh[0]);
-        gru_pack(b.rec, m.rec[0], p.rec_w_ih[0], p.rec_w_hh[0]);
+        for (size_t l = 0; l < m.gru.size(); ++l) gru_pack(b.gru[l], m.gru[l], p.gru_w_ih[l], p.gru_w_hh[l]);
+        for (size_t l = 0; l < m.rec.size(); ++l) gru_pack(b.rec[l], m.rec[l], p.rec_w_ih[l], p.rec_w_hh[l]);
         for (size_t i = 0; i < m.fc.size(); ++i) {
             const LinPlan& lp = m.fc[i];
             const float* w = p.fc_weight[i];

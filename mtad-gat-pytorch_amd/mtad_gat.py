@@ -18,10 +18,10 @@ Device contract.  Tensors on the GPU ('cuda' = HIP on PyTorch-ROCm) always run t
 HIP kernels in inference (no grad) and raise if `libmtadgat.so` is missing: there is no
 fallback for the inference forward of GPU tensors.  When gradients are wanted, the HIP
 training step (forward that keeps a tape + HIP backward behind a `torch.autograd.Function`)
-runs for the configurations it covers: GATv2 and GAT (v1) attention, one GRU layer and one
-decoder layer, attention layers of at most 128 nodes (window_size, n_features <= 128),
-parameter gradients only.  Outside of that (stacked recurrences, wider layers, an input
-that requires a gradient) the step is evaluated by torch ops on the GPU
+runs for the configurations it covers: GATv2 and GAT (v1) attention, any number of GRU and
+decoder layers (nn.GRU's inter-layer dropout included), attention layers of at most 128 nodes
+(window_size, n_features <= 128), parameter gradients only.  Outside of that (wider layers,
+an input that requires a gradient) the step is evaluated by torch ops on the GPU
 (`_torchpath.py`, autograd): `model.grad_path` names the route and the reason, a
 RuntimeWarning is raised once per reason, and `model.strict_hip_training = True` turns it
 into an error.  A model and input left on the CPU (the reference's

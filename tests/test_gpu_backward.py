@@ -28,6 +28,11 @@ CONFIGS = {
                       gru_hid_dim=20, forecast_n_layers=2, forecast_hid_dim=24, recon_hid_dim=18, dropout=0.2, alpha=0.2), 37),
     "v1_msl_shape": (dict(n_features=25, window_size=100, out_dim=1, kernel_size=7, use_gatv2=False, gru_hid_dim=150, forecast_n_layers=3,
                           forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 20),
+    # stacked recurrences: two GRU layers, two decoder layers (nn.GRU's inter-layer dropout in training)
+    "stacked": (dict(n_features=6, window_size=14, out_dim=2, kernel_size=3, gru_n_layers=2, gru_hid_dim=40, forecast_n_layers=1,
+                     forecast_hid_dim=20, recon_n_layers=2, recon_hid_dim=36, dropout=0.25, alpha=0.2), 21),
+    "stacked3_v1": (dict(n_features=5, window_size=10, out_dim=5, kernel_size=3, use_gatv2=False, gru_n_layers=3, gru_hid_dim=33,
+                         forecast_n_layers=2, forecast_hid_dim=16, recon_n_layers=1, recon_hid_dim=20, dropout=0.1, alpha=0.2), 9),
     "wide_nodes": (dict(n_features=70, window_size=120, out_dim=5, kernel_size=3, gru_hid_dim=64, forecast_n_layers=1,
                         forecast_hid_dim=32, recon_hid_dim=96, dropout=0.1, alpha=0.2), 9),
 }
@@ -98,7 +103,7 @@ def test_gradients_match_autograd_eval_mode(name, gpu_device):
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("name", ["small_v2", "odd_shapes"])
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "stacked"])
 def test_gradients_match_autograd_above_the_small_batch_kernels(name, gpu_device):
     """Up to 4096 windows the fp32 recurrences run in 16-window groups (k_gru16 / k_gru16_bwd), above that on the
     hidden-tile-split kernels (k_gru_split / k_gru_bwd): the same check on a 4100-window batch, and the two kernel
@@ -123,7 +128,7 @@ def test_gradients_match_autograd_above_the_small_batch_kernels(name, gpu_device
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape"])
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape", "stacked", "stacked3_v1"])
 def test_gradients_match_autograd_with_dropout(name, gpu_device):
     """train(): dropout inside the kernels; the same keep-masks (exported by the library) injected into the
     torch-op algebra must give the same outputs and gradients."""
