@@ -998,23 +998,31 @@ int launch_xdec(const float* hend, long ldh, int H, int T, long B, float* X, lon
     return 0;
 }
 
-__global__ void k_xdec_bwd(const float* __restrict__ dX, long ldx, int H, int T, long B, float* __restrict__ dhend, long ldh) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * H) return;
-    const long b = idx / H;
-    const int m = (int)(idx - b * H);
-    float v = 0.f;
-    for (int k = 0; k < T; ++k) {
-        const long f = (long)m * T + k;
-        const int t = (int)(f / H), j = (int)(f - (long)t * H);
-        v += dX[(b * T + t) * ldx + j];
+// adjoint of the decoder input x_t[j] = h_end[(t H + j) / T] (modules.py:279): d h_end[m] += sum of the T consecutive entries
+// m T .. m T + T - 1 of the window's flattened (T, H) block.  One workgroup per window: coalesced reads of the block, the
+// per-entry sums through LDS float atomics (H <= 256).
+__global__ __launch_bounds__(256) void k_xdec_bwd(const float* __restrict__ dX, long ldx, int H, int T, long B, float* __restrict__ dhend, long ldh) {
+    __shared__ float acc[256];
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    acc[tid] = 0.f;
+    __syncthreads();
+    const float* __restrict__ src = dX + b * T * ldx;
+    const int total = T * H;
+    for (int f0 = 0; f0 < total; f0 += 256) {
+        const int f = f0 + tid;
+        if (f < total) {
+            const int t = f / H, j = f - t * H;
+            atomicAdd(&acc[f / T], src[(long)t * ldx + j]);
+        }
     }
-    dhend[b * ldh + m] += v;
+    __syncthreads();
+    if (tid < H) dhend[b * ldh + tid] += acc[tid];
 }
 int launch_xdec_bwd(const float* dX, long ldx, int H, int T, long B, float* dhend, long ldh, hipStream_t s) {
-    const long total = B * H;
-    if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_xdec_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dX, ldx, H, T, B, dhend, ldh);
+    if (B <= 0) return 0;
+    if (H > 256) return -2;
+    hipLaunchKernelGGL(k_xdec_bwd, dim3((unsigned)B), dim3(256), 0, s, dX, ldx, H, T, B, dhend, ldh);
     LAUNCH_CHECK();
     return 0;
 }
