@@ -793,6 +793,7 @@ size_t gat_bwd_pair_lds(int K, int vld, int Ep) {
     const int njq = (nj8 + 3) / 4;
     const int NTn = (K + 31) >> 5;
     size_t f = (size_t)Kp16 * vld + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)32 * njq * 32 + 32 * njq + 64;
+    f += (size_t)K * K + 32 * njq;                  // the window's d e (read K / NW times per embedding column: from LDS, not memory)
     return f * sizeof(float);
 }
 
@@ -816,6 +817,7 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
     float* __restrict__ NS = Rs + NTn * 32 * GP_LLD;
     float* __restrict__ cs = NS + KJ * 32;
     float* __restrict__ daS = cs + KJ;
+    float* __restrict__ des = daS + 64;             // [K][K] + KJ slack (the last row's blocks read past it; masked)
     const int i = lane & 31, g = lane >> 5;
 
     // ---- stage V (+ the ones column D: the projection bias is weight row D), d e, clear the accumulators
@@ -841,11 +843,20 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
         for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
         if (tid < 64) daS[tid] = 0.f;
     }
-    const float* __restrict__ de = a.DE + win * (long)K * K;
-    for (int j = tid; j < KJ; j += nthr) {           // column sums of d e (coalesced over j)
+    // d e of the window into LDS once (coalesced): the pair phase walks its rows once per embedding column and 16-column
+    // pass -- from memory, one 8-key block ahead, that was a chain of exposed round trips (10.6 of the 60 ms of an
+    // 8 192-window step)
+    {
+        const float* __restrict__ deg = a.DE + win * (long)K * K;
+        for (int u = tid; u < K * K; u += nthr) des[u] = deg[u];
+        for (int u = tid; u < KJ; u += nthr) des[K * K + u] = 0.f;
+    }
+    __syncthreads();
+    const float* __restrict__ de = des;
+    for (int j = tid; j < KJ; j += nthr) {           // column sums of d e
         float s = 0.f;
         if (j < K)
-            for (int r = 0; r < K; ++r) s += de[(long)r * K + j];
+            for (int r = 0; r < K; ++r) s += de[r * K + j];
         cs[j] = s;
     }
     __syncthreads();
@@ -897,35 +908,29 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
             for (int j = 0; j < 8 * NJQ; ++j) Nacc[j] = 0.f;
             float s1 = 0.f, s2 = 0.f;
             const float* __restrict__ rsp = Rs + j0 * GP_LLD + k;
+            // the keys' R values of this column do not depend on the query row: registers, not one LDS read per pair
+            float Rv[8 * NJQ];
+#pragma unroll
+            for (int j = 0; j < 8 * NJQ; ++j) Rv[j] = rsp[j * GP_LLD];
             for (int r = wave; r < K; r += NW) {
                 const float L = Ls[r * GP_LLD + k];
-                const float* __restrict__ drow = de + (long)r * K + j0;
+                const float* __restrict__ drow = de + r * K + j0;
                 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // rows of K floats: dword aligned only
-                // the row's d e values of this quarter's keys, eight at a time, the next block requested before the current one
-                // is consumed (slots past K read on into the next row and are masked; the buffer is followed by other workspace
-                // regions).  sched_barrier keeps the blocks apart: all loads of the row hoisted together cost > 128 registers
-                f32x4u da = *reinterpret_cast<const f32x4u*>(drow), db = *reinterpret_cast<const f32x4u*>(drow + 4);
+                // the row's d e values of this quarter's keys (LDS; slots past K read on into the next row / the slack and are masked)
+                f32x4u dq[2 * NJQ];
+#pragma unroll
+                for (int jb = 0; jb < 2 * NJQ; ++jb) dq[jb] = *reinterpret_cast<const f32x4u*>(drow + 4 * jb);
                 float Macc = 0.f;
 #pragma unroll
-                for (int jb = 0; jb < NJQ; ++jb) {
-                    const f32x4u ca = da, cb = db;
-                    if (jb + 1 < NJQ) {
-                        da = *reinterpret_cast<const f32x4u*>(drow + 8 * jb + 8);
-                        db = *reinterpret_cast<const f32x4u*>(drow + 8 * jb + 12);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = 8 * jb + u;
-                        const float dvv = u < 4 ? ca[u & 3] : cb[u & 3];
-                        const float d = (j0 + j < K) ? dvv : 0.f;
-                        const float t = L + rsp[j * GP_LLD];
-                        const float mm = t > 0.f ? d : 0.f;
-                        Macc += mm;
-                        Nacc[j] += mm;
-                        s1 = __builtin_fmaf(d, t, s1);
-                        s2 = __builtin_fmaf(d, fabsf(t), s2);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 8 * NJQ; ++j) {
+                    const float dvv = dq[j >> 2][j & 3];
+                    const float d = (j0 + j < K) ? dvv : 0.f;
+                    const float t = L + Rv[j];
+                    const float mm = t > 0.f ? d : 0.f;
+                    Macc += mm;
+                    Nacc[j] += mm;
+                    s1 = __builtin_fmaf(d, t, s1);
+                    s2 = __builtin_fmaf(d, fabsf(t), s2);
                 }
                 Macc += __shfl_xor(Macc, 16);
                 Macc += __shfl_xor(Macc, 32);
