@@ -134,3 +134,30 @@ def test_torch_op_algebra_matches_the_reference_held_gradients(name):
         ref = c.grads[n]
         d = (prm.grad - ref).abs().max().item()
         assert d <= 1e-5 + 1e-4 * ref.abs().max().item() + c.noise[n], (n, d)
+
+
+def test_layer_by_layer_gru_equals_nn_gru_and_applies_explicit_masks():
+    """_torchpath._layered_gru (the torch-op side of the stacked-layer gradient tests): with all-ones masks it is nn.GRU in
+    eval mode; with a mask it is the per-layer recurrence on the masked, rescaled sequence."""
+    import _torchpath
+    torch.manual_seed(3)
+    rnn = torch.nn.GRU(7, 11, num_layers=3, batch_first=True, dropout=0.25).eval()
+    x = torch.rand(4, 9, 7)
+    ref, _ = rnn(x)
+    ones = [torch.ones(4, 9, 11), torch.ones(4, 9, 11)]
+    p = rnn.dropout
+    got = _torchpath._layered_gru(rnn, x, [m * (1.0 - p) for m in ones])      # keep-scale 1 / (1 - p) cancelled
+    assert (got - ref).abs().max().item() <= 1e-6
+    g = torch.Generator().manual_seed(1)
+    masks = [(torch.rand(4, 9, 11, generator=g) > p).float() for _ in range(2)]
+    got = _torchpath._layered_gru(rnn, x, masks)
+    single = [torch.nn.GRU(7 if l == 0 else 11, 11, batch_first=True) for l in range(3)]
+    for l, s1 in enumerate(single):
+        for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+            getattr(s1, k + "_l0").data.copy_(getattr(rnn, f"{k}_l{l}").data)
+    h = x
+    for l, s1 in enumerate(single):
+        h, _ = s1(h)
+        if l < 2:
+            h = h * masks[l] / (1.0 - p)
+    assert (got - h).abs().max().item() <= 1e-6
