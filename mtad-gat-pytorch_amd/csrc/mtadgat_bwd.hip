@@ -1004,30 +1004,46 @@ int launch_xdec(const float* hend, long ldh, int H, int T, long B, float* X, lon
 }
 
 // adjoint of the decoder input x_t[j] = h_end[(t H + j) / T] (modules.py:279): d h_end[m] += sum of the T consecutive entries
-// m T .. m T + T - 1 of the window's flattened (T, H) block.  One workgroup per window: coalesced reads of the block, the
-// per-entry sums through LDS float atomics (H <= 256).
+// m T .. m T + T - 1 of the window's flattened (T, H) block.  One workgroup per window: coalesced reads of the block into LDS,
+// then one thread per entry sums its T values (blocks beyond 60 KB: sums through LDS float atomics instead); H <= 256.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_xdec_bwd(const float* __restrict__ dX, long ldx, int H, int T, long B, float* __restrict__ dhend, long ldh) {
+    extern __shared__ float xs[];                   // STAGED: the window's T x H block, flattened without the row padding
     __shared__ float acc[256];
     const long b = blockIdx.x;
     const int tid = threadIdx.x;
-    acc[tid] = 0.f;
-    __syncthreads();
     const float* __restrict__ src = dX + b * T * ldx;
     const int total = T * H;
-    for (int f0 = 0; f0 < total; f0 += 256) {
-        const int f = f0 + tid;
-        if (f < total) {
-            const int t = f / H, j = f - t * H;
-            atomicAdd(&acc[f / T], src[(long)t * ldx + j]);
+    if constexpr (STAGED) {
+        for (int f = tid; f < total; f += 256) { const int t = f / H, j = f - t * H; xs[f] = src[(long)t * ldx + j]; }
+        __syncthreads();
+        if (tid < H) {
+            float v = 0.f;
+            for (int k = 0; k < T; ++k) v += xs[tid * T + k];
+            dhend[b * ldh + tid] += v;
         }
+    } else {
+        acc[tid] = 0.f;
+        __syncthreads();
+        for (int f0 = 0; f0 < total; f0 += 256) {
+            const int f = f0 + tid;
+            if (f < total) {
+                const int t = f / H, j = f - t * H;
+                atomicAdd(&acc[f / T], src[(long)t * ldx + j]);
+            }
+        }
+        __syncthreads();
+        if (tid < H) dhend[b * ldh + tid] += acc[tid];
     }
-    __syncthreads();
-    if (tid < H) dhend[b * ldh + tid] += acc[tid];
 }
 int launch_xdec_bwd(const float* dX, long ldx, int H, int T, long B, float* dhend, long ldh, hipStream_t s) {
     if (B <= 0) return 0;
     if (H > 256) return -2;
-    hipLaunchKernelGGL(k_xdec_bwd, dim3((unsigned)B), dim3(256), 0, s, dX, ldx, H, T, B, dhend, ldh);
+    const size_t lds = (size_t)T * H * sizeof(float);
+    if (lds <= 60 * 1024)       // (with the 1 KiB of acc below the 64 KiB that need no opt-in)
+        hipLaunchKernelGGL(k_xdec_bwd<true>, dim3((unsigned)B), dim3(256), lds, s, dX, ldx, H, T, B, dhend, ldh);
+    else
+        hipLaunchKernelGGL(k_xdec_bwd<false>, dim3((unsigned)B), dim3(256), 0, s, dX, ldx, H, T, B, dhend, ldh);
     LAUNCH_CHECK();
     return 0;
 }

@@ -230,7 +230,7 @@ bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n, bool 
     if (m.precision == 1) return !training && n <= 1024;
     // inference in the split-operand arithmetic: from SPLIT3_MIN_WINDOWS on the hidden-tile-split kernel's split-operand build
     // is the faster one (run_gru_layer); the measurement hook can force it at any size
-    if (m.precision == 2 && !training && (m.gru_kernel == 3 || (m.gru_kernel == 0 && n >= SPLIT3_MIN_WINDOWS))) return false;
+    if (m.precision == 2 && !training && stack[0].NCG >= 2 && (m.gru_kernel == 3 || (m.gru_kernel == 0 && n >= SPLIT3_MIN_WINDOWS))) return false;
     return n <= G16_MAX_WINDOWS;
 }
 
