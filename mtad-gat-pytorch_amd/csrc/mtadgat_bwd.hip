@@ -785,21 +785,32 @@ static inline int pair_nj8(int K) {
     return -1;
 }
 
-size_t gat_bwd_pair_lds(int K, int vld, int Ep) {
-    (void)Ep;
+static size_t pair_lds_base(int K, int vld) {
     const int Kp16 = (K + 15) & ~15;
     const int nj8 = pair_nj8(K);
     if (nj8 < 0) return (size_t)1 << 30;
     const int njq = (nj8 + 3) / 4;
     const int NTn = (K + 31) >> 5;
-    size_t f = (size_t)Kp16 * vld + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)32 * njq * 32 + 32 * njq + 64;
-    f += (size_t)K * K + 32 * njq;                  // the window's d e (read K / NW times per embedding column: from LDS, not memory)
-    return f * sizeof(float);
+    return ((size_t)Kp16 * vld + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)32 * njq * 32 + 32 * njq + 64) * sizeof(float);
+}
+// the window's d e in LDS: row r = four blocks (one per 16-lane quarter of the keys) of 8 NJQ + 4 floats -- the quarters then
+// read different banks (the plain [K][K] layout put all four on the same ones: 47 % of the kernel's wave cycles were spent
+// waiting to issue LDS instructions) and every block starts 16-byte aligned (one ds_read_b128 per four keys)
+static size_t pair_lds_de(int K) {
+    const int nj8 = pair_nj8(K);
+    if (nj8 < 0) return (size_t)1 << 30;
+    const int njq = (nj8 + 3) / 4;
+    return (size_t)K * 4 * (8 * njq + 4) * sizeof(float);
+}
+static bool pair_stages_de(int K, int vld) { return pair_lds_base(K, vld) + pair_lds_de(K) <= 160 * 1024; }
+size_t gat_bwd_pair_lds(int K, int vld, int Ep) {
+    (void)Ep;
+    return pair_lds_base(K, vld) + (pair_stages_de(K, vld) ? pair_lds_de(K) : 0);     // (too large: d e is read from memory)
 }
 
 // (from 80 keys on -- NJ8 >= 10: 32 key accumulators per lane -- the 128-register budget of two workgroups per CU spills 27 / 81
 // registers; those instantiations take the 256-register budget and one workgroup per CU)
-template <int NJ8>
+template <int NJ8, bool DES = true>
 __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const GatBwdPairArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NJQ = (NJ8 + 3) / 4;              // 8-key blocks per 16-lane quarter
@@ -817,7 +828,8 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
     float* __restrict__ NS = Rs + NTn * 32 * GP_LLD;
     float* __restrict__ cs = NS + KJ * 32;
     float* __restrict__ daS = cs + KJ;
-    float* __restrict__ des = daS + 64;             // [K][K] + KJ slack (the last row's blocks read past it; masked)
+    constexpr int DBS = 8 * NJQ + 4;                // floats per quarter block of a staged d e row
+    float* __restrict__ des = daS + 64;             // DES: [K][4][DBS]
     const int i = lane & 31, g = lane >> 5;
 
     // ---- stage V (+ the ones column D: the projection bias is weight row D), d e, clear the accumulators
@@ -843,20 +855,27 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
         for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
         if (tid < 64) daS[tid] = 0.f;
     }
-    // d e of the window into LDS once (coalesced): the pair phase walks its rows once per embedding column and 16-column
-    // pass -- from memory, one 8-key block ahead, that was a chain of exposed round trips (10.6 of the 60 ms of an
-    // 8 192-window step)
-    {
-        const float* __restrict__ deg = a.DE + win * (long)K * K;
-        for (int u = tid; u < K * K; u += nthr) des[u] = deg[u];
-        for (int u = tid; u < KJ; u += nthr) des[K * K + u] = 0.f;
+    // d e of the window into LDS once (coalesced reads): the pair phase walks its rows once per embedding column and
+    // 16-column pass.  Keys past K are stored as zeros (no masks in the pair loop).
+    const float* __restrict__ deg = a.DE + win * (long)K * K;
+    if constexpr (DES) {
+        for (int u = tid; u < K * 4 * (DBS - 4); u += nthr) {
+            const int r = u / (4 * (DBS - 4)), jj = u - r * 4 * (DBS - 4);       // key slot jj = 8 NJQ q + (position in the block)
+            const int q = jj / (DBS - 4), pq = jj - q * (DBS - 4);
+            des[(r * 4 + q) * DBS + pq] = jj < K ? deg[(long)r * K + jj] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const float* __restrict__ de = des;
     for (int j = tid; j < KJ; j += nthr) {           // column sums of d e
         float s = 0.f;
-        if (j < K)
-            for (int r = 0; r < K; ++r) s += de[r * K + j];
+        if (j < K) {
+            if constexpr (DES) {
+                const int q = j / (DBS - 4), pq = j - q * (DBS - 4);
+                for (int r = 0; r < K; ++r) s += des[(r * 4 + q) * DBS + pq];
+            } else {
+                for (int r = 0; r < K; ++r) s += deg[(long)r * K + j];
+            }
+        }
         cs[j] = s;
     }
     __syncthreads();
@@ -914,17 +933,27 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
             for (int j = 0; j < 8 * NJQ; ++j) Rv[j] = rsp[j * GP_LLD];
             for (int r = wave; r < K; r += NW) {
                 const float L = Ls[r * GP_LLD + k];
-                const float* __restrict__ drow = de + r * K + j0;
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // rows of K floats: dword aligned only
-                // the row's d e values of this quarter's keys (LDS; slots past K read on into the next row / the slack and are masked)
-                f32x4u dq[2 * NJQ];
+                // the row's d e values of this quarter's keys: its block of the staged row (aligned, conflict free, zeros past K), or
+                // -- d e not staged -- from memory (dword aligned rows; slots past K read on into the next row / region and are masked)
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+                f32x4 dq[2 * NJQ];
+                if constexpr (DES) {
+                    const f32x4* __restrict__ dblk = reinterpret_cast<const f32x4*>(des + (r * 4 + quarter) * DBS);
 #pragma unroll
-                for (int jb = 0; jb < 2 * NJQ; ++jb) dq[jb] = *reinterpret_cast<const f32x4u*>(drow + 4 * jb);
+                    for (int jb = 0; jb < 2 * NJQ; ++jb) dq[jb] = dblk[jb];
+                } else {
+                    const float* __restrict__ drow = deg + (long)r * K + j0;
+#pragma unroll
+                    for (int jb = 0; jb < 2 * NJQ; ++jb) {
+                        const f32x4u t4 = *reinterpret_cast<const f32x4u*>(drow + 4 * jb);
+                        dq[jb] = f32x4{t4[0], t4[1], t4[2], t4[3]};
+                    }
+                }
                 float Macc = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8 * NJQ; ++j) {
                     const float dvv = dq[j >> 2][j & 3];
-                    const float d = (j0 + j < K) ? dvv : 0.f;
+                    const float d = (DES || j0 + j < K) ? dvv : 0.f;
                     const float t = L + Rv[j];
                     const float mm = t > 0.f ? d : 0.f;
                     Macc += mm;
@@ -967,17 +996,24 @@ int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s
     // few windows: one workgroup per (window, group of parts) so that the launch still covers the machine twice
     const long want = (2L * cu_count() + a.nwin - 1) / a.nwin;
     const unsigned split = (unsigned)(want < 1 ? 1 : (want > a.NTu ? a.NTu : want));
-#define GBP_CASE(N)                                                                                                    \
-    if (nj8 == N) {                                                                                                    \
+    const bool des = pair_stages_de(a.K, a.vld);
+#define GBP_LAUNCH(N, D)                                                                                               \
+    {                                                                                                                  \
         if (lds_bytes > 64 * 1024) {                                                                                   \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_pair<N>),                     \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_pair<N, D>),                  \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
             if (e_ != hipSuccess) return (int)e_;                                                                      \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_gat_bwd_pair<N>), dim3(grid, split), dim3(512), lds_bytes, s, a);                        \
+        hipLaunchKernelGGL((k_gat_bwd_pair<N, D>), dim3(grid, split), dim3(512), lds_bytes, s, a);                     \
+    }
+#define GBP_CASE(N)                                                                                                    \
+    if (nj8 == N) {                                                                                                    \
+        if (des) GBP_LAUNCH(N, true) else if (N >= 10) GBP_LAUNCH((N >= 10 ? N : 16), false)                           \
+        else return -2;            /* (up to 64 keys the staged rows always fit) */                                    \
     }
     GBP_CASE(1) GBP_CASE(2) GBP_CASE(3) GBP_CASE(4) GBP_CASE(5) GBP_CASE(6) GBP_CASE(7) GBP_CASE(8) GBP_CASE(10) GBP_CASE(13) GBP_CASE(16)
 #undef GBP_CASE
+#undef GBP_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }
