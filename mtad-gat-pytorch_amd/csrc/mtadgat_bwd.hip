@@ -419,7 +419,8 @@ __device__ __forceinline__ float bw_row_sum(float v) {
     return v;
 }
 
-template <int IBL, int JPL, int RJ>
+// DTM: 16-feature blocks of d V a wave keeps per 64-key pass (4: D <= 64, 8: D <= 128)
+template <int IBL, int JPL, int RJ, int DTM = 8>
 __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
@@ -544,45 +545,73 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
                 if (irow < K && j < K) dep[j] = attv[jj] * (dat[jj] - csum);
             }
         }
-        // ---- d V (aggregation path): out[key][feature] += sum over this wave's 16 rows att'[row][key] d S[row][feature]
-        //   v_mfma_f32_16x16x4_f32: A[m = key][k = row], B[k = row][n = feature]; lane (nr = lane & 15, kb = lane >> 4)
-        //   holds A[nr][kb], B[kb][nr] of rows 4 s + kb for instruction s; D register q of lane (nr, kb) = out[4 kb + q][nr]
-        float* __restrict__ att = atts + wave * (IBW * GB_APITCH);
+    }
+    // ---- d V (aggregation path): out[key][feature] += sum over a wave's 16 rows att'[row][key] d S[row][feature]
+    //   v_mfma_f32_16x16x4_f32: A[m = key][k = row], B[k = row][n = feature]; lane (nr = lane & 15, kb = lane >> 4)
+    //   holds A[nr][kb], B[kb][nr] of rows 4 s + kb for instruction s; D register q of lane (nr, kb) = out[4 kb + q][nr]
+    // A wave keeps its 16 x 16 blocks of a 64-key pass in registers; the waves then add them into dVacc one after the other
+    // (plain read-add-write between barriers: LDS float atomics from all waves at once cost ~180 cycles per wave instruction,
+    // most of this kernel's time; the order of the sums is fixed as well).
+    {
+        float* __restrict__ att = atts + (rows_owner ? wave : 0) * (IBW * GB_APITCH);
         const int nr = lane & 15, kb = lane >> 4;
         constexpr int JPP = 64 / RJ;
         constexpr int PASSES = (JPL + JPP - 1) / JPP;
         const int DT = (D + 15) >> 4;
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
-            if (pass * 64 < K) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int ii = 0; ii < IBL; ++ii)
-#pragma unroll
-                    for (int j4 = 0; j4 < JPP; ++j4)   // every column of the pass (stale LDS contents must not reach the MFMA)
-                        att[(li + RI * ii) * GB_APITCH + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+            if (pass * 64 < K) {                           // (uniform over the workgroup)
                 const int jn = min(64, Kp16 - pass * 64);
-                for (int jt = 0; jt < (jn >> 4); ++jt) {
-                    float av[4];
+                f32x4 oacc[4][DTM];
+                if (rows_owner) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) av[s] = att[(4 * s + kb) * GB_APITCH + 16 * jt + nr];
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const int dcol = 16 * dt + nr;
-                        const int dcc = dcol < vld ? dcol : vld - 1;
-                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const float bv = dSs[(i0 + 4 * s + kb) * vld + dcc];
-                            o = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, o, 0, 0, 0);
-                        }
-                        if (dcol < D) {
+                        for (int j4 = 0; j4 < JPP; ++j4)   // every column of the pass (stale LDS contents must not reach the MFMA)
+                            att[(li + RI * ii) * GB_APITCH + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) atomicAdd(&dVacc[(pass * 64 + 16 * jt + 4 * kb + q) * vld + dcol], o[q]);
+                    for (int jt = 0; jt < 4; ++jt) {
+                        if (jt < (jn >> 4)) {
+                            float av[4];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) av[s] = att[(4 * s + kb) * GB_APITCH + 16 * jt + nr];
+#pragma unroll
+                            for (int dt = 0; dt < DTM; ++dt) {
+                                if (dt < DT) {
+                                    const int dcol = 16 * dt + nr;
+                                    const int dcc = dcol < vld ? dcol : vld - 1;
+                                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s) {
+                                        const float bv = dSs[(i0 + 4 * s + kb) * vld + dcc];
+                                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, o, 0, 0, 0);
+                                    }
+                                    oacc[jt][dt] = o;
+                                }
+                            }
                         }
                     }
+                }
+                for (int wq = 0; wq < NWA; ++wq) {
+                    if (wave == wq) {
+#pragma unroll
+                        for (int jt = 0; jt < 4; ++jt)
+                            if (jt < (jn >> 4)) {
+#pragma unroll
+                                for (int dt = 0; dt < DTM; ++dt) {
+                                    const int dcol = 16 * dt + nr;
+                                    if (dt < DT && dcol < D) {
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) dVacc[(pass * 64 + 16 * jt + 4 * kb + q) * vld + dcol] += oacc[jt][dt][q];
+                                    }
+                                }
+                            }
+                    }
+                    __syncthreads();
                 }
             }
         }
@@ -594,15 +623,19 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
     }
 }
 
-#define GBA_CASE(I, J, RJ_)                                                                                   \
-    if (IBL == I && JPL == J && rj == RJ_) {                                                                  \
-        if (lds_bytes > 64 * 1024) {                                                                          \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_att<I, J, RJ_>),     \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
-            if (e_ != hipSuccess) return (int)e_;                                                             \
-        }                                                                                                     \
-        hipLaunchKernelGGL((k_gat_bwd_att<I, J, RJ_>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);           \
-        launched = true;                                                                                      \
+#define GBA_LAUNCH(I, J, RJ_, DT_)                                                                              \
+    {                                                                                                            \
+        if (lds_bytes > 64 * 1024) {                                                                             \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_att<I, J, RJ_, DT_>),   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
+            if (e_ != hipSuccess) return (int)e_;                                                                \
+        }                                                                                                        \
+        hipLaunchKernelGGL((k_gat_bwd_att<I, J, RJ_, DT_>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);         \
+        launched = true;                                                                                         \
+    }
+#define GBA_CASE(I, J, RJ_)                                                                                      \
+    if (IBL == I && JPL == J && rj == RJ_) {                                                                     \
+        if (a.D <= 64) GBA_LAUNCH(I, J, RJ_, 4) else GBA_LAUNCH(I, J, RJ_, 8)                                    \
     }
 
 int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
