@@ -356,9 +356,11 @@ def train_mode(args, model, kw, dev, world, rank):
     tdims = [0] if kw["out_dim"] == 1 else None     # MSL / SMAP: target dimension 0 (reference utils.py:46-49)
     timings = {}
 
+    dist_on = dist.is_available() and dist.is_initialized()
+
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -369,10 +371,12 @@ def train_mode(args, model, kw, dev, world, rank):
     for _ in range(args.steps):
         rm = dp_training_step(model, x, y, opt, target_dims=tdims, timings=timings)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    mine = time.perf_counter() - t0                 # this rank's own time, before it waits for the others
+    if dist_on:
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = max_over_ranks(time.perf_counter() - t0, dev)
+    per_rank = per_rank_rates(mine, B * args.steps, dev)
     ar = {k: sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1) for k, v in timings.items()}
     if rank == 0:
         n_par = sum(p.numel() for p in model.parameters())
@@ -388,8 +392,41 @@ def train_mode(args, model, kw, dev, world, rank):
             "exchange_ms_per_step": {"stats_allreduce": round(ar.get("stats_events", 0.0), 4), "grad_allreduce": round(ar.get("grad_events", 0.0), 4),
                                      "note": "HIP events around the two collectives on the stream they are enqueued on; 0 at one GPU (skipped)"},
             "grad_path": getattr(model, "grad_path", None), "loss_rmse": [round(float(v), 6) for v in rm],
+            "rccl_ranks": dist.get_world_size() if dist_on else 0, "per_rank_windows_per_s": per_rank,
         }
         print(json.dumps(res))
+
+
+def per_rank_rates(seconds, windows, dev):
+    """Every rank's own windows/s (its time to its own last kernel, before the closing barrier), gathered on all ranks;
+    one entry when not distributed."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [round(windows / seconds, 1)]
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [round(windows / float(o.item()), 1) for o in out]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run
+    (one process per GPU of this node, rendezvous on 127.0.0.1 at a free port).  Fails loudly when the node has fewer
+    than N devices -- a silent one-GPU run reported as an N-GPU number is the failure mode this replaces."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); refusing to run fewer ranks than asked for", file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on these hosts (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -401,6 +438,7 @@ def main():
                     help="infer: MTAD_GAT.forward (the headline metric); train: the data-parallel training step (BASELINE config 5's exchange step)")
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU per step (default 65536, train mode 8192)")
     ap.add_argument("--chunk", type=int, default=0, help="windows per internal chunk (0 = library default)")
+    ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (torch.distributed.run + an RCCL process group) even at --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the batch256 / train_step / bf16 sub-records")
@@ -411,16 +449,26 @@ def main():
     if args.batch <= 0:
         args.batch = 65536 if args.mode == "infer" else 8192
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # `python bench.py --gpus N` with no launcher around it: become the launcher -- one rank per GPU under
+        # torch.distributed.run on this node, RCCL rendezvous on 127.0.0.1 -- and hand its exit code back
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts its own ranks)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank} but this node shows {torch.cuda.device_count()} device(s)")
+    distributed = "WORLD_SIZE" in os.environ and (world > 1 or args.spawn)
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks on {dist.get_backend()}, wanted {args.gpus} on nccl (RCCL)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -433,7 +481,7 @@ def main():
 
     if args.mode == "train":
         train_mode(args, model, kw, dev, world, rank)
-        if world > 1:
+        if distributed:
             dist.destroy_process_group()
         return
 
@@ -447,7 +495,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -461,7 +509,8 @@ def main():
         for _ in range(args.steps):
             preds, recons = model(x)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        mine = time.perf_counter() - t0             # this rank's own time, before it waits for the others
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
@@ -469,6 +518,7 @@ def main():
         eng.profile_enable(False)
     from sharding import max_over_ranks
     elapsed = max_over_ranks(elapsed, dev)      # the slowest rank's time is the job's time
+    per_rank = per_rank_rates(mine, B * args.steps, dev)
     assert torch.isfinite(preds).all() and torch.isfinite(recons).all()
 
     if rank == 0:
@@ -489,6 +539,7 @@ def main():
                                    "(conv + feature-GAT + temporal-GAT + GRU + forecasting/reconstruction heads), "
                                    "weights = shipped MSL checkpoint, x ~ U[0,1) seed 1234+rank, eval mode",
                        "windows_per_gpu_per_step": B, "parallelism": f"dp{world} (windows sharded, no collective)"},
+            "rccl_ranks": dist.get_world_size() if distributed else 0, "per_rank_windows_per_s": per_rank,
         }
         if prof:
             flops = algorithmic_flops(kw)
@@ -584,7 +635,7 @@ def main():
             except Exception as e:  # never lose the GPU number to a baseline problem
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -162,7 +162,10 @@ int mtadgat_bf16_ready(mtadgat_handle h);
 /* Testing / measurement hook (not needed for normal use).  "gru_kernel": which kernel runs the large-batch recurrences
  * (GRULayer.forward modules.py:235-238, the decoder modules.py:276-283) in precision mode 2:
  *   0 automatic (default), 1 the tile-major kernel at every batch size, 2 the chunk-major kernel wherever it applies,
- *   3 the hidden-tile-split kernel on split operands wherever it applies. */
+ *   3 the hidden-tile-split kernel on split operands wherever it applies.
+ * "gat_kernel": which kernel runs the fused attention layers (modules.py:65-95, :166-193) in precision mode 2:
+ *   0 automatic (default: the column-sliced kernel from 4096 windows per chunk on), 1 the row-split kernel k_gat at every batch
+ *   size, 2 the column-sliced kernel k_gat2 wherever it applies (GATv2, <= 104 nodes, convolution outputs below 2^15). */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
 /* Diagnostics for bench.py: the largest convolution output of the last forward() that used workspace `ws` (its last
  * chunk; synchronises `stream`).  Below 2^15 the large-batch kernels used two fp16 pieces per operand, otherwise three

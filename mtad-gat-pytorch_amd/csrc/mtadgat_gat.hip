@@ -185,6 +185,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     // per operand and three MFMA terms instead of three bf16 pieces and six; the weights then carry the layer's power of two
     bool useh = false;
     if constexpr (X3) useh = a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f;
+    if (X3 && a.skip_h && useh) return;                // k_gat2 has served this launch (uniform over the grid: no barrier is split)
     const int npw = X3 ? (useh ? 2 : 3) : 1;           // words per weight chunk and lane
     const f32x4* __restrict__ Wbase = (X3 && useh) ? a.Wp2 : a.Wp;
     f32x4 w[QB][NP];

@@ -35,6 +35,11 @@ struct GatPlan {
     size_t w3_off = 0;      // split-bf16 pack [tile][Q16][piece][64] of the fused projection, derived on the device
     size_t w2h_off = 0;     // two fp16 pieces of S * W, [tile][Q16][2][64]; gscale_off: [bits of max |W|, S, 1 / S, 0]
     size_t gscale_off = 0;
+    // column-sliced fused kernel (k_gat2, mtadgat_gat2.hip): plan, weight pack (fp16 [2 pieces][2 sides][TCP][KP], derived on the device),
+    // number of embedding columns with a' >= 0 (they come first in the pack)
+    Gat2Plan g2;
+    size_t w2g_off = 0;
+    int npos = 0;
 };
 
 struct LinPlan {
@@ -71,6 +76,7 @@ constexpr int64_t G16_MAX_WINDOWS = 4096;      // 16 windows per workgroup x 256
 constexpr int64_t CM_MIN_WINDOWS = 4097;
 // ... of which the hidden-tile-split kernel's split-operand build takes the lower band: five waves per 32 windows instead of
 // one, a round of 8 192 windows (one workgroup per CU) in ~1.2 ms (GRU + decoder) against the 4 ms of a k_gru_cm round
+constexpr int64_t GAT2_MIN_WINDOWS = 4096;     // the column-sliced attention kernel (one workgroup per CU) from here on: below, k_gat's several workgroups per CU hide each other's phases
 constexpr int64_t SPLIT3_MIN_WINDOWS = 2561, SPLIT3_MAX_WINDOWS = 8192;      // k_gru_cm (chunk-major recurrence, 128 windows per workgroup) from here on
 constexpr int64_t G1_MAX_WINDOWS = 1792;       // up to 7 windows per CU one after the other; beyond that 16-window groups pay
 
@@ -176,6 +182,8 @@ struct Model {
     bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
+    int gat2_stop = 0;               // measurement hook: Gat2Args::dbg_stop
+    int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic: 0 automatic, 1 row-split k_gat only, 2 column-sliced k_gat2 at any batch size (testing hook)
     int gru_kernel = 0;              // large-batch recurrence: 0 automatic, 1 tile-major k_gru, 2 chunk-major k_gru_cm (testing hook: mtadgat_set_option)
     DevTables dt;
     // profiling
@@ -212,7 +220,7 @@ std::string validate_and_plan(Model& m);                       // "" on success
 FlatOffsets flat_offsets(const Model& m);
 void params_from_flat(const Model& m, const FlatOffsets& fo, const float* flat, mtadgat_params& p);
 std::string build_device_tables(Model& m);                     // host side of DevTables ("" on success)
-void gat_column_order(const float* a, int E, double alpha, std::vector<int>& colk, int& P8, int& PT);
+void gat_column_order(const float* a, int E, double alpha, std::vector<int>& colk, int& P8, int& PT, int* npos = nullptr);
 void plan_workspace(const Model& m, int64_t n, Workspace& ws); // sizes for n windows
 void plan_tape(const Model& m, int64_t n, Tape& t);
 void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w);

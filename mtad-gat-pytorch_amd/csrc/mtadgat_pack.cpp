@@ -156,6 +156,8 @@ std::string validate_and_plan(Model& m) {
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
         g.w2h_off = take((size_t)g.NT * g.Q16 * 2 * 256);
         g.gscale_off = take(4);
+        g.g2 = Gat2Plan();
+        if (g.fused && c.use_gatv2 && gat2_plan(K, D, E, g.g2)) g.w2g_off = take((size_t)2 * g.g2.TCP * g.g2.KP);
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
@@ -516,9 +518,10 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
 }
 
 // embedding columns with a'_k = (1 - alpha)/2 a_k >= 0 first (padded to a multiple of 8), then the negative ones
-void gat_column_order(const float* a, int E, double alpha, std::vector<int>& colk, int& P8, int& PT) {
+void gat_column_order(const float* a, int E, double alpha, std::vector<int>& colk, int& P8, int& PT, int* npos) {
     std::vector<int> pos, neg;
     for (int k = 0; k < E; ++k) (((1.0 - alpha) * 0.5 * (double)a[k]) >= 0.0 ? pos : neg).push_back(k);
+    if (npos) *npos = (int)pos.size();
     P8 = round_up((int)pos.size(), 8);
     const int N8 = round_up((int)neg.size(), 8);
     PT = P8 + N8;
@@ -539,7 +542,7 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
         //      = c_i + d_j + sum_k a'_k |L_ik + R_jk|,  LeakyReLU(u) = (1+alpha)/2 u + (1-alpha)/2 |u|
         const int lin_in = 2 * D;
         std::vector<int> colk;
-        gat_column_order(a, E, alpha, colk, g.P8, g.PT);
+        gat_column_order(a, E, alpha, colk, g.P8, g.PT, &g.npos);
         for (int n = 0; n < g.PT; ++n) {
             const int k = colk[n];
             if (k < 0) continue;
@@ -909,10 +912,12 @@ std::string build_device_tables(Model& m) {
     mtadgat_params p;
     params_from_flat(m, t.fo, synth.data(), p);
     const int keep[4] = {m.feat.PT, m.feat.P8, m.temp.PT, m.temp.P8};
+    const int keep_np[2] = {m.feat.npos, m.temp.npos};
     const bool keep_bf = m.bf16_packed;
     std::vector<float> img;
     std::string err = pack_weights(m, p, img);
     m.feat.PT = keep[0]; m.feat.P8 = keep[1]; m.temp.PT = keep[2]; m.temp.P8 = keep[3];
+    m.feat.npos = keep_np[0]; m.temp.npos = keep_np[1];
     m.bf16_packed = keep_bf;
     if (!err.empty()) return err;
     t.gidx.assign(m.packed_floats, -1);

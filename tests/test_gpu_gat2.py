@@ -1,0 +1,132 @@
+"""The column-sliced attention kernel (k_gat2, csrc/mtadgat_gat2.hip; reference FeatureAttentionLayer.forward modules.py:65-95
+and TemporalAttentionLayer.forward :166-193).  In normal use it serves batches of 4096 windows and more (the 20 000- and
+65 573-window tests of test_gpu_parity.py go through it); here the engine's testing hook forces it at fixture size, so every
+window is compared with the reference's golden outputs, and odd node counts / embedding widths with the oracle."""
+import pytest
+import torch
+
+from helpers import Case, WideCase, gate
+from oracle import mtad_gat_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(model, dev):
+    return model._sync_engine(dev)
+
+
+@pytest.mark.parametrize("name", ["msl", "smap", "smd_1_1", "syn_v2_embed"])
+def test_fixture_windows_through_the_column_sliced_kernel(name, gpu_device):
+    case = Case(name)
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    x = case.x.to(gpu_device)
+    with torch.no_grad():
+        eng.set_option("gat_kernel", 2)
+        p2, r2 = model(x)
+        eng.set_option("gat_kernel", 1)
+        p1, r1 = model(x)
+        eng.set_option("gat_kernel", 0)
+    dp = gate(p2, case.preds, case.preds64, what=f"{name} predictions (k_gat2)")
+    dr = gate(r2, case.recons, case.recons64, what=f"{name} recons (k_gat2)")
+    print(f"{name}: k_gat2 |preds-ref|={dp:.2e} |recons-ref|={dr:.2e}  vs k_gat: {(p2 - p1).abs().max().item():.2e} {(r2 - r1).abs().max().item():.2e}")
+    assert (p2 - p1).abs().max().item() <= 2e-6 and (r2 - r1).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["msl_wide", "smd_1_1_wide", "msl_c1"])
+def test_wide_fixtures_through_the_column_sliced_kernel(name, gpu_device):
+    """300 / 320 windows per shipped checkpoint incl. the C1 input statistics (values outside [0, 1])."""
+    case = WideCase(name)
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    x = case.x.to(gpu_device)
+    with torch.no_grad():
+        eng.set_option("gat_kernel", 2)
+        preds, recons = model(x)
+        p_split = torch.cat([model(x[lo:lo + 77].contiguous())[0] for lo in range(0, x.shape[0], 77)])
+        eng.set_option("gat_kernel", 0)
+    assert torch.equal(p_split, preds)                      # windows are independent of their batch
+    gate(preds, case.preds, case.preds64, what=f"{name} predictions (k_gat2)")
+    gate(recons, case.recons, case.recons64, what=f"{name} recons (k_gat2)")
+
+
+SHAPES = [
+    # (nodes of the two layers = F and W) accumulator blocks 4..13, embedding widths that leave waves without columns,
+    # node dimensions of one to five 32-feature chunks, feature counts that are / are not multiples of 4
+    dict(n_features=25, window_size=100, out_dim=1, kernel_size=7, gru_hid_dim=40, recon_hid_dim=40),
+    dict(n_features=38, window_size=100, out_dim=38, kernel_size=7, gru_hid_dim=40, recon_hid_dim=40),
+    dict(n_features=32, window_size=104, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24),
+    dict(n_features=41, window_size=73, out_dim=3, kernel_size=5, gru_hid_dim=33, recon_hid_dim=20, feat_gat_embed_dim=3, time_gat_embed_dim=50),
+    dict(n_features=64, window_size=65, out_dim=4, kernel_size=3, gru_hid_dim=17, recon_hid_dim=30),
+    dict(n_features=100, window_size=28, out_dim=1, kernel_size=3, gru_hid_dim=20, recon_hid_dim=20, time_gat_embed_dim=9),
+    dict(n_features=57, window_size=88, out_dim=1, kernel_size=7, gru_hid_dim=20, recon_hid_dim=20, alpha=0.6),
+    dict(n_features=80, window_size=96, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24, feat_gat_embed_dim=60, time_gat_embed_dim=50),
+]
+
+
+@pytest.mark.parametrize("kw", SHAPES, ids=lambda k: f"F{k['n_features']}W{k['window_size']}")
+def test_shapes_against_the_oracle(kw, gpu_device):
+    from mtad_gat import MTAD_GAT
+    torch.manual_seed(29)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+        # both signs of `a` must occur in every wave's column slice for the test to mean something
+        assert (model.temporal_gat.a > 0).any() and (model.temporal_gat.a < 0).any()
+    x = torch.rand(19, kw["window_size"], kw["n_features"])
+    with torch.no_grad():
+        p_ref, r_ref = oracle.forward(x, model.state_dict(), alpha=kw.get("alpha", 0.2))
+        m = model.to(gpu_device)
+        eng = _engine(m, gpu_device)
+        eng.set_option("gat_kernel", 2)
+        p, r = m(x.to(gpu_device))
+        eng.set_option("gat_kernel", 1)
+        p1, r1 = m(x.to(gpu_device))
+    gate(p, p_ref, what="preds (k_gat2)")
+    gate(r, r_ref, what="recons (k_gat2)")
+    gate(p1, p_ref, what="preds (k_gat)")
+    assert (p - p1).abs().max().item() <= 2e-6 and (r - r1).abs().max().item() <= 2e-6
+
+
+def test_large_inputs_fall_back_to_the_row_split_kernel(gpu_device):
+    """Convolution outputs of 2^15 and more do not fit the fp16 pieces: the device-side range guard hands the launch to
+    k_gat's bf16-piece build (both kernels are enqueued, one of them returns at once)."""
+    case = Case("msl")
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(64, 100, 55, generator=g) * 3e4).to(gpu_device)
+    with torch.no_grad():
+        eng.set_option("gat_kernel", 2)
+        p2, r2 = model(x)
+        eng.set_option("gat_kernel", 1)
+        p1, r1 = model(x)
+        eng.set_option("gat_kernel", 0)
+    assert torch.isfinite(p2).all() and torch.isfinite(r2).all()
+    assert torch.equal(p2, p1) and torch.equal(r2, r1)
+
+
+def test_sign_flips_of_a_reach_the_column_sliced_pack(gpu_device):
+    """In-place weight changes that flip signs of the attention vector `a` change the column order of the pack (positive
+    columns first) on the device-side re-pack path; outputs must track the row-split kernel's."""
+    case = Case("msl")
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(40, 100, 55, generator=g).to(gpu_device)
+    with torch.no_grad():
+        for _ in range(2):
+            flip = (torch.rand(model.temporal_gat.a.shape, generator=g) < 0.3).to(gpu_device)
+            model.temporal_gat.a.mul_(torch.where(flip, -1.0, 1.0))
+            model.feature_gat.a.mul_(-1.0)
+            eng = _engine(model, gpu_device)
+            eng.set_option("gat_kernel", 2)
+            p2, r2 = model(x)
+            eng.set_option("gat_kernel", 1)
+            p1, r1 = model(x)
+            eng.set_option("gat_kernel", 0)
+            p_ref, r_ref = oracle.forward(x.cpu(), {k: v.cpu() for k, v in model.state_dict().items()}, alpha=0.2)
+            gate(p2, p_ref, what="preds after sign flips")
+            gate(r2, r_ref, what="recons after sign flips")
+            assert (p2 - p1).abs().max().item() <= 2e-6 and (r2 - r1).abs().max().item() <= 2e-6
