@@ -18,10 +18,13 @@
 //     which wave w owns the complete scores of the query rows {8 ii + li : ii = w, w + NWV, ...}: softmax in the 8-lane
 //     DPP groups, attention rows as fp16 pieces into LDS, aggregation att V on the 16-bit matrix pipe, sigmoid.
 //
-// Node maps: query row of (li, ii) = 8 ii + li (cyclic: the 8 rows an owner wave ends up with per ii are consecutive
-// nodes), key of (lj, jj) = IBL lj + jj (contiguous: bias rows and attention rows are read / written in runs).
+// Node map, the same for query rows and keys: node of (lane group g, index i) = IBL g + i (contiguous per lane: bias rows and
+// attention rows are read / written in runs, and both sides of the projection read the node pieces in the same row order).
 // LDS slot of (g, idx) inside a projected column: g * 4A + idx for idx < 4A (A = IBL / 4: 16-byte reads), the remaining
 // IBL % 4 values in an extra region (slot MAIN + g * EB + idx - 4A).
+//
+// Columns beyond what a wave's LDS slice holds are taken in rounds (project a round, run its pair grid, next round), so that
+// two workgroups fit a CU and the latency-bound phases of one hide behind the pair grid of the other.
 //
 // The kernel serves the default fp32 arithmetic of large batches when the producing convolution recorded node values
 // below 2^15 (GatArgs::vmax); otherwise it returns at once and k_gat (launched behind it with skip_h) does the work.
@@ -94,12 +97,37 @@ __device__ __forceinline__ f32x4 g2_mfma3(const f16x8 ah, const f16x8 al, const 
     return c;
 }
 
-constexpr int G2_IIP = 3;      // query-row indices per reduce-scatter pass
+// sum of the NWV partial rows of one query-row index (JQ float4 per wave, waves IIP * JQ * 64 float4 apart), in wave order
+template <int IBL, int NWV, int IIP>
+__device__ __forceinline__ void g2_gather(float (&dst)[IBL], const f32x4* __restrict__ src) {
+    constexpr int JQ = (IBL + 3) / 4, SB = 4;
+#pragma unroll
+    for (int s0 = 0; s0 < NWV; s0 += SB) {
+        f32x4 v[SB][JQ];
+#pragma unroll
+        for (int w = 0; w < SB; ++w)
+#pragma unroll
+            for (int q = 0; q < JQ; ++q) v[w][q] = src[((s0 + w < NWV ? s0 + w : 0) * IIP * JQ + q) * 64];
+#pragma unroll
+        for (int w = 0; w < SB; ++w)
+#pragma unroll
+            for (int q = 0; q < JQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (s0 + w < NWV && 4 * q + e < IBL) dst[4 * q + e] += v[w][q][e];
+    }
+}
+
+constexpr int G2_KCMAX = 5;    // 32-feature chunks of a node vector incl. the ones column (D <= 128)
+__host__ __device__ constexpr int g2_iip(int ibl) { return ibl >= 9 ? 3 : 2; }      // query-row indices per reduce-scatter pass
 
 }  // namespace
 
+// Two workgroups per CU: while one is in its latency-bound phases (staging, projection, exchange, softmax, aggregation)
+// the other one's pair grid keeps the vector ALU busy.  NT = 256 / 384 / 512 threads for accumulator blocks of
+// 11-13 / 9-10 / 4-8 (two, three, four waves per SIMD by registers).
 template <int IBL, int NT>
-__global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
+__global__ __launch_bounds__(NT, NT / 128) void k_gat2(const Gat2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
     using SL = G2Slots<IBL>;
     constexpr int NWV = NT / 64;
@@ -108,11 +136,19 @@ __global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
     constexpr int NTL = (TOTAL + 15) / 16;        // 16-slot tiles of the projection
     constexpr int JP = IBL <= 8 ? 8 : 16;         // key positions per lane in the attention rows (pad positions hold zeros)
     constexpr int JQ = (IBL + 3) / 4;
-    constexpr int NP = (IBL + G2_IIP - 1) / G2_IIP;
+    constexpr int IIP = g2_iip(IBL);
+    constexpr int NP = (IBL + IIP - 1) / IIP;
     constexpr int NOWN = (IBL + NWV - 1) / NWV;
     static_assert(IBL >= 4 && IBL <= 13, "accumulator block");
 
     if (a.vmax && __uint_as_float(*a.vmax) >= 32768.f) return;         // node values beyond the fp16 pieces: k_gat runs instead
+    // The first workgroups of a launch reach every CU at the same moment and would walk through their phases in step; a
+    // one-time pseudo-random start delay (0..7 x ~3.5 us) spreads them, and since all workgroups take the same time the
+    // spread persists: the pair grid of one workgroup then runs beside the latency-bound phases of its neighbour.
+    if (blockIdx.x < (unsigned)a.stagger_blocks) {
+        const unsigned nap = (blockIdx.x * 2654435761u) >> 29;
+        for (unsigned i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long win = blockIdx.x;
@@ -124,11 +160,13 @@ __global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
     float* __restrict__ cdL = reinterpret_cast<float*>(smem8 + a.off_cd);
     float* __restrict__ cdR = cdL + TOTAL;
 
-    // this wave's embedding columns [c0, c1) of the TC = E + 1 (the last one carries the rank-1 terms c_i / d_j)
+    // this wave's embedding columns [c0, c1) of the TC = E + 1 (the last one carries the rank-1 terms c_i / d_j), taken in
+    // rounds of at most CW columns (the LDS slice of a wave holds one round)
     const int TC = a.E + 1;
     const int c0 = (wave * TC) / NWV, c1 = ((wave + 1) * TC) / NWV;
-    const int ncol = c1 - c0;
-    const int nabs = (c1 < a.E ? c1 : a.E) - c0;
+
+    const _Float16* __restrict__ Wg = reinterpret_cast<const _Float16*>(a.W);
+    const long sstride = (long)a.TCP * a.KP, pstride = 2 * sstride;
 
     // ---- stage the window: node vectors as two fp16 pieces, Vh/Vl[node][feature], feature D = 1 (the projection bias is
     // weight row D), features (D, KP) = 0.  vt == 0: source rows are the nodes; vt == 1: source columns are the nodes.
@@ -140,7 +178,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
         const float rinv = 1.0f / (float)UR;
         const float* __restrict__ vsrc = a.V + win * (long)srows * a.ldv;
         const int c4last = ((scols - 1) >> 2) << 2;
-        constexpr int MAXU = 4;
+        constexpr int MAXU = NT >= 512 ? 3 : 6;
         for (int base = 0; base < total; base += MAXU * NT) {
             f32x4 v[MAXU];
             int rr[MAXU], cc[MAXU];
@@ -183,8 +221,10 @@ __global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
                 }
             }
         }
+        // the last node's chunk reads run past its row when the pitch is below KP: keep what they meet finite
+        for (int u = tid; u < a.KP; u += NT) reinterpret_cast<unsigned short*>(Vl)[K * pv + u] = 0;
         // ones column and zero padding (vt == 0: the columns the units above did not reach)
-        const int f0 = a.vt ? D : 4 * UR, nf = a.KP - f0;
+        const int f0 = a.vt ? D : 4 * UR, nf = (a.KP < pv ? a.KP : pv) - f0;       // (a pitch below KP: the tail of the last chunk reads on into the next row)
         if (nf > 0) {
             const float ninv = 1.0f / (float)nf;
             for (int u = tid; u < K * nf; u += NT) {
@@ -199,110 +239,136 @@ __global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
 
     float* __restrict__ Lw = reinterpret_cast<float*>(smem8 + a.off_lr) + wave * a.lr_wave_floats;
     float* __restrict__ Rw = Lw + a.CW * CS;
-
-    // ---- projection of this wave's columns: D[slot][col] = sum_f V[node(slot)][f] W[col][f] on v_mfma_f32_16x16x32_f16,
-    // A = node vectors (16 slots of a tile; lane (m, kb): 8 features), B = weights (lane (n, kb): column c0 + n).
-    // Result lane (n, mb): slots 16 T + 4 mb .. + 3 of column n -> one 16-byte LDS store.  The fp16 weights carry the
-    // layer's power of two S; it is taken out of the scores at the end.
-    if (ncol > 0) {
-        int offL[NTL], offR[NTL];
-#pragma unroll
-        for (int T = 0; T < NTL; ++T) {
-            int s = 16 * T + n16;
-            s = s < TOTAL ? s : TOTAL - 1;
-            int g, idx;
-            if (s < MAIN) { g = s / (4 * A4 > 0 ? 4 * A4 : 1); idx = s - g * 4 * A4; }
-            else { const int x = s - MAIN; g = x / (EB > 0 ? EB : 1); idx = 4 * A4 + (x - g * EB); }
-            idx = idx < IBL ? idx : IBL - 1;
-            int nl = idx * 8 + g, nr = g * IBL + idx;
-            nl = nl < K ? nl : K - 1;
-            nr = nr < K ? nr : K - 1;
-            offL[T] = nl * pv + 8 * kb;
-            offR[T] = nr * pv + 8 * kb;
-        }
-        f32x4 pacc[NTL][2];
-#pragma unroll
-        for (int T = 0; T < NTL; ++T) { pacc[T][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[T][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const _Float16* __restrict__ Wg = reinterpret_cast<const _Float16*>(a.W);
-        const long sstride = (long)a.TCP * a.KP, pstride = 2 * sstride;
-        const _Float16* __restrict__ wl = Wg + (long)(c0 + n16) * a.KP + 8 * kb;
-#pragma unroll 1
-        for (int c = 0; c < a.KC; ++c) {
-            f16x8 bh[2], bl[2];
-#pragma unroll
-            for (int sd = 0; sd < 2; ++sd) {
-                bh[sd] = *reinterpret_cast<const f16x8*>(wl + sd * sstride + 32 * c);
-                bl[sd] = *reinterpret_cast<const f16x8*>(wl + pstride + sd * sstride + 32 * c);
-            }
-#pragma unroll
-            for (int T = 0; T < NTL; ++T) {
-                const f16x8 ahl = *reinterpret_cast<const f16x8*>(Vh + offL[T] + 32 * c), all_ = *reinterpret_cast<const f16x8*>(Vl + offL[T] + 32 * c);
-                const f16x8 ahr = *reinterpret_cast<const f16x8*>(Vh + offR[T] + 32 * c), alr = *reinterpret_cast<const f16x8*>(Vl + offR[T] + 32 * c);
-                pacc[T][0] = g2_mfma3(ahl, all_, bh[0], bl[0], pacc[T][0]);
-                pacc[T][1] = g2_mfma3(ahr, alr, bh[1], bl[1], pacc[T][1]);
-            }
-        }
-        if (n16 < ncol) {
-#pragma unroll
-            for (int T = 0; T < NTL; ++T)
-                if (16 * T + 4 * kb < TOTAL) {
-                    *reinterpret_cast<f32x4*>(Lw + n16 * CS + 16 * T + 4 * kb) = pacc[T][0];
-                    *reinterpret_cast<f32x4*>(Rw + n16 * CS + 16 * T + 4 * kb) = pacc[T][1];
-                }
-        }
-    }
-
-    if (a.dbg_stop == 2) return;
-    // ---- pair grid over this wave's columns (no barrier: the slice is private to the wave, LDS operations of a wave
-    // execute in order).  Two operand sets alternate: the reads of the next column are in flight during a column.
     float acc[IBL][IBL];
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
         for (int jj = 0; jj < IBL; ++jj) acc[ii][jj] = 0.f;
-    {
-        const lds_cptr lm = (lds_cptr)Lw + li * 4 * A4, le = (lds_cptr)Lw + MAIN + li * EB;
-        const lds_cptr rm = (lds_cptr)Rw + lj * 4 * A4, re = (lds_cptr)Rw + MAIN + lj * EB;
-        float lA[IBL], rA[IBL], lB[IBL], rB[IBL];
-        if (nabs > 0) {
-            g2_load_col<IBL>(lA, lm, le, 0);
-            g2_load_col<IBL>(rA, rm, re, 0);
-        }
-        int k = 0, off = 0;
-        const int npos_w = a.npos - c0;                 // columns [0, npos_w) of the slice have a' >= 0
+
 #pragma unroll 1
-        for (; k + 1 < nabs; k += 2) {
-            float s0 = k < npos_w ? 1.f : -1.f, s1 = k + 1 < npos_w ? 1.f : -1.f;
-            asm volatile("" : "+v"(s0), "+v"(s1));
-            g2_load_col<IBL>(lB, lm, le, off + CS);
-            g2_load_col<IBL>(rB, rm, re, off + CS);
-            __builtin_amdgcn_sched_barrier(0);
-            g2_pair_step<IBL>(acc, lA, rA, s0);
-            __builtin_amdgcn_sched_barrier(0);
-            g2_load_col<IBL>(lA, lm, le, off + 2 * CS);          // (past the last column of the slice: never consumed)
-            g2_load_col<IBL>(rA, rm, re, off + 2 * CS);
-            __builtin_amdgcn_sched_barrier(0);
-            g2_pair_step<IBL>(acc, lB, rB, s1);
-            __builtin_amdgcn_sched_barrier(0);
-            off += 2 * CS;
+    for (int rd = 0; rd < a.NR; ++rd) {
+        const int cb = c0 + rd * a.CW;                  // first column of the round
+        int ncol = c1 - cb;
+        ncol = ncol > a.CW ? a.CW : ncol;
+        if (ncol <= 0) break;
+        int nabs = (c1 < a.E ? c1 : a.E) - cb;
+        nabs = nabs > a.CW ? a.CW : (nabs < 0 ? 0 : nabs);
+        // ---- projection of the round's columns: D[slot][col] = sum_f V[node(slot)][f] W[col][f] on v_mfma_f32_16x16x32_f16,
+        // A = node vectors (16 slots of a tile; lane (m, kb): 8 features), B = weights (lane (n, kb): 8 features of column
+        // cb + n).  Result lane (n, mb): slots 16 T + 4 mb .. + 3 of column n -> one 16-byte LDS store.  The fp16 weights
+        // carry the layer's power of two S; it is taken out of the scores at the end.  The accumulators of the pair grid are
+        // live here (from the second round on), so the projection runs on few registers: one side (query / key) at a time,
+        // one 32-feature chunk of weights at a time (the next one in flight), tiles in pairs whose MFMA chains alternate.
+        {
+            int offs[NTL];
+#pragma unroll
+            for (int T = 0; T < NTL; ++T) {
+                int s = 16 * T + n16;
+                s = s < TOTAL ? s : TOTAL - 1;
+                int g, idx;
+                if (s < MAIN) { g = s / (4 * A4 > 0 ? 4 * A4 : 1); idx = s - g * 4 * A4; }
+                else { const int x = s - MAIN; g = x / (EB > 0 ? EB : 1); idx = 4 * A4 + (x - g * EB); }
+                idx = idx < IBL ? idx : IBL - 1;
+                int nd = g * IBL + idx;
+                nd = nd < K ? nd : K - 1;
+                offs[T] = nd * pv + 8 * kb;
+            }
+            f32x4 pacc[NTL];
+#pragma unroll
+            for (int T = 0; T < NTL; ++T) pacc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const _Float16* __restrict__ wl = Wg + (long)(cb + n16) * a.KP + 8 * kb;
+            f16x8 wh = *reinterpret_cast<const f16x8*>(wl), wlo = *reinterpret_cast<const f16x8*>(wl + pstride);
+            const int nit = 2 * a.KC;                 // (side, chunk) steps: the query side's chunks, then the key side's
+            int c = 0, sd = 0;
+#pragma unroll 1
+            for (int it = 0; it < nit; ++it) {
+                // weights of the next step in flight during this one (also across the change of sides)
+                int cn = c + 1, sn = sd;
+                if (cn == a.KC) { cn = 0; sn = 1; }
+                if (it + 1 == nit) { cn = c; sn = sd; }
+                const _Float16* __restrict__ wn = wl + sn * sstride + 32 * cn;
+                f16x8 whn = *reinterpret_cast<const f16x8*>(wn), wln = *reinterpret_cast<const f16x8*>(wn + pstride);
+#pragma unroll
+                for (int T = 0; T < NTL; T += 2) {
+                    const f16x8 ah0 = *reinterpret_cast<const f16x8*>(Vh + offs[T] + 32 * c), al0 = *reinterpret_cast<const f16x8*>(Vl + offs[T] + 32 * c);
+                    if (T + 1 < NTL) {
+                        const int T1 = T + 1 < NTL ? T + 1 : T;
+                        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(Vh + offs[T1] + 32 * c), al1 = *reinterpret_cast<const f16x8*>(Vl + offs[T1] + 32 * c);
+                        pacc[T] = g2_mfma(al0, wh, pacc[T]);
+                        pacc[T1] = g2_mfma(al1, wh, pacc[T1]);
+                        pacc[T] = g2_mfma(ah0, wlo, pacc[T]);
+                        pacc[T1] = g2_mfma(ah1, wlo, pacc[T1]);
+                        pacc[T] = g2_mfma(ah0, wh, pacc[T]);
+                        pacc[T1] = g2_mfma(ah1, wh, pacc[T1]);
+                    } else {
+                        pacc[T] = g2_mfma(al0, wh, pacc[T]);
+                        pacc[T] = g2_mfma(ah0, wlo, pacc[T]);
+                        pacc[T] = g2_mfma(ah0, wh, pacc[T]);
+                    }
+                }
+                if (c + 1 == a.KC) {                    // a side is complete: its columns go to the slice
+                    float* __restrict__ dstw = sd ? Rw : Lw;
+                    if (n16 < ncol) {
+#pragma unroll
+                        for (int T = 0; T < NTL; ++T)
+                            if (16 * T + 4 * kb < TOTAL) *reinterpret_cast<f32x4*>(dstw + n16 * CS + 16 * T + 4 * kb) = pacc[T];
+                    }
+#pragma unroll
+                    for (int T = 0; T < NTL; ++T) pacc[T] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                wh = whn; wlo = wln;
+                asm volatile("" : "+v"(wh), "+v"(wlo));      // keep the two register sets apart (the compiler otherwise folds the prefetch away)
+                c = cn; sd = sn;
+            }
         }
-        if (k < nabs) {
-            float s0 = k < npos_w ? 1.f : -1.f;
-            asm volatile("" : "+v"(s0));
-            g2_pair_step<IBL>(acc, lA, rA, s0);
+        if (a.dbg_stop == 2) continue;
+        // ---- pair grid over the round's columns (no barrier: the slice is private to the wave, LDS operations of a wave
+        // execute in order).  Two operand sets alternate: the reads of the next column are in flight during a column.
+        {
+            const lds_cptr lm = (lds_cptr)Lw + li * 4 * A4, le = (lds_cptr)Lw + MAIN + li * EB;
+            const lds_cptr rm = (lds_cptr)Rw + lj * 4 * A4, re = (lds_cptr)Rw + MAIN + lj * EB;
+            float lA[IBL], rA[IBL], lB[IBL], rB[IBL];
+            if (nabs > 0) {
+                g2_load_col<IBL>(lA, lm, le, 0);
+                g2_load_col<IBL>(rA, rm, re, 0);
+            }
+            int k = 0, off = 0;
+            const int npos_w = a.npos - cb;             // columns [0, npos_w) of the round have a' >= 0
+#pragma unroll 1
+            for (; k + 1 < nabs; k += 2) {
+                float s0 = k < npos_w ? 1.f : -1.f, s1 = k + 1 < npos_w ? 1.f : -1.f;
+                asm volatile("" : "+v"(s0), "+v"(s1));
+                g2_load_col<IBL>(lB, lm, le, off + CS);
+                g2_load_col<IBL>(rB, rm, re, off + CS);
+                __builtin_amdgcn_sched_barrier(0);
+                g2_pair_step<IBL>(acc, lA, rA, s0);
+                __builtin_amdgcn_sched_barrier(0);
+                g2_load_col<IBL>(lA, lm, le, off + 2 * CS);          // (past the round's last column: never consumed)
+                g2_load_col<IBL>(rA, rm, re, off + 2 * CS);
+                __builtin_amdgcn_sched_barrier(0);
+                g2_pair_step<IBL>(acc, lB, rB, s1);
+                __builtin_amdgcn_sched_barrier(0);
+                off += 2 * CS;
+            }
+            if (k < nabs) {
+                float s0 = k < npos_w ? 1.f : -1.f;
+                asm volatile("" : "+v"(s0));
+                g2_pair_step<IBL>(acc, lA, rA, s0);
+            }
         }
-    }
-    if (c1 == TC && ncol > 0) {                         // the wave that projected the rank-1 column keeps it for the softmax
-        const int kc = a.E - c0;
-        for (int s = lane; s < TOTAL; s += 64) {
-            cdL[s] = Lw[kc * CS + s];
-            cdR[s] = Rw[kc * CS + s];
+        if (cb <= a.E && a.E < cb + ncol) {             // the round that projected the rank-1 column keeps it for the softmax
+            const int kc = a.E - cb;
+            for (int s = lane; s < TOTAL; s += 64) {
+                cdL[s] = Lw[kc * CS + s];
+                cdR[s] = Rw[kc * CS + s];
+            }
         }
     }
     __syncthreads();                                    // every slice is consumed: the region becomes the exchange scratch
+    if (a.dbg_stop == 2) return;
     if (a.dbg_stop == 3) { if (acc[0][0] == 12345.f) a.out[0] = acc[1][1]; return; }
 
-    // ---- reduce-scatter of the partial sums: pass p moves the rows ii in [3p, 3p + 3); wave ii % NWV adds the NWV
+    // ---- reduce-scatter of the partial sums: pass p moves the rows ii in [IIP p, IIP p + IIP); wave ii % NWV adds the NWV
     // partials in wave order
     float own[NOWN][IBL];
 #pragma unroll
@@ -313,81 +379,105 @@ __global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
         f32x4* __restrict__ scr = reinterpret_cast<f32x4*>(smem8 + a.off_lr);
         static_for<0, NP>([&](auto pc) {
             constexpr int p = decltype(pc)::value;
-            static_for<0, G2_IIP>([&](auto ic) {
-                constexpr int iloc = decltype(ic)::value, ii = p * G2_IIP + iloc;
+            static_for<0, IIP>([&](auto ic) {
+                constexpr int iloc = decltype(ic)::value, ii = p * IIP + iloc;
                 if constexpr (ii < IBL) {
 #pragma unroll
                     for (int q = 0; q < JQ; ++q) {
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = 4 * q + e < IBL ? acc[ii][4 * q + e < IBL ? 4 * q + e : 0] : 0.f;
-                        scr[((wave * G2_IIP + iloc) * JQ + q) * 64 + lane] = v;
+                        scr[((wave * IIP + iloc) * JQ + q) * 64 + lane] = v;
                     }
                 }
             });
             __syncthreads();
-            static_for<0, G2_IIP>([&](auto ic) {
-                constexpr int iloc = decltype(ic)::value, ii = p * G2_IIP + iloc;
-                if constexpr (ii < IBL) {
-                    constexpr int o = ii / NWV;
-                    if (wave == ii % NWV) {
-#pragma unroll 1
-                        for (int src = 0; src < NWV; ++src) {
-#pragma unroll
-                            for (int q = 0; q < JQ; ++q) {
-                                const f32x4 v = scr[((src * G2_IIP + iloc) * JQ + q) * 64 + lane];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (4 * q + e < IBL) own[o][4 * q + e] += v[e];
-                            }
-                        }
-                    }
-                }
+            // this wave's rows among those of the pass: ii = wave + o NWV (the accumulator index o is static, the position
+            // of the row inside the pass is not)
+            static_for<0, NOWN>([&](auto oc) {
+                constexpr int o = decltype(oc)::value;
+                const int ii = wave + o * NWV;
+                if (ii >= p * IIP && ii < (p + 1) * IIP && ii < IBL) g2_gather<IBL, NWV, IIP>(own[o], scr + ((ii - p * IIP) * JQ) * 64 + lane);
             });
             __syncthreads();
         });
     }
-
     if (a.dbg_stop == 4) { if (own[0][0] == 12345.f) a.out[0] = own[0][1]; return; }
-    // ---- the region now takes the transposed node pieces VT[feature][key position] and the attention rows
-    _Float16* __restrict__ VTh = reinterpret_cast<_Float16*>(smem8 + a.off_vt);
-    _Float16* __restrict__ VTl = VTh + D * pa;
-    _Float16* __restrict__ ATh = reinterpret_cast<_Float16*>(smem8 + a.off_att);
-    _Float16* __restrict__ ATl = ATh + 8 * IBL * pa;
-    {
-        constexpr int PP = 4 * JP;                      // position pairs per row
-        const int per_piece = D * PP;
-        for (int u = tid; u < 2 * per_piece; u += NT) {
-            const int piece = u >= per_piece ? 1 : 0;
-            const int v = u - piece * per_piece;
-            const int d = v / PP, p0 = 2 * (v - d * PP);
-            const int g = p0 / JP, jj = p0 - g * JP;
-            const int n0 = g * IBL + jj;
-            const unsigned short* __restrict__ src = reinterpret_cast<const unsigned short*>(piece ? Vl : Vh) + d;
-            const unsigned x0 = src[(n0 < K ? n0 : K - 1) * pv], x1 = src[(n0 + 1 < K ? n0 + 1 : K - 1) * pv];
-            const unsigned w0 = (jj < IBL && n0 < K) ? x0 : 0u, w1 = (jj + 1 < IBL && n0 + 1 < K) ? x1 : 0u;
-            *reinterpret_cast<unsigned*>((piece ? VTl : VTh) + d * pa + p0) = w0 | (w1 << 16);
+
+    // attention bias rows of this wave's query rows: requested now, consumed after the transposition below
+    float bq[NOWN][IBL];
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int ii = wave + o * NWV;
+        const int irow = li * IBL + ii;
+        const int irc = irow < K ? irow : K - 1;
+#pragma unroll
+        for (int jj = 0; jj < IBL; ++jj) {
+            const int j = lj * IBL + jj;
+            bq[o][jj] = (a.bias && ii < IBL) ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
         }
     }
-    // scores -> softmax over the keys (reference modules.py:85-89 / :184-188): a query row lives in 8 adjacent lanes
+
+    // ---- the slice region now takes the transposed node pieces VT[feature][key position] (B / A operand of the aggregation)
+    _Float16* __restrict__ VTh = reinterpret_cast<_Float16*>(smem8 + a.off_vt);
+    _Float16* __restrict__ VTl = VTh + D * pa;
     {
+        constexpr int PP = 4 * JP;                      // position pairs per row
+        constexpr int UN = 4;
+        const int per_piece = D * PP;
+        for (int base = 0; base < 2 * per_piece; base += UN * NT) {
+            unsigned x0[UN], x1[UN];
+            int dst[UN];
+#pragma unroll
+            for (int n = 0; n < UN; ++n) {
+                const int u = base + tid + n * NT;
+                const int uc = u < 2 * per_piece ? u : 2 * per_piece - 1;
+                const int piece = uc >= per_piece ? 1 : 0;
+                const int v = uc - piece * per_piece;
+                const int d = v / PP, p0 = 2 * (v - d * PP);
+                const int g = p0 / JP, jj = p0 - g * JP;
+                const int n0 = g * IBL + jj;
+                const unsigned short* __restrict__ src = reinterpret_cast<const unsigned short*>(Vh) + piece * (K * pv) + d;
+                const unsigned r0 = src[(n0 < K ? n0 : K - 1) * pv], r1 = src[(n0 + 1 < K ? n0 + 1 : K - 1) * pv];
+                x0[n] = (jj < IBL && n0 < K) ? r0 : 0u;
+                x1[n] = (jj + 1 < IBL && n0 + 1 < K) ? r1 : 0u;
+                dst[n] = u < 2 * per_piece ? (piece * (D * pa) + d * pa + p0) : -1;
+            }
+#pragma unroll
+            for (int n = 0; n < UN; ++n)
+                if (dst[n] >= 0) *reinterpret_cast<unsigned*>(VTh + dst[n]) = x0[n] | (x1[n] << 16);
+        }
+    }
+    __syncthreads();                                    // VT complete; the node pieces are dead: their region takes the attention rows
+    if (a.dbg_stop == 5) return;
+    // ---- per owned index ii (8 query rows: nodes IBL li + ii): scores -> softmax over the keys (reference modules.py:85-89 /
+    // :184-188; a query row lives in 8 adjacent lanes) -> attention rows as two fp16 pieces into this wave's private LDS
+    // rows -> h_i = sigmoid(sum_j att_ij V_j) (raw node vectors: modules.py:93 / :191) on the matrix pipe.
+    // Output: so_d == 1 (features of a row contiguous: temporal layer) straight from the registers, 16 bytes per lane;
+    // otherwise through an LDS tile [feature][node] that the whole workgroup then copies out in runs along so_i.
+    const bool feat_regs = a.so_d == 1;
+    float* __restrict__ otile = reinterpret_cast<float*>(smem8 + a.off_tile);
+    const int tpitch = K | 1;                           // odd pitch: the 4-byte tile writes of a lane group spread over the banks
+    if (wave < IBL) {
+        _Float16* __restrict__ ATh = reinterpret_cast<_Float16*>(smem8 + a.off_att) + wave * (2 * 8 * pa);
+        _Float16* __restrict__ ATl = ATh + 8 * pa;
         float dv[IBL];
         g2_load_col<IBL>(dv, (lds_cptr)cdR + lj * 4 * A4, (lds_cptr)cdR + MAIN + lj * EB, 0);
         const float sinv = a.scale2[1];
+        constexpr int KCP = JP / 4;                     // 32-position chunks
+        const int DT = (D + 15) >> 4;
         static_for<0, NOWN>([&](auto oc) {
             constexpr int o = decltype(oc)::value;
             const int ii = wave + o * NWV;
             if (ii < IBL) {
-                const int irow = ii * 8 + li;
-                const int irc = irow < K ? irow : K - 1;
+                const int irow = li * IBL + ii;
                 const float cv = cdL[ii < 4 * A4 ? li * 4 * A4 + ii : MAIN + li * EB + (ii - 4 * A4)];
                 float e[IBL];
                 float m = -INFINITY;
 #pragma unroll
                 for (int jj = 0; jj < IBL; ++jj) {
                     const int j = lj * IBL + jj;
-                    const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
-                    float v = __builtin_fmaf(own[o][jj] + cv + dv[jj], sinv, b);
+                    float v = __builtin_fmaf(own[o][jj] + cv + dv[jj], sinv, bq[o][jj]);
                     v = j < K ? v : -INFINITY;
                     e[jj] = v;
                     m = fmaxf(m, v);
@@ -411,78 +501,65 @@ __global__ __launch_bounds__(NT, NT / 256) void k_gat2(const Gat2Args a) {
                 }
 #pragma unroll
                 for (int q = 0; q < JP / 8; ++q) {
-                    *reinterpret_cast<u32x4*>(ATh + irow * pa + lj * JP + 8 * q) = u32x4{hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]};
-                    *reinterpret_cast<u32x4*>(ATl + irow * pa + lj * JP + 8 * q) = u32x4{lw[4 * q], lw[4 * q + 1], lw[4 * q + 2], lw[4 * q + 3]};
+                    *reinterpret_cast<u32x4*>(ATh + li * pa + lj * JP + 8 * q) = u32x4{hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]};
+                    *reinterpret_cast<u32x4*>(ATl + li * pa + lj * JP + 8 * q) = u32x4{lw[4 * q], lw[4 * q + 1], lw[4 * q + 2], lw[4 * q + 3]};
+                }
+                // aggregation for the 8 rows (tile rows 8..15 repeat them).  LDS operations of a wave execute in order: the
+                // reads below see the rows written above.  out^T = VT att^T: A = VT (16 features), B = attention rows;
+                // result lane (n = tile row, mb): features 16 dt + 4 mb + r of node IBL (n & 7) + ii
+                const int arow = n16 & 7;
+                f16x8 th[KCP], tl[KCP];
+#pragma unroll
+                for (int c = 0; c < KCP; ++c) {
+                    th[c] = *reinterpret_cast<const f16x8*>(ATh + arow * pa + 32 * c + 8 * kb);
+                    tl[c] = *reinterpret_cast<const f16x8*>(ATl + arow * pa + 32 * c + 8 * kb);
+                }
+                const int node = arow * IBL + ii;
+                const bool rv = node < K && n16 < 8;
+                float* __restrict__ orow = a.out + win * a.so_w + (long)node * a.so_i;
+#pragma unroll 1
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int drow = 16 * dt + n16 < D ? 16 * dt + n16 : D - 1;
+                    f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < KCP; ++c) {
+                        const f16x8 vh = *reinterpret_cast<const f16x8*>(VTh + drow * pa + 32 * c + 8 * kb), vl = *reinterpret_cast<const f16x8*>(VTl + drow * pa + 32 * c + 8 * kb);
+                        oa = g2_mfma(vl, th[c], oa);
+                        ob = g2_mfma(vh, tl[c], ob);
+                        oa = g2_mfma(vh, th[c], oa);
+                    }
+                    const int d0 = 16 * dt + 4 * kb;
+                    f32x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(oa[r] + ob[r]);
+                    if (feat_regs) {
+                        if (rv && d0 + 3 < D) {
+                            *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (rv && d0 + r < D) orow[d0 + r] = y[r];
+                        }
+                    } else if (a.off_tile >= 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (rv && d0 + r < D) otile[(d0 + r) * tpitch + node] = y[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (rv && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
+                    }
                 }
             }
         });
     }
-    __syncthreads();
-    if (a.dbg_stop == 5) return;
-    if (wave >= IBL) return;                            // no query rows (no barrier below this point)
-
-    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) (raw node vectors: modules.py:93 / :191) for the 8 or 16 query rows
-    // of this wave: tile row r -> node 8 wave + r (r < 8), 8 (wave + NWV) + r - 8 (a second owned index, else a repeat)
-    {
-        constexpr int KCP = JP / 4;                     // 32-position chunks
-        const bool two = wave + NWV < IBL;
-        auto tile_node = [&](int r) { return (r < 8 || !two) ? wave * 8 + (r & 7) : (wave + NWV) * 8 + (r - 8); };
-        const int DT = (D + 15) >> 4;
-        const int anode = tile_node(n16);
-        f16x8 th[KCP], tl[KCP];                         // this lane's attention-row operand: 8 positions per chunk
-#pragma unroll
-        for (int c = 0; c < KCP; ++c) {
-            th[c] = *reinterpret_cast<const f16x8*>(ATh + anode * pa + 32 * c + 8 * kb);
-            tl[c] = *reinterpret_cast<const f16x8*>(ATl + anode * pa + 32 * c + 8 * kb);
-        }
-        const bool feat_regs = a.so_d == 1 || a.so_i != 1;       // registers of a lane = 4 consecutive features of one row
-#pragma unroll 1
-        for (int dt = 0; dt < DT; ++dt) {
-            const int drow = 16 * dt + n16 < D ? 16 * dt + n16 : D - 1;
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-            if (feat_regs) {
-                // out^T = VT att^T: A = VT (16 features), B = attention rows; lane (n = tile row, mb): features 16 dt + 4 mb + r
-#pragma unroll
-                for (int c = 0; c < KCP; ++c) {
-                    const f16x8 vh = *reinterpret_cast<const f16x8*>(VTh + drow * pa + 32 * c + 8 * kb), vl = *reinterpret_cast<const f16x8*>(VTl + drow * pa + 32 * c + 8 * kb);
-                    o = g2_mfma3(vh, vl, th[c], tl[c], o);
-                }
-                const int d0 = 16 * dt + 4 * kb;
-                const bool rv = anode < K && (n16 < 8 || two);
-                float* __restrict__ orow = a.out + win * a.so_w + (long)anode * a.so_i;
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[r]);
-                if (a.so_d == 1 && rv && d0 + 3 < D) {
-                    *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (rv && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
-                }
-            } else {
-                // out = att VT^T: A = attention rows (16 tile rows), B = VT; lane (n = feature 16 dt + n, mb): tile rows 4 mb + r,
-                // i.e. 4 consecutive nodes -> one 16-byte store along so_i == 1
-#pragma unroll
-                for (int c = 0; c < KCP; ++c) {
-                    const f16x8 vh = *reinterpret_cast<const f16x8*>(VTh + drow * pa + 32 * c + 8 * kb), vl = *reinterpret_cast<const f16x8*>(VTl + drow * pa + 32 * c + 8 * kb);
-                    o = g2_mfma3(th[c], tl[c], vh, vl, o);
-                }
-                const int node0 = tile_node(4 * kb);
-                const int d = 16 * dt + n16;
-                const bool rv = d < D && (kb < 2 || two);
-                float* __restrict__ op = a.out + win * a.so_w + (long)d * a.so_d + node0;
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[r]);
-                if (rv && node0 + 3 < K) {
-                    *reinterpret_cast<f32x4_a4*>(op) = y;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (rv && node0 + r < K) op[r] = y[r];
-                }
-            }
+    if (!feat_regs && a.off_tile >= 0) {
+        __syncthreads();
+        // tile [feature d][node] -> out[win][d * so_d + node * so_i]: consecutive threads take consecutive nodes
+        const float kinv = 1.0f / (float)K;
+        for (int u = tid; u < D * K; u += NT) {
+            const int d = (int)(((float)u + 0.5f) * kinv), node = u - d * K;
+            a.out[win * a.so_w + (long)d * a.so_d + (long)node * a.so_i] = otile[d * tpitch + node];
         }
     }
 }
@@ -522,40 +599,59 @@ int launch_gat2_pack(const float* src, int NT_L, int Q, int D, int E, int npos, 
     return 0;
 }
 
-// LDS plan of k_gat2 for K nodes of dimension D and E embedding columns; returns false when the shape is not served
-bool gat2_plan(int K, int D, int E, Gat2Plan& p) {
+// LDS plan of k_gat2 for K nodes of dimension D and E embedding columns; returns false when the shape is not served.
+// Layout: [column slices of the waves | rank-1 terms | node pieces]; after the pair grid the slice region holds the exchange
+// scratch, then the transposed node pieces, and the (then dead) node-piece region the waves' private attention rows.
+bool gat2_plan(int K, int D, int E, bool tile_out, Gat2Plan& p) {
     p = Gat2Plan();
     if (K < 25 || K > 104 || D < 1 || D > 128 || E < 1) return false;
     const int IBL = (K + 7) / 8;
-    const int NT = IBL <= 8 ? 1024 : (IBL <= 10 ? 768 : 512);
+    const int NT = IBL <= 8 ? 512 : (IBL <= 10 ? 384 : 256);
     const int NWV = NT / 64;
     const int TC = E + 1;
-    const int CW = (TC + NWV - 1) / NWV;
-    if (CW > 16) return false;
+    const int per_wave = (TC + NWV - 1) / NWV;        // columns of the widest wave
     const int A = IBL / 4, B = IBL % 4, EB = B == 3 ? 4 : B;
     const int TOTAL = 32 * A + 8 * EB, CS = TOTAL + 4;
     const int JP = IBL <= 8 ? 8 : 16, JQ = (IBL + 3) / 4;
-    p.IBL = IBL; p.NT = NT; p.CW = CW;
-    p.KC = (D + 1 + 31) / 32; p.KP = 32 * p.KC; p.pv = p.KP + 24;
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    p.IBL = IBL; p.NT = NT;
+    p.KC = (D + 1 + 31) / 32; p.KP = 32 * p.KC;
     p.TCP = (TC + 16 + 7) & ~7;
     p.pa = 8 * JP + 16;
-    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    size_t off = 0;
-    p.off_v = (int)off; off = al(off + (size_t)2 * K * p.pv * 2 + 64);       // (+ slack: the last row's chunk reads stay inside)
-    p.off_cd = (int)off; off = al(off + (size_t)2 * TOTAL * 4);
-    p.off_lr = (int)off;
-    p.lr_wave_floats = 2 * CW * CS;
-    const size_t slices = (size_t)NWV * p.lr_wave_floats * 4 + 16 * CS * 4;  // (+ one tile of slack: the prefetch of the column past a slice)
-    const size_t scratch = (size_t)NWV * G2_IIP * JQ * 1024;
-    const size_t vt = al((size_t)2 * D * p.pa * 2), att = al((size_t)2 * 8 * IBL * p.pa * 2);
-    p.off_vt = p.off_lr; p.off_att = p.off_lr + (int)vt;
-    size_t region = slices > scratch ? slices : scratch;
-    if (vt + att > region) region = vt + att;
-    off = al(off + region);
-    p.lds_bytes = off;
-    if (off > 160 * 1024) return false;
-    p.ok = true;
-    return true;
+    const size_t cdbytes = al((size_t)2 * TOTAL * 4);
+    const size_t scratch = (size_t)NWV * g2_iip(IBL) * JQ * 1024;
+    const size_t vt = al((size_t)2 * D * p.pa * 2), att = al((size_t)NWV * 2 * 8 * p.pa * 2);
+    const size_t tile = tile_out ? al((size_t)D * (K | 1) * 4) : 0;
+    // fewest rounds (widest round) that leave room for two workgroups per CU; one per CU when even 4-column rounds do not.
+    // Node-piece pitch: the padded feature count + 8 (rows start 4 banks apart); the bare feature count rounded to 8 when
+    // that is what lets two workgroups fit (the last chunk's reads then run into the next row: finite values times zero weights)
+    for (int budget : {80 * 1024, 160 * 1024}) {
+        for (int nr = 1; nr <= per_wave; ++nr) {
+            const int cw = (per_wave + nr - 1) / nr;
+            if (cw > 16) continue;
+            for (int pv : {p.KP + 8, ((D + 1 + 7) & ~7) + 8, (D + 1 + 7) & ~7}) {
+                const size_t vbytes = al((size_t)2 * K * pv * 2 + 2 * (size_t)p.KP);
+                const size_t slices = (size_t)NWV * 2 * cw * CS * 4;
+                size_t region = slices > scratch ? slices : scratch;
+                if (vt + tile > region) region = vt + tile;
+                const size_t vreg = vbytes > att ? vbytes : att;
+                const size_t total = al(region) + cdbytes + vreg;
+                if (total <= (size_t)budget) {
+                    p.CW = cw; p.NR = nr; p.pv = pv;
+                    p.off_lr = 0; p.lr_wave_floats = 2 * cw * CS;
+                    p.off_cd = (int)al(region);
+                    p.off_v = p.off_cd + (int)cdbytes;
+                    p.off_vt = 0; p.off_att = p.off_v;
+                    p.off_tile = tile_out ? (int)vt : -1;
+                    p.lds_bytes = total;
+                    p.ok = true;
+                    return true;
+                }
+            }
+            if (cw <= 4) break;
+        }
+    }
+    return false;
 }
 
 #define GAT2_CASE(I, T)                                                                                          \
@@ -570,12 +666,15 @@ bool gat2_plan(int K, int D, int E, Gat2Plan& p) {
 int launch_gat2(Gat2Args a, const Gat2Plan& p, hipStream_t s) {
     if (a.nwin <= 0) return 0;
     if (!p.ok) return -2;
-    a.TCP = p.TCP; a.KP = p.KP; a.KC = p.KC; a.pv = p.pv; a.pa = p.pa; a.CW = p.CW;
+    a.TCP = p.TCP; a.KP = p.KP; a.KC = p.KC; a.pv = p.pv; a.pa = p.pa; a.CW = p.CW; a.NR = p.NR;
     a.off_v = p.off_v; a.off_cd = p.off_cd; a.off_lr = p.off_lr; a.lr_wave_floats = p.lr_wave_floats; a.off_vt = p.off_vt; a.off_att = p.off_att;
+    a.off_tile = a.so_d == 1 ? -1 : p.off_tile;
+    a.stagger_blocks = 1024;
+    if (const char* e_ = getenv("MTADGAT_G2_STAGGER")) a.stagger_blocks = atoi(e_);      // (measurement hook)
     bool launched = false;
-    GAT2_CASE(4, 1024) GAT2_CASE(5, 1024) GAT2_CASE(6, 1024) GAT2_CASE(7, 1024) GAT2_CASE(8, 1024)
-    GAT2_CASE(9, 768) GAT2_CASE(10, 768)
-    GAT2_CASE(11, 512) GAT2_CASE(12, 512) GAT2_CASE(13, 512)
+    GAT2_CASE(4, 512) GAT2_CASE(5, 512) GAT2_CASE(6, 512) GAT2_CASE(7, 512) GAT2_CASE(8, 512)
+    GAT2_CASE(9, 384) GAT2_CASE(10, 384)
+    GAT2_CASE(11, 256) GAT2_CASE(12, 256) GAT2_CASE(13, 256)
     if (!launched) return -2;
     LAUNCH_CHECK();
     return 0;

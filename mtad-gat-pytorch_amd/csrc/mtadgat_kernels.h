@@ -124,11 +124,11 @@ struct GatArgs {
 struct Gat2Plan {
     bool ok = false;
     int IBL = 0, NT = 0;        // accumulator block per lane (IBL x IBL, IBL = ceil(K / 8)), threads per workgroup
-    int CW = 0;                 // widest column slice of a wave
+    int CW = 0, NR = 0;         // columns of a wave per round (<= 16), rounds
     int KC = 0, KP = 0, pv = 0; // 32-feature chunks of a node vector incl. the ones column; padded features; LDS pitch (halfs)
     int TCP = 0;                // rows of the weight pack per side: E + 1 columns + a tile of zero rows
     int pa = 0;                 // LDS pitch (halfs) of the transposed node pieces / attention rows
-    int off_v = 0, off_cd = 0, off_lr = 0, lr_wave_floats = 0, off_vt = 0, off_att = 0;
+    int off_v = 0, off_cd = 0, off_lr = 0, lr_wave_floats = 0, off_vt = 0, off_att = 0, off_tile = -1;
     size_t lds_bytes = 0;
 };
 struct Gat2Args {
@@ -143,8 +143,10 @@ struct Gat2Args {
     float* out;          // out[win*so_w + i*so_i + d*so_d]
     long so_w, so_i, so_d;
     long nwin;
-    int pv, pa, CW;
+    int pv, pa, CW, NR;
     int off_v, off_cd, off_lr, lr_wave_floats, off_vt, off_att;
+    int off_tile;        // LDS output tile [feature][node] (layers whose output runs along the nodes: so_i == 1), -1: none
+    int stagger_blocks;  // workgroups with a smaller index start after a pseudo-random delay
     int dbg_stop;        // measurement hook: > 0 returns after phase dbg_stop (1 staging, 2 projection, 3 pair grid, 4 reduce-scatter, 5 softmax); results invalid
 };
 
@@ -348,7 +350,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
-bool gat2_plan(int K, int D, int E, Gat2Plan& p);
+bool gat2_plan(int K, int D, int E, bool tile_out, Gat2Plan& p);
 int launch_gat2(Gat2Args a, const Gat2Plan& p, hipStream_t s);
 int launch_gat2_pack(const float* src, int NT_L, int Q, int D, int E, int npos, int P8, int PT, int TCP, int KP, const float* scale,
                      void* dst, hipStream_t s);

@@ -157,7 +157,7 @@ std::string validate_and_plan(Model& m) {
         g.w2h_off = take((size_t)g.NT * g.Q16 * 2 * 256);
         g.gscale_off = take(4);
         g.g2 = Gat2Plan();
-        if (g.fused && c.use_gatv2 && gat2_plan(K, D, E, g.g2)) g.w2g_off = take((size_t)2 * g.g2.TCP * g.g2.KP);
+        if (g.fused && c.use_gatv2 && gat2_plan(K, D, E, &g == &m.feat, g.g2)) g.w2g_off = take((size_t)2 * g.g2.TCP * g.g2.KP);
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);
