@@ -164,8 +164,9 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   0 automatic (default), 1 the tile-major kernel at every batch size, 2 the chunk-major kernel wherever it applies,
  *   3 the hidden-tile-split kernel on split operands wherever it applies.
  * "gat_kernel": which kernel runs the fused attention layers (modules.py:65-95, :166-193) in precision mode 2:
- *   0 automatic (default: the column-sliced kernel from 4096 windows per chunk on), 1 the row-split kernel k_gat at every batch
- *   size, 2 the column-sliced kernel k_gat2 wherever it applies (GATv2, <= 104 nodes, convolution outputs below 2^15). */
+ *   0 automatic (default: from 4096 windows per chunk the fp16-piece build k_gath of the row-split kernel when the convolution's
+ *   outputs are below 2^15, else k_gat), 1 k_gat at every batch size, 2 the column-sliced kernel k_gat2 wherever it applies
+ *   (GATv2, <= 104 nodes; slower than k_gath on the shipped shapes: DESIGN.md section 4), 3 k_gath at every batch size. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
 /* Diagnostics for bench.py: the largest convolution output of the last forward() that used workspace `ws` (its last
  * chunk; synchronises `stream`).  Below 2^15 the large-batch kernels used two fp16 pieces per operand, otherwise three

@@ -189,7 +189,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
-    } else if (m.precision == 2 && (n >= 4096 || (m.gat_kernel == 2 && !att))) {
+    } else if (m.precision == 2 && (n >= 4096 || ((m.gat_kernel == 2 || m.gat_kernel == 3) && !att))) {
         // large batches: split-bf16 operands for the projection -- fp32-class L' / R' on the bf16 matrix pipe, which runs
         // beside the pair grid of the other waves (the fp32 MFMA does not: profiles/r02_mfma_valu_overlap.txt).  Measured at
         // (W=100, F=55): feature layer 5.90 -> 5.09 ms, temporal layer 7.40 -> 6.94 ms (two weight chunks in registers; with
@@ -212,7 +212,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     // the column-sliced kernel serves the two-fp16-piece arithmetic (inference, GATv2, node values below 2^15 -- decided on
     // the device from the convolution's recorded maximum: of the two launches exactly one does the work)
     const int scols = vt ? g.K : g.D;
-    if (a.bf16 == 2 && vmax && !att && g.g2.ok && m.gat_kernel != 1 && (n >= GAT2_MIN_WINDOWS || m.gat_kernel == 2) && aligned16(v) && (ldv & 3) == 0 &&
+    if (a.bf16 == 2 && vmax && !att && g.g2.ok && m.gat_kernel == 2 && aligned16(v) && (ldv & 3) == 0 &&
         ((scols + 3) & ~3) <= ldv) {
         Gat2Args b{};
         b.V = v; b.ldv = ldv; b.D = g.D; b.K = g.K; b.vt = vt;
@@ -222,6 +222,14 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
         b.out = out; b.so_w = so_w; b.so_i = so_i; b.so_d = so_d; b.nwin = n;
         b.dbg_stop = m.gat2_stop;
         K_TRY(launch_gat2(b, g.g2, s), "column-sliced gat");
+        a.skip_h = 1;
+    }
+    // the fp16-piece build of the row-split kernel (node vectors split once per window): same condition, decided on the device
+    else if (a.bf16 == 2 && vmax && !att && (m.gat_kernel == 0 || m.gat_kernel == 3) && g.fh_lds_bytes <= 160 * 1024 && aligned16(v) &&
+             (ldv & 3) == 0 && ((scols + 3) & ~3) <= ldv) {
+        GatArgs b = a;
+        b.vld = g.fh_vld;
+        K_TRY(launch_gath(b, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.fh_lds_bytes, s), "fused gat (fp16 pieces)");
         a.skip_h = 1;
     }
     K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.f_lds_bytes, s), "fused gat");
@@ -902,7 +910,7 @@ int mtadgat_bf16_ready(mtadgat_handle h) { return (h && h->m.have_weights && h->
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
     if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
-    if (std::strcmp(name, "gat_kernel") == 0 && value >= 0 && value <= 2) { h->m.gat_kernel = value; return 0; }
+    if (std::strcmp(name, "gat_kernel") == 0 && value >= 0 && value <= 3) { h->m.gat_kernel = value; return 0; }
     if (std::strcmp(name, "gat2_stop") == 0 && value >= 0 && value <= 5) { h->m.gat2_stop = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }

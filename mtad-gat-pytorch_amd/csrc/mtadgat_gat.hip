@@ -559,6 +559,363 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
 
 
 // ---------------------------------------------------------------------------
+// k_gath: k_gat for the two-fp16-piece arithmetic (inference, node values below 2^15) on a vector-ALU diet.  k_gat is bound by
+// VALU issue (profiles/r03_pmc_summary.txt: 72.9 k VALU instructions per temporal window, 44.9 k of them pair-grid), and 28 k of
+// its instructions are not the pair grid.  Here the node vectors are split into their two fp16 pieces ONCE, when the window is
+// staged (k_gat: again for every 32-column part, side and aggregation group -- 8 + 7 times per value), and kept in LDS as
+// pieces, row-major [node][feature]:
+//   * projection: the B operand of v_mfma_f32_32x32x16_f16 is two 8-byte LDS reads per piece, no VALU;
+//   * the power-of-two weight scale S stays in L', R', c, d and leaves with one multiply per score;
+//   * aggregation: the A operand (4 keys x 1 feature per lane) is gathered with 16-bit LDS reads and one shift-or per register;
+//     the softmax rows are split per 16-key group as before;
+//   * staging: one index computation per 16-byte unit, exp with one rounding-error term.
+// Same LDS budget as k_gat (pieces: 2 x 2 bytes per value), same pair grid (gat_tile), same launch geometry.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float gath_exp(float x) {      // e^x, x <= 0 (or -inf): the product x log2(e) in two pieces
+    const float c_hi = 1.4426950216293335f;
+    const float hi = x * c_hi;
+    const float lo = __builtin_fmaf(x, c_hi, -hi);
+    return __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(0.6931471805599453f, lo, 1.0f);
+}
+template <int IBL, int JPL, int RJ>
+__global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int RI = 64 / RJ;
+    constexpr int IBW = RI * IBL;                      // query rows per wave
+    constexpr int QB = MTADGAT_GAT_QB3;                // weight chunks held in registers per task batch
+    if (!(a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f)) return;     // k_gat's bf16-piece build serves this launch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const long win = blockIdx.x;
+    const int K = a.K, D = a.D, PT = a.PT;
+    const int pvh = a.vld;                             // piece pitch in halfs
+    const int Kp16 = (K + 15) & ~15;                   // rows of the pieces: real nodes then zero rows
+    const int NWA = (K + IBW - 1) / IBW;               // waves that own query rows (the rest only project)
+    float* __restrict__ Ls = smem;
+    float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;
+    unsigned short* __restrict__ Vh = reinterpret_cast<unsigned short*>(smem + a.lr_floats);
+    unsigned short* __restrict__ Vl = Vh + Kp16 * pvh;
+    const int i = lane & 31, g = lane >> 5;            // MFMA roles
+    const int lj = lane % RJ, li = lane / RJ;          // pair-grid roles
+
+    const int NTn = (K + 31) >> 5;                    // node tiles
+    const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
+    const int Q = a.Q;                                // 16-feature chunks incl. the ones column
+    const int ptile = a.P8 >> 3, ntile = PT >> 3;
+    const int nparts = (PT >> 5) + 1;
+
+    const f32x4* __restrict__ Wbase = a.Wp2;
+    f32x4 w[QB][2];
+    auto wfetch = [&](const f32x4* __restrict__ wp, int u, int q) {
+        w[u][0] = wp[((long)q * 2) * 64];
+        w[u][1] = wp[((long)q * 2 + 1) * 64];
+    };
+    auto prefetch = [&](int part) {
+        if (wave < ntask) {
+            const int wtile = wave >= NTn ? a.NT_L + part : part;
+            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + lane;
+#pragma unroll
+            for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
+        }
+    };
+
+    // ---- stage the window as fp16 pieces: Vh/Vl[node][feature], feature D = 1 (the projection bias is weight row D), the
+    // other features up to 16 Q and the rows K .. Kp16 zero.  vt == 0: source rows are the nodes; vt == 1: source columns.
+    {
+        const int nthr = blockDim.x;
+        const int srows = a.vt ? D : K, scols = a.vt ? K : D;
+        const int UR = (scols + 3) >> 2;
+        const int total = srows * UR;
+        const float rinv = 1.0f / (float)UR;
+        const float* __restrict__ vsrc = a.V + win * (long)srows * a.ldv;
+        const int c4last = ((scols - 1) >> 2) << 2;
+        constexpr int MAXU = 3;
+        for (int base = 0; base < total; base += MAXU * nthr) {
+            f32x4 v[MAXU];
+            int rr[MAXU], cc[MAXU];
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n) {
+                const int u = base + tid + n * nthr;
+                const int row = (int)(((float)u + 0.5f) * rinv), c4 = (u - row * UR) * 4;
+                rr[n] = u < total ? row : -1;
+                cc[n] = c4;
+                const int rc = row < srows ? row : srows - 1, cl = c4 < scols ? c4 : c4last;
+                v[n] = *reinterpret_cast<const f32x4*>(vsrc + (long)rc * a.ldv + cl);
+            }
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n) {
+                const int row = rr[n], c4 = cc[n];
+                if (row >= 0) {
+                    f32x4 t = v[n];
+                    unsigned h0, l0, h1, l1;
+                    if (!a.vt) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = c4 + e < D ? t[e] : (c4 + e == D ? 1.f : 0.f);
+                        split_pair_h(t[0], t[1], h0, l0);
+                        split_pair_h(t[2], t[3], h1, l1);
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2*>(Vh + row * pvh + c4) = u32x2{h0, h1};
+                        *reinterpret_cast<u32x2*>(Vl + row * pvh + c4) = u32x2{l0, l1};
+                    } else {
+                        split_pair_h(t[0], t[1], h0, l0);
+                        split_pair_h(t[2], t[3], h1, l1);
+                        const unsigned short hs[4] = {(unsigned short)h0, (unsigned short)(h0 >> 16), (unsigned short)h1, (unsigned short)(h1 >> 16)};
+                        const unsigned short ls[4] = {(unsigned short)l0, (unsigned short)(l0 >> 16), (unsigned short)l1, (unsigned short)(l1 >> 16)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c4 + e < K) {
+                                Vh[(c4 + e) * pvh + row] = hs[e];
+                                Vl[(c4 + e) * pvh + row] = ls[e];
+                            }
+                    }
+                }
+            }
+        }
+        // ones column and zero features of the real nodes; zero rows K .. Kp16 (the aggregation reads whole 16-key groups)
+        const int FP = 16 * Q;
+        const int f0 = a.vt ? D : 4 * UR, nf = FP - f0;
+        if (nf > 0) {
+            const float ninv = 1.0f / (float)nf;
+            for (int u = tid; u < K * nf; u += nthr) {
+                const int node = (int)(((float)u + 0.5f) * ninv), f = f0 + (u - node * nf);
+                Vh[node * pvh + f] = f == D ? (unsigned short)0x3C00 : (unsigned short)0;
+                Vl[node * pvh + f] = 0;
+            }
+        }
+        for (int u = tid; u < (Kp16 - K) * (FP >> 1); u += nthr) {
+            const int r = u / (FP >> 1), c2 = u - r * (FP >> 1);
+            reinterpret_cast<unsigned*>(Vh + (K + r) * pvh)[c2] = 0u;
+            reinterpret_cast<unsigned*>(Vl + (K + r) * pvh)[c2] = 0u;
+        }
+    }
+    prefetch(0);
+    __syncthreads();
+
+    const bool rows_owner = wave < NWA;
+    const int i0 = (rows_owner ? wave : 0) * IBW;
+    lds_cptr lp[IBL];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        lp[ii] = (lds_cptr)(Ls + (i0 + li + RI * ii) * GAT_LLD);
+        asm volatile("" : "+v"(lp[ii]));
+    }
+    const lds_cptr rp = (lds_cptr)(Rs + lj * GAT_LLD);
+    float acc[IBL][JPL];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = 0.f;
+
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    for (int part = 0; part < nparts; ++part) {
+        // ---- MFMA phase: project this part's 32 + 32 columns for all nodes into Ls / Rs (scaled by S: the weights carry it)
+        for (int task = wave; task < ntask; task += NW) {
+            const bool keyside = task >= NTn;
+            const int nt = keyside ? task - NTn : task;
+            const int wtile = keyside ? a.NT_L + part : part;
+            const int node = nt * 32 + i;
+            const unsigned short* __restrict__ vrh = Vh + (node < K ? node : K - 1) * pvh + 4 * g;
+            const unsigned short* __restrict__ vrl = Vl + (node < K ? node : K - 1) * pvh + 4 * g;
+            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + lane;
+            if (task != wave) {
+#pragma unroll
+                for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
+            }
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            for (int qb = 0; qb < Q; qb += QB) {
+#pragma unroll
+                for (int u = 0; u < QB; ++u)
+                    if (qb + u < Q) {
+                        // the lane's eight features of the chunk: 16 q + 4 g .. + 3 and 16 q + 8 + 4 g .. + 3 (mtadgat_device.h)
+                        const u32x2 ha = *reinterpret_cast<const u32x2*>(vrh + 16 * (qb + u)), hb = *reinterpret_cast<const u32x2*>(vrh + 16 * (qb + u) + 8);
+                        const u32x2 la = *reinterpret_cast<const u32x2*>(vrl + 16 * (qb + u)), lb = *reinterpret_cast<const u32x2*>(vrl + 16 * (qb + u) + 8);
+                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                        const f32x4 xh = __builtin_bit_cast(f32x4, u4{ha[0], ha[1], hb[0], hb[1]});
+                        const f32x4 xl = __builtin_bit_cast(f32x4, u4{la[0], la[1], lb[0], lb[1]});
+                        o = mfma_h(w[u][0], xl, o);
+                        o = mfma_h(w[u][1], xh, o);
+                        o = mfma_h(w[u][0], xh, o);
+                        if (qb + QB + u < Q) wfetch(wp, u, qb + QB + u);
+                    }
+            }
+            if (node < K) {
+                float* __restrict__ dst = (keyside ? Rs : Ls) + node * GAT_LLD + 4 * g;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x2 v0, v1;
+                    v0[0] = o[4 * m + 0]; v0[1] = o[4 * m + 1]; v1[0] = o[4 * m + 2]; v1[1] = o[4 * m + 3];
+                    *reinterpret_cast<f32x2*>(dst + 8 * m) = v0;
+                    *reinterpret_cast<f32x2*>(dst + 8 * m + 2) = v1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
+        int ntl = ntile - 4 * part;
+        ntl = ntl > 4 ? 4 : ntl;
+        if (ntl > 0 && rows_owner) {
+            f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
+            lds_cptr lq[IBL];
+#pragma unroll
+            for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
+            lds_cptr rq = rp;
+            gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
+            int npos = ptile - 4 * part;
+            npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
+            int kt = 0;
+#pragma unroll 1
+            for (; kt < npos; ++kt) {
+                gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                rq += 8;
+            }
+#pragma unroll 1
+            for (; kt < ntl; ++kt) {
+                gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                rq += 8;
+            }
+        }
+        if (part + 1 < nparts) {
+            prefetch(part + 1);
+            __syncthreads();
+        }
+    }
+    float cv[IBL], dv[JPL];
+    {
+        const int col = PT & 31;
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) cv[ii] = lp[ii][col];
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * RJ * GAT_LLD + col];
+    }
+    __syncthreads();
+    if (!rows_owner) return;                           // no barrier below this point
+
+    // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); S leaves the scores here
+    const float sinv = a.scale2[1];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        const int irow = i0 + li + RI * ii;
+        const int irc = irow < K ? irow : K - 1;
+        float e[JPL];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            const int j = lj + RJ * jj;
+            const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
+            float v;
+            if (a.v1) {
+                v = (acc[ii][jj] + cv[ii] + dv[jj]) * sinv;
+                v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f) + b;
+            } else {
+                v = __builtin_fmaf(acc[ii][jj] + cv[ii] + dv[jj], sinv, b);
+            }
+            v = j < K ? v : -INFINITY;
+            e[jj] = v;
+            m = fmaxf(m, v);
+        }
+        m = row_max<RJ>(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            e[jj] = (lj + RJ * jj < K) ? gath_exp(e[jj] - m) : 0.f;
+            sum += e[jj];
+        }
+        sum = row_sum<RJ>(sum);
+        const float inv = soft_rcp(sum);
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = irow < K ? e[jj] * inv : 0.f;
+    }
+
+    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) as out^T = V^T att^T on v_mfma_f32_16x16x16_f16, three terms per product
+    // (k_gat); the softmax rows go through this wave's slice of the (now free) Ls / Rs region 64 keys at a time and are split per
+    // 16-key group, the node values come as packed fp16 pieces straight from LDS
+    static_assert(IBW == 16, "one 16-row MFMA group per wave");
+    constexpr int DTMAX = 8;                           // D <= 128 (plan)
+    float* __restrict__ att = Ls + wave * (IBW * GAT_APITCH);
+    const int DT = (D + 15) >> 4;
+    const int nr = lane & 15, kb = lane >> 4;
+    constexpr int JPP = 64 / RJ;
+    constexpr int PASSES = (JPL + JPP - 1) / JPP;
+    f32x4 o[DTMAX];
+#pragma unroll
+    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const unsigned short* __restrict__ vkh = Vh + (4 * kb) * pvh + nr;      // (key 4 kb, feature nr) of the hi piece
+    const int lo_off = Kp16 * pvh;
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass * 64 < K) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                for (int j4 = 0; j4 < JPP; ++j4)
+                    att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int jn = min(64, K - pass * 64);
+            const int ngrp = (jn + 15) >> 4;                   // rows < Kp16 of the pieces: real or zero
+            for (int grp = 0; grp < ngrp; ++grp) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 16 * grp + 4 * kb);
+                unsigned h0, l0, h1, l1;
+                split_pair_h(bq[0], bq[1], h0, l0);
+                split_pair_h(bq[2], bq[3], h1, l1);
+                const f16x4 bhh = __builtin_bit_cast(f16x4, u32x2{h0, h1}), bll = __builtin_bit_cast(f16x4, u32x2{l0, l1});
+                const unsigned short* __restrict__ vg = vkh + (pass * 64 + 16 * grp) * pvh;
+                unsigned r[DTMAX][4];
+#pragma unroll
+                for (int dt = 0; dt < DTMAX; ++dt)
+                    if (dt < DT) {
+                        // four keys of feature 16 dt + nr, two per register (plain 16-bit reads: on this hardware the d16 forms do
+                        // not keep the other half of the destination)
+                        const unsigned short* __restrict__ p = vg + 16 * dt;
+                        r[dt][0] = (unsigned)p[0] | ((unsigned)p[pvh] << 16);
+                        r[dt][1] = (unsigned)p[2 * pvh] | ((unsigned)p[3 * pvh] << 16);
+                        r[dt][2] = (unsigned)p[lo_off] | ((unsigned)p[lo_off + pvh] << 16);
+                        r[dt][3] = (unsigned)p[lo_off + 2 * pvh] | ((unsigned)p[lo_off + 3 * pvh] << 16);
+                    }
+#pragma unroll
+                for (int dt = 0; dt < DTMAX; ++dt)
+                    if (dt < DT) {
+                        const f16x4 ahh = __builtin_bit_cast(f16x4, u32x2{r[dt][0], r[dt][1]}), all_ = __builtin_bit_cast(f16x4, u32x2{r[dt][2], r[dt][3]});
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahh, bll, o[dt], 0, 0, 0);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(all_, bhh, o[dt], 0, 0, 0);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahh, bhh, o[dt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    {
+        const int row = i0 + nr;
+        float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
+#pragma unroll
+        for (int dt = 0; dt < DTMAX; ++dt)
+            if (dt < DT) {
+                const int d0 = 16 * dt + 4 * kb;
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[dt][r]);
+                if (a.so_d == 1 && row < K && d0 + 3 < D) {
+                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (row < K && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // gat (wide): graph attention for node counts beyond the per-window fused kernel (128 < K <= 512, BASELINE
 // config 4: 512 features / 256 time steps).  The projected L', R' come from k_rowgemm through HBM (LC row-major
 // per query node, RT key-node-minor -- what k_attend consumed); everything after that is the fused kernel's
@@ -877,6 +1234,29 @@ int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_by
     bool launched = false;
     GAT_CASE(4, 1, 16) GAT_CASE(4, 2, 16) GAT_CASE(4, 3, 16) GAT_CASE(4, 4, 16) GAT_CASE(4, 5, 16) GAT_CASE(4, 6, 16) GAT_CASE(4, 7, 16) GAT_CASE(4, 8, 16)
     GAT_CASE(2, 1, 8) GAT_CASE(2, 3, 8) GAT_CASE(2, 5, 8) GAT_CASE(2, 7, 8)
+    if (!launched) return -2;
+    LAUNCH_CHECK();
+    return 0;
+}
+
+#define GATH_CASE(I, J, RJ)                                                                     \
+    if (IBL == I && JPL == J && rj == RJ) {                                                     \
+        if (lds_bytes > 64 * 1024) {                                                            \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gath<I, J, RJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e_ != hipSuccess) return (int)e_;                                               \
+        }                                                                                       \
+        hipLaunchKernelGGL((k_gath<I, J, RJ>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);     \
+        launched = true;                                                                        \
+    }
+
+// the fp16-piece build of the fused layer (a.vld = piece pitch in halfs, a.lr_floats as for k_gat, a.Q = 16-feature chunks)
+int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
+    if (a.nwin <= 0) return 0;
+    if (rj * JPL < a.K || nw * 16 < a.K || nw > 8 || a.ATT) return -2;
+    const unsigned grid = (unsigned)a.nwin;
+    bool launched = false;
+    GATH_CASE(4, 1, 16) GATH_CASE(4, 2, 16) GATH_CASE(4, 3, 16) GATH_CASE(4, 4, 16) GATH_CASE(4, 5, 16) GATH_CASE(4, 6, 16) GATH_CASE(4, 7, 16) GATH_CASE(4, 8, 16)
+    GATH_CASE(2, 1, 8) GATH_CASE(2, 3, 8) GATH_CASE(2, 5, 8) GATH_CASE(2, 7, 8)
     if (!launched) return -2;
     LAUNCH_CHECK();
     return 0;

@@ -86,6 +86,16 @@ __device__ __forceinline__ float g2_sum8(float v) {
     return v;
 }
 
+// e^x for x <= 0 (softmax arguments after the maximum is taken out; -inf gives 0): the product x log2(e) in two pieces (the
+// exact remainder of the leading piece), 5 VALU instructions instead of exp_fast's 9 (no clamp, no second piece of log2 e:
+// 2e-8 |x| relative)
+__device__ __forceinline__ float g2_exp(float x) {
+    const float c_hi = 1.4426950216293335f;
+    const float hi = x * c_hi;
+    const float lo = __builtin_fmaf(x, c_hi, -hi);
+    return __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(0.6931471805599453f, lo, 1.0f);
+}
+
 __device__ __forceinline__ f32x4 g2_mfma(const f16x8 a, const f16x8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_gat2(const Gat2Args a) {
     constexpr int A4 = SL::A, EB = SL::EB, MAIN = SL::MAIN, TOTAL = SL::TOTAL;
     constexpr int CS = TOTAL + 4;                 // floats between the columns of a slice
     constexpr int NTL = (TOTAL + 15) / 16;        // 16-slot tiles of the projection
-    constexpr int JP = IBL <= 8 ? 8 : 16;         // key positions per lane in the attention rows (pad positions hold zeros)
+    constexpr int KPOS = (8 * IBL + 31) / 32 * 32;    // key positions of an attention row: position = node index, zeros from K on
     constexpr int JQ = (IBL + 3) / 4;
     constexpr int IIP = g2_iip(IBL);
     constexpr int NP = (IBL + IIP - 1) / IIP;
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_gat2(const Gat2Args a) {
                 int cn = c + 1, sn = sd;
                 if (cn == a.KC) { cn = 0; sn = 1; }
                 if (it + 1 == nit) { cn = c; sn = sd; }
-                const _Float16* __restrict__ wn = wl + sn * sstride + 32 * cn;
+                const _Float16* __restrict__ wn = (a.dbg_flags & 1) ? wl : wl + sn * sstride + 32 * cn;      // (measurement: bit 0 = every step reads the same weights)
                 f16x8 whn = *reinterpret_cast<const f16x8*>(wn), wln = *reinterpret_cast<const f16x8*>(wn + pstride);
 #pragma unroll
                 for (int T = 0; T < NTL; T += 2) {
@@ -422,30 +432,34 @@ __global__ __launch_bounds__(NT, NT / 128) void k_gat2(const Gat2Args a) {
     _Float16* __restrict__ VTh = reinterpret_cast<_Float16*>(smem8 + a.off_vt);
     _Float16* __restrict__ VTl = VTh + D * pa;
     {
-        constexpr int PP = 4 * JP;                      // position pairs per row
-        constexpr int UN = 4;
-        const int per_piece = D * PP;
-        for (int base = 0; base < 2 * per_piece; base += UN * NT) {
-            unsigned x0[UN], x1[UN];
-            int dst[UN];
+        // lane = pair of adjacent nodes (positions 2 np, 2 np + 1; zeros from K on), wave = feature residue: VT[d][2 np ..] <-
+        // (V[2 np][d], V[2 np + 1][d]) for d = wave, wave + NWV, ...; the reads of a batch of features are issued together
+        constexpr int NPP = KPOS / 2, UN = 4;
+        const float ninv = 1.0f / (float)NPP;
+        const int fg = (int)(((float)tid + 0.5f) * ninv), np = tid - fg * NPP;      // (NT is not a multiple of NPP in general)
+        const int NFG = NT / NPP;                                                   // feature residues served per pass
+        const int n0 = 2 * np, n0c = n0 < K ? n0 : K - 1, n1c = n0 + 1 < K ? n0 + 1 : K - 1;
+        const unsigned m0 = n0 < K ? 0xffffu : 0u, m1 = n0 + 1 < K ? 0xffffu : 0u;
+        const unsigned short* __restrict__ sh = reinterpret_cast<const unsigned short*>(Vh);
+        const unsigned short* __restrict__ sl = reinterpret_cast<const unsigned short*>(Vl);
+        if (fg < NFG) {
+            for (int d0 = fg; d0 < D; d0 += UN * NFG) {
+                unsigned xh[UN], xl[UN];
 #pragma unroll
-            for (int n = 0; n < UN; ++n) {
-                const int u = base + tid + n * NT;
-                const int uc = u < 2 * per_piece ? u : 2 * per_piece - 1;
-                const int piece = uc >= per_piece ? 1 : 0;
-                const int v = uc - piece * per_piece;
-                const int d = v / PP, p0 = 2 * (v - d * PP);
-                const int g = p0 / JP, jj = p0 - g * JP;
-                const int n0 = g * IBL + jj;
-                const unsigned short* __restrict__ src = reinterpret_cast<const unsigned short*>(Vh) + piece * (K * pv) + d;
-                const unsigned r0 = src[(n0 < K ? n0 : K - 1) * pv], r1 = src[(n0 + 1 < K ? n0 + 1 : K - 1) * pv];
-                x0[n] = (jj < IBL && n0 < K) ? r0 : 0u;
-                x1[n] = (jj + 1 < IBL && n0 + 1 < K) ? r1 : 0u;
-                dst[n] = u < 2 * per_piece ? (piece * (D * pa) + d * pa + p0) : -1;
+                for (int n = 0; n < UN; ++n) {
+                    const int d = d0 + n * NFG < D ? d0 + n * NFG : D - 1;
+                    xh[n] = (sh[n0c * pv + d] & m0) | ((sh[n1c * pv + d] & m1) << 16);
+                    xl[n] = (sl[n0c * pv + d] & m0) | ((sl[n1c * pv + d] & m1) << 16);
+                }
+#pragma unroll
+                for (int n = 0; n < UN; ++n) {
+                    const int d = d0 + n * NFG;
+                    if (d < D) {
+                        *reinterpret_cast<unsigned*>(VTh + d * pa + n0) = xh[n];
+                        *reinterpret_cast<unsigned*>(VTl + d * pa + n0) = xl[n];
+                    }
+                }
             }
-#pragma unroll
-            for (int n = 0; n < UN; ++n)
-                if (dst[n] >= 0) *reinterpret_cast<unsigned*>(VTh + dst[n]) = x0[n] | (x1[n] << 16);
         }
     }
     __syncthreads();                                    // VT complete; the node pieces are dead: their region takes the attention rows
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(NT, NT / 128) void k_gat2(const Gat2Args a) {
         float dv[IBL];
         g2_load_col<IBL>(dv, (lds_cptr)cdR + lj * 4 * A4, (lds_cptr)cdR + MAIN + lj * EB, 0);
         const float sinv = a.scale2[1];
-        constexpr int KCP = JP / 4;                     // 32-position chunks
+        constexpr int KCP = KPOS / 32;                  // 32-position chunks
         const int DT = (D + 15) >> 4;
         static_for<0, NOWN>([&](auto oc) {
             constexpr int o = decltype(oc)::value;
@@ -486,27 +500,48 @@ __global__ __launch_bounds__(NT, NT / 128) void k_gat2(const Gat2Args a) {
                 float sum = 0.f;
 #pragma unroll
                 for (int jj = 0; jj < IBL; ++jj) {
-                    e[jj] = (lj * IBL + jj < K) ? soft_exp(e[jj] - m) : 0.f;
+                    e[jj] = (lj * IBL + jj < K) ? g2_exp(e[jj] - m) : 0.f;
                     sum += e[jj];
                 }
                 sum = g2_sum8(sum);
                 const float inv = irow < K ? soft_rcp(sum) : 0.f;
-                // two fp16 pieces of the attention weights, JP positions per lane (the last JP - IBL hold zeros)
-                unsigned hw[JP / 2], lw[JP / 2];
+                // two fp16 pieces of the attention weights at positions IBL lj + jj of row li: 4-byte stores of position pairs
+                // (the run of a lane starts at an odd position when IBL and lj are odd: its first element then goes alone, else
+                // its last one -- IBL odd only), then the zero tail of the row
+                {
+                    unsigned short* __restrict__ rh = reinterpret_cast<unsigned short*>(ATh) + li * pa + lj * IBL;
+                    unsigned short* __restrict__ rl = reinterpret_cast<unsigned short*>(ATl) + li * pa + lj * IBL;
+                    constexpr bool ODD = (IBL & 1) != 0;
+                    const bool shifted = ODD && (lj & 1);
 #pragma unroll
-                for (int w2 = 0; w2 < JP / 2; ++w2) {
-                    const float v0 = 2 * w2 < IBL ? e[2 * w2 < IBL ? 2 * w2 : 0] * inv : 0.f;
-                    const float v1 = 2 * w2 + 1 < IBL ? e[2 * w2 + 1 < IBL ? 2 * w2 + 1 : 0] * inv : 0.f;
-                    split_pair_h(v0, v1, hw[w2], lw[w2]);
-                }
-#pragma unroll
-                for (int q = 0; q < JP / 8; ++q) {
-                    *reinterpret_cast<u32x4*>(ATh + li * pa + lj * JP + 8 * q) = u32x4{hw[4 * q], hw[4 * q + 1], hw[4 * q + 2], hw[4 * q + 3]};
-                    *reinterpret_cast<u32x4*>(ATl + li * pa + lj * JP + 8 * q) = u32x4{lw[4 * q], lw[4 * q + 1], lw[4 * q + 2], lw[4 * q + 3]};
+                    for (int w2 = 0; w2 < IBL / 2; ++w2) {
+                        const float v0 = (shifted ? e[2 * w2 + 1 < IBL ? 2 * w2 + 1 : 0] : e[2 * w2]) * inv;
+                        const float v1 = (shifted ? e[2 * w2 + 2 < IBL ? 2 * w2 + 2 : 0] : e[2 * w2 + 1]) * inv;
+                        unsigned hw, lw;
+                        split_pair_h(v0, v1, hw, lw);
+                        const int pos = 2 * w2 + (shifted ? 1 : 0);
+                        *reinterpret_cast<unsigned*>(rh + pos) = hw;
+                        *reinterpret_cast<unsigned*>(rl + pos) = lw;
+                    }
+                    if (ODD) {
+                        const float vs = (shifted ? e[0] : e[IBL - 1]) * inv;
+                        unsigned hw, lw;
+                        split_pair_h(vs, 0.f, hw, lw);
+                        const int pos = shifted ? 0 : IBL - 1;
+                        rh[pos] = (unsigned short)hw;
+                        rl[pos] = (unsigned short)lw;
+                    }
+                    if (8 * IBL < KPOS) {
+                        for (int z = 8 * IBL + 2 * lj; z < KPOS; z += 16) {
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(ATh) + li * pa + z) = 0u;
+                            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(ATl) + li * pa + z) = 0u;
+                        }
+                    }
                 }
                 // aggregation for the 8 rows (tile rows 8..15 repeat them).  LDS operations of a wave execute in order: the
                 // reads below see the rows written above.  out^T = VT att^T: A = VT (16 features), B = attention rows;
-                // result lane (n = tile row, mb): features 16 dt + 4 mb + r of node IBL (n & 7) + ii
+                // result lane (n = tile row, mb): features 16 dt + 4 mb + r of node IBL (n & 7) + ii.  Two feature tiles in
+                // flight: their MFMA chains alternate.
                 const int arow = n16 & 7;
                 f16x8 th[KCP], tl[KCP];
 #pragma unroll
@@ -518,36 +553,44 @@ __global__ __launch_bounds__(NT, NT / 128) void k_gat2(const Gat2Args a) {
                 const bool rv = node < K && n16 < 8;
                 float* __restrict__ orow = a.out + win * a.so_w + (long)node * a.so_i;
 #pragma unroll 1
-                for (int dt = 0; dt < DT; ++dt) {
-                    const int drow = 16 * dt + n16 < D ? 16 * dt + n16 : D - 1;
+                for (int dt = 0; dt < DT; dt += 2) {
+                    const int dra = 16 * dt + n16 < D ? 16 * dt + n16 : D - 1;
+                    const int drb = 16 * dt + 16 + n16 < D ? 16 * dt + 16 + n16 : D - 1;
                     f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < KCP; ++c) {
-                        const f16x8 vh = *reinterpret_cast<const f16x8*>(VTh + drow * pa + 32 * c + 8 * kb), vl = *reinterpret_cast<const f16x8*>(VTl + drow * pa + 32 * c + 8 * kb);
-                        oa = g2_mfma(vl, th[c], oa);
-                        ob = g2_mfma(vh, tl[c], ob);
-                        oa = g2_mfma(vh, th[c], oa);
+                        const f16x8 vha = *reinterpret_cast<const f16x8*>(VTh + dra * pa + 32 * c + 8 * kb), vla = *reinterpret_cast<const f16x8*>(VTl + dra * pa + 32 * c + 8 * kb);
+                        const f16x8 vhb = *reinterpret_cast<const f16x8*>(VTh + drb * pa + 32 * c + 8 * kb), vlb = *reinterpret_cast<const f16x8*>(VTl + drb * pa + 32 * c + 8 * kb);
+                        oa = g2_mfma(vla, th[c], oa);
+                        ob = g2_mfma(vlb, th[c], ob);
+                        oa = g2_mfma(vha, tl[c], oa);
+                        ob = g2_mfma(vhb, tl[c], ob);
+                        oa = g2_mfma(vha, th[c], oa);
+                        ob = g2_mfma(vhb, th[c], ob);
                     }
-                    const int d0 = 16 * dt + 4 * kb;
-                    f32x4 y;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(oa[r] + ob[r]);
-                    if (feat_regs) {
-                        if (rv && d0 + 3 < D) {
-                            *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
+                    for (int half = 0; half < 2; ++half) {
+                        const int d0 = 16 * (dt + half) + 4 * kb;
+                        f32x4 y;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(half ? ob[r] : oa[r]);
+                        if (feat_regs) {
+                            if (rv && d0 + 3 < D) {
+                                *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (rv && d0 + r < D) orow[d0 + r] = y[r];
+                            }
+                        } else if (a.off_tile >= 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (rv && d0 + r < D) otile[(d0 + r) * tpitch + node] = y[r];
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (rv && d0 + r < D) orow[d0 + r] = y[r];
+                                if (rv && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
                         }
-                    } else if (a.off_tile >= 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (rv && d0 + r < D) otile[(d0 + r) * tpitch + node] = y[r];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (rv && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
                     }
                 }
             }
@@ -612,12 +655,12 @@ bool gat2_plan(int K, int D, int E, bool tile_out, Gat2Plan& p) {
     const int per_wave = (TC + NWV - 1) / NWV;        // columns of the widest wave
     const int A = IBL / 4, B = IBL % 4, EB = B == 3 ? 4 : B;
     const int TOTAL = 32 * A + 8 * EB, CS = TOTAL + 4;
-    const int JP = IBL <= 8 ? 8 : 16, JQ = (IBL + 3) / 4;
+    const int KPOS = (8 * IBL + 31) / 32 * 32, JQ = (IBL + 3) / 4;
     auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
     p.IBL = IBL; p.NT = NT;
     p.KC = (D + 1 + 31) / 32; p.KP = 32 * p.KC;
     p.TCP = (TC + 16 + 7) & ~7;
-    p.pa = 8 * JP + 16;
+    p.pa = KPOS + 16;
     const size_t cdbytes = al((size_t)2 * TOTAL * 4);
     const size_t scratch = (size_t)NWV * g2_iip(IBL) * JQ * 1024;
     const size_t vt = al((size_t)2 * D * p.pa * 2), att = al((size_t)NWV * 2 * 8 * p.pa * 2);
@@ -670,6 +713,8 @@ int launch_gat2(Gat2Args a, const Gat2Plan& p, hipStream_t s) {
     a.off_v = p.off_v; a.off_cd = p.off_cd; a.off_lr = p.off_lr; a.lr_wave_floats = p.lr_wave_floats; a.off_vt = p.off_vt; a.off_att = p.off_att;
     a.off_tile = a.so_d == 1 ? -1 : p.off_tile;
     a.stagger_blocks = 1024;
+    if (const char* e_ = getenv("MTADGAT_G2_FLAGS")) a.dbg_flags = atoi(e_);
+    if (const char* e_ = getenv("MTADGAT_G2_ONLY")) if (atoi(e_) != a.K) return 0;      // (measurement: only the layer with that many nodes runs)
     if (const char* e_ = getenv("MTADGAT_G2_STAGGER")) a.stagger_blocks = atoi(e_);      // (measurement hook)
     bool launched = false;
     GAT2_CASE(4, 512) GAT2_CASE(5, 512) GAT2_CASE(6, 512) GAT2_CASE(7, 512) GAT2_CASE(8, 512)

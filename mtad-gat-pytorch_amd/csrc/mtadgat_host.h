@@ -30,6 +30,8 @@ struct GatPlan {
     bool fused = false;
     int f_nw = 0, f_IBL = 0, f_JPL = 0, f_RJ = 16, f_vld = 0, f_lr = 0;
     size_t f_lds_bytes = 0;
+    int fh_vld = 0;         // k_gath (fp16-piece build of the fused kernel): piece pitch in halfs, LDS bytes
+    size_t fh_lds_bytes = 0;
     int Q16 = 0;            // bf16 build of the fused projection: 16-feature chunks incl. the bias row
     size_t w16_off = 0;
     size_t w3_off = 0;      // split-bf16 pack [tile][Q16][piece][64] of the fused projection, derived on the device
@@ -183,7 +185,7 @@ struct Model {
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
     int gat2_stop = 0;               // measurement hook: Gat2Args::dbg_stop
-    int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic: 0 automatic, 1 row-split k_gat only, 2 column-sliced k_gat2 at any batch size (testing hook)
+    int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic (testing hook): 0 automatic (k_gath, the fp16-piece build, from 4096 windows), 1 k_gat only, 2 column-sliced k_gat2 at any batch size, 3 k_gath at any batch size
     int gru_kernel = 0;              // large-batch recurrence: 0 automatic, 1 tile-major k_gru, 2 chunk-major k_gru_cm (testing hook: mtadgat_set_option)
     DevTables dt;
     // profiling

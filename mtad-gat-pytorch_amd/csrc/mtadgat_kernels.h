@@ -147,6 +147,7 @@ struct Gat2Args {
     int off_v, off_cd, off_lr, lr_wave_floats, off_vt, off_att;
     int off_tile;        // LDS output tile [feature][node] (layers whose output runs along the nodes: so_i == 1), -1: none
     int stagger_blocks;  // workgroups with a smaller index start after a pseudo-random delay
+    int dbg_flags;
     int dbg_stop;        // measurement hook: > 0 returns after phase dbg_stop (1 staging, 2 projection, 3 pair grid, 4 reduce-scatter, 5 softmax); results invalid
 };
 
@@ -350,6 +351,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
+int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
 bool gat2_plan(int K, int D, int E, bool tile_out, Gat2Plan& p);
 int launch_gat2(Gat2Args a, const Gat2Plan& p, hipStream_t s);
 int launch_gat2_pack(const float* src, int NT_L, int Q, int D, int E, int npos, int P8, int PT, int TCP, int KP, const float* scale,

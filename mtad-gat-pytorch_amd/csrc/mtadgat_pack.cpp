@@ -152,6 +152,10 @@ std::string validate_and_plan(Model& m) {
         g.b_off = take((size_t)g.NT * 32);
         g.bias_off = take((size_t)K * K);
         g.Q16 = g.fused ? (D + 1 + 15) / 16 : 0;
+        if (g.fused) {      // fp16-piece build: pitch 4 x odd halfs (conflict-free 8-byte operand reads of 32 consecutive nodes)
+            g.fh_vld = 16 * g.Q16 + 4;
+            g.fh_lds_bytes = (size_t)g.f_lr * sizeof(float) + (size_t)2 * round_up(K, 16) * g.fh_vld * 2;
+        }
         g.w16_off = take((size_t)g.NT * g.Q16 * 256);
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
         g.w2h_off = take((size_t)g.NT * g.Q16 * 2 * 256);

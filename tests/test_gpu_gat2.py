@@ -1,7 +1,9 @@
-"""The column-sliced attention kernel (k_gat2, csrc/mtadgat_gat2.hip; reference FeatureAttentionLayer.forward modules.py:65-95
-and TemporalAttentionLayer.forward :166-193).  In normal use it serves batches of 4096 windows and more (the 20 000- and
-65 573-window tests of test_gpu_parity.py go through it); here the engine's testing hook forces it at fixture size, so every
-window is compared with the reference's golden outputs, and odd node counts / embedding widths with the oracle."""
+"""The two-fp16-piece builds of the fused attention layer (reference FeatureAttentionLayer.forward modules.py:65-95 and
+TemporalAttentionLayer.forward :166-193): k_gath (csrc/mtadgat_gat.hip: the row-split kernel with the node vectors split once
+per window; engine option gat_kernel = 3; in normal use it serves batches of 4096 windows and more -- the 20 000- and
+65 573-window tests of test_gpu_parity.py go through it) and the column-sliced k_gat2 (csrc/mtadgat_gat2.hip; opt-in,
+gat_kernel = 2).  The testing hook forces them at fixture size, so every window is compared with the reference's golden
+outputs, and odd node counts / embedding widths with the oracle."""
 import pytest
 import torch
 
@@ -15,14 +17,18 @@ def _engine(model, dev):
     return model._sync_engine(dev)
 
 
-@pytest.mark.parametrize("name", ["msl", "smap", "smd_1_1", "syn_v2_embed"])
-def test_fixture_windows_through_the_column_sliced_kernel(name, gpu_device):
+KERNELS = [2, 3]
+
+
+@pytest.mark.parametrize("gk", KERNELS)
+@pytest.mark.parametrize("name", ["msl", "smap", "smd_1_1", "syn_v2_embed", "syn_v1_small"])
+def test_fixture_windows_through_the_column_sliced_kernel(name, gk, gpu_device):
     case = Case(name)
     model = case.build_model().to(gpu_device)
     eng = _engine(model, gpu_device)
     x = case.x.to(gpu_device)
     with torch.no_grad():
-        eng.set_option("gat_kernel", 2)
+        eng.set_option("gat_kernel", gk)
         p2, r2 = model(x)
         eng.set_option("gat_kernel", 1)
         p1, r1 = model(x)
@@ -33,15 +39,16 @@ def test_fixture_windows_through_the_column_sliced_kernel(name, gpu_device):
     assert (p2 - p1).abs().max().item() <= 2e-6 and (r2 - r1).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("gk", KERNELS)
 @pytest.mark.parametrize("name", ["msl_wide", "smd_1_1_wide", "msl_c1"])
-def test_wide_fixtures_through_the_column_sliced_kernel(name, gpu_device):
+def test_wide_fixtures_through_the_column_sliced_kernel(name, gk, gpu_device):
     """300 / 320 windows per shipped checkpoint incl. the C1 input statistics (values outside [0, 1])."""
     case = WideCase(name)
     model = case.build_model().to(gpu_device)
     eng = _engine(model, gpu_device)
     x = case.x.to(gpu_device)
     with torch.no_grad():
-        eng.set_option("gat_kernel", 2)
+        eng.set_option("gat_kernel", gk)
         preds, recons = model(x)
         p_split = torch.cat([model(x[lo:lo + 77].contiguous())[0] for lo in range(0, x.shape[0], 77)])
         eng.set_option("gat_kernel", 0)
@@ -64,8 +71,16 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("kw", SHAPES, ids=lambda k: f"F{k['n_features']}W{k['window_size']}")
-def test_shapes_against_the_oracle(kw, gpu_device):
+SHAPES_H = [   # k_gath also serves what k_gat2 does not: up to 128 nodes, fewer than 25, GAT (v1)
+    dict(n_features=128, window_size=96, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24),
+    dict(n_features=10, window_size=120, out_dim=1, kernel_size=7, use_gatv2=False, gru_hid_dim=30, recon_hid_dim=30),
+    dict(n_features=3, window_size=64, out_dim=1, kernel_size=1, gru_hid_dim=64, forecast_n_layers=2, recon_hid_dim=96),
+]
+
+
+@pytest.mark.parametrize("gk", KERNELS)
+@pytest.mark.parametrize("kw", SHAPES + SHAPES_H, ids=lambda k: f"F{k['n_features']}W{k['window_size']}")
+def test_shapes_against_the_oracle(kw, gk, gpu_device):
     from mtad_gat import MTAD_GAT
     torch.manual_seed(29)
     model = MTAD_GAT(**kw).eval()
@@ -73,13 +88,13 @@ def test_shapes_against_the_oracle(kw, gpu_device):
         model.feature_gat.bias.normal_()
         model.temporal_gat.bias.normal_()
         # both signs of `a` must occur in every wave's column slice for the test to mean something
-        assert (model.temporal_gat.a > 0).any() and (model.temporal_gat.a < 0).any()
+        assert not kw.get("use_gatv2", True) or ((model.temporal_gat.a > 0).any() and (model.temporal_gat.a < 0).any())
     x = torch.rand(19, kw["window_size"], kw["n_features"])
     with torch.no_grad():
         p_ref, r_ref = oracle.forward(x, model.state_dict(), alpha=kw.get("alpha", 0.2))
         m = model.to(gpu_device)
         eng = _engine(m, gpu_device)
-        eng.set_option("gat_kernel", 2)
+        eng.set_option("gat_kernel", gk)
         p, r = m(x.to(gpu_device))
         eng.set_option("gat_kernel", 1)
         p1, r1 = m(x.to(gpu_device))
@@ -89,7 +104,8 @@ def test_shapes_against_the_oracle(kw, gpu_device):
     assert (p - p1).abs().max().item() <= 2e-6 and (r - r1).abs().max().item() <= 2e-6
 
 
-def test_large_inputs_fall_back_to_the_row_split_kernel(gpu_device):
+@pytest.mark.parametrize("gk", KERNELS)
+def test_large_inputs_fall_back_to_the_row_split_kernel(gk, gpu_device):
     """Convolution outputs of 2^15 and more do not fit the fp16 pieces: the device-side range guard hands the launch to
     k_gat's bf16-piece build (both kernels are enqueued, one of them returns at once)."""
     case = Case("msl")
@@ -98,7 +114,7 @@ def test_large_inputs_fall_back_to_the_row_split_kernel(gpu_device):
     g = torch.Generator().manual_seed(3)
     x = (torch.rand(64, 100, 55, generator=g) * 3e4).to(gpu_device)
     with torch.no_grad():
-        eng.set_option("gat_kernel", 2)
+        eng.set_option("gat_kernel", gk)
         p2, r2 = model(x)
         eng.set_option("gat_kernel", 1)
         p1, r1 = model(x)
@@ -107,7 +123,8 @@ def test_large_inputs_fall_back_to_the_row_split_kernel(gpu_device):
     assert torch.equal(p2, p1) and torch.equal(r2, r1)
 
 
-def test_sign_flips_of_a_reach_the_column_sliced_pack(gpu_device):
+@pytest.mark.parametrize("gk", KERNELS)
+def test_sign_flips_of_a_reach_the_column_sliced_pack(gk, gpu_device):
     """In-place weight changes that flip signs of the attention vector `a` change the column order of the pack (positive
     columns first) on the device-side re-pack path; outputs must track the row-split kernel's."""
     case = Case("msl")
@@ -121,7 +138,7 @@ def test_sign_flips_of_a_reach_the_column_sliced_pack(gpu_device):
             model.temporal_gat.a.mul_(torch.where(flip, -1.0, 1.0))
             model.feature_gat.a.mul_(-1.0)
             eng = _engine(model, gpu_device)
-            eng.set_option("gat_kernel", 2)
+            eng.set_option("gat_kernel", gk)
             p2, r2 = model(x)
             eng.set_option("gat_kernel", 1)
             p1, r1 = model(x)
