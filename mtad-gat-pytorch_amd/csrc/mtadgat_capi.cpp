@@ -229,7 +229,9 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
              (ldv & 3) == 0 && ((scols + 3) & ~3) <= ldv) {
         GatArgs b = a;
         b.vld = g.fh_vld;
-        K_TRY(launch_gath(b, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.fh_lds_bytes, s), "fused gat (fp16 pieces)");
+        if (const char* e_ = getenv("MTADGAT_GATH_STAGGER")) b.stagger = atoi(e_);
+        b.dbg = m.gat2_stop;             // (measurement hook, shared with k_gat2's: mtadgat_set_option "gat2_stop")
+        K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, s), "fused gat (fp16 pieces)");
         a.skip_h = 1;
     }
     K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.f_lds_bytes, s), "fused gat");
@@ -911,7 +913,7 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
     if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
     if (std::strcmp(name, "gat_kernel") == 0 && value >= 0 && value <= 3) { h->m.gat_kernel = value; return 0; }
-    if (std::strcmp(name, "gat2_stop") == 0 && value >= 0 && value <= 5) { h->m.gat2_stop = value; return 0; }
+    if (std::strcmp(name, "gat2_stop") == 0 && value >= 0 && value <= 7) { h->m.gat2_stop = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
 

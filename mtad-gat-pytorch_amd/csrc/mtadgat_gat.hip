@@ -584,6 +584,10 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     constexpr int IBW = RI * IBL;                      // query rows per wave
     constexpr int QB = MTADGAT_GAT_QB3;                // weight chunks held in registers per task batch
     if (!(a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f)) return;     // k_gat's bf16-piece build serves this launch
+    if (a.stagger > 0 && blockIdx.x < 1024u) {         // (experiment: spread the first workgroups of a launch in time)
+        const unsigned nap = ((blockIdx.x * 2654435761u) >> 29) * (unsigned)a.stagger;
+        for (unsigned i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     for (int part = 0; part < nparts; ++part) {
         // ---- MFMA phase: project this part's 32 + 32 columns for all nodes into Ls / Rs (scaled by S: the weights carry it)
-        for (int task = wave; task < ntask; task += NW) {
+        for (int task = wave; task < ntask && !(a.dbg & 2); task += NW) {
             const bool keyside = task >= NTn;
             const int nt = keyside ? task - NTn : task;
             const int wtile = keyside ? a.NT_L + part : part;
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
         int ntl = ntile - 4 * part;
         ntl = ntl > 4 ? 4 : ntl;
-        if (ntl > 0 && rows_owner) {
+        if (ntl > 0 && rows_owner && !(a.dbg & 1)) {
             f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
             lds_cptr lq[IBL];
 #pragma unroll
@@ -796,6 +800,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     }
     __syncthreads();
     if (!rows_owner) return;                           // no barrier below this point
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.out[0] = cv[0] + dv[0]; return; }
 
     // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); S leaves the scores here
     const float sinv = a.scale2[1];
@@ -1256,7 +1261,7 @@ int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_b
     const unsigned grid = (unsigned)a.nwin;
     bool launched = false;
     GATH_CASE(4, 1, 16) GATH_CASE(4, 2, 16) GATH_CASE(4, 3, 16) GATH_CASE(4, 4, 16) GATH_CASE(4, 5, 16) GATH_CASE(4, 6, 16) GATH_CASE(4, 7, 16) GATH_CASE(4, 8, 16)
-    GATH_CASE(2, 1, 8) GATH_CASE(2, 3, 8) GATH_CASE(2, 5, 8) GATH_CASE(2, 7, 8)
+    GATH_CASE(2, 1, 8) GATH_CASE(2, 3, 8) GATH_CASE(2, 5, 8) GATH_CASE(2, 7, 8) GATH_CASE(2, 9, 8) GATH_CASE(2, 11, 8) GATH_CASE(2, 13, 8) GATH_CASE(2, 15, 8)
     if (!launched) return -2;
     LAUNCH_CHECK();
     return 0;

@@ -153,6 +153,11 @@ std::string validate_and_plan(Model& m) {
         g.bias_off = take((size_t)K * K);
         g.Q16 = g.fused ? (D + 1 + 15) / 16 : 0;
         if (g.fused) {      // fp16-piece build: pitch 4 x odd halfs (conflict-free 8-byte operand reads of 32 consecutive nodes)
+            g.fh_IBL = g.f_IBL; g.fh_JPL = g.f_JPL; g.fh_RJ = g.f_RJ;
+            // (8 lanes along the keys also where that pads them less than 16 -- K = 100: 104 instead of 112 keys -- costs as much in
+            // LDS operand reads as it saves in pair instructions: 10.15 vs 10.05 ms for the two layers; measurement hook)
+            if (const char* e_ = getenv("MTADGAT_GATH_RJ8"))
+                if (atoi(e_) && g.f_RJ == 16 && round_up(K, 8) < round_up(K, 16) && (K + 7) / 8 <= 15) { g.fh_RJ = 8; g.fh_IBL = 2; g.fh_JPL = (K + 7) / 8; }
             g.fh_vld = 16 * g.Q16 + 4;
             g.fh_lds_bytes = (size_t)g.f_lr * sizeof(float) + (size_t)2 * round_up(K, 16) * g.fh_vld * 2;
         }
