@@ -117,8 +117,9 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, vo
  * mtadgat_params (the order of the flat gradient buffer, mtadgat_grad_offsets / mtadgat_grad_floats), and the tile
  * image is rebuilt from it by kernels on `stream`; nothing but the sign pattern of the two attention vectors `a`
  * (a few hundred bytes; it fixes the column order of the folded GATv2 projection) travels to the host.  Requires one
- * earlier mtadgat_load_weights on this device and precision mode 0; MTADGAT_ERR_UNSUPPORTED otherwise (callers then
- * use mtadgat_load_weights).  The bf16 weight streams are not maintained: mtadgat_bf16_ready turns 0. */
+ * earlier mtadgat_load_weights on this device and precision mode 0 or 2 (the fp32 image; the split-operand packs of mode 2,
+ * k_gat2's pack included, are re-derived from it on the device); mode 1 returns MTADGAT_ERR_UNSUPPORTED (callers then use
+ * mtadgat_load_weights).  The bf16 weight streams are not maintained: mtadgat_bf16_ready turns 0. */
 int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64_t n_floats, void* stream);
 
 /* Bit-exact 64-bit checksum of a list of device tensors of 32-bit elements (the model's parameters), written to
@@ -245,8 +246,8 @@ int mtadgat_heads(mtadgat_handle h, const float* hend_dev, int64_t batch,
  * Gradients are ACCUMULATED (+=) into `grads_dev`, a flat float32 buffer of mtadgat_grad_floats()
  * entries holding the reference's parameters' gradients in their own shapes, in the field order of
  * mtadgat_params (offsets: mtadgat_grad_offsets); zero it before the first chunk of a step.
- * Not every configuration has a HIP backward (mtadgat_backward_supported; GATv2, single-layer GRU /
- * decoder, <= 128 nodes and features per attention layer do).  `batch` windows are processed as one
+ * Not every configuration has a HIP backward (mtadgat_backward_supported: GATv2 and GAT (v1), any number of stacked
+ * GRU / decoder layers, <= 128 nodes and features per attention layer do; wider attention layers do not).  `batch` windows are processed as one
  * chunk: tape and workspace grow linearly with it (~0.85 + 0.75 MB per window at W=100, F=55). */
 int     mtadgat_backward_supported(mtadgat_handle h);
 size_t  mtadgat_tape_bytes(mtadgat_handle h, int64_t batch);

@@ -123,5 +123,3 @@ def forward(model, x, masks=None):
     recons = recon_stage(model, h_end, masks.get("rec"))
     return preds, recons
 
-
-differentiable_forward = forward      # name used by round-1 tests

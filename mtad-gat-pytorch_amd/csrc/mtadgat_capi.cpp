@@ -117,8 +117,7 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
 bool conv_shared_applies(const Model& m, const XSource& src, int64_t n) {
     if (!src.gather || src.starts || src.stride != 1 || n < 1024 || m.precision == 1 || src.x_bf16) return false;   // (the bf16 build writes h_cat only)
     if (m.taps != 2 * m.pad + 1 || m.pad < 1 || m.W < 4 * m.pad) return false;
-    const int Fq = m.precision == 1 ? m.Fp16 : m.Fp;
-    return (size_t)(32 + m.taps - 1) * (Fq + 4) * sizeof(float) <= 20 * 1024;
+    return (size_t)(32 + m.taps - 1) * (m.Fp + 4) * sizeof(float) <= 20 * 1024;
 }
 int run_conv_shared(Model& m, const XSource& src, int64_t c0, int64_t n, float* hcat, float* cf, float* el, float* er, hipStream_t s,
                     unsigned* vmax) {
@@ -250,12 +249,23 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 // the small-batch fp32 recurrence kernels apply to a single-layer stack whose weights fit a wave's registers
 // (inference in the bf16 mode uses k_gru1 up to 1024 windows -- faster there than the bf16 build of the throughput
 // kernels, and exact; the training step keeps the bf16 recurrences it was asked for)
+// the part of run_gru_layer's `cm_fit` that does not depend on the call: can the split-operand kernels (k_gru_cm / the X3H
+// build of k_gru_split) serve this layer at all?  (hidden sizes above 160, wide windows, input packs that need the range guard
+// without a fused front end cannot: such layers keep k_gru16 up to G16_MAX_WINDOWS)
+bool split_kernels_fit(const Model& m, const GruPlan& g) {
+    if (m.W > 512 || !(g.Qxp16 == 1 || g.Qxp16 % 2 == 0)) return false;
+    if (g.xmode == 1) return g.Qxp16 == 1 && gru_cm_supported(g.NCG, 1, false, 0);
+    const bool guard = use_fused(m.temp) && use_fused(m.feat);           // the convolution records its output range only there
+    return gru_cm_supported(g.NCG, 0, false, 0) && g.wxq_off != 0 && g.Qx >= 3 && ((guard && g.wx2_off && g.qb3 > 0) || g.qb3 == 0);
+}
+
 bool use_g16(const Model& m, const std::vector<GruPlan>& stack, int64_t n, bool training = false) {
     if (stack.size() != 1 || !stack[0].has16) return false;
     if (m.precision == 1) return !training && n <= 1024;
     // inference in the split-operand arithmetic: from SPLIT3_MIN_WINDOWS on the hidden-tile-split kernel's split-operand build
-    // is the faster one (run_gru_layer); the measurement hook can force it at any size
-    if (m.precision == 2 && !training && stack[0].NCG >= 2 && (m.gru_kernel == 3 || (m.gru_kernel == 0 && n >= SPLIT3_MIN_WINDOWS))) return false;
+    // is the faster one (run_gru_layer) -- where it applies; the measurement hook can force it at any size
+    if (m.precision == 2 && !training && stack[0].NCG >= 2 && split_kernels_fit(m, stack[0]) &&
+        (m.gru_kernel == 3 || (m.gru_kernel == 0 && n >= SPLIT3_MIN_WINDOWS))) return false;
     return n <= G16_MAX_WINDOWS;
 }
 

@@ -499,8 +499,9 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
     w.de_t = take(N * m.W * m.W);
     w.dv_f = take(N * m.F * m.Wp);
     w.dv_t = take(N * m.W * m.Fp);
-    w.dlr_f = take(N * m.F * 2 * b.gat[0].Ep);
-    w.dlr_t = take(N * m.W * 2 * b.gat[1].Ep);
+    // (GAT v1 reuses these regions for its per-window partials [sum dc_i v_i | sum dd_j v_j | sc sd]: 2 D + 2 floats per window)
+    w.dlr_f = take(std::max(N * m.F * 2 * b.gat[0].Ep, m.cfg.use_gatv2 ? (size_t)0 : N * (2 * (size_t)m.W + 2)));
+    w.dlr_t = take(std::max(N * m.W * 2 * b.gat[1].Ep, m.cfg.use_gatv2 ? (size_t)0 : N * (2 * (size_t)m.F + 2)));
     w.dap_f = take(N * b.gat[0].Ep);
     w.dap_t = take(N * b.gat[1].Ep);
     w.dpre = take(N * m.W * m.Fp);

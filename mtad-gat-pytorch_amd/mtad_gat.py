@@ -245,8 +245,9 @@ class MTAD_GAT(nn.Module):
             # True: every GPU call fingerprints the parameter *contents* (one small reduction + a host
             # sync), so in-place edits that bypass autograd's version counter (`p.data.mul_()`,
             # `nn.init.*_(p.data)`) are seen.  False: trust (data_ptr, _version) only -- no sync per call;
-            # call refresh_weights() after such edits.  While the model is in train() mode the fingerprint is skipped
-            # (optimizers bump the version counter; one host sync less per training step) unless this is "always".
+            # call refresh_weights() after such edits.  "eval_only": fingerprint in eval() mode, trust the version
+            # counters in train() mode (optimizers bump them; saves the host sync of a training step -- but manual
+            # `p.data` edits between training steps then need refresh_weights()).  ("always" = True, kept for old callers.)
             object.__setattr__(self, "check_weight_contents", True)
         if "device_repack" not in self.__dict__:
             # True: after the first load, changed fp32 weights (an optimizer step) are re-packed on the GPU
@@ -294,11 +295,18 @@ class MTAD_GAT(nn.Module):
             object.__setattr__(self, "_engine", _native.Engine(self._native_cfg, device))
             object.__setattr__(self, "_weights_key", None)
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
-        if self.check_weight_contents == "always" or (self.check_weight_contents and not self.training):
+        # the content fingerprint is part of the key in train() and eval() mode alike (in-place `p.data` edits bump no version
+        # counter in either mode, and a key of the same shape in both modes means train() / eval() toggles force no re-pack);
+        # "eval_only" leaves it out -- in both positions of the key, as None -- while the model trains
+        fp = None
+        if self.check_weight_contents and not (self.check_weight_contents == "eval_only" and self.training):
             if all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
-                key = key + (self._engine.fingerprint(params, device),)
+                fp = self._engine.fingerprint(params, device)
             else:
-                key = key + (self._fingerprint(params),)
+                fp = self._fingerprint(params)
+        elif self.check_weight_contents == "eval_only" and self._weights_key is not None and self._weights_key[:-1] == key:
+            fp = self._weights_key[-1]           # training under "eval_only": versions unchanged -> keep the packed weights
+        key = key + (fp,)
         mode = 1 if bf16 else (0 if self.precision == "fp32_strict" else 2)
         self._engine.set_precision(mode)
         if key != self._weights_key or (bf16 and not self._engine.bf16_ready()):

@@ -124,3 +124,32 @@ def test_train_py_unchanged_one_epoch(tmp_path):
         va, vb = va[:-1] if a.startswith("[Epoch") else va, vb[:-1] if b.startswith("[Epoch") else vb   # drop the wall time
         assert len(va) == len(vb) and all(abs(x - y) <= 2e-4 for x, y in zip(va, vb)), (a, b)
     _close(summaries["ours"], summaries["reference"], 5e-3)
+
+
+def _cuda_here():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not _cuda_here(), reason="needs a GPU next to the reference tree")
+def test_predict_py_unchanged_with_use_cuda(tmp_path):
+    """Where a GPU and the reference tree sit on the same host ($MTADGAT_REFERENCE; never the case on the build or the test
+    boxes of this repo: one has no GPU, the other no reference tree), the UNCHANGED predict.py runs with `--use_cuda True`: our
+    module then serves Predictor.get_score's forwards on the HIP path (the reference module on stock PyTorch-ROCm ops), and
+    the two summaries must agree as on the CPU."""
+    summaries = {}
+    for which in ("ours", "reference"):
+        cwd = tmp_path / which
+        _make_smd(str(cwd), n_train=420, n_test=520)
+        dst = cwd / "output" / "SMD" / "1-1" / "27062021_114402"
+        os.makedirs(dst)
+        for fn in ("model.pt", "config.txt"):
+            shutil.copy(os.path.join(REF, "output", "SMD", "1-1", "27062021_114402", fn), dst / fn)
+        out, mod = _run(which, str(cwd), "predict.py", "--dataset", "SMD", "--group", "1-1", "--use_cuda", "True", "--level", "0.85")
+        assert ("mtad-gat-pytorch_amd" in mod) == (which == "ours"), mod
+        summaries[which] = json.load(open(dst / "summary.txt"))
+    _close(summaries["ours"], summaries["reference"], 1e-4)
