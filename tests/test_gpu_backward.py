@@ -128,6 +128,30 @@ def test_gradients_match_autograd_above_the_small_batch_kernels(name, gpu_device
     assert not bad, "\n".join(bad)
 
 
+def test_gradients_above_the_fp16_range_guard(gpu_device):
+    """From 2561 windows on the training forward's recurrences run on split operands, with two fp16 pieces for the
+    convolution's channels -- unless the convolution recorded outputs of 2^15 and more: then the device-side guard hands the
+    launch to the fp32 kernel (both are enqueued, one returns at once).  Un-normalised inputs must give the same gradients
+    as autograd through the torch-op algebra, and the guard must actually have tripped."""
+    kw, _ = CONFIGS["odd_shapes"]
+    b = 2600
+    model = _model(kw, gpu_device).eval()
+    g = torch.Generator().manual_seed(14)
+    x = (torch.rand(b, kw["window_size"], kw["n_features"], generator=g) * 4e5).to(gpu_device)
+    y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
+    pr_ref, rc_ref, ref = _reference_grads(model, x, y)
+    pr, rc = model(x)
+    assert model.grad_path == "hip", model.grad_path
+    # pre-activations of ~1e5: fp32 itself resolves ~1e-2 there, two summation orders differ by ~1e-4 in the outputs
+    assert (pr - pr_ref).abs().max().item() <= 5e-4 and (rc - rc_ref).abs().max().item() <= 5e-4
+    _loss(pr, rc, x, y).backward()
+    rows, bad = _grad_report(model, ref, tol_abs=1e-5, tol_rel=5e-3)
+    print("\n".join(rows))
+    assert not bad, "\n".join(bad)
+    with torch.no_grad():
+        assert model.conv(x[:64]).max().item() >= 32768.0            # the inputs do exceed the fp16 pieces' range
+
+
 @pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape", "stacked", "stacked3_v1"])
 def test_gradients_match_autograd_with_dropout(name, gpu_device):
     """train(): dropout inside the kernels; the same keep-masks (exported by the library) injected into the
