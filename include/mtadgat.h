@@ -167,7 +167,9 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  * "gat_kernel": which kernel runs the fused attention layers (modules.py:65-95, :166-193) in precision mode 2:
  *   0 automatic (default: from 4096 windows per chunk the fp16-piece build k_gath of the row-split kernel when the convolution's
  *   outputs are below 2^15, else k_gat), 1 k_gat at every batch size, 2 the column-sliced kernel k_gat2 wherever it applies
- *   (GATv2, <= 104 nodes; slower than k_gath on the shipped shapes: DESIGN.md section 4), 3 k_gath at every batch size. */
+ *   (GATv2, <= 104 nodes; slower than k_gath on the shipped shapes: DESIGN.md section 4), 3 k_gath at every batch size.
+ * "conv_kernel": the convolution of the fused front end (modules.py:18-22) in precision mode 2: 0 automatic (the
+ *   window-per-workgroup kernel on fp16 pieces from 4096 windows per chunk), 1 k_conv_lds (fp32 MFMA), 2 k_conv_win at any size. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
 /* Diagnostics for bench.py: the largest convolution output of the last forward() that used workspace `ws` (its last
  * chunk; synchronises `stream`).  Below 2^15 the large-batch kernels used two fp16 pieces per operand, otherwise three

@@ -105,6 +105,17 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
         if (!keep_vmax) HIP_TRY(hipMemsetAsync(vmax, 0, sizeof(unsigned), s));
         a.vmax = vmax;
     }
+    // mode 2, the fused front end's call (h_cat only) on whole windows: the window-per-workgroup kernel on fp16 pieces
+    if (m.precision == 2 && !geo_W && hcat && !xc && !xct && !y && m.conv_kernel != 1 && (n >= 4096 || m.conv_kernel == 2)) {
+        ConvArgs b = a;
+        b.Fq = m.Fp16;
+        b.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w2h_off);
+        b.wscale = m.packed_dev + m.conv_scale_off + 1;
+        if (conv_win_applies(b)) {
+            K_TRY(launch_conv_win(b, s), "conv (window per workgroup)");
+            return 0;
+        }
+    }
     K_TRY(launch_conv(a, s), "conv");
     return 0;
 }
@@ -638,6 +649,14 @@ static int run_split3(Model& m, hipStream_t s) {
     };
     for (const GruPlan& g : m.gru) { int rc = one(g); if (rc) return rc; }
     for (const GruPlan& g : m.rec) { int rc = one(g); if (rc) return rc; }
+    {   // the window convolution's pack: two fp16 pieces of S * W in the 16-channel geometry
+        float* sc = m.packed_dev + m.conv_scale_off;
+        const int q8 = m.taps * m.Fp16 / 8;
+        HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
+        K_TRY(launch_absmax(m.packed_dev + m.conv_wf16_off, (long)m.convNT * q8 * 256, sc, s), "convolution weight range");
+        K_TRY(launch_scale_from_max(sc, s), "convolution weight scale");
+        K_TRY(launch_split2h(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w2h_off, m.convNT, q8, q8 / 2, 1, sc + 1, s), "split-fp16 convolution weights");
+    }
     for (const GatPlan* g : {&m.feat, &m.temp})
         if (g->fused) {
             K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
@@ -834,6 +853,8 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     for (const GruPlan& g : m.rec) one(g);
     add(m.feat.w3_off, (size_t)m.feat.NT * m.feat.Q16 * 3 * 256);
     add(m.temp.w3_off, (size_t)m.temp.NT * m.temp.Q16 * 3 * 256);
+    add(m.conv_w2h_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 2 * 256);
+    add(m.conv_scale_off, 4);
     for (const GatPlan* g : {&m.feat, &m.temp}) {
         add(g->w2h_off, (size_t)g->NT * g->Q16 * 2 * 256);
         add(g->gscale_off, 4);
@@ -923,6 +944,7 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
     if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
     if (std::strcmp(name, "gat_kernel") == 0 && value >= 0 && value <= 3) { h->m.gat_kernel = value; return 0; }
+    if (std::strcmp(name, "conv_kernel") == 0 && value >= 0 && value <= 2) { h->m.conv_kernel = value; return 0; }
     if (std::strcmp(name, "gat2_stop") == 0 && value >= 0 && value <= 7) { h->m.gat2_stop = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }

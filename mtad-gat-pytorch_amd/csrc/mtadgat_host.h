@@ -170,6 +170,7 @@ struct Model {
     int Fp16 = 0;                    // bf16 conv build: channels padded to 16
     size_t conv_w16_off = 0;
     size_t conv_wf16_off = 0;        // fp32 tiles in the 16-channel geometry (source of the split-bf16 pack)
+    size_t conv_w2h_off = 0, conv_scale_off = 0;   // k_conv_win: two fp16 pieces of S * W [tile][taps * Fp16 / 16][2][64], [bits of max |W|, S, 1 / S, 0]
     GatPlan feat, temp;
     std::vector<GruPlan> gru, rec;
     std::vector<LinPlan> fc;
@@ -185,6 +186,7 @@ struct Model {
     bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
+    int conv_kernel = 0;             // convolution of the fused front end in mode 2 (testing hook): 0 automatic (k_conv_win from 4096 windows), 1 k_conv_lds, 2 k_conv_win at any batch size
     int gat2_stop = 0;               // measurement hook: Gat2Args::dbg_stop
     int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic (testing hook): 0 automatic (k_gath, the fp16-piece build, from 4096 windows), 1 k_gat only, 2 column-sliced k_gat2 at any batch size, 3 k_gath at any batch size
     int gru_kernel = 0;              // large-batch recurrence: 0 automatic, 1 tile-major k_gru, 2 chunk-major k_gru_cm (testing hook: mtadgat_set_option)

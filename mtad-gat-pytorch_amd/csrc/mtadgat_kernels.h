@@ -61,6 +61,7 @@ struct ConvArgs {
     int bf16;            // 1: Wp is the bf16 pack (k_conv_lds only)
     unsigned* vmax;      // k_conv_lds: bits of the largest output written so far (atomic max), or null
     int x_bf16;          // 1: X holds bfloat16 (read directly by k_conv_lds; no fp32 copy of the input exists)
+    const float* wscale; // k_conv_win: [S, 1 / S] of its two-fp16-piece weight pack (Wp then points at that pack, Fq = F rounded up to 16)
     const f32x4* Wp;     // packed (F x taps*Fq), NT tiles, Q = taps*Fq/8 (bf16: /16)
     const float* bias;   // NT*32
     int NT;
@@ -350,6 +351,8 @@ inline int cu_count() {
 
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t s);
 int launch_conv(const ConvArgs& a, hipStream_t s);
+bool conv_win_applies(const ConvArgs& a);
+int launch_conv_win(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);

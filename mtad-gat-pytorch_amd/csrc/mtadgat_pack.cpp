@@ -113,6 +113,8 @@ std::string validate_and_plan(Model& m) {
         m.Fp16 = round_up(m.F, 16);
         m.conv_w16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 256);
         m.conv_wf16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 8) * 256);
+        m.conv_w2h_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 2 * 256);
+        m.conv_scale_off = take(4);
     }
     // GAT layers
     auto plan_gat = [&](GatPlan& g, int K, int D, int E) {

@@ -147,3 +147,49 @@ def test_sign_flips_of_a_reach_the_column_sliced_pack(gk, gpu_device):
             gate(p2, p_ref, what="preds after sign flips")
             gate(r2, r_ref, what="recons after sign flips")
             assert (p2 - p1).abs().max().item() <= 2e-6 and (r2 - r1).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["msl", "smap", "smd_1_1", "syn_v2_embed", "syn_v1_small"])
+def test_window_convolution_on_fp16_pieces(name, gpu_device):
+    """k_conv_win (csrc/mtadgat_convw.hip; reference ConvLayer.forward modules.py:18-22): one workgroup per window, the window
+    scaled by a power of two and split into two fp16 pieces, weights likewise -- forced at fixture size through the testing
+    hook; the forward must still match the reference's golden outputs, and the fp32-MFMA convolution's to rounding."""
+    case = Case(name)
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    x = case.x.to(gpu_device)
+    with torch.no_grad():
+        eng.set_option("conv_kernel", 2)
+        p2, r2 = model(x)
+        eng.set_option("conv_kernel", 1)
+        p1, r1 = model(x)
+        eng.set_option("conv_kernel", 0)
+    gate(p2, case.preds, case.preds64, what=f"{name} predictions (k_conv_win)")
+    gate(r2, case.recons, case.recons64, what=f"{name} recons (k_conv_win)")
+    assert (p2 - p1).abs().max().item() <= 2e-6 and (r2 - r1).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 3e4, 1e9])
+def test_window_convolution_at_any_input_scale(scale, gpu_device):
+    """The per-window power-of-two scaling makes the fp16 pieces independent of the input's magnitude: the forward must
+    track the one on the fp32-MFMA convolution for normalised, tiny and un-normalised series alike, with windows of very
+    different magnitude in one batch and an outlier that sets one window's scale."""
+    case = Case("msl")
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(96, 100, 55, generator=g) * scale
+    x[::3] *= 1e-3                                         # every third window three orders of magnitude smaller
+    x[5, 17, 3] = 40.0 * scale
+    x = x.to(gpu_device)
+    with torch.no_grad():
+        eng.set_option("conv_kernel", 2)
+        eng.set_option("gat_kernel", 1)
+        p2, r2 = model(x)
+        eng.set_option("conv_kernel", 1)
+        p1, r1 = model(x)
+        eng.set_option("conv_kernel", 0)
+        eng.set_option("gat_kernel", 0)
+    assert torch.isfinite(p2).all() and torch.isfinite(r2).all()
+    tol = 2e-6 if scale <= 1.0 else 5e-3 * max(1.0, r1.abs().max().item())     # (pre-activations of ~1e4 and more: see test_gpu_parity)
+    assert (p2 - p1).abs().max().item() <= tol and (r2 - r1).abs().max().item() <= tol
