@@ -18,22 +18,27 @@
 
 namespace mtadgat {
 
-namespace {
-constexpr int CW_RT = 2;        // 32-row tiles per wave
-}
-
-template <int NTB>
-__global__ __launch_bounds__(128, 3) void k_conv_win(const ConvArgs a) {
+// CW_RT 32-row tiles per wave, NWV = 4 / CW_RT waves per window (W <= 128)
+template <int NTB, int CW_RT>
+__global__ __launch_bounds__(256 / CW_RT, CW_RT == 1 ? 4 : 3) void k_conv_win(const ConvArgs a) {
+    constexpr int NTHR = 256 / CW_RT, NWV = NTHR / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+    if ((a.dbg & 8) && blockIdx.x < 4096u) {           // (experiment: spread the first workgroups in time)
+        const unsigned nap = (blockIdx.x * 2654435761u) >> 28;
+        for (unsigned k = 0; k < nap; ++k) __builtin_amdgcn_s_sleep(100);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long win = blockIdx.x;
     const int W = a.W, F = a.F, Fq = a.Fq, taps = a.taps, pad = a.pad;
-    const int pvh = Fq + 4;                            // piece pitch in halfs: 4 x odd -> conflict-free 8-byte operand reads
+    // piece pitch in halfs: 4 x odd -> conflict-free 8-byte operand reads.  The smallest such pitch that holds the F channels: the
+    // last chunk of a row then reads on into the next row (or the spare row) -- finite values against zero weights -- and a
+    // workgroup takes 25.7 instead of 29.1 KB of LDS at (W = 100, F = 55): six of them per CU instead of five
+    const int pvh = a.pvh;
     const int nrows = W + taps - 1;                    // staged rows: the window between its zero halos
     unsigned short* __restrict__ Xh = reinterpret_cast<unsigned short*>(smem8);
-    unsigned short* __restrict__ Xl = Xh + (nrows + 1) * pvh;
-    float* __restrict__ red = reinterpret_cast<float*>(Xl + (nrows + 1) * pvh);      // [2] wave maxima, [2] the window's scale and its inverse
+    unsigned short* __restrict__ Xl = Xh + (nrows + 2) * pvh;        // (two spare zero rows per piece: padding rows of the last tile, overrun of the last chunk)
+    float* __restrict__ red = reinterpret_cast<float*>(Xl + (nrows + 2) * pvh);      // [4] wave maxima, [2] the window's scale and its inverse
 
     // ---- the window as a flat array of W F floats (16-byte loads when its base allows), largest |x| of the window
     const long s0 = a.gather ? (a.starts ? a.starts[win] : a.start0 + win * a.stride) : win * (long)W;
@@ -41,13 +46,13 @@ __global__ __launch_bounds__(128, 3) void k_conv_win(const ConvArgs a) {
     const unsigned short* __restrict__ xw16 = reinterpret_cast<const unsigned short*>(a.X) + s0 * F;     // x_bf16: bfloat16 elements, read directly
     const int total = W * F;
     const bool vec = a.x_bf16 ? (reinterpret_cast<unsigned long>(xw16) & 7) == 0 : (reinterpret_cast<unsigned long>(xw) & 15) == 0;
-    constexpr int MAXU = 12;                           // 16-byte units per thread held in registers (W F <= 128 * 48 ... plan)
+    constexpr int MAXU = 6 * CW_RT;                    // 16-byte units per thread held in registers (W F <= 6144: plan)
     f32x4 v[MAXU];
     const int nunit = (total + 3) >> 2;
     float mx = 0.f;
 #pragma unroll
     for (int n = 0; n < MAXU; ++n) {
-        const int u = tid + n * 128;
+        const int u = tid + n * NTHR;
         const int uc = u < nunit ? u : nunit - 1;
         if (a.x_bf16) {
             typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
@@ -74,40 +79,43 @@ __global__ __launch_bounds__(128, 3) void k_conv_win(const ConvArgs a) {
     // zero halo rows, the spare row behind them and the channel padding [F, Fq) of the window's rows
     {
         const int hw = pvh >> 1;                       // dwords per row
-        for (int u = tid; u < 2 * pad * hw; u += 128) {
+        for (int u = tid; u < 2 * pad * hw; u += NTHR) {
             const int r = u / hw, c = u - r * hw;
             const int row = r < pad ? r : nrows - 2 * pad + r;
             reinterpret_cast<unsigned*>(Xh + row * pvh)[c] = 0u;
             reinterpret_cast<unsigned*>(Xl + row * pvh)[c] = 0u;
         }
-        for (int u = tid; u < hw; u += 128) {
+        for (int u = tid; u < 2 * hw; u += NTHR) {
             reinterpret_cast<unsigned*>(Xh + nrows * pvh)[u] = 0u;
             reinterpret_cast<unsigned*>(Xl + nrows * pvh)[u] = 0u;
         }
-        const int npadc = Fq - F;
-        for (int u = tid; u < W * npadc; u += 128) {
+        const int npadc = (Fq < pvh ? Fq : pvh) - F;
+        for (int u = tid; u < W * npadc; u += NTHR) {
             const int r = u / npadc, c = F + (u - r * npadc);
             Xh[(pad + r) * pvh + c] = 0;
             Xl[(pad + r) * pvh + c] = 0;
         }
     }
     __syncthreads();
+    if (a.dbg & 4) return;
     if (tid == 0) {
-        const float m = fmaxf(red[0], red[1]);
+        float m = red[0];
+#pragma unroll
+        for (int w2 = 1; w2 < NWV; ++w2) m = fmaxf(m, red[w2]);
         // sx = 2^(13 - floor(log2 m)): exponent field 267 - e (m = 0, denormal or not finite: 1)
         const unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
         const unsigned es = (e == 0u || e >= 254u) ? 127u : 267u - e;
         const unsigned ec = es < 1u ? 1u : (es > 253u ? 253u : es);
-        red[2] = __uint_as_float(ec << 23);
-        red[3] = __uint_as_float((254u - ec) << 23);
+        red[4] = __uint_as_float(ec << 23);
+        red[5] = __uint_as_float((254u - ec) << 23);
     }
     __syncthreads();
-    const float sx = red[2], sxi = red[3];
+    const float sx = red[4], sxi = red[5];
     {
         const float finv = 1.0f / (float)F;
 #pragma unroll
         for (int n = 0; n < MAXU; ++n) {
-            const int u = tid + n * 128;
+            const int u = tid + n * NTHR;
             if (u < nunit) {
                 const int f0 = 4 * u;
                 int row = (int)(((float)f0 + 0.5f) * finv), col = f0 - row * F;
@@ -146,48 +154,58 @@ __global__ __launch_bounds__(128, 3) void k_conv_win(const ConvArgs a) {
         const int t = 32 * (CW_RT * wave + rt) + i;
         xoff[rt] = (t < W ? t : nrows - taps + 1) * pvh + 4 * g;        // rows past the window read the spare zero rows
     }
-    f32x4 wa[NTB][2], wb[NTB][2];
+    // weight words of a chunk: [tile][piece]; a ring of four chunks: the words of chunk q + 3 are requested before the MFMAs
+    // of chunk q (the L2 round trip is longer than the 12 MFMAs of a chunk: with one chunk of lookahead the loop ran at the
+    // memory latency, 2.0 ms per 65 536 windows)
+    constexpr int RING = 4;
+    f32x4 wr[RING][NTB][2];
+    auto wload = [&](f32x4 (&w)[NTB][2], int q) {
+        const int qc = q < Q ? q : Q - 1;
 #pragma unroll
-    for (int nb = 0; nb < NTB; ++nb) {
-        wa[nb][0] = Wp[((long)nb * Q * 2) * 64 + lane];
-        wa[nb][1] = Wp[((long)nb * Q * 2 + 1) * 64 + lane];
-    }
+        for (int nb = 0; nb < NTB; ++nb) {
+            w[nb][0] = Wp[(((long)nb * Q + qc) * 2) * 64 + lane];
+            w[nb][1] = Wp[(((long)nb * Q + qc) * 2 + 1) * 64 + lane];
+        }
+    };
+    wload(wr[0], 0);
+    wload(wr[1], 1);
+    wload(wr[2], 2);
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     int tap = 0, cb = 0;
 #pragma unroll 1
-    for (int q = 0; q < Q; ++q) {
-        const int q1 = q + 1 < Q ? q + 1 : q;
+    for (int q0 = 0; q0 < ((a.dbg & 1) ? 0 : Q); q0 += RING) {
 #pragma unroll
-        for (int nb = 0; nb < NTB; ++nb) {
-            wb[nb][0] = Wp[(((long)nb * Q + q1) * 2) * 64 + lane];
-            wb[nb][1] = Wp[(((long)nb * Q + q1) * 2 + 1) * 64 + lane];
-        }
-        const int ko = tap * pvh + 16 * cb;
+        for (int u = 0; u < RING; ++u) {
+            const int q = q0 + u;
+            wload(wr[(u + 3) % RING], q + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < Q) {
+                const int ko = tap * pvh + 16 * cb;
 #pragma unroll
-        for (int rt = 0; rt < CW_RT; ++rt) {
-            const unsigned short* __restrict__ ph = Xh + xoff[rt] + ko;
-            const unsigned short* __restrict__ pl = Xl + xoff[rt] + ko;
-            const u32x2 ha = *reinterpret_cast<const u32x2*>(ph), hb = *reinterpret_cast<const u32x2*>(ph + 8);
-            const u32x2 la = *reinterpret_cast<const u32x2*>(pl), lb = *reinterpret_cast<const u32x2*>(pl + 8);
-            const f32x4 xh = __builtin_bit_cast(f32x4, u4{ha[0], ha[1], hb[0], hb[1]});
-            const f32x4 xl = __builtin_bit_cast(f32x4, u4{la[0], la[1], lb[0], lb[1]});
+                for (int rt = 0; rt < CW_RT; ++rt) {
+                    const unsigned short* __restrict__ ph = Xh + xoff[rt] + ko;
+                    const unsigned short* __restrict__ pl = Xl + xoff[rt] + ko;
+                    const u32x2 ha = *reinterpret_cast<const u32x2*>(ph), hb = *reinterpret_cast<const u32x2*>(ph + 8);
+                    const u32x2 la = *reinterpret_cast<const u32x2*>(pl), lb = *reinterpret_cast<const u32x2*>(pl + 8);
+                    const f32x4 xh = __builtin_bit_cast(f32x4, u4{ha[0], ha[1], hb[0], hb[1]});
+                    const f32x4 xl = __builtin_bit_cast(f32x4, u4{la[0], la[1], lb[0], lb[1]});
 #pragma unroll
-            for (int nb = 0; nb < NTB; ++nb) {
-                acc[rt][nb] = mfma_h(wa[nb][0], xl, acc[rt][nb]);
-                acc[rt][nb] = mfma_h(wa[nb][1], xh, acc[rt][nb]);
-                acc[rt][nb] = mfma_h(wa[nb][0], xh, acc[rt][nb]);
+                    for (int nb = 0; nb < NTB; ++nb) {
+                        acc[rt][nb] = mfma_h(wr[u][nb][0], xl, acc[rt][nb]);
+                        acc[rt][nb] = mfma_h(wr[u][nb][1], xh, acc[rt][nb]);
+                        acc[rt][nb] = mfma_h(wr[u][nb][0], xh, acc[rt][nb]);
+                    }
+                }
+                if (++cb == QF) { cb = 0; ++tap; }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (++cb == QF) { cb = 0; ++tap; }
-#pragma unroll
-        for (int nb = 0; nb < NTB; ++nb) { wa[nb][0] = wb[nb][0]; wa[nb][1] = wb[nb][1]; }
-        asm volatile("" : "+v"(wa[0][0]), "+v"(wa[0][1]));        // (keeps the prefetch a prefetch: see mtadgat_gat2.hip)
-        if (NTB > 1) asm volatile("" : "+v"(wa[NTB - 1][0]), "+v"(wa[NTB - 1][1]));
     }
 
     // ---- epilogue: 1 / (S sx), bias, ReLU; h_cat[:, :F] (+ the zero alignment padding of the row), range of the outputs
     const float osc = a.wscale[1] * sxi;               // both factors are powers of two
+    if (a.dbg & 2) { if (acc[0][0][0] == 12345.f) a.HCAT[0] = osc; return; }
     float vmx = 0.f;
 #pragma unroll
     for (int rt = 0; rt < CW_RT; ++rt) {
@@ -224,27 +242,41 @@ __global__ __launch_bounds__(128, 3) void k_conv_win(const ConvArgs a) {
     }
 }
 
-size_t conv_win_lds(int W, int Fq, int taps) {
-    return (size_t)2 * (W + taps) * (Fq + 4) * 2 + 4 * sizeof(float);
+int conv_win_pitch(int F, int Fq) {
+    int p = (F + 3) & ~3;
+    if ((p >> 2) % 2 == 0) p += 4;                     // 4 x odd
+    return p < Fq + 4 ? p : Fq + 4;
+}
+size_t conv_win_lds(int W, int F, int Fq, int taps) {
+    // (+ one row of slack per piece: the last row's last chunk reads up to Fq - pitch halfs past its end)
+    return (size_t)2 * (W + taps + 1) * conv_win_pitch(F, Fq) * 2 + 8 * sizeof(float);          // (W + taps - 1 staged rows + 2 spare)
 }
 
 // window-per-workgroup convolution: fp32 or bfloat16 windows (materialised or gathered from a series), h_cat output only
 bool conv_win_applies(const ConvArgs& a) {
     if (a.bf16 || !a.HCAT || a.XC || a.XCT || a.Y || !a.wscale) return false;
-    if (a.taps != 2 * a.pad + 1 || a.NT > 2 || a.W > 64 * CW_RT || a.W < 1) return false;
+    if (a.taps != 2 * a.pad + 1 || a.NT > 2 || a.W > 128 || a.W < 1) return false;
     if ((long)a.W * a.F > 12L * 128 * 4 || (a.Fq & 15) != 0 || a.Fq < a.F) return false;
     if ((a.Dp & 3) != 0) return false;
-    return conv_win_lds(a.W, a.Fq, a.taps) <= 64 * 1024;
+    return conv_win_lds(a.W, a.F, a.Fq, a.taps) <= 64 * 1024;
 }
 
 int launch_conv_win(const ConvArgs& a, hipStream_t s) {
     if (a.B <= 0) return 0;
     if (!conv_win_applies(a)) return -2;
-    const size_t lds = conv_win_lds(a.W, a.Fq, a.taps);
-    if (a.NT >= 2)
-        hipLaunchKernelGGL((k_conv_win<2>), dim3((unsigned)a.B), dim3(128), lds, s, a);
-    else
-        hipLaunchKernelGGL((k_conv_win<1>), dim3((unsigned)a.B), dim3(128), lds, s, a);
+    const size_t lds = conv_win_lds(a.W, a.F, a.Fq, a.taps);
+    ConvArgs& am = const_cast<ConvArgs&>(a);
+    am.pvh = conv_win_pitch(a.F, a.Fq);
+    if (getenv("MTADGAT_CONVW_WIDE")) am.pvh = a.Fq + 4;
+    if (const char* e_ = getenv("MTADGAT_CONVW_DBG")) am.dbg = atoi(e_);
+    static const int rt = getenv("MTADGAT_CONVW_RT") ? atoi(getenv("MTADGAT_CONVW_RT")) : 2;      // (measurement hook: row tiles per wave)
+    if (a.NT >= 2) {
+        if (rt == 1) hipLaunchKernelGGL((k_conv_win<2, 1>), dim3((unsigned)a.B), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_conv_win<2, 2>), dim3((unsigned)a.B), dim3(128), lds, s, a);
+    } else {
+        if (rt == 1) hipLaunchKernelGGL((k_conv_win<1, 1>), dim3((unsigned)a.B), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((k_conv_win<1, 2>), dim3((unsigned)a.B), dim3(128), lds, s, a);
+    }
     LAUNCH_CHECK();
     return 0;
 }

@@ -61,6 +61,8 @@ struct ConvArgs {
     int bf16;            // 1: Wp is the bf16 pack (k_conv_lds only)
     unsigned* vmax;      // k_conv_lds: bits of the largest output written so far (atomic max), or null
     int x_bf16;          // 1: X holds bfloat16 (read directly by k_conv_lds; no fp32 copy of the input exists)
+    int pvh;             // k_conv_win: LDS pitch of the staged pieces (halfs), set by its launcher
+    int dbg;             // k_conv_win measurement hook (bit 0: no MFMA loop, 1: no epilogue, 2: loads + halo only)
     const float* wscale; // k_conv_win: [S, 1 / S] of its two-fp16-piece weight pack (Wp then points at that pack, Fq = F rounded up to 16)
     const f32x4* Wp;     // packed (F x taps*Fq), NT tiles, Q = taps*Fq/8 (bf16: /16)
     const float* bias;   // NT*32

@@ -18,7 +18,7 @@ for f in ("pmc_sq1.csv", "pmc_sq2.csv"):
         k = r["Kernel_Name"][:60]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
     for k, v in acc.items():
-        if "gat" in k:
+        if "gat" in k or "conv" in k:
             print(k, {c: "%.3e" % x for c, x in v.items()})
 PY
 head -8 $OUT/kernel_stats.csv | cut -c1-160
