@@ -595,7 +595,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const int K = a.K, D = a.D, PT = a.PT;
     const int pvh = a.vld;                             // piece pitch in halfs
     const int Kp16 = (K + 15) & ~15;                   // rows of the pieces: real nodes then zero rows
-    const int NWA = (K + IBW - 1) / IBW;               // waves that own query rows (the rest only project)
+    // waves that own query rows (the rest only project): n_full of them 4 RI = 16 rows (IBL per lane), n_short one row per lane
+    // less (IBL - 1: 12 rows, or 8 with 8 lanes along the keys) -- 100 rows = 4 x 16 + 3 x 12, 55 = 3 x 16 + 8: no padded rows
+    const int NWA = a.n_full + a.n_short;
     float* __restrict__ Ls = smem;
     float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;
     unsigned short* __restrict__ Vh = reinterpret_cast<unsigned short*>(smem + a.lr_floats);
@@ -697,7 +699,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     __syncthreads();
 
     const bool rows_owner = wave < NWA;
-    const int i0 = (rows_owner ? wave : 0) * IBW;
+    const bool full = wave < a.n_full;
+    const int i0 = !rows_owner ? 0 : (full ? wave * IBW : a.n_full * IBW + (wave - a.n_full) * (IBW - RI));
+    const int iblw = full ? IBL : IBL - 1;             // rows per lane of this wave
     lds_cptr lp[IBL];
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) {
@@ -761,28 +765,52 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         int ntl = ntile - 4 * part;
         ntl = ntl > 4 ? 4 : ntl;
         if (ntl > 0 && rows_owner && !(a.dbg & 1)) {
-            f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
-            lds_cptr lq[IBL];
-#pragma unroll
-            for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
-            lds_cptr rq = rp;
-            gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
             int npos = ptile - 4 * part;
             npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
+            lds_cptr rq = rp;
             int kt = 0;
-#pragma unroll 1
-            for (; kt < npos; ++kt) {
-                gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
+            if (full) {
+                f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
+                lds_cptr lq[IBL];
 #pragma unroll
-                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
-                rq += 8;
-            }
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
+                gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
 #pragma unroll 1
-            for (; kt < ntl; ++kt) {
-                gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
+                for (; kt < npos; ++kt) {
+                    gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
 #pragma unroll
-                for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
-                rq += 8;
+                    for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                    rq += 8;
+                }
+#pragma unroll 1
+                for (; kt < ntl; ++kt) {
+                    gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                    for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                    rq += 8;
+                }
+            } else {
+                constexpr int IS = IBL - 1;             // the short block: the lane's last row belongs to the next wave
+                float (&accs)[IS][JPL] = reinterpret_cast<float (&)[IS][JPL]>(acc);
+                f32x2 lA[IS], rA[JPL], lB[IS], rB[JPL];
+                lds_cptr lq[IS];
+#pragma unroll
+                for (int ii = 0; ii < IS; ++ii) lq[ii] = lp[ii];
+                gat_load<IS, JPL, RJ>(lA, rA, lq, rq, 0);
+#pragma unroll 1
+                for (; kt < npos; ++kt) {
+                    gat_tile<IS, JPL, RJ, false>(accs, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                    for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
+                    rq += 8;
+                }
+#pragma unroll 1
+                for (; kt < ntl; ++kt) {
+                    gat_tile<IS, JPL, RJ, true>(accs, lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                    for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
+                    rq += 8;
+                }
             }
         }
         if (part + 1 < nparts) {
@@ -807,6 +835,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) {
         const int irow = i0 + li + RI * ii;
+        const bool rowok = ii < iblw && irow < K;
         const int irc = irow < K ? irow : K - 1;
         float e[JPL];
         float m = -INFINITY;
@@ -835,7 +864,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         sum = row_sum<RJ>(sum);
         const float inv = soft_rcp(sum);
 #pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = irow < K ? e[jj] * inv : 0.f;
+        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = rowok ? e[jj] * inv : 0.f;
     }
 
     // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) as out^T = V^T att^T on v_mfma_f32_16x16x16_f16, three terms per product
@@ -900,6 +929,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     }
     {
         const int row = i0 + nr;
+        const bool rv = nr < RI * iblw && row < K;
         float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
 #pragma unroll
         for (int dt = 0; dt < DTMAX; ++dt)
@@ -908,13 +938,13 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                 f32x4 y;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[dt][r]);
-                if (a.so_d == 1 && row < K && d0 + 3 < D) {
+                if (a.so_d == 1 && rv && d0 + 3 < D) {
                     typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
                     *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (row < K && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
+                        if (rv && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
                 }
             }
     }
@@ -1257,7 +1287,7 @@ int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_by
 // the fp16-piece build of the fused layer (a.vld = piece pitch in halfs, a.lr_floats as for k_gat, a.Q = 16-feature chunks)
 int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
     if (a.nwin <= 0) return 0;
-    if (rj * JPL < a.K || nw * 16 < a.K || nw > 8 || a.ATT) return -2;
+    if (rj * JPL < a.K || nw > 8 || a.ATT || a.n_full + a.n_short > nw || a.n_full * 16 + a.n_short * (16 - 64 / rj) < a.K) return -2;
     const unsigned grid = (unsigned)a.nwin;
     bool launched = false;
     GATH_CASE(4, 1, 16) GATH_CASE(4, 2, 16) GATH_CASE(4, 3, 16) GATH_CASE(4, 4, 16) GATH_CASE(4, 5, 16) GATH_CASE(4, 6, 16) GATH_CASE(4, 7, 16) GATH_CASE(4, 8, 16)

@@ -120,6 +120,7 @@ struct GatArgs {
     float* ATT;          // (B, K, K) or null
     DropArgs drop;
     unsigned drop_stream;
+    int n_full, n_short; // k_gath: waves owning 16 query rows / 16 - 64 / RJ query rows (the rest of the workgroup only projects)
     int stagger;         // k_gath experiment: start delay unit (x 3.5 us x 0..7) of the first 1024 workgroups
     int dbg;             // k_gath measurement hook (bit 0: no pair grid, 1: no projection, 2: return before the softmax); results invalid
     int skip_h;          // 1: return at once when *vmax < 2^15 -- k_gat2 (launched ahead of this kernel) serves that case

@@ -160,8 +160,19 @@ std::string validate_and_plan(Model& m) {
             // LDS operand reads as it saves in pair instructions: 10.15 vs 10.05 ms for the two layers; measurement hook)
             if (const char* e_ = getenv("MTADGAT_GATH_RJ8"))
                 if (atoi(e_) && g.f_RJ == 16 && round_up(K, 8) < round_up(K, 16) && (K + 7) / 8 <= 15) { g.fh_RJ = 8; g.fh_IBL = 2; g.fh_JPL = (K + 7) / 8; }
+            {   // row blocks of the owning waves: as few padded rows as 16-row and short (12- / 8-row) blocks allow
+                const int shortrows = 16 - 64 / g.fh_RJ;
+                int best_rows = 1 << 30, bf = 0, bs = 0;
+                for (int nf = 0; nf <= g.f_nw; ++nf)
+                    for (int ns = 0; nf + ns <= g.f_nw; ++ns) {
+                        const int rows = 16 * nf + shortrows * ns;
+                        if (rows >= K && (rows < best_rows || (rows == best_rows && nf + ns < bf + bs))) { best_rows = rows; bf = nf; bs = ns; }
+                    }
+                g.fh_full = bf; g.fh_short = bs;
+            }
             g.fh_vld = 16 * g.Q16 + 4;
-            g.fh_lds_bytes = (size_t)g.f_lr * sizeof(float) + (size_t)2 * round_up(K, 16) * g.fh_vld * 2;
+            g.fh_lr = (int)round_up((int)std::max((size_t)((g.fh_full + g.fh_short) * 16 + K) * 34, (size_t)(g.fh_full + g.fh_short) * 16 * 68), 4);
+            g.fh_lds_bytes = (size_t)g.fh_lr * sizeof(float) + (size_t)2 * round_up(K, 16) * g.fh_vld * 2;
         }
         g.w16_off = take((size_t)g.NT * g.Q16 * 256);
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
