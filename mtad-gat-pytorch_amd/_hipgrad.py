@@ -74,6 +74,10 @@ class _HipStep(torch.autograd.Function):
                     _, _, scratch = eng.forward_train(xc, ctx.p, ctx.seed, ctx.w0 + lo, tape=scratch)
                     eng.backward(xc, ctx.p, ctx.seed, d_preds[lo:hi].contiguous(), d_recons[lo:hi].contiguous(), scratch, grads, ctx.w0 + lo)
         ctx.tape = None
+        # the parameters' gradients are views of ONE flat buffer (field order of mtadgat_params): autograd adopts them as
+        # `.grad` without copying, and a data-parallel step can exchange the whole buffer with a single collective
+        # (sharding.dp_training_step looks for it here)
+        eng._flat_grads = (grads, list(offs))
         out = [grads[o:o + n].view(shape) for o, (shape, n) in zip(offs, ctx.shapes)]
         return (None, None, None, None, None, *out)
 

@@ -59,6 +59,29 @@ def gather_windows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
 
 
+def _flat_gradient_buffer(model):
+    """The HIP backward's flat gradient buffer when every parameter's `.grad` is (still) a view of it at its offset -- then the
+    buffer IS the gradient bucket; None otherwise (torch-op backward, accumulated gradients, parameters without a gradient)."""
+    eng = getattr(model, "_engine", None)
+    held = getattr(eng, "_flat_grads", None) if eng is not None else None
+    if held is None or getattr(model, "grad_path", None) != "hip":
+        return None
+    flat, offs = held
+    try:
+        import _hipgrad
+        params = _hipgrad.param_order(model)
+    except Exception:
+        return None
+    if len(params) != len(offs):
+        return None
+    base, esz = flat.data_ptr(), flat.element_size()
+    for p, o in zip(params, offs):
+        g = p.grad
+        if g is None or g.dtype != flat.dtype or not g.is_contiguous() or g.data_ptr() != base + o * esz:
+            return None
+    return flat
+
+
 def dp_training_step(model, x, y, optimizer, target_dims=None, timings=None):
     """One data-parallel optimisation step with the semantics of a single process seeing the
     global batch (reference training.py:106-127: loss = sqrt(MSE(y, preds)) + sqrt(MSE(x, recons))).
@@ -120,13 +143,18 @@ def dp_training_step(model, x, y, optimizer, target_dims=None, timings=None):
     surrogate = sse_f / (2.0 * rmse_f * stats[1].to(sse_f.dtype)) + sse_r / (2.0 * rmse_r * stats[3].to(sse_r.dtype))
     surrogate.backward()
     if distributed:
-        params = [p for p in model.parameters() if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        _timed("grad_events", lambda: all_reduce_(flat))
-        off = 0
-        for p in params:
-            n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
+        flat = _flat_gradient_buffer(model)
+        if flat is not None:
+            # HIP backward: every p.grad is a view of the backward's flat gradient buffer -- one all-reduce in place, no copies
+            _timed("grad_events", lambda: all_reduce_(flat))
+        else:
+            params = [p for p in model.parameters() if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            _timed("grad_events", lambda: all_reduce_(flat))
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
     optimizer.step()
     return float(rmse_f), float(rmse_r)

@@ -356,3 +356,30 @@ def test_sharded_dropout_stream_equals_the_single_process_step(gpu_device):
     for n, p in model.named_parameters():
         d = (p.grad - g_all[n]).abs().max().item()
         assert d <= 1e-6 + 1e-5 * g_all[n].abs().max().item(), (n, d)
+
+
+def test_gradients_are_views_of_one_flat_buffer(gpu_device):
+    """The HIP backward fills one flat buffer in the field order of mtadgat_params; autograd adopts its per-parameter views as
+    `.grad` without copying, so sharding.dp_training_step exchanges the whole gradient with one in-place all-reduce (no
+    torch.cat, no per-parameter copies)."""
+    import sharding
+    kw, b = CONFIGS["odd_shapes"]
+    model = _model(kw, gpu_device).train()
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
+    y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
+    for p in model.parameters():
+        p.grad = None
+    pr, rc = model(x)
+    assert model.grad_path == "hip"
+    _loss(pr, rc, x, y).backward()
+    flat = sharding._flat_gradient_buffer(model)
+    assert flat is not None and flat.numel() == sum(p.numel() for p in model.parameters())
+    total = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert total.abs().sum().item() > 0 and abs(flat.sum().item() - total.sum().item()) <= 1e-3 * total.abs().sum().item()
+    flat.mul_(2.0)                                              # the bucket IS the gradients
+    assert torch.allclose(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).abs().sum(), 2.0 * total.abs().sum(), rtol=1e-5)
+    # a second backward into existing gradients accumulates into autograd's own tensors: then the views no longer alias
+    pr, rc = model(x)
+    _loss(pr, rc, x, y).backward()
+    assert sharding._flat_gradient_buffer(model) is None

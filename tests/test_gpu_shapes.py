@@ -130,3 +130,31 @@ def test_recurrence_kernel_bands_on_random_shapes(idx, gpu_device):
             assert torch.equal(pser, pd) and torch.equal(rser, rd), (kw, n)
             gate(pd[:6], p_ref, what=f"preds, {n} windows")
             gate(rd[:6], r_ref, what=f"recons, {n} windows")
+
+
+def test_config4_chunked_batch_against_the_oracle(gpu_device):
+    """BASELINE config 4 (F = 512, W = 256, out_dim = 512; the un-fused wide attention path: projections through HBM,
+    k_gat_wide) on a batch that the library walks in several chunks (64 = 24 + 24 + 16 windows), every window against
+    oracle.forward_chunked (the reference's algorithm on the CPU, two windows at a time: it materialises 0.8 GB of pairwise
+    inputs per window)."""
+    from mtad_gat import MTAD_GAT
+    kw = dict(n_features=512, window_size=256, out_dim=512, kernel_size=7, gru_hid_dim=150, forecast_n_layers=3, forecast_hid_dim=150,
+              recon_hid_dim=150)
+    torch.manual_seed(0)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(64, 256, 512, generator=g)
+    with torch.no_grad():
+        p_ref, r_ref = oracle.forward_chunked(x, model.state_dict(), alpha=0.2, chunk=2)
+        m = model.to(gpu_device)
+        eng = m._sync_engine(gpu_device)
+        eng.set_chunk_windows(24)
+        p, r = m(x.to(gpu_device))
+        eng.set_chunk_windows(64)
+        p1, r1 = m(x.to(gpu_device))
+    assert torch.equal(p, p1) and torch.equal(r, r1)            # chunking does not change a window's result
+    gate(p, p_ref, what="config 4 preds, 64 windows in 3 chunks")
+    gate(r, r_ref, what="config 4 recons, 64 windows in 3 chunks")
