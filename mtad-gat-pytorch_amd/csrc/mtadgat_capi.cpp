@@ -241,7 +241,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
         b.vld = g.fh_vld; b.lr_floats = g.fh_lr; b.n_full = g.fh_full; b.n_short = g.fh_short;
         if (const char* e_ = getenv("MTADGAT_GATH_STAGGER")) b.stagger = atoi(e_);
         b.dbg = m.gat2_stop;             // (measurement hook, shared with k_gat2's: mtadgat_set_option "gat2_stop")
-        K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, s), "fused gat (fp16 pieces)");
+        K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, g.fh_lean, s), "fused gat (fp16 pieces)");
         a.skip_h = 1;
     }
     K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.f_lds_bytes, s), "fused gat");

@@ -116,6 +116,19 @@ __device__ __forceinline__ void gat_tile_lean(float (&acc)[IBL][JPL], f32x2 (&lA
 }
 #endif
 
+// one register set for the pair operands (k_gath's lean build: ~22 fewer VGPRs -> six waves per SIMD; the other waves of the
+// SIMD, not a second register set, cover the LDS latency)
+template <int IBL, int JPL, int RJ, bool NEG>
+__device__ __forceinline__ void gath_tile_lean(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
+#pragma unroll
+    for (int st = 1; st <= 4; ++st) {
+        gat_step<IBL, JPL, NEG>(acc, lA, rA);
+        __builtin_amdgcn_sched_barrier(0);
+        gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 2 * st);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // all-reduce over the RJ (16 or 8) adjacent lanes that hold one query row
 template <int RJ>
 __device__ __forceinline__ float row_max(float v) {
@@ -577,8 +590,9 @@ __device__ __forceinline__ float gath_exp(float x) {      // e^x, x <= 0 (or -in
     const float lo = __builtin_fmaf(x, c_hi, -hi);
     return __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(0.6931471805599453f, lo, 1.0f);
 }
-template <int IBL, int JPL, int RJ>
-__global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a) {
+// LEAN: one operand register set in the pair loop and at most 80 VGPRs (six waves per SIMD: three 8-wave workgroups per CU)
+template <int IBL, int JPL, int RJ, bool LEAN>
+__global__ __launch_bounds__(512, LEAN ? 6 : MTADGAT_GAT_MINW) void k_gath(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
     constexpr int IBW = RI * IBL;                      // query rows per wave
@@ -594,14 +608,14 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const long win = blockIdx.x;
     const int K = a.K, D = a.D, PT = a.PT;
     const int pvh = a.vld;                             // piece pitch in halfs
-    const int Kp16 = (K + 15) & ~15;                   // rows of the pieces: real nodes then zero rows
+    const int KR = K + 1;                              // rows of the pieces: the nodes and one zero row (keys past K of a 16-key group)
     // waves that own query rows (the rest only project): n_full of them 4 RI = 16 rows (IBL per lane), n_short one row per lane
     // less (IBL - 1: 12 rows, or 8 with 8 lanes along the keys) -- 100 rows = 4 x 16 + 3 x 12, 55 = 3 x 16 + 8: no padded rows
     const int NWA = a.n_full + a.n_short;
     float* __restrict__ Ls = smem;
     float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;
     unsigned short* __restrict__ Vh = reinterpret_cast<unsigned short*>(smem + a.lr_floats);
-    unsigned short* __restrict__ Vl = Vh + Kp16 * pvh;
+    unsigned short* __restrict__ Vl = Vh + KR * pvh + 16;          // (+ 16 zero halfs: chunk reads of the last row run past its end when the pitch is below 16 Q)
     const int i = lane & 31, g = lane >> 5;            // MFMA roles
     const int lj = lane % RJ, li = lane / RJ;          // pair-grid roles
 
@@ -678,8 +692,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                 }
             }
         }
-        // ones column and zero features of the real nodes; zero rows K .. Kp16 (the aggregation reads whole 16-key groups)
-        const int FP = 16 * Q;
+        // ones column and zero features of the real nodes (up to the pitch; chunk reads beyond it meet the next row: finite values
+        // against zero weights), the zero row K and the 16 halfs behind each piece
+        const int FP = 16 * Q < pvh ? 16 * Q : pvh;
         const int f0 = a.vt ? D : 4 * UR, nf = FP - f0;
         if (nf > 0) {
             const float ninv = 1.0f / (float)nf;
@@ -689,10 +704,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                 Vl[node * pvh + f] = 0;
             }
         }
-        for (int u = tid; u < (Kp16 - K) * (FP >> 1); u += nthr) {
-            const int r = u / (FP >> 1), c2 = u - r * (FP >> 1);
-            reinterpret_cast<unsigned*>(Vh + (K + r) * pvh)[c2] = 0u;
-            reinterpret_cast<unsigned*>(Vl + (K + r) * pvh)[c2] = 0u;
+        for (int u = tid; u < ((pvh + 16) >> 1); u += nthr) {
+            reinterpret_cast<unsigned*>(Vh + K * pvh)[u] = 0u;
+            reinterpret_cast<unsigned*>(Vl + K * pvh)[u] = 0u;
         }
     }
     prefetch(0);
@@ -770,21 +784,23 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             lds_cptr rq = rp;
             int kt = 0;
             if (full) {
-                f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
+                f32x2 lA[IBL], rA[JPL], lB[LEAN ? 1 : IBL], rB[LEAN ? 1 : JPL];
                 lds_cptr lq[IBL];
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
                 gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
 #pragma unroll 1
                 for (; kt < npos; ++kt) {
-                    gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
+                    if constexpr (LEAN) gath_tile_lean<IBL, JPL, RJ, false>(acc, lA, rA, lq, rq);
+                    else gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                     rq += 8;
                 }
 #pragma unroll 1
                 for (; kt < ntl; ++kt) {
-                    gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
+                    if constexpr (LEAN) gath_tile_lean<IBL, JPL, RJ, true>(acc, lA, rA, lq, rq);
+                    else gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                     rq += 8;
@@ -792,21 +808,23 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             } else {
                 constexpr int IS = IBL - 1;             // the short block: the lane's last row belongs to the next wave
                 float (&accs)[IS][JPL] = reinterpret_cast<float (&)[IS][JPL]>(acc);
-                f32x2 lA[IS], rA[JPL], lB[IS], rB[JPL];
+                f32x2 lA[IS], rA[JPL], lB[LEAN ? 1 : IS], rB[LEAN ? 1 : JPL];
                 lds_cptr lq[IS];
 #pragma unroll
                 for (int ii = 0; ii < IS; ++ii) lq[ii] = lp[ii];
                 gat_load<IS, JPL, RJ>(lA, rA, lq, rq, 0);
 #pragma unroll 1
                 for (; kt < npos; ++kt) {
-                    gat_tile<IS, JPL, RJ, false>(accs, lA, rA, lB, rB, lq, rq);
+                    if constexpr (LEAN) gath_tile_lean<IS, JPL, RJ, false>(accs, lA, rA, lq, rq);
+                    else gat_tile<IS, JPL, RJ, false>(accs, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
                     rq += 8;
                 }
 #pragma unroll 1
                 for (; kt < ntl; ++kt) {
-                    gat_tile<IS, JPL, RJ, true>(accs, lA, rA, lB, rB, lq, rq);
+                    if constexpr (LEAN) gath_tile_lean<IS, JPL, RJ, true>(accs, lA, rA, lq, rq);
+                    else gat_tile<IS, JPL, RJ, true>(accs, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
                     rq += 8;
@@ -872,49 +890,51 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     // 16-key group, the node values come as packed fp16 pieces straight from LDS
     static_assert(IBW == 16, "one 16-row MFMA group per wave");
     constexpr int DTMAX = 8;                           // D <= 128 (plan)
-    float* __restrict__ att = Ls + wave * (IBW * GAT_APITCH);
+    constexpr int APP = 36;                            // pitch of the restaged rows: 32 keys per pass
+    float* __restrict__ att = Ls + wave * (IBW * APP);
     const int DT = (D + 15) >> 4;
     const int nr = lane & 15, kb = lane >> 4;
-    constexpr int JPP = 64 / RJ;
+    constexpr int JPP = 32 / RJ;                       // key registers per 32-key pass
     constexpr int PASSES = (JPL + JPP - 1) / JPP;
     f32x4 o[DTMAX];
 #pragma unroll
     for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    const unsigned short* __restrict__ vkh = Vh + (4 * kb) * pvh + nr;      // (key 4 kb, feature nr) of the hi piece
-    const int lo_off = Kp16 * pvh;
+    const int lo_off = (int)(Vl - Vh);
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
-        if (pass * 64 < K) {
+        if (pass * 32 < K) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
                 for (int j4 = 0; j4 < JPP; ++j4)
-                    att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
+                    att[(li + RI * ii) * APP + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            const int jn = min(64, K - pass * 64);
-            const int ngrp = (jn + 15) >> 4;                   // rows < Kp16 of the pieces: real or zero
+            const int jn = min(32, K - pass * 32);
+            const int ngrp = (jn + 15) >> 4;
             for (int grp = 0; grp < ngrp; ++grp) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 16 * grp + 4 * kb);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * APP + 16 * grp + 4 * kb);
                 unsigned h0, l0, h1, l1;
                 split_pair_h(bq[0], bq[1], h0, l0);
                 split_pair_h(bq[2], bq[3], h1, l1);
                 const f16x4 bhh = __builtin_bit_cast(f16x4, u32x2{h0, h1}), bll = __builtin_bit_cast(f16x4, u32x2{l0, l1});
-                const unsigned short* __restrict__ vg = vkh + (pass * 64 + 16 * grp) * pvh;
+                // four keys of this lane (rows of the pieces; keys past K read the zero row), feature nr of tile dt
+                const int key0 = pass * 32 + 16 * grp + 4 * kb;
+                int ko[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ko[t] = (key0 + t < K ? key0 + t : K) * pvh + nr;
                 unsigned r[DTMAX][4];
 #pragma unroll
                 for (int dt = 0; dt < DTMAX; ++dt)
                     if (dt < DT) {
-                        // four keys of feature 16 dt + nr, two per register (plain 16-bit reads: on this hardware the d16 forms do
-                        // not keep the other half of the destination)
-                        const unsigned short* __restrict__ p = vg + 16 * dt;
-                        r[dt][0] = (unsigned)p[0] | ((unsigned)p[pvh] << 16);
-                        r[dt][1] = (unsigned)p[2 * pvh] | ((unsigned)p[3 * pvh] << 16);
-                        r[dt][2] = (unsigned)p[lo_off] | ((unsigned)p[lo_off + pvh] << 16);
-                        r[dt][3] = (unsigned)p[lo_off + 2 * pvh] | ((unsigned)p[lo_off + 3 * pvh] << 16);
+                        const unsigned short* __restrict__ p = Vh + 16 * dt;
+                        r[dt][0] = (unsigned)p[ko[0]] | ((unsigned)p[ko[1]] << 16);
+                        r[dt][1] = (unsigned)p[ko[2]] | ((unsigned)p[ko[3]] << 16);
+                        r[dt][2] = (unsigned)p[lo_off + ko[0]] | ((unsigned)p[lo_off + ko[1]] << 16);
+                        r[dt][3] = (unsigned)p[lo_off + ko[2]] | ((unsigned)p[lo_off + ko[3]] << 16);
                     }
 #pragma unroll
                 for (int dt = 0; dt < DTMAX; ++dt)
@@ -1277,15 +1297,16 @@ int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_by
 #define GATH_CASE(I, J, RJ)                                                                     \
     if (IBL == I && JPL == J && rj == RJ) {                                                     \
         if (lds_bytes > 64 * 1024) {                                                            \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gath<I, J, RJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(lean ? (const void*)&k_gath<I, J, RJ, true> : (const void*)&k_gath<I, J, RJ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e_ != hipSuccess) return (int)e_;                                               \
         }                                                                                       \
-        hipLaunchKernelGGL((k_gath<I, J, RJ>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);     \
+        if (lean) hipLaunchKernelGGL((k_gath<I, J, RJ, true>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);  \
+        else hipLaunchKernelGGL((k_gath<I, J, RJ, false>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);      \
         launched = true;                                                                        \
     }
 
 // the fp16-piece build of the fused layer (a.vld = piece pitch in halfs, a.lr_floats as for k_gat, a.Q = 16-feature chunks)
-int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
+int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, bool lean, hipStream_t s) {
     if (a.nwin <= 0) return 0;
     if (rj * JPL < a.K || nw > 8 || a.ATT || a.n_full + a.n_short > nw || a.n_full * 16 + a.n_short * (16 - 64 / rj) < a.K) return -2;
     const unsigned grid = (unsigned)a.nwin;

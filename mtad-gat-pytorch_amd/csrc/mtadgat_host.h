@@ -32,6 +32,7 @@ struct GatPlan {
     size_t f_lds_bytes = 0;
     int fh_full = 0, fh_short = 0;   // k_gath: row-owning waves with 16 rows / with 16 - 64 / RJ rows
     int fh_JPL = 0, fh_RJ = 16, fh_IBL = 4;   // k_gath's pair-grid blocking (8 lanes along the keys whenever that pads them less)
+    bool fh_lean = false;   // k_gath: the <= 80-VGPR build (three 8-wave workgroups per CU)
     int fh_lr = 0;          // k_gath: LDS floats of the L' / R' (and attention-row) region
     int fh_vld = 0;         // k_gath (fp16-piece build of the fused kernel): piece pitch in halfs, LDS bytes
     size_t fh_lds_bytes = 0;

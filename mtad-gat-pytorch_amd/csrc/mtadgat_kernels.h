@@ -359,7 +359,7 @@ int launch_conv_win(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
-int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
+int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, bool lean, hipStream_t s);
 bool gat2_plan(int K, int D, int E, bool tile_out, Gat2Plan& p);
 int launch_gat2(Gat2Args a, const Gat2Plan& p, hipStream_t s);
 int launch_gat2_pack(const float* src, int NT_L, int Q, int D, int E, int npos, int P8, int PT, int TCP, int KP, const float* scale,

@@ -170,9 +170,18 @@ std::string validate_and_plan(Model& m) {
                     }
                 g.fh_full = bf; g.fh_short = bs;
             }
-            g.fh_vld = 16 * g.Q16 + 4;
-            g.fh_lr = (int)round_up((int)std::max((size_t)((g.fh_full + g.fh_short) * 16 + K) * 34, (size_t)(g.fh_full + g.fh_short) * 16 * 68), 4);
-            g.fh_lds_bytes = (size_t)g.fh_lr * sizeof(float) + (size_t)2 * round_up(K, 16) * g.fh_vld * 2;
+            // piece pitch: the smallest 4 x odd halfs that holds the D + 1 features (conflict-free 8-byte operand reads of 32
+            // consecutive nodes; the last chunk of a row may read on into the next row: finite values against zero weights)
+            g.fh_vld = (D + 1 + 3) & ~3;
+            if ((g.fh_vld >> 2) % 2 == 0) g.fh_vld += 4;
+            if (g.fh_vld > 16 * g.Q16 + 4) g.fh_vld = 16 * g.Q16 + 4;
+            const int orows = (g.fh_full + g.fh_short) * 16;     // rows of L' the owning waves address
+            g.fh_lr = (int)round_up((int)std::max((size_t)(orows + K) * 34, (size_t)orows * 36), 4);
+            g.fh_lds_bytes = (size_t)g.fh_lr * sizeof(float) + (size_t)2 * ((K + 1) * g.fh_vld + 16) * 2;
+            // (the lean build -- <= 80 VGPRs, one operand register set, a third 8-wave workgroup per CU -- spills and loses:
+            // 12.0 vs 9.6 ms for the two layers at (W = 100, F = 55); measurement hook)
+            g.fh_lean = false;
+            if (const char* e_ = getenv("MTADGAT_GATH_LEAN")) g.fh_lean = atoi(e_) != 0;
         }
         g.w16_off = take((size_t)g.NT * g.Q16 * 256);
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
