@@ -169,7 +169,11 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   outputs are below 2^15, else k_gat), 1 k_gat at every batch size, 2 the column-sliced kernel k_gat2 wherever it applies
  *   (GATv2, <= 104 nodes; slower than k_gath on the shipped shapes: DESIGN.md section 4), 3 k_gath at every batch size.
  * "conv_kernel": the convolution of the fused front end (modules.py:18-22) in precision mode 2: 0 automatic (the
- *   window-per-workgroup kernel on fp16 pieces from 4096 windows per chunk), 1 k_conv_lds (fp32 MFMA), 2 k_conv_win at any size. */
+ *   window-per-workgroup kernel on fp16 pieces from 4096 windows per chunk), 1 k_conv_lds (fp32 MFMA), 2 k_conv_win at any size.
+ * "conv_shared": stride-1 series scoring in precision mode 2: 0 automatic (k_conv_win reads each window out of the series where it
+ *   applies, the shared-row convolution of k_conv_lds otherwise), 1 the shared-row convolution wherever it applies.
+ * "wgrad_kernel": the weight-gradient GEMMs of mtadgat_backward (training.py:126): 0 automatic (three bf16 pieces per operand on
+ *   the 16-bit matrix pipe in precision mode 2), 1 fp32 MFMA, 2 the split-bf16 build in every mode. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
 /* Diagnostics for bench.py: the largest convolution output of the last forward() that used workspace `ws` (its last
  * chunk; synchronises `stream`).  Below 2^15 the large-batch kernels used two fp16 pieces per operand, otherwise three

@@ -24,7 +24,10 @@ namespace mtadgat {
 constexpr int WG_ROWS = 16;
 // VEC: A and B rows are 16-byte aligned with row strides that are multiples of 4 floats (all internal buffers):
 // the pieces are staged with one float4 load per 4 columns (few, wide requests) instead of dword loads.
-template <int BMODE, bool VEC>
+// X3: the products from three bf16 pieces per operand on the 16-bit matrix pipe (six v_mfma_f32_32x32x16_bf16 per 16 data rows and
+// tile instead of eight v_mfma_f32_32x32x2_f32: 2.7x less matrix time, fp32-class sums -- mtadgat_device.h); the 16 rows of a
+// staging step are exactly one chunk, a lane gathers its eight rows of a column from the fp32 tile and splits them
+template <int BMODE, bool VEC, bool X3 = false>
 __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][WG_ROWS][128];
     __shared__ __attribute__((aligned(16))) float Bs[2][WG_ROWS][128];
@@ -142,6 +145,24 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
         for (long r = rbeg; r < rend; r += WG_ROWS) {
             const bool more = r + WG_ROWS < rend;
             if (more) gload(r + WG_ROWS);                    // in flight during the MFMAs below
+            if constexpr (X3) {
+                static_assert(WG_ROWS == 16, "one 16-row chunk per staging step");
+                f32x4 ap[2][3], bp[2][3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = As[buf][4 * kk + s4][64 * wm + 32 * u + c]; hi[s4] = As[buf][8 + 4 * kk + s4][64 * wm + 32 * u + c]; }
+                    split3(lo, hi, ap[u][0], ap[u][1], ap[u][2]);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = Bs[buf][4 * kk + s4][64 * wn + 32 * u + c]; hi[s4] = Bs[buf][8 + 4 * kk + s4][64 * wn + 32 * u + c]; }
+                    split3(lo, hi, bp[u][0], bp[u][1], bp[u][2]);
+                }
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_s3(ap[x], bp[y], acc[x][y]);
+            } else
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -201,7 +222,14 @@ int launch_wgrad(const WgradArgs& a, hipStream_t s) {
         const dim3 grid((unsigned)(((a.Mp + 127) / 128) * ((a.Np + 127) / 128)), (unsigned)a.nslab);
         const bool vec = a.bmode == 0 && (a.lda & 3) == 0 && (a.ldb & 3) == 0 && a.lda >= 4 && a.ldb >= 4 &&
                          (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;
-        if (a.bmode == 1)
+        if (a.x3) {
+            if (a.bmode == 1)
+                hipLaunchKernelGGL((k_wgrad_lds<1, false, true>), grid, dim3(256), 0, s, a);
+            else if (vec)
+                hipLaunchKernelGGL((k_wgrad_lds<0, true, true>), grid, dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((k_wgrad_lds<0, false, true>), grid, dim3(256), 0, s, a);
+        } else if (a.bmode == 1)
             hipLaunchKernelGGL((k_wgrad_lds<1, false>), grid, dim3(256), 0, s, a);
         else if (vec)
             hipLaunchKernelGGL((k_wgrad_lds<0, true>), grid, dim3(256), 0, s, a);

@@ -72,6 +72,11 @@ struct XSource {
     int64_t start0 = 0, stride = 1;
 };
 
+// the batch sizes / options at which the fused front end's convolution is the window-per-workgroup kernel on fp16 pieces
+static bool conv_win_selected(const Model& m, int64_t n) {
+    return m.precision == 2 && m.conv_kernel != 1 && (n >= 4096 || m.conv_kernel == 2);
+}
+
 // geo (optional): the rows are cut into `geo_W`-row windows instead of the model's W-row ones (run_conv_shared)
 int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s,
              unsigned* vmax = nullptr, int64_t geo_W = 0, bool keep_vmax = false) {
@@ -106,7 +111,7 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
         a.vmax = vmax;
     }
     // mode 2, the fused front end's call (h_cat only) on whole windows: the window-per-workgroup kernel on fp16 pieces
-    if (m.precision == 2 && !geo_W && hcat && !xc && !xct && !y && m.conv_kernel != 1 && (n >= 4096 || m.conv_kernel == 2)) {
+    if (conv_win_selected(m, n) && !geo_W && hcat && !xc && !xct && !y) {
         ConvArgs b = a;
         b.Fq = m.Fp16;
         b.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w2h_off);
@@ -127,6 +132,14 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
 // copy that places the rows into h_cat.  Applies when the LDS-staged kernel does (it records the output range).
 bool conv_shared_applies(const Model& m, const XSource& src, int64_t n) {
     if (!src.gather || src.starts || src.stride != 1 || n < 1024 || m.precision == 1 || src.x_bf16) return false;   // (the bf16 build writes h_cat only)
+    // the window-per-workgroup kernel reads its window out of the series itself (the rows it re-reads are L2 hits) and is the
+    // faster of the two where it runs; taking it here also keeps forward_series == forward on the stacked windows bit for bit
+    if (conv_win_selected(m, n) && m.conv_shared != 1) {
+        ConvArgs b{};
+        b.F = m.F; b.Fp = m.Fp; b.Fq = m.Fp16; b.taps = m.taps; b.pad = m.pad; b.W = m.W; b.Dp = m.Dp; b.NT = m.convNT;
+        b.HCAT = m.packed_dev; b.wscale = m.packed_dev;      // (only looked at for presence)
+        if (conv_win_applies(b)) return false;
+    }
     if (m.taps != 2 * m.pad + 1 || m.pad < 1 || m.W < 4 * m.pad) return false;
     return (size_t)(32 + m.taps - 1) * (m.Fp + 4) * sizeof(float) <= 20 * 1024;
 }
@@ -944,7 +957,9 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
     if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
     if (std::strcmp(name, "gat_kernel") == 0 && value >= 0 && value <= 3) { h->m.gat_kernel = value; return 0; }
+    if (std::strcmp(name, "wgrad_kernel") == 0 && value >= 0 && value <= 2) { h->m.wgrad_kernel = value; return 0; }
     if (std::strcmp(name, "conv_kernel") == 0 && value >= 0 && value <= 2) { h->m.conv_kernel = value; return 0; }
+    if (std::strcmp(name, "conv_shared") == 0 && value >= 0 && value <= 1) { h->m.conv_shared = value; return 0; }
     if (std::strcmp(name, "gat2_stop") == 0 && value >= 0 && value <= 7) { h->m.gat2_stop = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
@@ -1246,6 +1261,8 @@ int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, float* wpart, flo
     rps = (rps + 15) / 16 * 16;
     a.rows_per_slab = rps;
     a.P = wpart; a.Mp = p.Mp; a.Np = p.Np;
+    // default fp32 arithmetic: the products from three bf16 pieces per operand (the fp32 MFMA is 2.7x the matrix time)
+    a.x3 = (m.precision == 2 && m.wgrad_kernel != 1) || m.wgrad_kernel == 2;
     K_TRY(launch_wgrad(a, s), "weight-gradient GEMM");
     WgradReduceArgs r{};
     r.P = wpart; r.nslab = a.nslab; r.Mp = p.Mp; r.Np = p.Np; r.M = p.M; r.N = p.N;

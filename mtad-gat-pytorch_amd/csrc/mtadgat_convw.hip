@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256 / CW_RT, CW_RT == 1 ? 4 : 3) void k_conv_win(co
 int conv_win_pitch(int F, int Fq) {
     int p = (F + 3) & ~3;
     if ((p >> 2) % 2 == 0) p += 4;                     // 4 x odd
+    while (2 * p < Fq) p += 8;                         // a row's last chunk reads Fq - p halfs past its end: within the two spare rows
     return p < Fq + 4 ? p : Fq + 4;
 }
 size_t conv_win_lds(int W, int F, int Fq, int taps) {

@@ -189,6 +189,8 @@ struct Model {
     bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
+    int wgrad_kernel = 0;            // weight-gradient GEMMs of the training step (testing hook): 0 automatic (split-bf16 operands in mode 2), 1 fp32 MFMA, 2 split-bf16 always
+    int conv_shared = 0;             // series scoring (testing hook): 1 keeps the shared-row convolution where the window-per-workgroup kernel would run
     int conv_kernel = 0;             // convolution of the fused front end in mode 2 (testing hook): 0 automatic (k_conv_win from 4096 windows), 1 k_conv_lds, 2 k_conv_win at any batch size
     int gat2_stop = 0;               // measurement hook: Gat2Args::dbg_stop
     int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic (testing hook): 0 automatic (k_gath, the fp16-piece build, from 4096 windows), 1 k_gat only, 2 column-sliced k_gat2 at any batch size, 3 k_gath at any batch size

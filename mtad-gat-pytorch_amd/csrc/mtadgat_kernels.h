@@ -221,6 +221,7 @@ struct WgradArgs {
     int nslab;
     float* P;            // partial sums [nslab][Mp][Np],  Mp = 32*ceil(M/32), Np = 32*ceil((N+1)/32)
     int Mp, Np;
+    int x3;              // 1: products from three bf16 pieces per operand on the 16-bit matrix pipe (fp32-class sums)
 };
 
 // out[rowmap[m] + colmap[n]] += sum_slab P[slab][m][n];  column N (ones) -> outB[rowmapB[m]]
