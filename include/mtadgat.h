@@ -172,6 +172,10 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   window-per-workgroup kernel on fp16 pieces from 4096 windows per chunk), 1 k_conv_lds (fp32 MFMA), 2 k_conv_win at any size.
  * "conv_shared": stride-1 series scoring in precision mode 2: 0 automatic (k_conv_win reads each window out of the series where it
  *   applies, the shared-row convolution of k_conv_lds otherwise), 1 the shared-row convolution wherever it applies.
+ * "series_band": stride-1 series scoring (mtadgat_forward_series without `starts`, stride 1, >= 1024 windows per chunk, GATv2):
+ *   the temporal layer's pair scores of interior rows are computed once per pair of SERIES rows and shared by the windows that
+ *   contain both (prediction.py:51-63 scores every stride-1 window; modules.py:174-191): 0 automatic (embeddings of >= 100
+ *   columns, where it was measured to win), 1 off, 2 wherever the kernels apply (<= 128 time steps, <= 64 features, kernel_size <= 7).
  * "wgrad_kernel": the weight-gradient GEMMs of mtadgat_backward (training.py:126): 0 automatic (three bf16 pieces per operand on
  *   the 16-bit matrix pipe in precision mode 2), 1 fp32 MFMA, 2 the split-bf16 build in every mode. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);

@@ -249,6 +249,13 @@ class MTAD_GAT(nn.Module):
             # counters in train() mode (optimizers bump them; saves the host sync of a training step -- but manual
             # `p.data` edits between training steps then need refresh_weights()).  ("always" = True, kept for old callers.)
             object.__setattr__(self, "check_weight_contents", True)
+        if "share_series_pair_scores" not in self.__dict__:
+            # forward_series / score_series over stride-1 windows (Predictor.get_score, prediction.py:51-63): the temporal
+            # layer's pair scores of interior rows computed once per pair of SERIES rows instead of once per window (SURVEY
+            # section 8f row 3).  "auto": where it was measured to win (embeddings of >= 100 columns), True: wherever the
+            # kernels apply, False: never (every window computes its own pair grid; outputs then equal forward() on the
+            # materialised windows bit for bit)
+            object.__setattr__(self, "share_series_pair_scores", "auto")
         if "device_repack" not in self.__dict__:
             # True: after the first load, changed fp32 weights (an optimizer step) are re-packed on the GPU
             # (mtadgat_update_weights_device); False: every load goes through the host packer
@@ -309,6 +316,7 @@ class MTAD_GAT(nn.Module):
         key = key + (fp,)
         mode = 1 if bf16 else (0 if self.precision == "fp32_strict" else 2)
         self._engine.set_precision(mode)
+        self._engine.set_option("series_band", {"auto": 0, False: 1, True: 2}[self.share_series_pair_scores])
         if key != self._weights_key or (bf16 and not self._engine.bf16_ready()):
             self._engine.load_weights(self.state_dict(), device, allow_device_pack=self.device_repack)
             object.__setattr__(self, "_weights_key", key)
