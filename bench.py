@@ -242,6 +242,22 @@ def sub_records(model, kw, dev, args_precision="fp32"):
             "what": "the flagship workload (MSL shape, 65536 windows, fp32 tensors in/out) with precision='bf16': bf16 MFMA operands "
                     "where a bf16 build of the kernel exists, fp32 accumulation, state, gates and softmax; <= 2e-2 of the fp32 reference"}
         del xb
+        # the same 65 536 windows as stride-1 windows of one series (Predictor.get_score's access
+        # pattern, prediction.py:51-63), gathered on the GPU; with and without the temporal pair scores shared between windows
+        try:
+            series = torch.rand(65536 + kw["window_size"] - 1, kw["n_features"], generator=g).to(dev)
+            rec = {}
+            for name, share in (("per_window_pair_grid", False), ("shared_pair_scores", True)):
+                model.share_series_pair_scores = share
+                tser = _timed(lambda: model.forward_series(series, start=0, stride=1, count=65536), dev, 3, warm=1)
+                rec[name] = {"ms": round(1e3 * tser, 3), "windows_per_s": round(65536 / tser, 1)}
+            model.share_series_pair_scores = "auto"
+            rec["what"] = ("forward_series over 65 536 stride-1 windows of one (65 635, F) series: no (b, W, F) batch is materialised; "
+                           "shared_pair_scores = k_tband (the temporal layer's interior pair scores once per pair of series rows)")
+            out["series_b65536"] = rec
+            del series
+        except Exception as e:
+            out["series_b65536"] = {"error": repr(e)}
     # BASELINE config 3 shape: SMD machine-1-1, F=38 -> out 38, batch 256 (args.py:47), dropout 0.3
     kw3 = dict(kw, n_features=38, out_dim=38, dropout=0.3)
     torch.manual_seed(0)
@@ -568,10 +584,18 @@ def main():
                 tot[fam] = (ms, n, fl)
                 tf = fl * B * args.steps / (ms * 1e-3) / 1e12
                 split = args.precision == "fp32" and fam == "k_gru"
-                pk = BF16_MFMA_PEAK_TFLOPS if (split or (args.precision == "bf16" and fam != "k_rowgemm(fc)")) else FP32_MFMA_PEAK_TFLOPS
+                # from 4 096 windows per chunk the convolution (k_conv_win) and, below the range guard, the attention layers' projection
+                # and aggregation (k_gath) also form their products from two fp16 pieces on the 16-bit pipe
+                chunk_w = min(B, eng.chunk_windows())
+                pieces16 = args.precision == "fp32" and chunk_w >= 4096 and (fam == "k_conv" or (fam == "k_gat" and two_piece))
+                pk = BF16_MFMA_PEAK_TFLOPS if (split or pieces16 or (args.precision == "bf16" and fam != "k_rowgemm(fc)")) else FP32_MFMA_PEAK_TFLOPS
                 fams[fam] = {"ms_per_step": round(ms / args.steps, 3), "launches": int(n),
                              "alg_mfma_gflop_per_launch": round(fl * B * args.steps / n / 1e9, 3),
                              "mfma_tflops": round(tf, 2), "mfma_peak_tflops": round(pk, 1), "mfma_alg_frac": round(tf / pk, 4)}
+                if pieces16 and fam == "k_conv":
+                    cf = 3.0 * (((kw["n_features"] + 15) // 16 * 16) / kw["n_features"]) * (((kw["n_features"] + 31) // 32 * 32) / kw["n_features"])
+                    fams[fam]["mfma_issued_per_alg_mac"] = round(cf, 3)       # three fp16 terms, input channels padded to 16, outputs to 32
+                    fams[fam]["mfma_issued_frac"] = round(tf * cf / pk, 4)
                 if split:
                     fams[fam]["mfma_issued_per_alg_mac"] = round(sf, 3)
                     fams[fam]["mfma_issued_frac"] = round(tf * sf / pk, 4)

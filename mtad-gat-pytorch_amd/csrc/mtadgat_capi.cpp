@@ -676,6 +676,12 @@ int mtadgat_destroy(mtadgat_handle h) {
         (void)hipEventSynchronize(h->m.upload_ev);
         (void)hipEventDestroy(h->m.upload_ev);
     }
+    if (h->m.lane_stream) {
+        (void)hipStreamSynchronize(h->m.lane_stream);
+        (void)hipStreamDestroy(h->m.lane_stream);
+        (void)hipEventDestroy(h->m.lane_begin);
+        (void)hipEventDestroy(h->m.lane_end);
+    }
     if (h->m.staging_pinned) (void)hipHostFree(h->m.staging_pinned);
     if (h->m.packed_dev) (void)hipFree(h->m.packed_dev);
     for (auto& v : h->m.ev)
@@ -1008,20 +1014,82 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (std::strcmp(name, "conv_kernel") == 0 && value >= 0 && value <= 2) { h->m.conv_kernel = value; return 0; }
     if (std::strcmp(name, "conv_shared") == 0 && value >= 0 && value <= 1) { h->m.conv_shared = value; return 0; }
     if (std::strcmp(name, "series_band") == 0 && value >= 0 && value <= 2) { h->m.series_band = value; return 0; }
+    if (std::strcmp(name, "lanes") == 0 && value >= 0 && value <= 1) { h->m.lanes = value; return 0; }
     if (std::strcmp(name, "gat2_stop") == 0 && value >= 0 && value <= 7) { h->m.gat2_stop = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
 
+// How forward() walks a call of `batch` windows: chunks of at most m.chunk windows one after the other (each planned for its own
+// size: a short last chunk gets the small-batch kernels and their buffers), and -- fused front end, split-operand arithmetic --
+// a chunk in PIECES that alternate between two lanes (the caller's stream and the handle's own), each lane with its own
+// workspace.  Why: the large-batch recurrence (k_gru_cm) is a 100-step latency chain on one 4-wave workgroup per 128 windows
+// and per CU, so its time is the same for any chunk up to 32 768 windows and doubles at 32 769; and while it runs it owns the
+// register file but not the vector ALU.  Two lanes let one piece's convolution / attention fill the other's recurrence:
+// measured (MSL shape, profiles/r04_overlap_experiment.txt) 10 240 windows 6.0 -> 5.4 ms, 12 288: 6.3 -> 5.7, 36 864:
+// 15.9 -> 12.4, 40 960: 16.7 -> 14.1, 49 152: 18.0 -> 16.4; no gain at 16 384 .. 32 768 (one piece) and at whole multiples of
+// 32 768.  The pieces' results are those of forward() called on each piece (the kernels are chosen by the piece's size).
+struct Piece { int64_t c0, n; int lane; };
+static void forward_schedule(const Model& m, int64_t batch, std::vector<Piece>& out) {
+    out.clear();
+    const bool two = m.lanes == 0 && m.precision == 2 && m.temp.fused && m.feat.fused;
+    for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
+        const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
+        int64_t k = 1, base = n;
+        if (two && n > SPLIT3_MAX_WINDOWS && n <= 2 * SPLIT3_MAX_WINDOWS) {                // two halves for the hidden-tile-split kernel
+            k = 2;
+            base = n / 2 / 32 * 32;                                                        // (whole 32-window groups, the last piece takes the rest)
+        } else if (two && n > 32768 && n % 32768 != 0) {                                   // full k_gru_cm rounds (256 workgroups of 128 windows), then the rest
+            // (whole multiples of 32 768 gain nothing from the second lane -- every round is full -- and stay one piece on the caller's stream)
+            k = (n + 32767) / 32768;
+            base = 32768;
+        }
+        if (const char* e_ = getenv("MTADGAT_PIECES")) {                                   // measurement hook: "a,b,c": piece sizes, alternating lanes
+            int64_t at = 0;
+            int lane = 0;
+            for (const char* q = e_; *q && at < n;) {
+                int64_t len = std::min<int64_t>(n - at, strtoll(q, const_cast<char**>(&q), 10));
+                if (*q == ',') ++q;
+                if (len <= 0) break;
+                out.push_back({c0 + at, len, lane});
+                lane ^= 1; at += len;
+            }
+            if (at < n) out.push_back({c0 + at, n - at, lane});
+            continue;
+        }
+        for (int64_t i = 0, at = 0; i < k; ++i) {
+            const int64_t len = i + 1 < k ? base : n - at;
+            out.push_back({c0 + at, len, (int)(i & 1)});
+            at += len;
+        }
+    }
+}
+// workspace: per lane the largest plan of the pieces it runs; lane 1 starts behind lane 0
+static void lane_floats(const Model& m, int64_t batch, size_t (&need)[2]) {
+    std::vector<Piece> sched;
+    forward_schedule(m, batch, sched);
+    need[0] = need[1] = 0;
+    int64_t seen[2][2] = {{0, 0}, {0, 0}};                    // (plans repeat: sizes seen last per lane)
+    for (const Piece& pc : sched) {
+        if (pc.n == seen[pc.lane][0] || pc.n == seen[pc.lane][1]) continue;
+        seen[pc.lane][1] = seen[pc.lane][0]; seen[pc.lane][0] = pc.n;
+        Workspace o;
+        plan_workspace(m, pc.n, o);
+        need[pc.lane] = std::max(need[pc.lane], o.total);
+    }
+}
 /* Largest value the convolution wrote during the last forward() on this workspace (of its last chunk), read back after
  * the stream has drained: below 2^15 the large-batch kernels formed their products from two fp16 pieces per operand, above
  * from three bf16 pieces (the device-side range guard).  0 when the forward did not record it (un-fused attention path). */
 int mtadgat_last_conv_max(mtadgat_handle h, const void* ws, int64_t batch, float* out_host, void* stream) {
     if (!h || !ws || !out_host || batch <= 0) return fail(MTADGAT_ERR_INVALID, "null argument");
     Workspace o;
-    const int64_t tail = batch % h->m.chunk;                  // the layout of the call's last chunk (each chunk has its own plan)
-    plan_workspace(h->m, batch <= h->m.chunk ? batch : (tail ? tail : h->m.chunk), o);
+    std::vector<Piece> sched;                                 // the layout of the call's last piece (each piece has its own plan, each lane its own workspace)
+    forward_schedule(h->m, batch, sched);
+    size_t need[2];
+    lane_floats(h->m, batch, need);
+    plan_workspace(h->m, sched.back().n, o);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemcpy(out_host, static_cast<const float*>(ws) + o.vmax, sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_host, static_cast<const float*>(ws) + (sched.back().lane ? need[0] : 0) + o.vmax, sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1032,17 +1100,12 @@ int mtadgat_set_chunk_windows(mtadgat_handle h, int64_t w) {
     return 0;
 }
 
-// Every chunk is planned for its own number of windows (a short last chunk gets the small-batch kernels and their
-// buffers, not the layout of a full chunk): the workspace must hold the larger of the two plans.
 static size_t workspace_floats(const Model& m, int64_t batch) {
-    Workspace o;
+    size_t need[2];
+    lane_floats(m, batch, need);
+    Workspace o;                                              // (the stage entry points plan one chunk on one lane)
     plan_workspace(m, std::min<int64_t>(batch, m.chunk), o);
-    size_t need = o.total;
-    if (batch > m.chunk && batch % m.chunk != 0) {
-        plan_workspace(m, batch % m.chunk, o);
-        need = std::max(need, o.total);
-    }
-    return need;
+    return std::max(need[0] + need[1], o.total);
 }
 size_t mtadgat_workspace_bytes(mtadgat_handle h, int64_t batch) {
     if (!h || batch <= 0) return 0;
@@ -1056,11 +1119,33 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
     if (batch == 0) return 0;
     if (!src.x) return fail(MTADGAT_ERR_INVALID, "input is NULL");
     Model& m = h->m;
-    hipStream_t s = (hipStream_t)stream;
-    float* ws = static_cast<float*>(ws_);
+    hipStream_t s0 = (hipStream_t)stream;
     const int F = m.F, W = m.W;
-    for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
-        const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
+    std::vector<Piece> sched;
+    forward_schedule(m, batch, sched);
+    size_t lane_need[2];
+    lane_floats(m, batch, lane_need);
+    bool second = false;
+    for (const Piece& pc : sched) second = second || pc.lane == 1;
+    if (second) {
+        if (!m.lane_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&m.lane_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&m.lane_begin, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&m.lane_end, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(m.lane_begin, s0));            // the second lane starts after whatever the caller queued before this call
+        HIP_TRY(hipStreamWaitEvent(m.lane_stream, m.lane_begin, 0));
+    }
+    struct Joiner {                                           // the caller's stream waits for the second lane on every way out
+        Model& m; hipStream_t s0; bool on;
+        ~Joiner() {
+            if (on && hipEventRecord(m.lane_end, m.lane_stream) == hipSuccess) (void)hipStreamWaitEvent(s0, m.lane_end, 0);
+        }
+    } joiner{m, s0, second};
+    for (const Piece& pc : sched) {
+        const int64_t c0 = pc.c0, n = pc.n;
+        hipStream_t s = pc.lane ? m.lane_stream : s0;
+        float* ws = static_cast<float*>(ws_) + (pc.lane ? lane_need[0] : 0);
         Workspace o;
         plan_workspace(m, n, o);
         float* xc = ws + o.xc;

@@ -185,6 +185,10 @@ struct Model {
     float* staging_pinned = nullptr; // pinned host image of the last upload (source of the async copy)
     size_t staging_floats = 0;
     hipEvent_t upload_ev = nullptr;  // recorded after the last upload
+    // second lane of forward(): pieces of a call alternate between the caller's stream and this one (forward_schedule, mtadgat_capi.cpp)
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t lane_begin = nullptr, lane_end = nullptr;
+    int lanes = 0;                   // 0 automatic, 1 everything on the caller's stream
     bool have_weights = false;
     bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
