@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the files under profiles/ on a GPU box:  bash profiles/collect.sh r03 <git rev>
+# Regenerates the files under profiles/ on a GPU box:  bash profiles/collect.sh r04 <git rev>
 # (rocprofv3 passes are separate: --kernel-trace --stats, then one --pmc pass per counter group).
 set -u
 TAG=${1:-r03}
@@ -20,6 +20,9 @@ rm -rf /tmp/ktt8 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp
 cp "$(find /tmp/ktt8 -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_train8192.csv"
 rm -rf /tmp/ktf && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -- python "$ROOT/profiles/forward_small.py" 256 > "$OUT/forward_256.txt" 2> /dev/null
 cp "$(find /tmp/ktf -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_fwd256.csv"
+rm -rf /tmp/kts && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kts -- python "$ROOT/profiles/series_bench.py" > "$OUT/series_65536.txt" 2> /dev/null
+cp "$(find /tmp/kts -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_series.csv"
+python "$ROOT/profiles/batch_sweep.py" 2048 4096 8192 9216 10240 12288 16384 24576 32768 36864 40960 49152 65536 131072 > "$OUT/batch_sweep.txt" 2> /dev/null
 # 2. HBM traffic (FETCH_SIZE / WRITE_SIZE, one counter per pass) and the SQ group
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C && rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_$C -- python "$ROOT/bench.py" --steps 1 --warmup 1 --batch 65536 --no-cpu-baseline --no-sub > /dev/null 2>&1

@@ -58,7 +58,9 @@ stats_table("kernel_stats_train8192.csv", f"{tag}_kernel_trace_stats_train8192.t
             "# rocprofv3 --kernel-trace --stats -- python bench.py --mode train --steps 3 --warmup 1   (MSL shape, 8192 windows per step, 4 training steps)")
 stats_table("kernel_stats_fwd256.csv", f"{tag}_kernel_trace_stats_fwd256.txt",
             "# rocprofv3 --kernel-trace --stats -- python profiles/forward_small.py 256   (MSL shape, 55 eval forwards of 256 windows)")
-for extra in ("train_step_256.txt", "forward_256.txt", "train_bench_line.json"):
+stats_table("kernel_stats_series.csv", f"{tag}_kernel_trace_stats_series.txt",
+            "# rocprofv3 --kernel-trace --stats -- python profiles/series_bench.py   (MSL shape, score_series over 65 536 stride-1 windows, 8 calls)")
+for extra in ("train_step_256.txt", "forward_256.txt", "train_bench_line.json", "series_65536.txt", "batch_sweep.txt"):
     if os.path.exists(os.path.join(d, extra)):
         open(os.path.join(d, f"{tag}_{extra}"), "w").write(open(os.path.join(d, extra)).read())
 
