@@ -8,6 +8,7 @@
 //   small kernels              decoder-input adjoint (modules.py:279), conv pre-activation gradient, dropout masks
 //
 // The data gradients of the Linear layers (d X = d Y W) reuse k_rowgemm with transposed weight packs.
+#include <cstdlib>
 #include "mtadgat_device.h"
 
 namespace mtadgat {
@@ -36,8 +37,19 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int c = lane & 31, kk = lane >> 5;
     const int Nb = (a.Np + 127) >> 7;
-    const int mb = blockIdx.x / Nb, nb = blockIdx.x - mb * Nb;
-    const int slab = blockIdx.y;
+    // XCD-aware map: workgroups go to the 8 XCDs round-robin in linear id order; the output tiles of one row slab read the same
+    // A / B rows, so they are given ids that land on ONE XCD (ids k, k + 8, ...): the slab then comes from HBM once and serves the
+    // other tiles from that XCD's L2 (with the plain (tile, slab) grid and 8 tiles, tile x of every slab ran on XCD x: A was
+    // fetched once per column block of B and B once per column block of A)
+    unsigned tile_id = blockIdx.x, slab_id = blockIdx.y;
+    if ((gridDim.y & 7u) == 0u && !a.plain_map) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned k = lin >> 3;
+        slab_id = (k / gridDim.x) * 8u + (lin & 7u);
+        tile_id = k % gridDim.x;
+    }
+    const int mb = (int)tile_id / Nb, nb = (int)tile_id - mb * Nb;
+    const int slab = (int)slab_id;
     const long rbeg = (long)slab * a.rows_per_slab;
     const long rend = rbeg + a.rows_per_slab < a.R ? rbeg + a.rows_per_slab : a.R;
     const int T = a.T > 0 ? a.T : 1;
@@ -219,6 +231,8 @@ __global__ void k_wgrad_reduce(const WgradReduceArgs a) {
 int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     if (a.R <= 0 || a.M <= 0 || a.N <= 0) return 0;
     {
+        static const int plain = getenv("MTADGAT_WGRAD_PLAIN") ? 1 : 0;       // measurement hook: the (tile, slab) grid as launched
+        const_cast<WgradArgs&>(a).plain_map = plain;
         const dim3 grid((unsigned)(((a.Mp + 127) / 128) * ((a.Np + 127) / 128)), (unsigned)a.nslab);
         const bool vec = a.bmode == 0 && (a.lda & 3) == 0 && (a.ldb & 3) == 0 && a.lda >= 4 && a.ldb >= 4 &&
                          (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;

@@ -222,6 +222,7 @@ struct WgradArgs {
     float* P;            // partial sums [nslab][Mp][Np],  Mp = 32*ceil(M/32), Np = 32*ceil((N+1)/32)
     int Mp, Np;
     int x3;              // 1: products from three bf16 pieces per operand on the 16-bit matrix pipe (fp32-class sums)
+    int plain_map;       // measurement hook: 1 = no XCD-aware tile / slab remap
 };
 
 // out[rowmap[m] + colmap[n]] += sum_slab P[slab][m][n];  column N (ones) -> outB[rowmapB[m]]

@@ -466,6 +466,7 @@ int wgrad_slabs(long R, int Mp, int Np) {
     const long rmax = (R + 127) / 128;
     if (s > rmax) s = rmax;
     if (s > 512) s = 512;
+    if (s >= 8) s = s / 8 * 8;                 // whole groups of 8 slabs: the kernel's XCD-aware block map (k_wgrad_lds)
     return (int)(s < 1 ? 1 : s);
 }
 
