@@ -176,6 +176,8 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   the temporal layer's pair scores of interior rows are computed once per pair of SERIES rows and shared by the windows that
  *   contain both (prediction.py:51-63 scores every stride-1 window; modules.py:174-191): 0 automatic (embeddings of >= 100
  *   columns, where it was measured to win), 1 off, 2 wherever the kernels apply (<= 128 time steps, <= 64 features, kernel_size <= 7).
+ * "rowgemm_kernel": the data-gradient products d X = d Y W of mtadgat_backward: 0 automatic (three bf16 pieces per operand from
+ *   4096 rows in precision mode 2), 1 fp32 MFMA, 2 the split-bf16 build always.
  * "lanes": 0 automatic: mtadgat_forward / _forward_series walk calls of 8 193 .. 16 384 and of more than 32 768 windows per chunk in
  *   pieces that alternate between `stream` and a second stream owned by the handle (each with its own half of the workspace;
  *   `stream` waits for the second lane before the call's work on it counts as complete, so the caller's ordering rules do not

@@ -723,6 +723,18 @@ static int run_split3(Model& m, hipStream_t s) {
         K_TRY(launch_scale_from_max(sc, s), "convolution weight scale");
         K_TRY(launch_split2h(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w2h_off, m.convNT, q8, q8 / 2, 1, sc + 1, s), "split-fp16 convolution weights");
     }
+    if (m.bw.supported) {   // transposed packs of the backward's data-gradient products
+        std::vector<const LinTPlan*> lt;
+        for (const GruBwdPlan& gb : m.bw.gru) lt.push_back(&gb.wihT);
+        for (const GruBwdPlan& gb : m.bw.rec) lt.push_back(&gb.wihT);
+        for (const LinTPlan& p : m.bw.fcT) lt.push_back(&p);
+        lt.push_back(&m.bw.recfcT);
+        lt.push_back(&m.bw.gat[0].lrT);
+        lt.push_back(&m.bw.gat[1].lrT);
+        for (const LinTPlan* p : lt)
+            if (p->w3_off && p->NT > 0)
+                K_TRY(launch_split3(m.packed_dev + p->w_off, m.packed_dev + p->w3_off, p->NT, p->Q, p->Q16, 1, nullptr, s), "split-bf16 transposed weights");
+    }
     for (const GatPlan* g : {&m.feat, &m.temp})
         if (g->fused) {
             K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
@@ -919,6 +931,13 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     for (const GruPlan& g : m.rec) one(g);
     add(m.feat.w3_off, (size_t)m.feat.NT * m.feat.Q16 * 3 * 256);
     add(m.temp.w3_off, (size_t)m.temp.NT * m.temp.Q16 * 3 * 256);
+    if (m.bw.supported) {
+        for (const GruBwdPlan& gb : m.bw.gru) add(gb.wihT.w3_off, (size_t)gb.wihT.NT * gb.wihT.Q16 * 3 * 256);
+        for (const GruBwdPlan& gb : m.bw.rec) add(gb.wihT.w3_off, (size_t)gb.wihT.NT * gb.wihT.Q16 * 3 * 256);
+        for (const LinTPlan& p : m.bw.fcT) add(p.w3_off, (size_t)p.NT * p.Q16 * 3 * 256);
+        add(m.bw.recfcT.w3_off, (size_t)m.bw.recfcT.NT * m.bw.recfcT.Q16 * 3 * 256);
+        for (int k = 0; k < 2; ++k) add(m.bw.gat[k].lrT.w3_off, (size_t)m.bw.gat[k].lrT.NT * m.bw.gat[k].lrT.Q16 * 3 * 256);
+    }
     add(m.conv_w2h_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 2 * 256);
     add(m.conv_scale_off, 4);
     for (const GatPlan* g : {&m.feat, &m.temp}) {
@@ -1012,6 +1031,7 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (std::strcmp(name, "gat_kernel") == 0 && value >= 0 && value <= 3) { h->m.gat_kernel = value; return 0; }
     if (std::strcmp(name, "wgrad_kernel") == 0 && value >= 0 && value <= 2) { h->m.wgrad_kernel = value; return 0; }
     if (std::strcmp(name, "conv_kernel") == 0 && value >= 0 && value <= 2) { h->m.conv_kernel = value; return 0; }
+    if (std::strcmp(name, "rowgemm_kernel") == 0 && value >= 0 && value <= 2) { h->m.rowgemm_kernel = value; return 0; }
     if (std::strcmp(name, "conv_shared") == 0 && value >= 0 && value <= 1) { h->m.conv_shared = value; return 0; }
     if (std::strcmp(name, "series_band") == 0 && value >= 0 && value <= 2) { h->m.series_band = value; return 0; }
     if (std::strcmp(name, "lanes") == 0 && value >= 0 && value <= 1) { h->m.lanes = value; return 0; }
@@ -1377,6 +1397,10 @@ int run_rowgemm_T(Model& m, const LinTPlan& p, const float* X, long ldx, long R,
     a.R = R; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
     a.accumulate = accumulate ? 1 : 0;
     a.gate = gate; a.ldg = ldg; a.gate_scale = gate_scale;
+    if (p.w3_off && ((m.precision == 2 && m.rowgemm_kernel != 1 && R >= 4096) || m.rowgemm_kernel == 2)) {
+        a.x3 = 1; a.Q16 = p.Q16;
+        a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + p.w3_off);
+    }
     K_TRY(launch_rowgemm(a, s), "data-gradient rowgemm");
     return 0;
 }

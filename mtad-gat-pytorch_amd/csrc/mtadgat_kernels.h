@@ -37,6 +37,10 @@ struct RowGemmArgs {
     unsigned drop_thresh, seed_lo, seed_hi, drop_stream;
     float keep_scale;
     long row0;
+    // split-bf16 build (k_rowgemm_x3): three bf16 pieces per operand on the 16-bit matrix pipe, fp32-class products
+    int x3;              // 1: use Wp3 / Q16 instead of Wp / Q
+    const f32x4* Wp3;    // [tile][Q16][3 pieces][64]
+    int Q16;
 };
 
 // dropout streams (one per dropout site of the reference: modules.py:90, :189, :310)

@@ -10,6 +10,64 @@ namespace mtadgat {
 //   describes) and Forecasting_Model (modules.py:307-311).
 // ---------------------------------------------------------------------------
 template <int NTB>
+__device__ __forceinline__ void rowgemm_epilogue(const RowGemmArgs& a, const f32x16 (&acc)[NTB], int n0, long row, long rowc, int g) {
+#pragma unroll
+    for (int nb = 0; nb < NTB; ++nb) {
+        if (n0 + nb >= a.NT) break;
+        const bool transposed = (n0 + nb) >= a.NT_rm;
+        const long grp = row / a.group;
+        const int member = (int)(row - grp * a.group);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int col = 32 * (n0 + nb) + 8 * m + 4 * g;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+            f32x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float t = acc[nb][4 * m + s] + bv[s];
+                v[s] = a.relu ? fmaxf(t, 0.f) : t;
+            }
+            if (a.drop_thresh) {      // training forward: dropout after the ReLU (modules.py:309-310)
+                const DropArgs dd{a.drop_thresh, a.seed_lo, a.seed_hi, a.keep_scale, a.row0};
+                const unsigned key = drop_window_key(dd, a.drop_stream, rowc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[s] = drop_keep(key, (unsigned)(col + s), a.drop_thresh) ? v[s] * a.keep_scale : 0.f;
+            }
+            if (a.gate) {             // backward through ReLU (+ dropout): the kept activation tells which units were live
+                const float* gp = a.gate + rowc * a.ldg;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float gv = (col + s < a.Nvalid) ? gp[col + s] : 0.f;
+                    v[s] = gv > 0.f ? v[s] * a.gate_scale : 0.f;
+                }
+            }
+            if (a.accumulate && row < a.R && !transposed) {
+                const float* yo = a.Y + row * a.ldy + col;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (col + s < a.Nvalid) v[s] += yo[s];
+            }
+            if (row < a.R) {
+                if (transposed) {   // lanes i <-> consecutive group members: coalesced 4-byte stores
+                    float* tp = a.YT + (grp * a.YT_rows + (col - 32 * a.NT_rm)) * (long)a.YT_ld + member;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tp[(long)s * a.YT_ld] = v[s];
+                } else {
+                    float* yp = a.Y + row * a.ldy + col;
+                    if (a.vec_store && col + 3 < a.Nvalid) {
+                        *reinterpret_cast<f32x4*>(yp) = v;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            if (col + s < a.Nvalid) yp[s] = v[s];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NTB>
 __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
     const int lane = threadIdx.x;
     const int i = lane & 31, g = lane >> 5;
@@ -50,61 +108,54 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) w[nb] = wn[nb];
         }
-        // epilogue
+        rowgemm_epilogue<NTB>(a, acc, n0, row, rowc, g);
+    }
+}
+
+// split-bf16 build: the same rows / tiles, the K loop in 16-feature chunks -- the eight values a lane holds of a chunk are split
+// into three bf16 pieces (split3), the weights come pre-split ([tile][Q16][piece][64], derived on the device), six
+// v_mfma_f32_32x32x16_bf16 per chunk and tile (mfma_s3): 2.7 x less matrix time than the four fp32 MFMAs of two 8-feature
+// chunks, products of 24-bit significands.  Used by the data-gradient products of mtadgat_backward (d X = d Y W over all
+// (window, step) rows), which ran at the fp32-MFMA rate.
+template <int NTB>
+__global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
+    const int lane = threadIdx.x;
+    const int i = lane & 31, g = lane >> 5;
+    const long row = (long)blockIdx.x * 32 + i;
+    const long rowc = row < a.R ? row : a.R - 1;
+    const float* __restrict__ xrow = a.X + rowc * a.ldx;
+    const bool xvec = (a.ldx & 3) == 0;
+    const f32x4* __restrict__ Wp = a.Wp3;
+    const int Q = a.Q16;
+    for (int n0 = blockIdx.y * NTB; n0 < a.NT; n0 += NTB * gridDim.y) {
+        f32x16 acc[NTB];
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        f32x4 xa = load_feat4(xrow, 4 * g, a.Kvalid, xvec), xb = load_feat4(xrow, 8 + 4 * g, a.Kvalid, xvec);
+        f32x4 w[NTB][3];
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
-            if (n0 + nb >= a.NT) break;
-            const bool transposed = (n0 + nb) >= a.NT_rm;
-            const long grp = row / a.group;
-            const int member = (int)(row - grp * a.group);
+            const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int col = 32 * (n0 + nb) + 8 * m + 4 * g;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
-                f32x4 v;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float t = acc[nb][4 * m + s] + bv[s];
-                    v[s] = a.relu ? fmaxf(t, 0.f) : t;
-                }
-                if (a.drop_thresh) {      // training forward: dropout after the ReLU (modules.py:309-310)
-                    const DropArgs dd{a.drop_thresh, a.seed_lo, a.seed_hi, a.keep_scale, a.row0};
-                    const unsigned key = drop_window_key(dd, a.drop_stream, rowc);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) v[s] = drop_keep(key, (unsigned)(col + s), a.drop_thresh) ? v[s] * a.keep_scale : 0.f;
-                }
-                if (a.gate) {             // backward through ReLU (+ dropout): the kept activation tells which units were live
-                    const float* gp = a.gate + rowc * a.ldg;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const float gv = (col + s < a.Nvalid) ? gp[col + s] : 0.f;
-                        v[s] = gv > 0.f ? v[s] * a.gate_scale : 0.f;
-                    }
-                }
-                if (a.accumulate && row < a.R && !transposed) {
-                    const float* yo = a.Y + row * a.ldy + col;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        if (col + s < a.Nvalid) v[s] += yo[s];
-                }
-                if (row < a.R) {
-                    if (transposed) {   // lanes i <-> consecutive group members: coalesced 4-byte stores
-                        float* tp = a.YT + (grp * a.YT_rows + (col - 32 * a.NT_rm)) * (long)a.YT_ld + member;
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) tp[(long)s * a.YT_ld] = v[s];
-                    } else {
-                        float* yp = a.Y + row * a.ldy + col;
-                        if (a.vec_store && col + 3 < a.Nvalid) {
-                            *reinterpret_cast<f32x4*>(yp) = v;
-                        } else {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                if (col + s < a.Nvalid) yp[s] = v[s];
-                        }
-                    }
-                }
-            }
+            for (int pc = 0; pc < 3; ++pc) w[nb][pc] = Wp[(((long)n * Q) * 3 + pc) * 64 + lane];
         }
+        for (int q = 0; q < Q; ++q) {
+            const int qn = (q + 1 < Q) ? q + 1 : q;
+            const f32x4 xan = load_feat4(xrow, 16 * qn + 4 * g, a.Kvalid, xvec), xbn = load_feat4(xrow, 16 * qn + 8 + 4 * g, a.Kvalid, xvec);
+            f32x4 xp[3];
+            split3(xa, xb, xp[0], xp[1], xp[2]);
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) {
+                acc[nb] = mfma_s3(w[nb], xp, acc[nb]);
+                const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) w[nb][pc] = Wp[(((long)n * Q + qn) * 3 + pc) * 64 + lane];       // the next chunk's words, behind this tile's MFMAs
+            }
+            xa = xan; xb = xbn;
+        }
+        rowgemm_epilogue<NTB>(a, acc, n0, row, rowc, g);
     }
 }
 
@@ -497,6 +548,18 @@ int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
     if (a.R <= 0) return 0;
     const unsigned grid = (unsigned)((a.R + 31) / 32);
     const long groups4 = (a.NT + 3) / 4;
+    if (a.x3) {
+        if (a.NT >= 4) {
+            const long want = (4096 + grid - 1) / grid;
+            const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
+            hipLaunchKernelGGL(k_rowgemm_x3<4>, dim3(grid, split), dim3(64), 0, s, a);
+        } else if (a.NT >= 2)
+            hipLaunchKernelGGL(k_rowgemm_x3<2>, dim3(grid), dim3(64), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_rowgemm_x3<1>, dim3(grid), dim3(64), 0, s, a);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (a.NT >= 2 && (long)grid * groups4 < 1024) {
         // a latency chain on a few waves (a head Linear on 256 rows): one output tile per wave
         hipLaunchKernelGGL(k_rowgemm<1>, dim3(grid, (unsigned)a.NT), dim3(64), 0, s, a);

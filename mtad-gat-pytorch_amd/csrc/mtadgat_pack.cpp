@@ -304,6 +304,8 @@ std::string validate_and_plan(Model& m) {
             p.in_dim = kdim; p.out_dim = outdim;
             p.NT = (outdim + 31) / 32; p.Q = (kdim + 7) / 8;
             p.w_off = take((size_t)p.NT * p.Q * 256);
+            p.Q16 = (kdim + 15) / 16;
+            p.w3_off = take((size_t)p.NT * p.Q16 * 3 * 256);
         };
         auto wg = [&](WgradPlan& p, int M, int N, bool bias) {
             p.M = M; p.N = N; p.has_bias = bias;
