@@ -723,18 +723,7 @@ static int run_split3(Model& m, hipStream_t s) {
         K_TRY(launch_scale_from_max(sc, s), "convolution weight scale");
         K_TRY(launch_split2h(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w2h_off, m.convNT, q8, q8 / 2, 1, sc + 1, s), "split-fp16 convolution weights");
     }
-    if (m.bw.supported) {   // transposed packs of the backward's data-gradient products
-        std::vector<const LinTPlan*> lt;
-        for (const GruBwdPlan& gb : m.bw.gru) lt.push_back(&gb.wihT);
-        for (const GruBwdPlan& gb : m.bw.rec) lt.push_back(&gb.wihT);
-        for (const LinTPlan& p : m.bw.fcT) lt.push_back(&p);
-        lt.push_back(&m.bw.recfcT);
-        lt.push_back(&m.bw.gat[0].lrT);
-        lt.push_back(&m.bw.gat[1].lrT);
-        for (const LinTPlan* p : lt)
-            if (p->w3_off && p->NT > 0)
-                K_TRY(launch_split3(m.packed_dev + p->w_off, m.packed_dev + p->w3_off, p->NT, p->Q, p->Q16, 1, nullptr, s), "split-bf16 transposed weights");
-    }
+    ++m.weights_version;                 // (the transposed packs of the backward's data-gradient products are split on first use: run_rowgemm_T)
     for (const GatPlan* g : {&m.feat, &m.temp})
         if (g->fused) {
             K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
@@ -1397,7 +1386,13 @@ int run_rowgemm_T(Model& m, const LinTPlan& p, const float* X, long ldx, long R,
     a.R = R; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
     a.accumulate = accumulate ? 1 : 0;
     a.gate = gate; a.ldg = ldg; a.gate_scale = gate_scale;
-    if (p.w3_off && ((m.precision == 2 && m.rowgemm_kernel != 1 && R >= 4096) || m.rowgemm_kernel == 2)) {
+    // split-bf16 operands from 64 Ki rows on (batches of >= 656 windows at W = 100: below that the product is a few tens of
+    // microseconds either way and the pack would have to be re-split after every optimizer step for nothing)
+    if (p.w3_off && ((m.precision == 2 && m.rowgemm_kernel != 1 && R >= 65536) || m.rowgemm_kernel == 2)) {
+        if (p.w3_version != m.weights_version) {
+            K_TRY(launch_split3(m.packed_dev + p.w_off, m.packed_dev + p.w3_off, p.NT, p.Q, p.Q16, 1, nullptr, s), "split-bf16 transposed weights");
+            p.w3_version = m.weights_version;
+        }
         a.x3 = 1; a.Q16 = p.Q16;
         a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + p.w3_off);
     }

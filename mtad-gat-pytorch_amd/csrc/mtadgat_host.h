@@ -95,6 +95,7 @@ struct LinTPlan {
     size_t w_off = 0;
     int Q16 = 0;         // 16-feature chunks of the split-bf16 pack [tile][Q16][3 pieces][64], derived on the device (k_rowgemm_x3)
     size_t w3_off = 0;
+    mutable uint64_t w3_version = 0;   // the weight upload the split pack was derived from (derived on first use after an upload)
 };
 // one weight-gradient GEMM: shapes, index maps into the flat gradient buffer (ints stored in the packed buffer)
 struct WgradPlan {
@@ -198,6 +199,7 @@ struct Model {
     int wgrad_kernel = 0;            // weight-gradient GEMMs of the training step (testing hook): 0 automatic (split-bf16 operands in mode 2), 1 fp32 MFMA, 2 split-bf16 always
     int series_band = 0;             // stride-1 series scoring, temporal pair scores shared between the windows (k_tband): 0 automatic (embeddings of >= 100 columns), 1 off, 2 wherever it applies
     int conv_shared = 0;             // series scoring (testing hook): 1 keeps the shared-row convolution where the window-per-workgroup kernel would run
+    uint64_t weights_version = 0;    // counts weight uploads / device-side re-packs
     int rowgemm_kernel = 0;          // data-gradient row GEMMs of mtadgat_backward in mode 2 (testing hook): 0 automatic (split-bf16 operands from 4096 rows), 1 fp32 MFMA, 2 split-bf16 always
     int conv_kernel = 0;             // convolution of the fused front end in mode 2 (testing hook): 0 automatic (k_conv_win from 4096 windows), 1 k_conv_lds, 2 k_conv_win at any batch size
     int gat2_stop = 0;               // measurement hook: Gat2Args::dbg_stop
