@@ -152,6 +152,20 @@ def test_create_validates_and_plans_without_a_gpu():
     assert 60_000 < lib.mtadgat_workspace_bytes(h, 65536) / 65536 < 80_000
     chunk = lib.mtadgat_chunk_windows(h)
     assert lib.mtadgat_workspace_bytes(h, 10 * chunk) == lib.mtadgat_workspace_bytes(h, chunk)
+    # the piece schedule of mode 2 (two lanes, each with its own part of the workspace): calls of 8 193 .. 16 384 windows are two
+    # halves, calls beyond 32 768 with a partial last round are rounds of 32 768 + the rest; "lanes" = 1 keeps one plan per chunk
+    assert lib.mtadgat_set_precision(h, 2) == 0
+    per = lambda n: lib.mtadgat_workspace_bytes(h, n) / n
+    assert per(10240) == pytest.approx(per(5120), rel=0.02)                       # 2 x 5 120 windows, hoisted GRU input and all
+    assert lib.mtadgat_workspace_bytes(h, 36864) >= lib.mtadgat_workspace_bytes(h, 32768) + lib.mtadgat_workspace_bytes(h, 4096) - 4096
+    assert per(65536) == pytest.approx(per(32768), rel=0.01)                      # a whole multiple of 32 768: one piece
+    assert lib.mtadgat_set_option(h, b"lanes", 1) == 0
+    assert lib.mtadgat_workspace_bytes(h, 36864) < lib.mtadgat_workspace_bytes(h, 32768) * 1.2
+    assert lib.mtadgat_set_option(h, b"lanes", 0) == 0 and lib.mtadgat_set_option(h, b"lanes", 2) != 0
+    for name, top in ((b"series_band", 2), (b"rowgemm_kernel", 2), (b"wgrad_kernel", 2), (b"conv_kernel", 2), (b"gat_kernel", 3)):
+        assert lib.mtadgat_set_option(h, name, top) == 0 and lib.mtadgat_set_option(h, name, top + 1) != 0
+        assert lib.mtadgat_set_option(h, name, 0) == 0
+    assert lib.mtadgat_set_option(h, b"no_such_option", 0) != 0
     # arithmetic switch: 0 fp32 MFMA, 1 bf16 operands, 2 fp32 through split 16-bit operands; anything else is refused
     for mode, ok in ((0, True), (1, True), (2, True), (3, False), (-1, False)):
         assert (lib.mtadgat_set_precision(h, mode) == 0) == ok
