@@ -81,6 +81,9 @@ __global__ __launch_bounds__(256) void k_tband_scores(const TBandArgs a) {
 // whole: lanes 0-31 its key side R'_p (16 bytes each) against the EW edge queries -> EQ[w][q][p], lanes 32-63 its query side
 // L'_p against the EW edge keys -> EK[w][p][q]: coalesced reads of the row-major projections, the edge rows' words stay in
 // registers for the whole window, sums over the 32 lanes of a half by DPP + one cross-row exchange.
+// (Tried instead: a workgroup per window, 32 embedding columns at a time transposed through LDS so that a thread owns a row and no
+// reduction is needed -- 1.48 ms against the 1.33 ms of this version: four stage / barrier rounds per window cost more than the 36
+// reduction instructions per row pair they save.)
 __device__ __forceinline__ float half_sum(float v) {
     v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
     v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
