@@ -121,6 +121,12 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
             return 0;
         }
     }
+    // wide models (rows too long for the LDS-staged kernels): the straight-from-memory kernel on three bf16 pieces per operand
+    if (m.precision == 2 && !a.bf16 && !src.x_bf16 && m.conv_kernel != 1 && (n * Wk >= 65536 || m.conv_kernel == 2) &&
+        (size_t)(32 + m.taps - 1) * (m.Fp + 4) * sizeof(float) > 20 * 1024) {
+        a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w3_off);
+        a.Fq = m.Fp16;
+    }
     K_TRY(launch_conv(a, s), "conv");
     return 0;
 }
@@ -214,6 +220,10 @@ int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nro
     a.Y = lc; a.ldy = g.ldl; a.Nvalid = g.ldl; a.vec_store = 1;
     a.R = nrows; a.NT = g.NT; a.relu = 0;
     a.NT_rm = g.NT_L; a.YT = rt; a.group = g.K; a.YT_rows = g.rt_rows; a.YT_ld = g.Kp;
+    if (m.precision == 2 && g.uw3_off && g.uQ16 > 0 && m.rowgemm_kernel != 1 && (nrows >= 65536 || m.rowgemm_kernel == 2)) {       // wide layers: three bf16 pieces per operand
+        a.x3 = 1; a.Q16 = g.uQ16;
+        a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + g.uw3_off);
+    }
     K_TRY(launch_rowgemm(a, s), "gat projection");
     return 0;
 }
@@ -724,6 +734,11 @@ static int run_split3(Model& m, hipStream_t s) {
         K_TRY(launch_split2h(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w2h_off, m.convNT, q8, q8 / 2, 1, sc + 1, s), "split-fp16 convolution weights");
     }
     ++m.weights_version;                 // (the transposed packs of the backward's data-gradient products are split on first use: run_rowgemm_T)
+    K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, nullptr, s),
+          "split-bf16 convolution weights");
+    for (const GatPlan* g : {&m.feat, &m.temp})
+        if (!g->fused && g->uQ16 > 0)
+            K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->uw3_off, g->NT, g->Q, g->uQ16, 1, nullptr, s), "split-bf16 projection weights (row GEMM)");
     for (const GatPlan* g : {&m.feat, &m.temp})
         if (g->fused) {
             K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
@@ -927,6 +942,8 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
         add(m.bw.recfcT.w3_off, (size_t)m.bw.recfcT.NT * m.bw.recfcT.Q16 * 3 * 256);
         for (int k = 0; k < 2; ++k) add(m.bw.gat[k].lrT.w3_off, (size_t)m.bw.gat[k].lrT.NT * m.bw.gat[k].lrT.Q16 * 3 * 256);
     }
+    add(m.conv_w3_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
+    for (const GatPlan* g : {&m.feat, &m.temp}) add(g->uw3_off, (size_t)g->NT * g->uQ16 * 3 * 256);
     add(m.conv_w2h_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 2 * 256);
     add(m.conv_scale_off, 4);
     for (const GatPlan* g : {&m.feat, &m.temp}) {

@@ -77,6 +77,7 @@ struct ConvArgs {
     float* HCAT;         // (B*W, Dp) columns [0,F)   or null
     int Dp;
     float* Y;            // (B*W, F) plain output   or null
+    const f32x4* Wp3;    // split-bf16 pack [tile][taps Fq / 16][3][64] (k_conv_x3; Fq = F rounded up to 16)
 };
 
 struct AttendArgs {

@@ -259,6 +259,98 @@ __global__ __launch_bounds__(64) void k_conv(const ConvArgs a) {
     }
 }
 
+// conv straight from memory on split-bf16 operands (wide models, whose rows do not fit the LDS-staged kernels): the K loop
+// in 16-channel chunks of one tap, the eight input values a lane holds of a chunk split into three bf16 pieces (split3), the
+// weights pre-split on the device ([tile][taps Fq / 16][3][64], Fq = F rounded up to 16), six v_mfma_f32_32x32x16_bf16 per
+// chunk and tile (mfma_s3) instead of eight v_mfma_f32_32x32x2_f32: 2.7 x less matrix time, products of 24-bit significands.
+template <int NTB>
+__global__ __launch_bounds__(64) void k_conv_x3(const ConvArgs a) {
+    const int lane = threadIdx.x;
+    const int i = lane & 31, g = lane >> 5;
+    const long row = (long)blockIdx.x * 32 + i;
+    const long R = a.B * a.W;
+    const long rowc = row < R ? row : R - 1;
+    const long win = rowc / a.W;
+    const int t = (int)(rowc - win * a.W);
+    const float* __restrict__ xwin = a.gather ? a.X + (a.starts ? a.starts[win] : a.start0 + win * a.stride) * (long)a.F
+                                              : a.X + win * (long)a.W * a.F;
+    const int QF = a.Fq >> 4;
+    const int Q = a.taps * QF;
+    const f32x4* __restrict__ Wp = a.Wp3;
+    if (a.HCAT && row < R && g == 0)
+        for (int c = 3 * a.F; c < a.Dp; ++c) a.HCAT[row * a.Dp + c] = 0.f;
+    const bool xvec4 = (a.F & 3) == 0;
+    auto loadx = [&](int q, int half) -> f32x4 {      // channels 16 cb + 8 half + 4 g .. + 3 of input row t + tap - pad
+        const int tap = q / QF;
+        const int cb = q - tap * QF;
+        const int tt = t + tap - a.pad;
+        const int c0 = 16 * cb + 8 * half + 4 * g;
+        const bool tok = tt >= 0 && tt < a.W;
+        const int ttc = tt < 0 ? 0 : (tt < a.W ? tt : a.W - 1);
+        const float* p = xwin + (long)ttc * a.F;
+        f32x4 v;
+        if (xvec4) {
+            const int cc = c0 + 3 < a.F ? c0 : a.F - 4;
+            v = *reinterpret_cast<const f32x4*>(p + cc);
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) v[s4] = p[c0 + s4 < a.F ? c0 + s4 : a.F - 1];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) v[s4] = (tok && c0 + s4 < a.F) ? v[s4] : 0.f;
+        return v;
+    };
+    for (int n0 = 0; n0 < a.NT; n0 += NTB) {
+        f32x16 acc[NTB];
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        f32x4 xa = loadx(0, 0), xb = loadx(0, 1);
+        f32x4 w[NTB][3];
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) {
+            const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) w[nb][pc] = Wp[(((long)n * Q) * 3 + pc) * 64 + lane];
+        }
+        for (int q = 0; q < Q; ++q) {
+            const int qn = (q + 1 < Q) ? q + 1 : q;
+            const f32x4 xan = loadx(qn, 0), xbn = loadx(qn, 1);
+            f32x4 xp[3];
+            split3(xa, xb, xp[0], xp[1], xp[2]);
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) {
+                acc[nb] = mfma_s3(w[nb], xp, acc[nb]);
+                const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) w[nb][pc] = Wp[(((long)n * Q + qn) * 3 + pc) * 64 + lane];
+            }
+            xa = xan; xb = xbn;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NTB; ++nb) {
+            if (n0 + nb >= a.NT) break;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int col = 32 * (n0 + nb) + 8 * m + 4 * g;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int o = col + s;
+                    const float v = fmaxf(acc[nb][4 * m + s] + bv[s], 0.f);
+                    if (row < R && o < a.F) {
+                        if (a.XC) a.XC[row * a.Fp + o] = v;
+                        if (a.XCT) a.XCT[(win * a.F + o) * (long)a.Wpad + t] = v;
+                        if (a.HCAT) a.HCAT[row * a.Dp + o] = v;
+                        if (a.Y) a.Y[row * a.F + o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // conv, LDS-staged variant (used when 32+taps-1 input rows of Fp floats fit a wave's LDS budget):
 // the wave copies the input rows its 32 output rows touch into LDS once with coalesced loads and
 // takes every MFMA B operand from there -- the straight-from-global version above re-reads each
@@ -601,7 +693,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     } else {
         // the straight-from-memory kernel does not record the output range: mark it unknown (a NaN pattern)
         if (a.vmax && hipMemsetAsync(a.vmax, 0xFF, sizeof(unsigned), s) != hipSuccess) return -3;
-        if (a.NT >= 2)
+        if (a.Wp3) {                 // split-bf16 operands (precision mode 2, large launches: run_conv)
+            if (a.NT >= 4)
+                hipLaunchKernelGGL(k_conv_x3<4>, dim3(grid), dim3(64), 0, s, a);
+            else if (a.NT >= 2)
+                hipLaunchKernelGGL(k_conv_x3<2>, dim3(grid), dim3(64), 0, s, a);
+            else
+                hipLaunchKernelGGL(k_conv_x3<1>, dim3(grid), dim3(64), 0, s, a);
+        } else if (a.NT >= 2)
             hipLaunchKernelGGL(k_conv<2>, dim3(grid), dim3(64), 0, s, a);
         else
             hipLaunchKernelGGL(k_conv<1>, dim3(grid), dim3(64), 0, s, a);

@@ -113,6 +113,7 @@ std::string validate_and_plan(Model& m) {
         m.Fp16 = round_up(m.F, 16);
         m.conv_w16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 256);
         m.conv_wf16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 8) * 256);
+        m.conv_w3_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
         m.conv_w2h_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 2 * 256);
         m.conv_scale_off = take(4);
     }
@@ -187,6 +188,8 @@ std::string validate_and_plan(Model& m) {
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
         g.w2h_off = take((size_t)g.NT * g.Q16 * 2 * 256);
         g.gscale_off = take(4);
+        g.uQ16 = g.fused ? 0 : (g.Q + 1) / 2;
+        g.uw3_off = take((size_t)g.NT * g.uQ16 * 3 * 256);
         g.g2 = Gat2Plan();
         if (g.fused && c.use_gatv2 && gat2_plan(K, D, E, &g == &m.feat, g.g2)) g.w2g_off = take((size_t)2 * g.g2.TCP * g.g2.KP);
     };

@@ -156,6 +156,19 @@ def test_config4_chunked_batch_against_the_oracle(gpu_device):
         p, r = m(x.to(gpu_device))
         eng.set_chunk_windows(64)
         p1, r1 = m(x.to(gpu_device))
+        # the split-bf16 builds of the wide path's convolution and projections (k_conv_x3, k_rowgemm_x3: chunks of >= 65 536 rows
+        # by default -- BASELINE config 4's chunk of 896 windows), forced here
+        eng.set_option("conv_kernel", 2)
+        eng.set_option("rowgemm_kernel", 2)
+        try:
+            p2, r2 = m(x.to(gpu_device))
+        finally:
+            eng.set_option("conv_kernel", 0)
+            eng.set_option("rowgemm_kernel", 0)
     assert torch.equal(p, p1) and torch.equal(r, r1)            # chunking does not change a window's result
     gate(p, p_ref, what="config 4 preds, 64 windows in 3 chunks")
     gate(r, r_ref, what="config 4 recons, 64 windows in 3 chunks")
+    assert not (torch.equal(p2, p1) and torch.equal(r2, r1)), "the split-bf16 kernels did not run"
+    gate(p2, p_ref, what="config 4 preds, split-bf16 convolution / projections")
+    gate(r2, r_ref, what="config 4 recons, split-bf16 convolution / projections")
+    assert (p2 - p1).abs().max().item() <= 2e-6 * max(1.0, p1.abs().max().item()) and (r2 - r1).abs().max().item() <= 2e-6 * max(1.0, r1.abs().max().item())
