@@ -278,6 +278,10 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x_dev, int64_t batch, i
 int mtadgat_backward(mtadgat_handle h, const float* x_dev, int64_t batch, int64_t window0, float dropout_p, uint64_t seed,
                      const float* d_preds_dev, const float* d_recons_dev, const void* tape_dev, size_t tape_bytes,
                      float* grads_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* Gradient with respect to the input windows (the reference's autograd provides it when x.requires_grad: mtad_gat.py:64-79 under
+ * training.py:126; none of its callers asks).  Call right after mtadgat_backward of the same chunk, on the same stream, with the
+ * same workspace: the convolution's pre-activation gradients are still in it.  dx_dev: (batch, W, F) float32, overwritten. */
+int mtadgat_backward_input(mtadgat_handle h, int64_t batch, const void* workspace_dev, size_t workspace_bytes, float* dx_dev, void* stream);
 /* Diagnostics for the tests: the keep-masks (1 / 0) the kernels apply -- mask_feat (batch, F, F), mask_temp
  * (batch, W, W), mask_fc (forecast_n_linear - 1, batch, forecast_hid_dim), any may be NULL -- and the offsets
  * (floats) of the tape / backward-workspace regions (order: see mtadgat_capi.cpp). */

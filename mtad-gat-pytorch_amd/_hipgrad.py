@@ -64,22 +64,33 @@ class _HipStep(torch.autograd.Function):
         grads = torch.zeros(total, dtype=torch.float32, device=x.device)
         d_preds = d_preds.contiguous().float()
         d_recons = d_recons.contiguous().float()
+        want_dx = ctx.needs_input_grad[1]
+        dx = None
         if x.shape[0]:
             if ctx.tape is not None:
                 eng.backward(x, ctx.p, ctx.seed, d_preds, d_recons, ctx.tape, grads, ctx.w0)
+                if want_dx:
+                    dx = eng.backward_input(x)       # (the convolution's pre-activation gradients are still in the backward's workspace)
             else:
                 scratch = getattr(eng, "_train_tape", None)
+                parts = []
                 for lo, hi in ctx.chunks:
                     xc = x[lo:hi]
                     _, _, scratch = eng.forward_train(xc, ctx.p, ctx.seed, ctx.w0 + lo, tape=scratch)
                     eng.backward(xc, ctx.p, ctx.seed, d_preds[lo:hi].contiguous(), d_recons[lo:hi].contiguous(), scratch, grads, ctx.w0 + lo)
+                    if want_dx:
+                        parts.append(eng.backward_input(xc))
+                if want_dx:
+                    dx = torch.cat(parts)
+        elif want_dx:
+            dx = torch.zeros_like(x)
         ctx.tape = None
         # the parameters' gradients are views of ONE flat buffer (field order of mtadgat_params): autograd adopts them as
         # `.grad` without copying, and a data-parallel step can exchange the whole buffer with a single collective
         # (sharding.dp_training_step looks for it here)
         eng._flat_grads = (grads, list(offs))
         out = [grads[o:o + n].view(shape) for o, (shape, n) in zip(offs, ctx.shapes)]
-        return (None, None, None, None, None, *out)
+        return (None, dx, None, None, None, *out)
 
 
 _warned = set()      # reasons already reported (one warning per reason and process)
@@ -90,8 +101,6 @@ def forward(model, eng, x):
     why = None
     if not eng.backward_supported():
         why = eng.why_not()
-    elif x.requires_grad and torch.is_grad_enabled():
-        why = "the input requires a gradient (the HIP backward produces parameter gradients only)"
     if why is not None:
         # Not silent: the torch-op route materialises the (b, K, K, 2E) attention tensors and runs MIOpen's GRU -- a caller
         # who expects the HIP training step must learn that this configuration does not have one.
@@ -116,4 +125,5 @@ def forward(model, eng, x):
     else:
         seed, w0 = (int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0), 0
     params = param_order(model)
-    return _HipStep.apply(eng, x.detach().contiguous().float(), p, seed, w0, *params)
+    # (x keeps its autograd history: when it requires a gradient the backward also returns d x -- mtadgat_backward_input)
+    return _HipStep.apply(eng, x.contiguous().float(), p, seed, w0, *params)

@@ -86,6 +86,8 @@ def load_library():
     lib.mtadgat_tape_bytes.argtypes = [vp, i64]
     lib.mtadgat_tape_bytes.restype = sz
     lib.mtadgat_backward_workspace_bytes.argtypes = [vp, i64]
+    lib.mtadgat_backward_input.argtypes = [vp, i64, vp, sz, vp, vp]
+    lib.mtadgat_backward_input.restype = ctypes.c_int
     lib.mtadgat_backward_workspace_bytes.restype = sz
     lib.mtadgat_grad_floats.argtypes = [vp]
     lib.mtadgat_grad_floats.restype = i64
@@ -218,6 +220,18 @@ class Engine:
         self._call(self.lib.mtadgat_backward, "backward", x.device, xp, b, int(window0), float(p), int(seed),
                    _dev_ptr(d_preds, "d_preds", (b, c.out_dim)), _dev_ptr(d_recons, "d_recons", (b, c.window_size, c.out_dim)),
                    _dev_ptr(tape, "tape"), need_t, _dev_ptr(grads, "grads"), _dev_ptr(ws, "workspace"), need_w)
+
+    def backward_input(self, x_like):
+        """d loss / d x of the chunk mtadgat_backward just processed (same stream, same workspace): (b, W, F)."""
+        c = self.cfg
+        b = x_like.shape[0]
+        dx = torch.empty((b, c.window_size, c.n_features), dtype=torch.float32, device=x_like.device)
+        if b == 0:
+            return dx
+        need_w = self.lib.mtadgat_backward_workspace_bytes(self.handle, b)
+        ws = self._buf("_bws", need_w, x_like.device)
+        self._call(self.lib.mtadgat_backward_input, "backward_input", x_like.device, b, _dev_ptr(ws, "workspace"), need_w, _dev_ptr(dx, "dx"))
+        return dx
 
     def dropout_masks(self, batch, p, seed, device, window0=0):
         """The keep-masks the kernels apply: {"feat": (b,F,F), "temp": (b,W,W), "fc": [(b,hid)] * hidden layers}."""

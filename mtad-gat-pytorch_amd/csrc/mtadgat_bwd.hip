@@ -1193,6 +1193,42 @@ int launch_dxc(const float* hcat, const float* dhcat, long ldh, const float* dvt
     return 0;
 }
 
+// Input gradient of the convolution (reference: autograd through ConvLayer.forward, modules.py:18-22; no caller of the reference
+// asks for it, so this is a plain kernel, not a tuned one): one workgroup per window, the window's pre-activation gradients
+// in LDS, a thread per (t, i) output, the (F, F, taps) weights from L2.
+__global__ __launch_bounds__(256) void k_conv_dx(const float* __restrict__ dpre, long ldp, const float* __restrict__ w, long B, int T, int F,
+                                                 int taps, int pad, float* __restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* __restrict__ g = dpre + b * T * ldp;
+    for (int u = tid; u < T * F; u += 256) {
+        const int t = u / F, o = u - t * F;
+        smem[t * F + o] = g[(long)t * ldp + o];
+    }
+    __syncthreads();
+    for (int u = tid; u < T * F; u += 256) {
+        const int t = u / F, i = u - t * F;
+        float acc = 0.f;
+        for (int j = 0; j < taps; ++j) {
+            const int tt = t - j + pad;
+            if (tt < 0 || tt >= T) continue;
+            const float* __restrict__ gr = smem + tt * F;
+            const float* __restrict__ wp = w + (long)i * taps + j;
+            for (int o = 0; o < F; ++o) acc = __builtin_fmaf(wp[(long)o * F * taps], gr[o], acc);
+        }
+        dx[(b * T + t) * (long)F + i] = acc;
+    }
+}
+int launch_conv_dx(const float* dpre, long ldp, const float* w, long B, int T, int F, int taps, int pad, float* dx, hipStream_t s) {
+    if (B <= 0) return 0;
+    const size_t lds = (size_t)T * F * sizeof(float);
+    if (lds > 64 * 1024) return -2;
+    hipLaunchKernelGGL(k_conv_dx, dim3((unsigned)B), dim3(256), lds, s, dpre, ldp, w, B, T, F, taps, pad, dx);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void k_dropmask(const DropArgs d, unsigned stream, long nwin, long n, float* __restrict__ mask) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nwin * n) return;

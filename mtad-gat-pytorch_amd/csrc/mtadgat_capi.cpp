@@ -1804,6 +1804,21 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
 
 /* The keep-masks of nn.GRU's dropout between stacked layers (reference modules.py:233 / :253): mask_gru (gru_n_layers - 1, batch, W, H),
  * mask_rec (recon_n_layers - 1, batch, W, recon_hid_dim); either may be NULL */
+int mtadgat_backward_input(mtadgat_handle h, int64_t batch, const void* ws_, size_t ws_bytes, float* dx, void* stream) {
+    int rc = check_train(h, batch, 0.f);
+    if (rc) return rc;
+    if (batch == 0) return 0;
+    if (!ws_ || !dx) return fail(MTADGAT_ERR_INVALID, "null tensor");
+    Model& m = h->m;
+    BwdWorkspace w;
+    plan_bwd_workspace(m, batch, w);
+    if (!aligned16(ws_) || ws_bytes < w.total * sizeof(float)) return fail(MTADGAT_ERR_WORKSPACE, "backward workspace too small or misaligned");
+    if ((size_t)m.W * m.F * sizeof(float) > 64 * 1024) return fail(MTADGAT_ERR_UNSUPPORTED, "input gradient: window too large for one workgroup's LDS");
+    const float* ws = static_cast<const float*>(ws_);
+    K_TRY(launch_conv_dx(ws + w.dpre, m.Fp, m.packed_dev + m.conv_wraw_off, batch, m.W, m.F, m.taps, m.pad, dx, (hipStream_t)stream), "input gradient");
+    return 0;
+}
+
 int mtadgat_dropout_masks_rnn(mtadgat_handle h, int64_t batch, int64_t window0, float dropout_p, uint64_t seed, float* mask_gru,
                               float* mask_rec, void* stream) {
     if (!h) return fail(MTADGAT_ERR_INVALID, "null handle");

@@ -179,6 +179,7 @@ struct Model {
     int Fp16 = 0;                    // bf16 conv build: channels padded to 16
     size_t conv_w16_off = 0;
     size_t conv_wf16_off = 0;        // fp32 tiles in the 16-channel geometry (source of the split-bf16 pack)
+    size_t conv_wraw_off = 0;        // conv.weight as the reference stores it, (F, F, taps): the input gradient of mtadgat_backward_input
     size_t conv_w3_off = 0;          // three bf16 pieces of those tiles [tile][taps Fp16 / 16][3][64], derived on the device (k_conv_x3: wide models)
     size_t conv_w2h_off = 0, conv_scale_off = 0;   // k_conv_win: two fp16 pieces of S * W [tile][taps * Fp16 / 16][2][64], [bits of max |W|, S, 1 / S, 0]
     GatPlan feat, temp;

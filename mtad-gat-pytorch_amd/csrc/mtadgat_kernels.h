@@ -419,6 +419,8 @@ int launch_xdec(const float* hend, long ldh, int H, int T, long B, float* X, lon
 // and its adjoint: dhend[b*ldh + m] += sum over the flat positions f = t*H + j with f / T == m of dX[(b*T + t)*ldx + j]
 int launch_xdec_bwd(const float* dX, long ldx, int H, int T, long B, float* dhend, long ldh, hipStream_t s);
 // dpre[(b*T + t)*ldp + f] = xc > 0 ? dhcat[.., f] + dvt[(b*T + t)*ldt + f] + dvf[(b*F + f)*ldf + t] : 0   (xc = hcat[.., f])
+// d x of the convolution (the input gradient of mtadgat_backward_input): dx[b, t, i] = sum_{o, j} w[o, i, j] dpre[b, t - j + pad, o]
+int launch_conv_dx(const float* dpre, long ldp, const float* w, long B, int T, int F, int taps, int pad, float* dx, hipStream_t s);
 int launch_dxc(const float* hcat, const float* dhcat, long ldh, const float* dvt, long ldt, const float* dvf, long ldf,
                long B, int T, int F, float* dpre, long ldp, hipStream_t s);
 // keep-mask (1 / 0) of a dropout stream: mask[w*n + idx] for windows win0 + w (test hook)

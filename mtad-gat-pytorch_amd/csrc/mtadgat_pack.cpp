@@ -110,6 +110,7 @@ std::string validate_and_plan(Model& m) {
         const int Q = m.taps * m.Fp / 8;
         m.conv_w_off = take((size_t)m.convNT * Q * 256);
         m.conv_b_off = take((size_t)m.convNT * 32);
+        m.conv_wraw_off = take((size_t)m.F * m.F * m.taps);
         m.Fp16 = round_up(m.F, 16);
         m.conv_w16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 16) * 256);
         m.conv_wf16_off = take((size_t)m.convNT * (m.taps * m.Fp16 / 8) * 256);
@@ -728,6 +729,7 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
             return (n < F && ch < F && tap < taps) ? p.conv_weight[((size_t)n * F + ch) * taps + tap] : 0.f;
         });
         for (int n = 0; n < F; ++n) out[m.conv_b_off + n] = p.conv_bias[n];
+        for (size_t k = 0; k < (size_t)F * F * taps; ++k) out[m.conv_wraw_off + k] = p.conv_weight[k];
         const int Fp16 = m.Fp16;
         pack_tiles(out.data() + m.conv_wf16_off, m.convNT, taps * Fp16 / 8, [&](int n, int k) -> float {
             const int tap = k / Fp16, ch = k % Fp16;

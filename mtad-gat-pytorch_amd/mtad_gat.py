@@ -20,8 +20,8 @@ fallback for the inference forward of GPU tensors.  When gradients are wanted, t
 training step (forward that keeps a tape + HIP backward behind a `torch.autograd.Function`)
 runs for the configurations it covers: GATv2 and GAT (v1) attention, any number of GRU and
 decoder layers (nn.GRU's inter-layer dropout included), attention layers of at most 128 nodes
-(window_size, n_features <= 128), parameter gradients only.  Outside of that (wider layers,
-an input that requires a gradient) the step is evaluated by torch ops on the GPU
+(window_size, n_features <= 128); parameter gradients, and the input's when `x.requires_grad`
+(mtadgat_backward_input).  Outside of that (wider layers) the step is evaluated by torch ops on the GPU
 (`_torchpath.py`, autograd): `model.grad_path` names the route and the reason, a
 RuntimeWarning is raised once per reason, and `model.strict_hip_training = True` turns it
 into an error.  A model and input left on the CPU (the reference's

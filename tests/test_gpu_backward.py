@@ -383,3 +383,38 @@ def test_gradients_are_views_of_one_flat_buffer(gpu_device):
     pr, rc = model(x)
     _loss(pr, rc, x, y).backward()
     assert sharding._flat_gradient_buffer(model) is None
+
+
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "stacked"])
+def test_input_gradient_matches_autograd(name, gpu_device, monkeypatch):
+    """x.requires_grad: the HIP step also returns d loss / d x (mtadgat_backward_input: the convolution's data gradient of the
+    pre-activation gradients the backward leaves in its workspace) -- against autograd through the torch-op algebra, same
+    weights; also when the batch is walked in several chunks."""
+    import _hipgrad
+    kw, b = CONFIGS[name]
+    model = _model(kw, gpu_device).eval()
+    g = torch.Generator().manual_seed(13)
+    x0 = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
+    y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
+    import _torchpath
+    xr = x0.clone().requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        pr, rc = _torchpath.forward(model, xr)
+        _loss(pr, rc, xr, y).backward()
+    dx_ref = xr.grad.clone()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for chunk in (None, 16):
+        if chunk:
+            monkeypatch.setattr(_hipgrad, "TRAIN_CHUNK", chunk)
+        for p in model.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        pr, rc = model(x)
+        assert model.grad_path == "hip", model.grad_path
+        _loss(pr, rc, x, y).backward()
+        assert x.grad is not None and x.grad.shape == x.shape and torch.isfinite(x.grad).all()
+        d, scale = (x.grad - dx_ref).abs().max().item(), dx_ref.abs().max().item()
+        print(f"{name} chunk={chunk}: |dx - ref| = {d:.3e}, scale {scale:.3e}")
+        assert d <= 1e-6 + 1e-4 * scale
+        rows, bad = _grad_report(model, ref)
+        assert not bad, "\n".join(bad)
