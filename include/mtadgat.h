@@ -117,8 +117,8 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, vo
  * mtadgat_params (the order of the flat gradient buffer, mtadgat_grad_offsets / mtadgat_grad_floats), and the tile
  * image is rebuilt from it by kernels on `stream`; nothing but the sign pattern of the two attention vectors `a`
  * (a few hundred bytes; it fixes the column order of the folded GATv2 projection) travels to the host.  Requires one
- * earlier mtadgat_load_weights on this device and precision mode 0 or 2 (the fp32 image; the split-operand packs of mode 2,
- * k_gat2's pack included, are re-derived from it on the device); mode 1 returns MTADGAT_ERR_UNSUPPORTED (callers then use
+ * earlier mtadgat_load_weights on this device and precision mode 0 or 2 (the fp32 image; the split-operand packs of mode 2
+ * are re-derived from it on the device); mode 1 returns MTADGAT_ERR_UNSUPPORTED (callers then use
  * mtadgat_load_weights).  The bf16 weight streams are not maintained: mtadgat_bf16_ready turns 0. */
 int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64_t n_floats, void* stream);
 
@@ -166,8 +166,8 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   3 the hidden-tile-split kernel on split operands wherever it applies.
  * "gat_kernel": which kernel runs the fused attention layers (modules.py:65-95, :166-193) in precision mode 2:
  *   0 automatic (default: from 4096 windows per chunk the fp16-piece build k_gath of the row-split kernel when the convolution's
- *   outputs are below 2^15, else k_gat), 1 k_gat at every batch size, 2 the column-sliced kernel k_gat2 wherever it applies
- *   (GATv2, <= 104 nodes; slower than k_gath on the shipped shapes: DESIGN.md section 4), 3 k_gath at every batch size.
+ *   outputs are below 2^15, else k_gat), 1 k_gat at every batch size, 3 k_gath at every batch size (2 was round 4's
+ *   column-sliced kernel, removed: it lost to k_gath on every shipped shape).
  * "conv_kernel": the convolution of the fused front end (modules.py:18-22) in precision mode 2: 0 automatic (the
  *   window-per-workgroup kernel on fp16 pieces from 4096 windows per chunk), 1 k_conv_lds (fp32 MFMA), 2 k_conv_win at any size.
  * "conv_shared": stride-1 series scoring in precision mode 2: 0 automatic (k_conv_win reads each window out of the series where it

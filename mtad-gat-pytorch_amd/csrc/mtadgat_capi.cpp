@@ -269,7 +269,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
-    } else if (m.precision == 2 && (n >= 4096 || ((m.gat_kernel == 2 || m.gat_kernel == 3) && !att))) {
+    } else if (m.precision == 2 && (n >= 4096 || (m.gat_kernel == 3 && !att))) {
         // large batches: split-bf16 operands for the projection -- fp32-class L' / R' on the bf16 matrix pipe, which runs
         // beside the pair grid of the other waves (the fp32 MFMA does not: profiles/r02_mfma_valu_overlap.txt).  Measured at
         // (W=100, F=55): feature layer 5.90 -> 5.09 ms, temporal layer 7.40 -> 6.94 ms (two weight chunks in registers; with
@@ -289,29 +289,16 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     a.ATT = att;
     if (drop) a.drop = *drop;
     a.drop_stream = drop_stream;
-    // the column-sliced kernel serves the two-fp16-piece arithmetic (inference, GATv2, node values below 2^15 -- decided on
-    // the device from the convolution's recorded maximum: of the two launches exactly one does the work)
+    // the fp16-piece build of the row-split kernel (node vectors split once per window) serves the two-fp16-piece arithmetic
+    // (inference, node values below 2^15 -- decided on the device from the convolution's recorded maximum: of the two launches
+    // exactly one does the work)
     const int scols = vt ? g.K : g.D;
-    if (a.bf16 == 2 && vmax && !att && g.g2.ok && m.gat_kernel == 2 && aligned16(v) && (ldv & 3) == 0 &&
-        ((scols + 3) & ~3) <= ldv) {
-        Gat2Args b{};
-        b.V = v; b.ldv = ldv; b.D = g.D; b.K = g.K; b.vt = vt;
-        b.W = m.packed_dev + g.w2g_off;
-        b.E = g.E; b.npos = g.npos;
-        b.scale2 = a.scale2; b.vmax = vmax; b.bias = a.bias;
-        b.out = out; b.so_w = so_w; b.so_i = so_i; b.so_d = so_d; b.nwin = n;
-        b.dbg_stop = m.gat2_stop;
-        K_TRY(launch_gat2(b, g.g2, s), "column-sliced gat");
-        a.skip_h = 1;
-    }
-    // the fp16-piece build of the row-split kernel (node vectors split once per window): same condition, decided on the device
-    else if (a.bf16 == 2 && vmax && !att && (m.gat_kernel == 0 || m.gat_kernel == 3) && g.fh_lds_bytes <= 160 * 1024 && aligned16(v) &&
-             (ldv & 3) == 0 && ((scols + 3) & ~3) <= ldv) {
+    if (a.bf16 == 2 && vmax && !att && (m.gat_kernel == 0 || m.gat_kernel == 3) && g.fh_lds_bytes <= 160 * 1024 && aligned16(v) &&
+        (ldv & 3) == 0 && ((scols + 3) & ~3) <= ldv) {
         GatArgs b = a;
         b.vld = g.fh_vld; b.lr_floats = g.fh_lr; b.n_full = g.fh_full; b.n_short = g.fh_short;
-        if (const char* e_ = getenv("MTADGAT_GATH_STAGGER")) b.stagger = atoi(e_);
-        b.dbg = m.gat2_stop;             // (measurement hook, shared with k_gat2's: mtadgat_set_option "gat2_stop")
-        K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, g.fh_lean, s), "fused gat (fp16 pieces)");
+        b.dbg = m.gath_dbg;              // (measurement hook: mtadgat_set_option "gath_dbg", profiles/gath_knockout.py)
+        K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, s), "fused gat (fp16 pieces)");
         a.skip_h = 1;
     }
     K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.f_lds_bytes, s), "fused gat");
@@ -747,9 +734,6 @@ static int run_split3(Model& m, hipStream_t s) {
             K_TRY(launch_absmax(m.packed_dev + g->w_off, (long)g->NT * g->Q * 256, sc, s), "projection weight range");
             K_TRY(launch_scale_from_max(sc, s), "projection weight scale");
             K_TRY(launch_split2h(m.packed_dev + g->w_off, m.packed_dev + g->w2h_off, g->NT, g->Q, g->Q16, 1, sc + 1, s), "split-fp16 projection weights");
-            if (g->g2.ok)
-                K_TRY(launch_gat2_pack(m.packed_dev + g->w_off, g->NT_L, g->Q, g->D, g->E, g->npos, g->P8, g->PT, g->g2.TCP, g->g2.KP, sc + 1,
-                                       m.packed_dev + g->w2g_off, s), "column-sliced projection weights");
         }
     return 0;
 }
@@ -949,7 +933,6 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     for (const GatPlan* g : {&m.feat, &m.temp}) {
         add(g->w2h_off, (size_t)g->NT * g->Q16 * 2 * 256);
         add(g->gscale_off, 4);
-        if (g->g2.ok) add(g->w2g_off, (size_t)2 * g->g2.TCP * g->g2.KP);
     }
     return n;
 }
@@ -1034,14 +1017,14 @@ int mtadgat_bf16_ready(mtadgat_handle h) { return (h && h->m.have_weights && h->
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (!h || !name) return fail(MTADGAT_ERR_INVALID, "null argument");
     if (std::strcmp(name, "gru_kernel") == 0 && value >= 0 && value <= 3) { h->m.gru_kernel = value; return 0; }
-    if (std::strcmp(name, "gat_kernel") == 0 && value >= 0 && value <= 3) { h->m.gat_kernel = value; return 0; }
+    if (std::strcmp(name, "gat_kernel") == 0 && (value == 0 || value == 1 || value == 3)) { h->m.gat_kernel = value; return 0; }
     if (std::strcmp(name, "wgrad_kernel") == 0 && value >= 0 && value <= 2) { h->m.wgrad_kernel = value; return 0; }
     if (std::strcmp(name, "conv_kernel") == 0 && value >= 0 && value <= 2) { h->m.conv_kernel = value; return 0; }
     if (std::strcmp(name, "rowgemm_kernel") == 0 && value >= 0 && value <= 2) { h->m.rowgemm_kernel = value; return 0; }
     if (std::strcmp(name, "conv_shared") == 0 && value >= 0 && value <= 1) { h->m.conv_shared = value; return 0; }
     if (std::strcmp(name, "series_band") == 0 && value >= 0 && value <= 2) { h->m.series_band = value; return 0; }
     if (std::strcmp(name, "lanes") == 0 && value >= 0 && value <= 1) { h->m.lanes = value; return 0; }
-    if (std::strcmp(name, "gat2_stop") == 0 && value >= 0 && value <= 7) { h->m.gat2_stop = value; return 0; }
+    if (std::strcmp(name, "gath_dbg") == 0 && value >= 0 && value <= 7) { h->m.gath_dbg = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
 

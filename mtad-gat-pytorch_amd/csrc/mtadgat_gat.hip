@@ -97,38 +97,6 @@ __device__ __forceinline__ void gat_tile(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Experiment switch (-DMTADGAT_GAT_LEAN=1, with -DMTADGAT_GAT_MINW=6 -DMTADGAT_GAT_QB=4): one register set for the
-// pair loads instead of two -- ~25 fewer VGPRs, so that three 8-wave workgroups fit a CU and the other waves of
-// the SIMD, not a second register set, cover the LDS latency.
-#ifndef MTADGAT_GAT_LEAN
-#define MTADGAT_GAT_LEAN 0
-#endif
-#if MTADGAT_GAT_LEAN
-template <int IBL, int JPL, int RJ, bool NEG>
-__device__ __forceinline__ void gat_tile_lean(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
-#pragma unroll
-    for (int st = 1; st <= 4; ++st) {
-        gat_step<IBL, JPL, NEG>(acc, lA, rA);
-        __builtin_amdgcn_sched_barrier(0);
-        gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 2 * st);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-#endif
-
-// one register set for the pair operands (k_gath's lean build: ~22 fewer VGPRs -> six waves per SIMD; the other waves of the
-// SIMD, not a second register set, cover the LDS latency)
-template <int IBL, int JPL, int RJ, bool NEG>
-__device__ __forceinline__ void gath_tile_lean(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
-#pragma unroll
-    for (int st = 1; st <= 4; ++st) {
-        gat_step<IBL, JPL, NEG>(acc, lA, rA);
-        __builtin_amdgcn_sched_barrier(0);
-        gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 2 * st);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // all-reduce over the RJ (16 or 8) adjacent lanes that hold one query row
 template <int RJ>
 __device__ __forceinline__ float row_max(float v) {
@@ -198,7 +166,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     // per operand and three MFMA terms instead of three bf16 pieces and six; the weights then carry the layer's power of two
     bool useh = false;
     if constexpr (X3) useh = a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f;
-    if (X3 && a.skip_h && useh) return;                // k_gat2 has served this launch (uniform over the grid: no barrier is split)
+    if (X3 && a.skip_h && useh) return;                // k_gath has served this launch (uniform over the grid: no barrier is split)
     const int npw = X3 ? (useh ? 2 : 3) : 1;           // words per weight chunk and lane
     const f32x4* __restrict__ Wbase = (X3 && useh) ? a.Wp2 : a.Wp;
     f32x4 w[QB][NP];
@@ -388,22 +356,14 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
             // keeps two register copies of the accumulators (and spills)
 #pragma unroll 1
             for (; kt < npos; ++kt) {
-#if MTADGAT_GAT_LEAN
-                gat_tile_lean<IBL, JPL, RJ, false>(acc, lA, rA, lq, rq);
-#else
                 gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
-#endif
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                 rq += 8;
             }
 #pragma unroll 1
             for (; kt < ntl; ++kt) {
-#if MTADGAT_GAT_LEAN
-                gat_tile_lean<IBL, JPL, RJ, true>(acc, lA, rA, lq, rq);
-#else
                 gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
-#endif
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                 rq += 8;
@@ -590,18 +550,15 @@ __device__ __forceinline__ float gath_exp(float x) {      // e^x, x <= 0 (or -in
     const float lo = __builtin_fmaf(x, c_hi, -hi);
     return __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(0.6931471805599453f, lo, 1.0f);
 }
-// LEAN: one operand register set in the pair loop and at most 80 VGPRs (six waves per SIMD: three 8-wave workgroups per CU)
-template <int IBL, int JPL, int RJ, bool LEAN>
-__global__ __launch_bounds__(512, LEAN ? 6 : MTADGAT_GAT_MINW) void k_gath(const GatArgs a) {
+// (A <= 80-VGPR build with one operand register set -- three 8-wave workgroups per CU -- was measured at 12.0 against 9.6 ms for
+// the two layers and is gone; so are staggered workgroup starts, which changed nothing: DESIGN.md section 4.)
+template <int IBL, int JPL, int RJ>
+__global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
     constexpr int IBW = RI * IBL;                      // query rows per wave
     constexpr int QB = MTADGAT_GAT_QB3;                // weight chunks held in registers per task batch
     if (!(a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f)) return;     // k_gat's bf16-piece build serves this launch
-    if (a.stagger > 0 && blockIdx.x < 1024u) {         // (experiment: spread the first workgroups of a launch in time)
-        const unsigned nap = ((blockIdx.x * 2654435761u) >> 29) * (unsigned)a.stagger;
-        for (unsigned i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
@@ -784,23 +741,21 @@ __global__ __launch_bounds__(512, LEAN ? 6 : MTADGAT_GAT_MINW) void k_gath(const
             lds_cptr rq = rp;
             int kt = 0;
             if (full) {
-                f32x2 lA[IBL], rA[JPL], lB[LEAN ? 1 : IBL], rB[LEAN ? 1 : JPL];
+                f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
                 lds_cptr lq[IBL];
 #pragma unroll
                 for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
                 gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
 #pragma unroll 1
                 for (; kt < npos; ++kt) {
-                    if constexpr (LEAN) gath_tile_lean<IBL, JPL, RJ, false>(acc, lA, rA, lq, rq);
-                    else gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
+                    gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                     rq += 8;
                 }
 #pragma unroll 1
                 for (; kt < ntl; ++kt) {
-                    if constexpr (LEAN) gath_tile_lean<IBL, JPL, RJ, true>(acc, lA, rA, lq, rq);
-                    else gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
+                    gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                     rq += 8;
@@ -808,23 +763,21 @@ __global__ __launch_bounds__(512, LEAN ? 6 : MTADGAT_GAT_MINW) void k_gath(const
             } else {
                 constexpr int IS = IBL - 1;             // the short block: the lane's last row belongs to the next wave
                 float (&accs)[IS][JPL] = reinterpret_cast<float (&)[IS][JPL]>(acc);
-                f32x2 lA[IS], rA[JPL], lB[LEAN ? 1 : IS], rB[LEAN ? 1 : JPL];
+                f32x2 lA[IS], rA[JPL], lB[IS], rB[JPL];
                 lds_cptr lq[IS];
 #pragma unroll
                 for (int ii = 0; ii < IS; ++ii) lq[ii] = lp[ii];
                 gat_load<IS, JPL, RJ>(lA, rA, lq, rq, 0);
 #pragma unroll 1
                 for (; kt < npos; ++kt) {
-                    if constexpr (LEAN) gath_tile_lean<IS, JPL, RJ, false>(accs, lA, rA, lq, rq);
-                    else gat_tile<IS, JPL, RJ, false>(accs, lA, rA, lB, rB, lq, rq);
+                    gat_tile<IS, JPL, RJ, false>(accs, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
                     rq += 8;
                 }
 #pragma unroll 1
                 for (; kt < ntl; ++kt) {
-                    if constexpr (LEAN) gath_tile_lean<IS, JPL, RJ, true>(accs, lA, rA, lq, rq);
-                    else gat_tile<IS, JPL, RJ, true>(accs, lA, rA, lB, rB, lq, rq);
+                    gat_tile<IS, JPL, RJ, true>(accs, lA, rA, lB, rB, lq, rq);
 #pragma unroll
                     for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
                     rq += 8;
@@ -1297,16 +1250,15 @@ int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_by
 #define GATH_CASE(I, J, RJ)                                                                     \
     if (IBL == I && JPL == J && rj == RJ) {                                                     \
         if (lds_bytes > 64 * 1024) {                                                            \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(lean ? (const void*)&k_gath<I, J, RJ, true> : (const void*)&k_gath<I, J, RJ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gath<I, J, RJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e_ != hipSuccess) return (int)e_;                                               \
         }                                                                                       \
-        if (lean) hipLaunchKernelGGL((k_gath<I, J, RJ, true>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);  \
-        else hipLaunchKernelGGL((k_gath<I, J, RJ, false>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);      \
+        hipLaunchKernelGGL((k_gath<I, J, RJ>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);                  \
         launched = true;                                                                        \
     }
 
 // the fp16-piece build of the fused layer (a.vld = piece pitch in halfs, a.lr_floats as for k_gat, a.Q = 16-feature chunks)
-int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, bool lean, hipStream_t s) {
+int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
     if (a.nwin <= 0) return 0;
     if (rj * JPL < a.K || nw > 8 || a.ATT || a.n_full + a.n_short > nw || a.n_full * 16 + a.n_short * (16 - 64 / rj) < a.K) return -2;
     const unsigned grid = (unsigned)a.nwin;

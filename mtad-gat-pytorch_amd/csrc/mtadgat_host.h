@@ -32,7 +32,6 @@ struct GatPlan {
     size_t f_lds_bytes = 0;
     int fh_full = 0, fh_short = 0;   // k_gath: row-owning waves with 16 rows / with 16 - 64 / RJ rows
     int fh_JPL = 0, fh_RJ = 16, fh_IBL = 4;   // k_gath's pair-grid blocking (8 lanes along the keys whenever that pads them less)
-    bool fh_lean = false;   // k_gath: the <= 80-VGPR build (three 8-wave workgroups per CU)
     int fh_lr = 0;          // k_gath: LDS floats of the L' / R' (and attention-row) region
     int fh_vld = 0;         // k_gath (fp16-piece build of the fused kernel): piece pitch in halfs, LDS bytes
     size_t fh_lds_bytes = 0;
@@ -41,11 +40,7 @@ struct GatPlan {
     size_t w3_off = 0;      // split-bf16 pack [tile][Q16][piece][64] of the fused projection, derived on the device
     size_t w2h_off = 0;     // two fp16 pieces of S * W, [tile][Q16][2][64]; gscale_off: [bits of max |W|, S, 1 / S, 0]
     size_t gscale_off = 0;
-    // column-sliced fused kernel (k_gat2, mtadgat_gat2.hip): plan, weight pack (fp16 [2 pieces][2 sides][TCP][KP], derived on the device),
-    // number of embedding columns with a' >= 0 (they come first in the pack)
-    Gat2Plan g2;
-    size_t w2g_off = 0;
-    int npos = 0;
+    int npos = 0;           // embedding columns with a' >= 0 (they come first in the pack)
     // un-fused path (projections through HBM, wide layers): split-bf16 pack of the row GEMM's tiles [tile][uQ16][3][64] (k_rowgemm_x3)
     int uQ16 = 0;
     size_t uw3_off = 0;
@@ -85,7 +80,6 @@ constexpr int64_t G16_MAX_WINDOWS = 4096;      // 16 windows per workgroup x 256
 constexpr int64_t CM_MIN_WINDOWS = 4097;
 // ... of which the hidden-tile-split kernel's split-operand build takes the lower band: five waves per 32 windows instead of
 // one, a round of 8 192 windows (one workgroup per CU) in ~1.2 ms (GRU + decoder) against the 4 ms of a k_gru_cm round
-constexpr int64_t GAT2_MIN_WINDOWS = 4096;     // the column-sliced attention kernel (one workgroup per CU) from here on: below, k_gat's several workgroups per CU hide each other's phases
 constexpr int64_t SPLIT3_MIN_WINDOWS = 2561, SPLIT3_MAX_WINDOWS = 8192;      // k_gru_cm (chunk-major recurrence, 128 windows per workgroup) from here on
 constexpr int64_t G1_MAX_WINDOWS = 1792;       // up to 7 windows per CU one after the other; beyond that 16-window groups pay
 
@@ -207,8 +201,8 @@ struct Model {
     uint64_t weights_version = 0;    // counts weight uploads / device-side re-packs
     int rowgemm_kernel = 0;          // data-gradient row GEMMs of mtadgat_backward in mode 2 (testing hook): 0 automatic (split-bf16 operands from 4096 rows), 1 fp32 MFMA, 2 split-bf16 always
     int conv_kernel = 0;             // convolution of the fused front end in mode 2 (testing hook): 0 automatic (k_conv_win from 4096 windows), 1 k_conv_lds, 2 k_conv_win at any batch size
-    int gat2_stop = 0;               // measurement hook: Gat2Args::dbg_stop
-    int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic (testing hook): 0 automatic (k_gath, the fp16-piece build, from 4096 windows), 1 k_gat only, 2 column-sliced k_gat2 at any batch size, 3 k_gath at any batch size
+    int gath_dbg = 0;                // measurement hook: GatArgs::dbg of k_gath (knock-out bits, profiles/gath_knockout.py)
+    int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic (testing hook): 0 automatic (k_gath, the fp16-piece build, from 4096 windows), 1 k_gat only, 3 k_gath at any batch size
     int gru_kernel = 0;              // large-batch recurrence: 0 automatic, 1 tile-major k_gru, 2 chunk-major k_gru_cm (testing hook: mtadgat_set_option)
     DevTables dt;
     // profiling

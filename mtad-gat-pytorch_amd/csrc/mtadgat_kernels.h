@@ -126,40 +126,8 @@ struct GatArgs {
     DropArgs drop;
     unsigned drop_stream;
     int n_full, n_short; // k_gath: waves owning 16 query rows / 16 - 64 / RJ query rows (the rest of the workgroup only projects)
-    int stagger;         // k_gath experiment: start delay unit (x 3.5 us x 0..7) of the first 1024 workgroups
     int dbg;             // k_gath measurement hook (bit 0: no pair grid, 1: no projection, 2: return before the softmax); results invalid
-    int skip_h;          // 1: return at once when *vmax < 2^15 -- k_gat2 (launched ahead of this kernel) serves that case
-};
-
-// column-sliced fused graph-attention layer (mtadgat_gat2.hip): GATv2, inference, node values below 2^15 (two fp16 pieces)
-struct Gat2Plan {
-    bool ok = false;
-    int IBL = 0, NT = 0;        // accumulator block per lane (IBL x IBL, IBL = ceil(K / 8)), threads per workgroup
-    int CW = 0, NR = 0;         // columns of a wave per round (<= 16), rounds
-    int KC = 0, KP = 0, pv = 0; // 32-feature chunks of a node vector incl. the ones column; padded features; LDS pitch (halfs)
-    int TCP = 0;                // rows of the weight pack per side: E + 1 columns + a tile of zero rows
-    int pa = 0;                 // LDS pitch (halfs) of the transposed node pieces / attention rows
-    int off_v = 0, off_cd = 0, off_lr = 0, lr_wave_floats = 0, off_vt = 0, off_att = 0, off_tile = -1;
-    size_t lds_bytes = 0;
-};
-struct Gat2Args {
-    const float* V;      // as GatArgs (vt == 1: the nodes are the source's columns)
-    int ldv, D, K, vt;
-    const void* W;       // fp16 [2 pieces][2 sides][TCP][KP] (k_gat2_pack)
-    int TCP, KP, KC;
-    int E, npos;         // embedding columns with a' != 0; the first npos of them have a' > 0
-    const float* scale2; // [S, 1 / S] of the layer's projection weights
-    const unsigned* vmax;// the kernel runs only while *vmax < 2^15 (null: always)
-    const float* bias;   // (K, K) or null
-    float* out;          // out[win*so_w + i*so_i + d*so_d]
-    long so_w, so_i, so_d;
-    long nwin;
-    int pv, pa, CW, NR;
-    int off_v, off_cd, off_lr, lr_wave_floats, off_vt, off_att;
-    int off_tile;        // LDS output tile [feature][node] (layers whose output runs along the nodes: so_i == 1), -1: none
-    int stagger_blocks;  // workgroups with a smaller index start after a pseudo-random delay
-    int dbg_flags;
-    int dbg_stop;        // measurement hook: > 0 returns after phase dbg_stop (1 staging, 2 projection, 3 pair grid, 4 reduce-scatter, 5 softmax); results invalid
+    int skip_h;          // 1: return at once when *vmax < 2^15 -- k_gath (launched ahead of this kernel) serves that case
 };
 
 // backward of one graph-attention layer, part 1 (per window): d e_ij (the gradient of the attention scores
@@ -366,11 +334,7 @@ int launch_conv_win(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
-int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, bool lean, hipStream_t s);
-bool gat2_plan(int K, int D, int E, bool tile_out, Gat2Plan& p);
-int launch_gat2(Gat2Args a, const Gat2Plan& p, hipStream_t s);
-int launch_gat2_pack(const float* src, int NT_L, int Q, int D, int E, int npos, int P8, int PT, int TCP, int KP, const float* scale,
-                     void* dst, hipStream_t s);
+int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
 int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int Kp, int PT, int P8, const float* bias,
                     const float* V, int ldv, int D, int K, float* out, long so_w, long so_i, long so_d, long nwin, int v1,
                     float alpha, hipStream_t s);

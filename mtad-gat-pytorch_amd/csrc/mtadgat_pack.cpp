@@ -180,10 +180,6 @@ std::string validate_and_plan(Model& m) {
             const int orows = (g.fh_full + g.fh_short) * 16;     // rows of L' the owning waves address
             g.fh_lr = (int)round_up((int)std::max((size_t)(orows + K) * 34, (size_t)orows * 36), 4);
             g.fh_lds_bytes = (size_t)g.fh_lr * sizeof(float) + (size_t)2 * ((K + 1) * g.fh_vld + 16) * 2;
-            // (the lean build -- <= 80 VGPRs, one operand register set, a third 8-wave workgroup per CU -- spills and loses:
-            // 12.0 vs 9.6 ms for the two layers at (W = 100, F = 55); measurement hook)
-            g.fh_lean = false;
-            if (const char* e_ = getenv("MTADGAT_GATH_LEAN")) g.fh_lean = atoi(e_) != 0;
         }
         g.w16_off = take((size_t)g.NT * g.Q16 * 256);
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
@@ -191,8 +187,6 @@ std::string validate_and_plan(Model& m) {
         g.gscale_off = take(4);
         g.uQ16 = g.fused ? 0 : (g.Q + 1) / 2;
         g.uw3_off = take((size_t)g.NT * g.uQ16 * 3 * 256);
-        g.g2 = Gat2Plan();
-        if (g.fused && c.use_gatv2 && gat2_plan(K, D, E, &g == &m.feat, g.g2)) g.w2g_off = take((size_t)2 * g.g2.TCP * g.g2.KP);
     };
     plan_gat(m.feat, m.F, m.W, c.feat_embed);
     plan_gat(m.temp, m.W, m.F, c.time_embed);

@@ -1,4 +1,4 @@
-"""Knock-out timing of k_gath (measurement hook "gat2_stop" as a bit mask: 1 no pair grid, 2 no projection, 4 return before the
+"""Knock-out timing of k_gath (measurement hook "gath_dbg" as a bit mask: 1 no pair grid, 2 no projection, 4 return before the
 softmax; results invalid).  usage: python profiles/gath_knockout.py [windows]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,11 +16,11 @@ names = {0: "full kernel", 1: "no pair grid", 2: "no projection", 3: "no pair gr
          5: "staging + projection only", 6: "staging + pair grid only", 7: "staging only"}
 with torch.no_grad():
     for mask in (0, 1, 2, 3, 4, 5, 6, 7):
-        eng.set_option("gat2_stop", mask)
+        eng.set_option("gath_dbg", mask)
         for _ in range(2): model(x)
         torch.cuda.synchronize(); eng.profile_enable(True)
         for _ in range(5): model(x)
         torch.cuda.synchronize(); prof = eng.profile_read(); eng.profile_enable(False)
         ms = sum(prof[k][0] for k in ("proj", "attend")) / 5
         print(f"k_gath {names[mask]:40s} both layers {ms:7.3f} ms per {n} windows")
-    eng.set_option("gat2_stop", 0)
+    eng.set_option("gath_dbg", 0)

@@ -1,9 +1,10 @@
-"""The two-fp16-piece builds of the fused attention layer (reference FeatureAttentionLayer.forward modules.py:65-95 and
+"""The two-fp16-piece build of the fused attention layer (reference FeatureAttentionLayer.forward modules.py:65-95 and
 TemporalAttentionLayer.forward :166-193): k_gath (csrc/mtadgat_gat.hip: the row-split kernel with the node vectors split once
 per window; engine option gat_kernel = 3; in normal use it serves batches of 4096 windows and more -- the 20 000- and
-65 573-window tests of test_gpu_parity.py go through it) and the column-sliced k_gat2 (csrc/mtadgat_gat2.hip; opt-in,
-gat_kernel = 2).  The testing hook forces them at fixture size, so every window is compared with the reference's golden
-outputs, and odd node counts / embedding widths with the oracle."""
+65 573-window tests of test_gpu_parity.py go through it).  The testing hook forces it at fixture size, so every window is
+compared with the reference's golden outputs, and odd node counts / embedding widths with the oracle.  (Round 4's
+column-sliced k_gat2 lost to it on every shipped shape and was removed in round 5; profiles/ubench_gat2.hip keeps its pair
+phase as a microbenchmark.)  Also here: the window convolution on fp16 pieces (k_conv_win)."""
 import pytest
 import torch
 
@@ -17,12 +18,12 @@ def _engine(model, dev):
     return model._sync_engine(dev)
 
 
-KERNELS = [2, 3]
+KERNELS = [3]
 
 
 @pytest.mark.parametrize("gk", KERNELS)
 @pytest.mark.parametrize("name", ["msl", "smap", "smd_1_1", "syn_v2_embed", "syn_v1_small"])
-def test_fixture_windows_through_the_column_sliced_kernel(name, gk, gpu_device):
+def test_fixture_windows_through_the_fp16_piece_kernel(name, gk, gpu_device):
     case = Case(name)
     model = case.build_model().to(gpu_device)
     eng = _engine(model, gpu_device)
@@ -33,15 +34,15 @@ def test_fixture_windows_through_the_column_sliced_kernel(name, gk, gpu_device):
         eng.set_option("gat_kernel", 1)
         p1, r1 = model(x)
         eng.set_option("gat_kernel", 0)
-    dp = gate(p2, case.preds, case.preds64, what=f"{name} predictions (k_gat2)")
-    dr = gate(r2, case.recons, case.recons64, what=f"{name} recons (k_gat2)")
-    print(f"{name}: k_gat2 |preds-ref|={dp:.2e} |recons-ref|={dr:.2e}  vs k_gat: {(p2 - p1).abs().max().item():.2e} {(r2 - r1).abs().max().item():.2e}")
+    dp = gate(p2, case.preds, case.preds64, what=f"{name} predictions (k_gath)")
+    dr = gate(r2, case.recons, case.recons64, what=f"{name} recons (k_gath)")
+    print(f"{name}: k_gath |preds-ref|={dp:.2e} |recons-ref|={dr:.2e}  vs k_gat: {(p2 - p1).abs().max().item():.2e} {(r2 - r1).abs().max().item():.2e}")
     assert (p2 - p1).abs().max().item() <= 2e-6 and (r2 - r1).abs().max().item() <= 2e-6
 
 
 @pytest.mark.parametrize("gk", KERNELS)
 @pytest.mark.parametrize("name", ["msl_wide", "smd_1_1_wide", "msl_c1"])
-def test_wide_fixtures_through_the_column_sliced_kernel(name, gk, gpu_device):
+def test_wide_fixtures_through_the_fp16_piece_kernel(name, gk, gpu_device):
     """300 / 320 windows per shipped checkpoint incl. the C1 input statistics (values outside [0, 1])."""
     case = WideCase(name)
     model = case.build_model().to(gpu_device)
@@ -53,8 +54,8 @@ def test_wide_fixtures_through_the_column_sliced_kernel(name, gk, gpu_device):
         p_split = torch.cat([model(x[lo:lo + 77].contiguous())[0] for lo in range(0, x.shape[0], 77)])
         eng.set_option("gat_kernel", 0)
     assert torch.equal(p_split, preds)                      # windows are independent of their batch
-    gate(preds, case.preds, case.preds64, what=f"{name} predictions (k_gat2)")
-    gate(recons, case.recons, case.recons64, what=f"{name} recons (k_gat2)")
+    gate(preds, case.preds, case.preds64, what=f"{name} predictions (k_gath)")
+    gate(recons, case.recons, case.recons64, what=f"{name} recons (k_gath)")
 
 
 SHAPES = [
@@ -71,7 +72,7 @@ SHAPES = [
 ]
 
 
-SHAPES_H = [   # k_gath also serves what k_gat2 does not: up to 128 nodes, fewer than 25, GAT (v1)
+SHAPES_H = [   # up to 128 nodes, fewer than 25, GAT (v1)
     dict(n_features=128, window_size=96, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24),
     dict(n_features=10, window_size=120, out_dim=1, kernel_size=7, use_gatv2=False, gru_hid_dim=30, recon_hid_dim=30),
     dict(n_features=3, window_size=64, out_dim=1, kernel_size=1, gru_hid_dim=64, forecast_n_layers=2, recon_hid_dim=96),
@@ -98,8 +99,8 @@ def test_shapes_against_the_oracle(kw, gk, gpu_device):
         p, r = m(x.to(gpu_device))
         eng.set_option("gat_kernel", 1)
         p1, r1 = m(x.to(gpu_device))
-    gate(p, p_ref, what="preds (k_gat2)")
-    gate(r, r_ref, what="recons (k_gat2)")
+    gate(p, p_ref, what="preds (k_gath)")
+    gate(r, r_ref, what="recons (k_gath)")
     gate(p1, p_ref, what="preds (k_gat)")
     assert (p - p1).abs().max().item() <= 2e-6 and (r - r1).abs().max().item() <= 2e-6
 
@@ -124,9 +125,9 @@ def test_large_inputs_fall_back_to_the_row_split_kernel(gk, gpu_device):
 
 
 @pytest.mark.parametrize("gk", KERNELS)
-def test_sign_flips_of_a_reach_the_column_sliced_pack(gk, gpu_device):
+def test_sign_flips_of_a_reach_the_fp16_piece_pack(gk, gpu_device):
     """In-place weight changes that flip signs of the attention vector `a` change the column order of the pack (positive
-    columns first) on the device-side re-pack path; outputs must track the row-split kernel's."""
+    columns first) on the device-side re-pack path; outputs must track the fp32 kernel's."""
     case = Case("msl")
     model = case.build_model().to(gpu_device)
     eng = _engine(model, gpu_device)
