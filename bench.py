@@ -204,10 +204,16 @@ def sub_records(model, kw, dev, args_precision="fp32"):
     g = torch.Generator().manual_seed(99)
     with torch.no_grad():
         x256 = torch.rand(256, kw["window_size"], kw["n_features"], generator=g).to(dev)
+        default_cwc = type(model)(**kw).check_weight_contents          # what an unchanged caller gets
+        model.check_weight_contents = default_cwc
+        t = _timed(lambda: model(x256), dev, 20)
+        out["batch256_default"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1), "check_weight_contents": repr(default_cwc),
+                                   "what": "one eval forward of the reference Predictor's fixed 256-window batch (prediction.py:31), MSL shape, "
+                                           "module settings at their defaults (the per-call parameter-content check included)"}
         model.check_weight_contents = False
         t = _timed(lambda: model(x256), dev, 20)
         out["batch256"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(256 / t, 1),
-                           "what": "one eval forward of the reference Predictor's fixed 256-window batch (prediction.py:31), MSL shape"}
+                           "what": "the same with check_weight_contents = False (parameter versions trusted: no content check)"}
         model.precision = "bf16"
         t = _timed(lambda: model(x256), dev, 20)
         model.precision = args_precision
@@ -347,14 +353,22 @@ def sub_records(model, kw, dev, args_precision="fp32"):
         fl4 = algorithmic_flops(kw4)
         km = {k: round(v[0], 2) for k, v in p4.items() if v[1]}
         dom4 = max(km, key=km.get)
-        tf4 = fl4[dom4] * 8192 / (km[dom4] * 1e-3) / 1e12
+        if dom4 == "attend":
+            # the attention family is bound by the vector ALU (the pair grid), not by the matrix pipe: price it there
+            tl4 = valu_lane_ops(kw4)["attend"] * 8192 / (km[dom4] * 1e-3) / 1e12
+            roof4 = {"kernel": "attend (k_gat_wide, both attention layers)", "bound": "valu", "achieved": round(tl4, 2),
+                     "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-op/s", "frac": round(tl4 / VALU_PEAK_TLANEOPS, 4),
+                     "note": "largest launch family of this shape by time; 2 lane-operations per (query, key, embedding column) element "
+                             "of the GATv2 scores / its time vs the vector-ALU peak (4 SIMD-32 per CU x 2.4 GHz)"}
+        else:
+            tf4 = fl4[dom4] * 8192 / (km[dom4] * 1e-3) / 1e12
+            roof4 = {"kernel": dom4, "bound": "mfma", "achieved": round(tf4, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf4 / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "note": "largest launch family of this shape by time; algorithmic matrix FLOPs of that family / its time vs the fp32 MFMA peak"}
         out["config4_f512_w256"] = {
             "ms": round(1e3 * t4, 2), "windows_per_s": round(8192 / t4, 1), "chunk_windows": int(e4.chunk_windows()),
             "kernel_ms": km,
-            "roofline": {"kernel": dom4, "bound": "mfma", "achieved": round(tf4, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf4 / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "note": "largest launch family of this shape by time; algorithmic matrix FLOPs of that family / its time vs the fp32 MFMA peak "
-                                 "(wide attention layers run the un-fused fp32 path: projections through HBM, k_gat_wide)"},
+            "roofline": roof4,
             "what": "BASELINE config 4: F=512, W=256, out_dim=512, H=150, 8192 windows per call (processed in chunks of chunk_windows), "
                     "fp32, random-init weights"}
         del m4, x4
@@ -414,7 +428,8 @@ def train_mode(args, model, kw, dev, world, rank):
             "exchange_ms_per_step": {"stats_allreduce": round(ar.get("stats_events", 0.0), 4), "grad_allreduce": round(ar.get("grad_events", 0.0), 4),
                                      "note": "HIP events around the two collectives on the stream they are enqueued on; 0 at one GPU (skipped)"},
             "grad_path": getattr(model, "grad_path", None), "loss_rmse": [round(float(v), 6) for v in rm],
-            "rccl_ranks": dist.get_world_size() if dist_on else 0, "per_rank_windows_per_s": per_rank,
+            "rccl_ranks": dist.get_world_size() if (dist_on and dist.get_backend() == "nccl") else 0, "per_rank_windows_per_s": per_rank,
+            "backend": dist.get_backend() if dist_on else None,
         }
         print(json.dumps(res))
 
@@ -425,20 +440,20 @@ def per_rank_rates(seconds, windows, dev):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return [round(windows / seconds, 1)]
-    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    t = torch.tensor([seconds], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else dev)
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [round(windows / float(o.item()), 1) for o in out]
 
 
-def self_launch(n):
+def self_launch(n, share_devices=False):
     """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run
     (one process per GPU of this node, rendezvous on 127.0.0.1 at a free port).  Fails loudly when the node has fewer
     than N devices -- a silent one-GPU run reported as an N-GPU number is the failure mode this replaces."""
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not (share_devices and have >= 1):
         print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); refusing to run fewer ranks than asked for", file=sys.stderr)
         return 2
     with socket.socket() as so:
@@ -461,6 +476,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU per step (default 65536, train mode 8192)")
     ap.add_argument("--chunk", type=int, default=0, help="windows per internal chunk (0 = library default)")
     ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (torch.distributed.run + an RCCL process group) even at --gpus 1")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend.  nccl (= RCCL) is the default and the only one whose numbers count; gloo is a TEST-ONLY escape "
+                         "hatch that lets N ranks share the GPUs that exist (rank r on cuda:(r mod devices), collectives staged through host "
+                         "memory) so that the N-rank code path can be exercised on a one-GPU box -- the line then says backend: gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="skip the batch256 / train_step / bf16 sub-records")
@@ -474,13 +493,17 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         # `python bench.py --gpus N` with no launcher around it: become the launcher -- one rank per GPU under
         # torch.distributed.run on this node, RCCL rendezvous on 127.0.0.1 -- and hand its exit code back
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, share_devices=args.backend == "gloo"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                          f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts its own ranks)")
+    if args.backend == "gloo":
+        if torch.cuda.device_count() < 1:
+            raise SystemExit("bench.py: no GPU on this node")
+        local_rank = local_rank % torch.cuda.device_count()          # test-only: ranks share the devices that exist
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank} but this node shows {torch.cuda.device_count()} device(s)")
     distributed = "WORLD_SIZE" in os.environ and (world > 1 or args.spawn)
@@ -488,9 +511,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        if dist.get_world_size() != args.gpus or dist.get_backend() != "nccl":
-            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks on {dist.get_backend()}, wanted {args.gpus} on nccl (RCCL)")
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus or dist.get_backend() != args.backend:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks on {dist.get_backend()}, wanted {args.gpus} on {args.backend}")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -561,7 +587,8 @@ def main():
                                    "(conv + feature-GAT + temporal-GAT + GRU + forecasting/reconstruction heads), "
                                    "weights = shipped MSL checkpoint, x ~ U[0,1) seed 1234+rank, eval mode",
                        "windows_per_gpu_per_step": B, "parallelism": f"dp{world} (windows sharded, no collective)"},
-            "rccl_ranks": dist.get_world_size() if distributed else 0, "per_rank_windows_per_s": per_rank,
+            "rccl_ranks": dist.get_world_size() if (distributed and args.backend == "nccl") else 0, "per_rank_windows_per_s": per_rank,
+            "backend": args.backend if distributed else None,
         }
         if prof:
             flops = algorithmic_flops(kw)
@@ -650,7 +677,10 @@ def main():
                                  "(MI355X_MICROARCH.md), frac_vs_r03_peak = against the 16-lanes/clk/SIMD figure rounds 1-3 used"}
             # `roofline` = the launch family that takes most of the step; both families are also in the line under their own names
             roof_gru["largest_family_by_time"] = dom
-            res["roofline"] = dict(roof_valu if dom == "k_gat" else roof_gru, largest_family_by_time=dom)
+            # (the two families are within a few per cent of each other at this shape: which one `roofline` names can flip from box
+            # to box -- roofline_mfma and roofline_valu always carry both)
+            res["roofline"] = dict(roof_valu if dom == "k_gat" else roof_gru, largest_family_by_time=dom,
+                                   families_ms_per_step={k: v["ms_per_step"] for k, v in fams.items()})
             res["roofline_mfma"] = roof_gru
             res["roofline_valu"] = roof_valu
         gbs = value * alg_bytes / 1e9

@@ -2,9 +2,10 @@
 activations the backward needs in a tape, dropout inside the kernels) and the HIP backward
 (`mtadgat_forward_train` / `mtadgat_backward`, include/mtadgat.h).
 
-Configurations without a HIP backward (`Engine.backward_supported()` false: attention layers beyond 128 nodes) and inputs that themselves require a gradient are evaluated by the
-package's torch-op algebra (`_torchpath.py`) with autograd; `MTAD_GAT.grad_path` says which path the last
-differentiable call took ("hip" / "torch-ops: <reason>").
+Configurations without a HIP backward (`Engine.backward_supported()` false; `Engine.why_not()` says why) are evaluated by
+the package's torch-op algebra (`_torchpath.py`) with autograd; `MTAD_GAT.grad_path` says which path the last differentiable
+call took ("hip" / "torch-ops: <reason>").  Inputs that themselves require a gradient stay on the HIP path: the backward
+returns d x as well (`mtadgat_backward_input`).
 """
 import warnings
 

@@ -666,6 +666,22 @@ static void free_device_tables(Model& m) {
     t.device = -1;
 }
 
+// the second lane's stream and events belong to the device they were created on (a handle may move: mtadgat_load_weights)
+static void free_lane(Model& m) {
+    if (!m.lane_stream) return;
+    int cur = 0;
+    const bool sw = m.lane_device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != m.lane_device;
+    if (sw) (void)hipSetDevice(m.lane_device);
+    (void)hipStreamSynchronize(m.lane_stream);
+    (void)hipStreamDestroy(m.lane_stream);
+    (void)hipEventDestroy(m.lane_begin);
+    (void)hipEventDestroy(m.lane_end);
+    if (sw) (void)hipSetDevice(cur);
+    m.lane_stream = nullptr;
+    m.lane_begin = m.lane_end = nullptr;
+    m.lane_device = -1;
+}
+
 int mtadgat_destroy(mtadgat_handle h) {
     if (!h) return 0;
     free_device_tables(h->m);
@@ -673,12 +689,7 @@ int mtadgat_destroy(mtadgat_handle h) {
         (void)hipEventSynchronize(h->m.upload_ev);
         (void)hipEventDestroy(h->m.upload_ev);
     }
-    if (h->m.lane_stream) {
-        (void)hipStreamSynchronize(h->m.lane_stream);
-        (void)hipStreamDestroy(h->m.lane_stream);
-        (void)hipEventDestroy(h->m.lane_begin);
-        (void)hipEventDestroy(h->m.lane_end);
-    }
+    free_lane(h->m);
     if (h->m.staging_pinned) (void)hipHostFree(h->m.staging_pinned);
     if (h->m.packed_dev) (void)hipFree(h->m.packed_dev);
     for (auto& v : h->m.ev)
@@ -1137,7 +1148,11 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
     bool second = false;
     for (const Piece& pc : sched) second = second || pc.lane == 1;
     if (second) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (m.lane_stream && m.lane_device != dev) free_lane(m);        // the handle moved to another GPU since the lane was made
         if (!m.lane_stream) {
+            m.lane_device = dev;
             HIP_TRY(hipStreamCreateWithFlags(&m.lane_stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&m.lane_begin, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&m.lane_end, hipEventDisableTiming));

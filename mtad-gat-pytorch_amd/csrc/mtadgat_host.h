@@ -190,6 +190,7 @@ struct Model {
     // second lane of forward(): pieces of a call alternate between the caller's stream and this one (forward_schedule, mtadgat_capi.cpp)
     hipStream_t lane_stream = nullptr;
     hipEvent_t lane_begin = nullptr, lane_end = nullptr;
+    int lane_device = -1;            // the device the second lane's stream and events were created on
     int lanes = 0;                   // 0 automatic, 1 everything on the caller's stream
     bool have_weights = false;
     bool bf16_packed = false;        // the bf16 streams of the packed image are current (packed only when precision == 1 at load time)

@@ -447,7 +447,10 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     {
         const GatPlan& g = m.temp;
         const size_t ldp = (size_t)g.NT * 32;
-        const bool tb = both_fused && m.cfg.use_gatv2 && tband_applies(g.K, g.D, g.PT, m.pad, g.ldl, (int)ldp);
+        // (only where tband_selected, mtadgat_capi.cpp, can say yes: not for plain forward() sizes below its threshold, not with the
+        // band switched off or in the bf16 mode, not -- automatic choice -- for embeddings it never picks the band for)
+        const bool tb = both_fused && m.cfg.use_gatv2 && m.series_band != 1 && m.precision != 1 && n >= 1024 &&
+                        (m.series_band == 2 || g.PT >= 112) && tband_applies(g.K, g.D, g.PT, m.pad, g.ldl, (int)ldp);
         ws.pj = take(tb ? (N + m.W) * ldp : 0);
         ws.pjt = take(tb ? N * 2 * m.pad * ldp : 0);
         ws.pjb = take(tb ? N * 2 * m.pad * ldp : 0);

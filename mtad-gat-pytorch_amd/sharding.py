@@ -40,7 +40,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
     """Slowest rank's time (the job's time); identity when not running distributed."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -80,6 +80,24 @@ def _flat_gradient_buffer(model):
         if g is None or g.dtype != flat.dtype or not g.is_contiguous() or g.data_ptr() != base + o * esz:
             return None
     return flat
+
+
+def _bucket_params(model):
+    """Parameters of the copy-path gradient bucket, in ONE order on every rank: the field order of mtadgat_params when the model
+    has it (the order of the in-place bucket), model.parameters() order otherwise; parameters without a gradient get zeros so
+    that the bucket has the same length everywhere."""
+    try:
+        import _hipgrad
+        params = _hipgrad.param_order(model)
+        if len(params) != len(list(model.parameters())):
+            params = list(model.parameters())
+    except Exception:
+        params = list(model.parameters())
+    params = [p for p in params if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    return params
 
 
 def dp_training_step(model, x, y, optimizer, target_dims=None, timings=None):
@@ -144,11 +162,17 @@ def dp_training_step(model, x, y, optimizer, target_dims=None, timings=None):
     surrogate.backward()
     if distributed:
         flat = _flat_gradient_buffer(model)
-        if flat is not None:
+        # The in-place bucket (field order of mtadgat_params) and the copy path below lay the elements out differently: every
+        # rank must take the same one, or a collective of matching size would silently sum misaligned gradients (a rank with
+        # pre-existing .grad tensors, a torch-op fallback or a frozen parameter decides differently).  One MIN over a flag.
+        agree = torch.tensor([1 if flat is not None else 0], dtype=torch.int32,
+                             device=torch.device("cpu") if dist.get_backend() == "gloo" else x.device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if flat is not None and int(agree.item()) == 1:
             # HIP backward: every p.grad is a view of the backward's flat gradient buffer -- one all-reduce in place, no copies
             _timed("grad_events", lambda: all_reduce_(flat))
         else:
-            params = [p for p in model.parameters() if p.grad is not None]
+            params = _bucket_params(model)
             flat = torch.cat([p.grad.reshape(-1) for p in params])
             _timed("grad_events", lambda: all_reduce_(flat))
             off = 0
