@@ -170,6 +170,10 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   column-sliced kernel, removed: it lost to k_gath on every shipped shape).
  * "conv_kernel": the convolution of the fused front end (modules.py:18-22) in precision mode 2: 0 automatic (the
  *   window-per-workgroup kernel on fp16 pieces from 4096 windows per chunk), 1 k_conv_lds (fp32 MFMA), 2 k_conv_win at any size.
+ * "conv_fused": 0 automatic -- in precision mode 2, wherever k_conv_win and k_gath both apply (from 4096 windows per chunk), the
+ *   workgroup that runs the temporal attention layer on a window computes that window's convolution itself (mtad_gat.py:67-70 is
+ *   one dataflow): no convolution launch, h_cat[:, :F] written once and not read back by that layer; the fp16 range guard is then
+ *   per window.  1: always two launches.
  * "conv_shared": stride-1 series scoring in precision mode 2: 0 automatic (k_conv_win reads each window out of the series where it
  *   applies, the shared-row convolution of k_conv_lds otherwise), 1 the shared-row convolution wherever it applies.
  * "series_band": stride-1 series scoring (mtadgat_forward_series without `starts`, stride 1, >= 1024 windows per chunk, GATv2):

@@ -257,9 +257,10 @@ int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, con
 bool use_fused(const GatPlan& g) { return g.fused; }
 
 // fused layer: V rows (n*K, ldv) -> out, nothing but V read from / out written to HBM
+// cv (temporal layer, inference): the window convolution runs inside k_gath's workgroup (fused_conv_args below said it can)
 int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, int64_t n, float* out, long so_w, long so_i,
                   long so_d, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0,
-                  const unsigned* vmax = nullptr) {
+                  const unsigned* vmax = nullptr, const GatConvIn* cv = nullptr) {
     Scope sc(m, S_ATTEND, s);
     GatArgs a{};
     a.V = v; a.ldv = ldv; a.vt = vt; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.lr_floats = g.f_lr;
@@ -298,11 +299,44 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
         GatArgs b = a;
         b.vld = g.fh_vld; b.lr_floats = g.fh_lr; b.n_full = g.fh_full; b.n_short = g.fh_short;
         b.dbg = m.gath_dbg;              // (measurement hook: mtadgat_set_option "gath_dbg", profiles/gath_knockout.py)
-        K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, s), "fused gat (fp16 pieces)");
+        if (cv) b.cv = *cv;
+        K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, cv != nullptr, s), cv ? "fused convolution + gat (fp16 pieces)" : "fused gat (fp16 pieces)");
         a.skip_h = 1;
+        if (cv) a.winflag = cv->flag;    // per-window range guard: k_gat serves exactly the windows k_gath flagged
+    } else if (cv) {
+        return fail(MTADGAT_ERR_INVALID, "internal: fused convolution without k_gath");
     }
     K_TRY(launch_gat(a, g.f_IBL, g.f_JPL, g.f_RJ, g.f_nw, g.f_lds_bytes, s), "fused gat");
     return 0;
+}
+
+// Can the temporal layer's k_gath workgroup compute the convolution of its window itself (mtadgat_gath.hip, CONV build)?  The
+// conditions of k_conv_win and of k_gath's launch in run_gat_fused, and the staged input must fit the L' / R' region.  Fills `cv`.
+bool fused_conv_args(const Model& m, const XSource& src, int64_t c0, int64_t n, float* hcat, unsigned* vmax, unsigned char* flag, GatConvIn& cv) {
+    const GatPlan& g = m.temp;
+    if (m.conv_fused == 1 || m.precision != 2 || !conv_win_selected(m, n) || !g.fused || !m.feat.fused) return false;
+    if (!(n >= 4096 || m.gat_kernel == 3) || !(m.gat_kernel == 0 || m.gat_kernel == 3) || g.fh_lds_bytes > 160 * 1024) return false;
+    if (g.K != m.W || g.D != m.F || !aligned16(hcat) || (m.Dp & 3) != 0 || ((g.D + 3) & ~3) > m.Dp) return false;
+    cv = GatConvIn{};
+    if (src.gather) {
+        cv.X = src.x; cv.gather = 1;
+        cv.starts = src.starts ? reinterpret_cast<const long*>(src.starts + c0) : nullptr;
+        cv.start0 = src.start0 + c0 * src.stride; cv.stride = src.stride;
+    } else if (src.x_bf16) {
+        cv.X = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(src.x) + c0 * (int64_t)m.W * m.F);
+    } else {
+        cv.X = src.x + c0 * (int64_t)m.W * m.F;
+    }
+    cv.x_bf16 = src.x_bf16;
+    cv.taps = m.taps; cv.pad = m.pad; cv.Fq = m.Fp16; cv.NT = m.convNT; cv.Dp = m.Dp;
+    cv.pvx = conv_win_pitch(m.F, m.Fp16);
+    cv.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w2h_off);
+    cv.bias = m.packed_dev + m.conv_b_off;
+    cv.wscale = m.packed_dev + m.conv_scale_off + 1;
+    cv.HCAT = hcat; cv.vmax = vmax; cv.flag = flag;
+    GatArgs probe{};
+    probe.vt = 0; probe.K = g.K; probe.D = g.D; probe.lr_floats = g.fh_lr; probe.cv = cv;
+    return gath_conv_applies(probe, g.f_nw, m.F, m.W);
 }
 
 // one graph-attention layer from its node rows, fused when the plan allows
@@ -1033,6 +1067,7 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (std::strcmp(name, "conv_kernel") == 0 && value >= 0 && value <= 2) { h->m.conv_kernel = value; return 0; }
     if (std::strcmp(name, "rowgemm_kernel") == 0 && value >= 0 && value <= 2) { h->m.rowgemm_kernel = value; return 0; }
     if (std::strcmp(name, "conv_shared") == 0 && value >= 0 && value <= 1) { h->m.conv_shared = value; return 0; }
+    if (std::strcmp(name, "conv_fused") == 0 && value >= 0 && value <= 1) { h->m.conv_fused = value; return 0; }
     if (std::strcmp(name, "series_band") == 0 && value >= 0 && value <= 2) { h->m.series_band = value; return 0; }
     if (std::strcmp(name, "lanes") == 0 && value >= 0 && value <= 1) { h->m.lanes = value; return 0; }
     if (std::strcmp(name, "gath_dbg") == 0 && value >= 0 && value <= 7) { h->m.gath_dbg = value; return 0; }
@@ -1180,12 +1215,20 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
             // there (the feature layer transposes on the way into LDS) -- no xc / xc^T / L' / R' in HBM
             unsigned* vmax = reinterpret_cast<unsigned*>(ws + o.vmax);
             const bool band = tband_selected(m, src, n);
+            GatConvIn cv{};
+            bool conv_in_gat = false;
             if (band || conv_shared_applies(m, src, n)) {
                 if ((rc = run_conv_shared(m, src, c0, n, hcat, ws + o.cf, ws + o.el, ws + o.er, s, vmax))) return rc;
+            } else if (fused_conv_args(m, src, c0, n, hcat, vmax, reinterpret_cast<unsigned char*>(ws + o.winflag), cv)) {
+                // the temporal layer's workgroups compute the convolution of their windows themselves: no convolution launch,
+                // h_cat[:, :F] is written once and not read back by that layer
+                conv_in_gat = true;
+                HIP_TRY(hipMemsetAsync(vmax, 0, sizeof(unsigned), s));
             } else if ((rc = run_conv(m, src, c0, n, nullptr, nullptr, hcat, nullptr, s, vmax))) return rc;
             if (band) {
                 if ((rc = run_tband(m, n, ws, o, hcat, s))) return rc;
-            } else if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, nullptr, nullptr, 0, vmax))) return rc;
+            } else if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, nullptr, nullptr, 0, vmax,
+                                           conv_in_gat ? &cv : nullptr))) return rc;
             if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, nullptr, nullptr, 0, vmax))) return rc;
         } else {
             if ((rc = run_conv(m, src, c0, n, xc, xct, hcat, nullptr, s))) return rc;

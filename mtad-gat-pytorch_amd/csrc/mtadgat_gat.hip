@@ -1,5 +1,5 @@
 // k_gat: fused graph-attention layer, one workgroup per window + launcher
-#include "mtadgat_device.h"
+#include "mtadgat_gat_impl.h"
 
 namespace mtadgat {
 
@@ -30,91 +30,6 @@ namespace mtadgat {
 // flight while the current pair is consumed.  Row strides of 34 floats keep every ds_read_b64 wave
 // access conflict-free (16 distinct keys x 2 banks each cover 32 bank pairs).
 // ---------------------------------------------------------------------------
-typedef const __attribute__((address_space(3))) float* lds_cptr;      // explicit LDS pointer (32-bit)
-constexpr int GAT_LLD = 34;     // 32 columns + 2: rows 8-byte aligned, 16 consecutive rows start on 16 distinct bank pairs
-constexpr int GAT_APITCH = 68;
-
-// lp[ii]: one base pointer per query row.  The pointers are made opaque to the compiler on purpose:
-// with a common base it merges row pairs into ds_read2_b64, which runs at half the LDS rate of two
-// ds_read_b64 (MI355X: 8 vs 2 x 2 LDS cycles per wave instruction).
-template <int IBL, int JPL, int RJ>
-__device__ __forceinline__ void gat_load(f32x2 (&l)[IBL], f32x2 (&r)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp, int col) {
-    typedef const __attribute__((address_space(3))) f32x2* lds_c2;
-#pragma unroll
-    for (int ii = 0; ii < IBL; ++ii) l[ii] = *(lds_c2)(lp[ii] + col);
-#pragma unroll
-    for (int jj = 0; jj < JPL; ++jj) r[jj] = *(lds_c2)(rp + jj * RJ * GAT_LLD + col);
-}
-
-// The two instructions per pair are written as (volatile) inline asm: left to itself the compiler packs
-// the column pair into v_pk_add_f32 (no faster -- neither its form with shuffles nor, round 3, a hand-placed
-// v_pk_add_f32 on the 8-byte words as loaded, 3 instructions per 2 pair-columns: 10.91 -> 10.82 ms, the pair grid is
-// not bound by VALU issue alone) and schedules all sums of a step
-// ahead of their uses, which costs > 100 VGPRs of temporaries and spills the accumulators.
-template <int IBL, int JPL, bool NEG>
-__device__ __forceinline__ void gat_step(float (&acc)[IBL][JPL], const f32x2 (&l)[IBL], const f32x2 (&r)[JPL]) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-        for (int ii = 0; ii < IBL; ++ii) {
-            float t[JPL];
-            const float lv = l[ii][e];
-#pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) {
-                const float rv = r[jj][e];
-                asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(t[jj]) : "v"(lv), "v"(rv));
-            }
-#pragma unroll
-            for (int jj = 0; jj < JPL; ++jj) {
-                if (NEG)
-                    asm volatile("v_sub_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t[jj]));
-                else
-                    asm volatile("v_add_f32_e64 %0, %0, |%1|" : "+v"(acc[ii][jj]) : "v"(t[jj]));
-            }
-        }
-}
-
-// one 8-column k tile; on entry set A holds columns 0,1 of the tile (loads possibly still in flight),
-// on exit it holds columns 0,1 of the next tile (pad columns past the end of a part: never consumed)
-template <int IBL, int JPL, int RJ, bool NEG>
-__device__ __forceinline__ void gat_tile(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], f32x2 (&lB)[IBL],
-                                         f32x2 (&rB)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp) {
-    gat_load<IBL, JPL, RJ>(lB, rB, lp, rp, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    gat_step<IBL, JPL, NEG>(acc, lA, rA);
-    __builtin_amdgcn_sched_barrier(0);
-    gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    gat_step<IBL, JPL, NEG>(acc, lB, rB);
-    __builtin_amdgcn_sched_barrier(0);
-    gat_load<IBL, JPL, RJ>(lB, rB, lp, rp, 6);
-    __builtin_amdgcn_sched_barrier(0);
-    gat_step<IBL, JPL, NEG>(acc, lA, rA);
-    __builtin_amdgcn_sched_barrier(0);
-    gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 8);
-    __builtin_amdgcn_sched_barrier(0);
-    gat_step<IBL, JPL, NEG>(acc, lB, rB);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// all-reduce over the RJ (16 or 8) adjacent lanes that hold one query row
-template <int RJ>
-__device__ __forceinline__ float row_max(float v) {
-    v = fmaxf(v, dpp_move<0xB1>(v));
-    v = fmaxf(v, dpp_move<0x4E>(v));
-    v = fmaxf(v, dpp_move<0x141>(v));
-    if (RJ == 16) v = fmaxf(v, dpp_move<0x140>(v));
-    return v;
-}
-template <int RJ>
-__device__ __forceinline__ float row_sum(float v) {
-    v += dpp_move<0xB1>(v);
-    v += dpp_move<0x4E>(v);
-    v += dpp_move<0x141>(v);
-    if (RJ == 16) v += dpp_move<0x140>(v);
-    return v;
-}
-
 // RJ = lanes along the key axis (16, or 8 when that pads K less: 55 features -> 56 instead of 64 keys);
 // RI = 64 / RJ lanes along the row axis; a wave owns RI*IBL = 16 query rows either way.
 // BF: bf16 operand build of the projection (16 features per chunk, fp32 accumulation); the pair grid, softmax and
@@ -166,7 +81,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     // per operand and three MFMA terms instead of three bf16 pieces and six; the weights then carry the layer's power of two
     bool useh = false;
     if constexpr (X3) useh = a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f;
-    if (X3 && a.skip_h && useh) return;                // k_gath has served this launch (uniform over the grid: no barrier is split)
+    if (a.winflag) {                                   // behind a CONV launch of k_gath: only the windows it flagged (uniform per workgroup)
+        if (!a.winflag[win]) return;
+    } else if (X3 && a.skip_h && useh) return;         // k_gath has served this launch (uniform over the grid: no barrier is split)
     const int npw = X3 ? (useh ? 2 : 3) : 1;           // words per weight chunk and lane
     const f32x4* __restrict__ Wbase = (X3 && useh) ? a.Wp2 : a.Wp;
     f32x4 w[QB][NP];
@@ -532,398 +449,6 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
 
 
 // ---------------------------------------------------------------------------
-// k_gath: k_gat for the two-fp16-piece arithmetic (inference, node values below 2^15) on a vector-ALU diet.  k_gat is bound by
-// VALU issue (profiles/r03_pmc_summary.txt: 72.9 k VALU instructions per temporal window, 44.9 k of them pair-grid), and 28 k of
-// its instructions are not the pair grid.  Here the node vectors are split into their two fp16 pieces ONCE, when the window is
-// staged (k_gat: again for every 32-column part, side and aggregation group -- 8 + 7 times per value), and kept in LDS as
-// pieces, row-major [node][feature]:
-//   * projection: the B operand of v_mfma_f32_32x32x16_f16 is two 8-byte LDS reads per piece, no VALU;
-//   * the power-of-two weight scale S stays in L', R', c, d and leaves with one multiply per score;
-//   * aggregation: the A operand (4 keys x 1 feature per lane) is gathered with 16-bit LDS reads and one shift-or per register;
-//     the softmax rows are split per 16-key group as before;
-//   * staging: one index computation per 16-byte unit, exp with one rounding-error term.
-// Same LDS budget as k_gat (pieces: 2 x 2 bytes per value), same pair grid (gat_tile), same launch geometry.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float gath_exp(float x) {      // e^x, x <= 0 (or -inf): the product x log2(e) in two pieces
-    const float c_hi = 1.4426950216293335f;
-    const float hi = x * c_hi;
-    const float lo = __builtin_fmaf(x, c_hi, -hi);
-    return __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(0.6931471805599453f, lo, 1.0f);
-}
-// (A <= 80-VGPR build with one operand register set -- three 8-wave workgroups per CU -- was measured at 12.0 against 9.6 ms for
-// the two layers and is gone; so are staggered workgroup starts, which changed nothing: DESIGN.md section 4.)
-template <int IBL, int JPL, int RJ>
-__global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int RI = 64 / RJ;
-    constexpr int IBW = RI * IBL;                      // query rows per wave
-    constexpr int QB = MTADGAT_GAT_QB3;                // weight chunks held in registers per task batch
-    if (!(a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f)) return;     // k_gat's bf16-piece build serves this launch
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = blockDim.x >> 6;
-    const long win = blockIdx.x;
-    const int K = a.K, D = a.D, PT = a.PT;
-    const int pvh = a.vld;                             // piece pitch in halfs
-    const int KR = K + 1;                              // rows of the pieces: the nodes and one zero row (keys past K of a 16-key group)
-    // waves that own query rows (the rest only project): n_full of them 4 RI = 16 rows (IBL per lane), n_short one row per lane
-    // less (IBL - 1: 12 rows, or 8 with 8 lanes along the keys) -- 100 rows = 4 x 16 + 3 x 12, 55 = 3 x 16 + 8: no padded rows
-    const int NWA = a.n_full + a.n_short;
-    float* __restrict__ Ls = smem;
-    float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;
-    unsigned short* __restrict__ Vh = reinterpret_cast<unsigned short*>(smem + a.lr_floats);
-    unsigned short* __restrict__ Vl = Vh + KR * pvh + 16;          // (+ 16 zero halfs: chunk reads of the last row run past its end when the pitch is below 16 Q)
-    const int i = lane & 31, g = lane >> 5;            // MFMA roles
-    const int lj = lane % RJ, li = lane / RJ;          // pair-grid roles
-
-    const int NTn = (K + 31) >> 5;                    // node tiles
-    const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
-    const int Q = a.Q;                                // 16-feature chunks incl. the ones column
-    const int ptile = a.P8 >> 3, ntile = PT >> 3;
-    const int nparts = (PT >> 5) + 1;
-
-    const f32x4* __restrict__ Wbase = a.Wp2;
-    f32x4 w[QB][2];
-    auto wfetch = [&](const f32x4* __restrict__ wp, int u, int q) {
-        w[u][0] = wp[((long)q * 2) * 64];
-        w[u][1] = wp[((long)q * 2 + 1) * 64];
-    };
-    auto prefetch = [&](int part) {
-        if (wave < ntask) {
-            const int wtile = wave >= NTn ? a.NT_L + part : part;
-            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + lane;
-#pragma unroll
-            for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
-        }
-    };
-
-    // ---- stage the window as fp16 pieces: Vh/Vl[node][feature], feature D = 1 (the projection bias is weight row D), the
-    // other features up to 16 Q and the rows K .. Kp16 zero.  vt == 0: source rows are the nodes; vt == 1: source columns.
-    {
-        const int nthr = blockDim.x;
-        const int srows = a.vt ? D : K, scols = a.vt ? K : D;
-        const int UR = (scols + 3) >> 2;
-        const int total = srows * UR;
-        const float rinv = 1.0f / (float)UR;
-        const float* __restrict__ vsrc = a.V + win * (long)srows * a.ldv;
-        const int c4last = ((scols - 1) >> 2) << 2;
-        constexpr int MAXU = 3;
-        for (int base = 0; base < total; base += MAXU * nthr) {
-            f32x4 v[MAXU];
-            int rr[MAXU], cc[MAXU];
-#pragma unroll
-            for (int n = 0; n < MAXU; ++n) {
-                const int u = base + tid + n * nthr;
-                const int row = (int)(((float)u + 0.5f) * rinv), c4 = (u - row * UR) * 4;
-                rr[n] = u < total ? row : -1;
-                cc[n] = c4;
-                const int rc = row < srows ? row : srows - 1, cl = c4 < scols ? c4 : c4last;
-                v[n] = *reinterpret_cast<const f32x4*>(vsrc + (long)rc * a.ldv + cl);
-            }
-#pragma unroll
-            for (int n = 0; n < MAXU; ++n) {
-                const int row = rr[n], c4 = cc[n];
-                if (row >= 0) {
-                    f32x4 t = v[n];
-                    unsigned h0, l0, h1, l1;
-                    if (!a.vt) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = c4 + e < D ? t[e] : (c4 + e == D ? 1.f : 0.f);
-                        split_pair_h(t[0], t[1], h0, l0);
-                        split_pair_h(t[2], t[3], h1, l1);
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        *reinterpret_cast<u32x2*>(Vh + row * pvh + c4) = u32x2{h0, h1};
-                        *reinterpret_cast<u32x2*>(Vl + row * pvh + c4) = u32x2{l0, l1};
-                    } else {
-                        split_pair_h(t[0], t[1], h0, l0);
-                        split_pair_h(t[2], t[3], h1, l1);
-                        const unsigned short hs[4] = {(unsigned short)h0, (unsigned short)(h0 >> 16), (unsigned short)h1, (unsigned short)(h1 >> 16)};
-                        const unsigned short ls[4] = {(unsigned short)l0, (unsigned short)(l0 >> 16), (unsigned short)l1, (unsigned short)(l1 >> 16)};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c4 + e < K) {
-                                Vh[(c4 + e) * pvh + row] = hs[e];
-                                Vl[(c4 + e) * pvh + row] = ls[e];
-                            }
-                    }
-                }
-            }
-        }
-        // ones column and zero features of the real nodes (up to the pitch; chunk reads beyond it meet the next row: finite values
-        // against zero weights), the zero row K and the 16 halfs behind each piece
-        const int FP = 16 * Q < pvh ? 16 * Q : pvh;
-        const int f0 = a.vt ? D : 4 * UR, nf = FP - f0;
-        if (nf > 0) {
-            const float ninv = 1.0f / (float)nf;
-            for (int u = tid; u < K * nf; u += nthr) {
-                const int node = (int)(((float)u + 0.5f) * ninv), f = f0 + (u - node * nf);
-                Vh[node * pvh + f] = f == D ? (unsigned short)0x3C00 : (unsigned short)0;
-                Vl[node * pvh + f] = 0;
-            }
-        }
-        for (int u = tid; u < ((pvh + 16) >> 1); u += nthr) {
-            reinterpret_cast<unsigned*>(Vh + K * pvh)[u] = 0u;
-            reinterpret_cast<unsigned*>(Vl + K * pvh)[u] = 0u;
-        }
-    }
-    prefetch(0);
-    __syncthreads();
-
-    const bool rows_owner = wave < NWA;
-    const bool full = wave < a.n_full;
-    const int i0 = !rows_owner ? 0 : (full ? wave * IBW : a.n_full * IBW + (wave - a.n_full) * (IBW - RI));
-    const int iblw = full ? IBL : IBL - 1;             // rows per lane of this wave
-    lds_cptr lp[IBL];
-#pragma unroll
-    for (int ii = 0; ii < IBL; ++ii) {
-        lp[ii] = (lds_cptr)(Ls + (i0 + li + RI * ii) * GAT_LLD);
-        asm volatile("" : "+v"(lp[ii]));
-    }
-    const lds_cptr rp = (lds_cptr)(Rs + lj * GAT_LLD);
-    float acc[IBL][JPL];
-#pragma unroll
-    for (int ii = 0; ii < IBL; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = 0.f;
-
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    for (int part = 0; part < nparts; ++part) {
-        // ---- MFMA phase: project this part's 32 + 32 columns for all nodes into Ls / Rs (scaled by S: the weights carry it)
-        for (int task = wave; task < ntask && !(a.dbg & 2); task += NW) {
-            const bool keyside = task >= NTn;
-            const int nt = keyside ? task - NTn : task;
-            const int wtile = keyside ? a.NT_L + part : part;
-            const int node = nt * 32 + i;
-            const unsigned short* __restrict__ vrh = Vh + (node < K ? node : K - 1) * pvh + 4 * g;
-            const unsigned short* __restrict__ vrl = Vl + (node < K ? node : K - 1) * pvh + 4 * g;
-            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + lane;
-            if (task != wave) {
-#pragma unroll
-                for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
-            }
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-            for (int qb = 0; qb < Q; qb += QB) {
-#pragma unroll
-                for (int u = 0; u < QB; ++u)
-                    if (qb + u < Q) {
-                        // the lane's eight features of the chunk: 16 q + 4 g .. + 3 and 16 q + 8 + 4 g .. + 3 (mtadgat_device.h)
-                        const u32x2 ha = *reinterpret_cast<const u32x2*>(vrh + 16 * (qb + u)), hb = *reinterpret_cast<const u32x2*>(vrh + 16 * (qb + u) + 8);
-                        const u32x2 la = *reinterpret_cast<const u32x2*>(vrl + 16 * (qb + u)), lb = *reinterpret_cast<const u32x2*>(vrl + 16 * (qb + u) + 8);
-                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                        const f32x4 xh = __builtin_bit_cast(f32x4, u4{ha[0], ha[1], hb[0], hb[1]});
-                        const f32x4 xl = __builtin_bit_cast(f32x4, u4{la[0], la[1], lb[0], lb[1]});
-                        o = mfma_h(w[u][0], xl, o);
-                        o = mfma_h(w[u][1], xh, o);
-                        o = mfma_h(w[u][0], xh, o);
-                        if (qb + QB + u < Q) wfetch(wp, u, qb + QB + u);
-                    }
-            }
-            if (node < K) {
-                float* __restrict__ dst = (keyside ? Rs : Ls) + node * GAT_LLD + 4 * g;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    f32x2 v0, v1;
-                    v0[0] = o[4 * m + 0]; v0[1] = o[4 * m + 1]; v1[0] = o[4 * m + 2]; v1[1] = o[4 * m + 3];
-                    *reinterpret_cast<f32x2*>(dst + 8 * m) = v0;
-                    *reinterpret_cast<f32x2*>(dst + 8 * m + 2) = v1;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
-        int ntl = ntile - 4 * part;
-        ntl = ntl > 4 ? 4 : ntl;
-        if (ntl > 0 && rows_owner && !(a.dbg & 1)) {
-            int npos = ptile - 4 * part;
-            npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
-            lds_cptr rq = rp;
-            int kt = 0;
-            if (full) {
-                f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
-                lds_cptr lq[IBL];
-#pragma unroll
-                for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
-                gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
-#pragma unroll 1
-                for (; kt < npos; ++kt) {
-                    gat_tile<IBL, JPL, RJ, false>(acc, lA, rA, lB, rB, lq, rq);
-#pragma unroll
-                    for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
-                    rq += 8;
-                }
-#pragma unroll 1
-                for (; kt < ntl; ++kt) {
-                    gat_tile<IBL, JPL, RJ, true>(acc, lA, rA, lB, rB, lq, rq);
-#pragma unroll
-                    for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
-                    rq += 8;
-                }
-            } else {
-                constexpr int IS = IBL - 1;             // the short block: the lane's last row belongs to the next wave
-                float (&accs)[IS][JPL] = reinterpret_cast<float (&)[IS][JPL]>(acc);
-                f32x2 lA[IS], rA[JPL], lB[IS], rB[JPL];
-                lds_cptr lq[IS];
-#pragma unroll
-                for (int ii = 0; ii < IS; ++ii) lq[ii] = lp[ii];
-                gat_load<IS, JPL, RJ>(lA, rA, lq, rq, 0);
-#pragma unroll 1
-                for (; kt < npos; ++kt) {
-                    gat_tile<IS, JPL, RJ, false>(accs, lA, rA, lB, rB, lq, rq);
-#pragma unroll
-                    for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
-                    rq += 8;
-                }
-#pragma unroll 1
-                for (; kt < ntl; ++kt) {
-                    gat_tile<IS, JPL, RJ, true>(accs, lA, rA, lB, rB, lq, rq);
-#pragma unroll
-                    for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
-                    rq += 8;
-                }
-            }
-        }
-        if (part + 1 < nparts) {
-            prefetch(part + 1);
-            __syncthreads();
-        }
-    }
-    float cv[IBL], dv[JPL];
-    {
-        const int col = PT & 31;
-#pragma unroll
-        for (int ii = 0; ii < IBL; ++ii) cv[ii] = lp[ii][col];
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * RJ * GAT_LLD + col];
-    }
-    __syncthreads();
-    if (!rows_owner) return;                           // no barrier below this point
-    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.out[0] = cv[0] + dv[0]; return; }
-
-    // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); S leaves the scores here
-    const float sinv = a.scale2[1];
-#pragma unroll
-    for (int ii = 0; ii < IBL; ++ii) {
-        const int irow = i0 + li + RI * ii;
-        const bool rowok = ii < iblw && irow < K;
-        const int irc = irow < K ? irow : K - 1;
-        float e[JPL];
-        float m = -INFINITY;
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) {
-            const int j = lj + RJ * jj;
-            const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
-            float v;
-            if (a.v1) {
-                v = (acc[ii][jj] + cv[ii] + dv[jj]) * sinv;
-                v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f) + b;
-            } else {
-                v = __builtin_fmaf(acc[ii][jj] + cv[ii] + dv[jj], sinv, b);
-            }
-            v = j < K ? v : -INFINITY;
-            e[jj] = v;
-            m = fmaxf(m, v);
-        }
-        m = row_max<RJ>(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) {
-            e[jj] = (lj + RJ * jj < K) ? gath_exp(e[jj] - m) : 0.f;
-            sum += e[jj];
-        }
-        sum = row_sum<RJ>(sum);
-        const float inv = soft_rcp(sum);
-#pragma unroll
-        for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = rowok ? e[jj] * inv : 0.f;
-    }
-
-    // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) as out^T = V^T att^T on v_mfma_f32_16x16x16_f16, three terms per product
-    // (k_gat); the softmax rows go through this wave's slice of the (now free) Ls / Rs region 64 keys at a time and are split per
-    // 16-key group, the node values come as packed fp16 pieces straight from LDS
-    static_assert(IBW == 16, "one 16-row MFMA group per wave");
-    constexpr int DTMAX = 8;                           // D <= 128 (plan)
-    constexpr int APP = 36;                            // pitch of the restaged rows: 32 keys per pass
-    float* __restrict__ att = Ls + wave * (IBW * APP);
-    const int DT = (D + 15) >> 4;
-    const int nr = lane & 15, kb = lane >> 4;
-    constexpr int JPP = 32 / RJ;                       // key registers per 32-key pass
-    constexpr int PASSES = (JPL + JPP - 1) / JPP;
-    f32x4 o[DTMAX];
-#pragma unroll
-    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    const int lo_off = (int)(Vl - Vh);
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        if (pass * 32 < K) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int ii = 0; ii < IBL; ++ii)
-#pragma unroll
-                for (int j4 = 0; j4 < JPP; ++j4)
-                    att[(li + RI * ii) * APP + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            const int jn = min(32, K - pass * 32);
-            const int ngrp = (jn + 15) >> 4;
-            for (int grp = 0; grp < ngrp; ++grp) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * APP + 16 * grp + 4 * kb);
-                unsigned h0, l0, h1, l1;
-                split_pair_h(bq[0], bq[1], h0, l0);
-                split_pair_h(bq[2], bq[3], h1, l1);
-                const f16x4 bhh = __builtin_bit_cast(f16x4, u32x2{h0, h1}), bll = __builtin_bit_cast(f16x4, u32x2{l0, l1});
-                // four keys of this lane (rows of the pieces; keys past K read the zero row), feature nr of tile dt
-                const int key0 = pass * 32 + 16 * grp + 4 * kb;
-                int ko[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) ko[t] = (key0 + t < K ? key0 + t : K) * pvh + nr;
-                unsigned r[DTMAX][4];
-#pragma unroll
-                for (int dt = 0; dt < DTMAX; ++dt)
-                    if (dt < DT) {
-                        const unsigned short* __restrict__ p = Vh + 16 * dt;
-                        r[dt][0] = (unsigned)p[ko[0]] | ((unsigned)p[ko[1]] << 16);
-                        r[dt][1] = (unsigned)p[ko[2]] | ((unsigned)p[ko[3]] << 16);
-                        r[dt][2] = (unsigned)p[lo_off + ko[0]] | ((unsigned)p[lo_off + ko[1]] << 16);
-                        r[dt][3] = (unsigned)p[lo_off + ko[2]] | ((unsigned)p[lo_off + ko[3]] << 16);
-                    }
-#pragma unroll
-                for (int dt = 0; dt < DTMAX; ++dt)
-                    if (dt < DT) {
-                        const f16x4 ahh = __builtin_bit_cast(f16x4, u32x2{r[dt][0], r[dt][1]}), all_ = __builtin_bit_cast(f16x4, u32x2{r[dt][2], r[dt][3]});
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahh, bll, o[dt], 0, 0, 0);
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(all_, bhh, o[dt], 0, 0, 0);
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(ahh, bhh, o[dt], 0, 0, 0);
-                    }
-            }
-        }
-    }
-    {
-        const int row = i0 + nr;
-        const bool rv = nr < RI * iblw && row < K;
-        float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
-#pragma unroll
-        for (int dt = 0; dt < DTMAX; ++dt)
-            if (dt < DT) {
-                const int d0 = 16 * dt + 4 * kb;
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[dt][r]);
-                if (a.so_d == 1 && rv && d0 + 3 < D) {
-                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-                    *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (rv && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
-                }
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // gat (wide): graph attention for node counts beyond the per-window fused kernel (128 < K <= 512, BASELINE
 // config 4: 512 features / 256 time steps).  The projected L', R' come from k_rowgemm through HBM (LC row-major
 // per query node, RT key-node-minor -- what k_attend consumed); everything after that is the fused kernel's
@@ -1242,29 +767,6 @@ int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_by
     bool launched = false;
     GAT_CASE(4, 1, 16) GAT_CASE(4, 2, 16) GAT_CASE(4, 3, 16) GAT_CASE(4, 4, 16) GAT_CASE(4, 5, 16) GAT_CASE(4, 6, 16) GAT_CASE(4, 7, 16) GAT_CASE(4, 8, 16)
     GAT_CASE(2, 1, 8) GAT_CASE(2, 3, 8) GAT_CASE(2, 5, 8) GAT_CASE(2, 7, 8)
-    if (!launched) return -2;
-    LAUNCH_CHECK();
-    return 0;
-}
-
-#define GATH_CASE(I, J, RJ)                                                                     \
-    if (IBL == I && JPL == J && rj == RJ) {                                                     \
-        if (lds_bytes > 64 * 1024) {                                                            \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gath<I, J, RJ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            if (e_ != hipSuccess) return (int)e_;                                               \
-        }                                                                                       \
-        hipLaunchKernelGGL((k_gath<I, J, RJ>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);                  \
-        launched = true;                                                                        \
-    }
-
-// the fp16-piece build of the fused layer (a.vld = piece pitch in halfs, a.lr_floats as for k_gat, a.Q = 16-feature chunks)
-int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
-    if (a.nwin <= 0) return 0;
-    if (rj * JPL < a.K || nw > 8 || a.ATT || a.n_full + a.n_short > nw || a.n_full * 16 + a.n_short * (16 - 64 / rj) < a.K) return -2;
-    const unsigned grid = (unsigned)a.nwin;
-    bool launched = false;
-    GATH_CASE(4, 1, 16) GATH_CASE(4, 2, 16) GATH_CASE(4, 3, 16) GATH_CASE(4, 4, 16) GATH_CASE(4, 5, 16) GATH_CASE(4, 6, 16) GATH_CASE(4, 7, 16) GATH_CASE(4, 8, 16)
-    GATH_CASE(2, 1, 8) GATH_CASE(2, 3, 8) GATH_CASE(2, 5, 8) GATH_CASE(2, 7, 8) GATH_CASE(2, 9, 8) GATH_CASE(2, 11, 8) GATH_CASE(2, 13, 8) GATH_CASE(2, 15, 8)
     if (!launched) return -2;
     LAUNCH_CHECK();
     return 0;

@@ -203,6 +203,7 @@ struct Model {
     int rowgemm_kernel = 0;          // data-gradient row GEMMs of mtadgat_backward in mode 2 (testing hook): 0 automatic (split-bf16 operands from 4096 rows), 1 fp32 MFMA, 2 split-bf16 always
     int conv_kernel = 0;             // convolution of the fused front end in mode 2 (testing hook): 0 automatic (k_conv_win from 4096 windows), 1 k_conv_lds, 2 k_conv_win at any batch size
     int gath_dbg = 0;                // measurement hook: GatArgs::dbg of k_gath (knock-out bits, profiles/gath_knockout.py)
+    int conv_fused = 0;              // the convolution inside the temporal layer's k_gath workgroup: 0 automatic (wherever both kernels apply), 1 off
     int gat_kernel = 0;              // fused attention layers in the split-operand arithmetic (testing hook): 0 automatic (k_gath, the fp16-piece build, from 4096 windows), 1 k_gat only, 3 k_gath at any batch size
     int gru_kernel = 0;              // large-batch recurrence: 0 automatic, 1 tile-major k_gru, 2 chunk-major k_gru_cm (testing hook: mtadgat_set_option)
     DevTables dt;
@@ -217,6 +218,7 @@ struct Workspace {
     bool has_xp;         // room for the pre-projected GRU input (batches the hidden-tile-split kernel serves)
     bool rec16;          // room for the decoder's pre-projected input and state sequence (k_gru16)
     size_t vmax;         // one word: bits of the largest convolution output of the chunk (range guard of the fp16 operand pieces)
+    size_t winflag;      // one byte per window: the fused convolution's per-window range flag (k_gath CONV build -> k_gat)
     size_t cf, el, er;   // convolution rows shared by stride-1 windows of a series (run_conv_shared): segment rows, edge rows
     size_t pj, pjt, pjb, band, eq, ek;   // shared temporal pair scores of stride-1 windows (run_tband): projections of the segment / edge rows, score band
 };

@@ -98,6 +98,24 @@ struct AttendArgs {
     float* ATT;          // optional (B, K, K) dump of the attention matrix
 };
 
+// the window convolution computed inside the temporal layer's k_gath workgroup (mtadgat_gath.hip, CONV build): what k_conv_win
+// takes (ConvArgs), for one window per workgroup
+struct GatConvIn {
+    const float* X;      // (B, W, F) windows, or -- gather -- the series (n_rows, F); bfloat16 elements when x_bf16
+    const long* starts;
+    long start0, stride;
+    int gather, x_bf16;
+    int taps, pad, Fq, NT;
+    int pvx;             // LDS pitch (halfs) of the staged input pieces: conv_win_pitch(F, Fq)
+    int Dp;              // row stride of h_cat
+    const f32x4* Wp;     // two fp16 pieces of S * W, [tile][taps Fq / 16][2][64]
+    const float* bias;   // NT * 32
+    const float* wscale; // [S, 1 / S]
+    float* HCAT;         // (B*W, Dp): columns [0, F) and the zero padding [3F, Dp) are written
+    unsigned* vmax;      // bits of the largest output written so far (atomic max; zeroed by the caller), or null
+    unsigned char* flag; // (B): 1 = the window's outputs reach 2^15 -- k_gat's bf16-piece build has to serve it; or null
+};
+
 // fused per-window graph-attention layer (projection + scores + softmax + aggregation in one workgroup)
 struct GatArgs {
     const float* V;      // vt == 0: (B*K, ldv) node rows; vt == 1: (B*D, ldv) rows whose columns are the nodes
@@ -128,6 +146,8 @@ struct GatArgs {
     int n_full, n_short; // k_gath: waves owning 16 query rows / 16 - 64 / RJ query rows (the rest of the workgroup only projects)
     int dbg;             // k_gath measurement hook (bit 0: no pair grid, 1: no projection, 2: return before the softmax); results invalid
     int skip_h;          // 1: return at once when *vmax < 2^15 -- k_gath (launched ahead of this kernel) serves that case
+    const unsigned char* winflag;   // k_gat behind a CONV launch of k_gath: serve exactly the windows whose flag is set
+    GatConvIn cv;        // k_gath, CONV build
 };
 
 // backward of one graph-attention layer, part 1 (per window): d e_ij (the gradient of the attention scores
@@ -334,7 +354,10 @@ int launch_conv_win(const ConvArgs& a, hipStream_t s);
 void attend_plan(int K, int* rows_per_blk, int* nblk, int* IB);
 int launch_attend(const AttendArgs& a, int IB, hipStream_t s);
 int launch_gat(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
-int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
+int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, bool conv, hipStream_t s);
+bool gath_conv_applies(const GatArgs& a, int nw, int F, int W);
+int conv_win_pitch(int F, int Fq);
+size_t conv_win_lds(int W, int F, int Fq, int taps);
 int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int Kp, int PT, int P8, const float* bias,
                     const float* V, int ldv, int D, int K, float* out, long so_w, long so_i, long so_d, long nwin, int v1,
                     float alpha, hipStream_t s);

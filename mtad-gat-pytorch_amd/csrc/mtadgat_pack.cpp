@@ -439,6 +439,7 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     ws.has_xp = m.gru[0].has_xproj && n <= 16384;          // 64 windows per CU x 256 CUs: above that k_gru streams x itself
     ws.xp = take((ws.has_xp || rec16) ? N * m.W * 3 * std::max(m.gru[0].Hp, m.rec[0].Hp) : 0);
     ws.vmax = take(64);
+    ws.winflag = take(both_fused ? (N + 3) / 4 + 16 : 0);
     // series path with stride-1 windows: the convolution of the segment (n + W - 1 rows) and of the windows' edge rows
     ws.cf = take(both_fused ? (N + m.W) * m.Fp : 0);
     ws.el = take(both_fused ? N * 2 * m.pad * m.Fp : 0);

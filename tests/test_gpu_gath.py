@@ -194,3 +194,91 @@ def test_window_convolution_at_any_input_scale(scale, gpu_device):
     assert torch.isfinite(p2).all() and torch.isfinite(r2).all()
     tol = 2e-6 if scale <= 1.0 else 5e-3 * max(1.0, r1.abs().max().item())     # (pre-activations of ~1e4 and more: see test_gpu_parity)
     assert (p2 - p1).abs().max().item() <= tol and (r2 - r1).abs().max().item() <= tol
+
+
+# ---- round 5: the window convolution inside the temporal layer's k_gath workgroup (csrc/mtadgat_gath.hip, CONV build) -------------
+def _fused(eng, on):
+    eng.set_option("conv_fused", 0 if on else 1)
+
+
+@pytest.mark.parametrize("name", ["msl", "smap", "smd_1_1", "syn_v2_embed", "syn_v1_small"])
+def test_convolution_inside_the_temporal_workgroup(name, gpu_device):
+    """ConvLayer.forward (modules.py:18-22) computed by the workgroup that runs TemporalAttentionLayer.forward (modules.py:166-193)
+    on the same window -- forced at fixture size (conv_kernel = 2, gat_kernel = 3).  Gated against the reference's outputs; and
+    it is k_conv_win's arithmetic instruction for instruction, so the forward must equal the two-launch path bit for bit."""
+    case = Case(name)
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    x = case.x.to(gpu_device)
+    with torch.no_grad():
+        eng.set_option("conv_kernel", 2)
+        eng.set_option("gat_kernel", 3)
+        _fused(eng, True)
+        p2, r2 = model(x)
+        h2 = eng.forward(x, want_hend=True)[2]
+        _fused(eng, False)
+        p1, r1 = model(x)
+        h1 = eng.forward(x, want_hend=True)[2]
+        _fused(eng, True)
+        eng.set_option("conv_kernel", 0)
+        eng.set_option("gat_kernel", 0)
+    gate(p2, case.preds, case.preds64, what=f"{name} predictions (fused convolution)")
+    gate(r2, case.recons, case.recons64, what=f"{name} recons (fused convolution)")
+    assert torch.equal(p2, p1) and torch.equal(r2, r1) and torch.equal(h2, h1)
+
+
+@pytest.mark.parametrize("kw", SHAPES + SHAPES_H, ids=lambda k: f"F{k['n_features']}W{k['window_size']}")
+def test_fused_convolution_shapes_against_the_oracle(kw, gpu_device):
+    from mtad_gat import MTAD_GAT
+    torch.manual_seed(31)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+    x = torch.rand(21, kw["window_size"], kw["n_features"])
+    with torch.no_grad():
+        p_ref, r_ref = oracle.forward(x, model.state_dict(), alpha=kw.get("alpha", 0.2))
+        m = model.to(gpu_device)
+        eng = _engine(m, gpu_device)
+        eng.set_option("conv_kernel", 2)
+        eng.set_option("gat_kernel", 3)
+        p, r = m(x.to(gpu_device))
+        _fused(eng, False)
+        p1, r1 = m(x.to(gpu_device))
+        _fused(eng, True)
+    gate(p, p_ref, what="preds (fused convolution)")
+    gate(r, r_ref, what="recons (fused convolution)")
+    assert torch.equal(p, p1) and torch.equal(r, r1)       # (shapes the fused form does not take run the two launches both times)
+
+
+def test_fused_convolution_range_guard_is_per_window(gpu_device):
+    """Windows whose convolution outputs reach 2^15 do not fit the fp16 pieces: the workgroup flags its window and k_gat's
+    bf16-piece build, enqueued behind, serves exactly the flagged ones -- mixed in one batch with ordinary windows."""
+    case = Case("msl")
+    model = case.build_model().to(gpu_device)
+    eng = _engine(model, gpu_device)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(96, 100, 55, generator=g)
+    x[::5] *= 3e4                                          # every fifth window un-normalised
+    x[7] *= 1e-4
+    x = x.to(gpu_device)
+    with torch.no_grad():
+        eng.set_option("conv_kernel", 2)
+        eng.set_option("gat_kernel", 3)
+        p2, r2 = model(x)
+        small = model(x[1:2].contiguous())                 # an ordinary window on its own: the fp16-piece path
+        eng.set_option("gat_kernel", 1)
+        _fused(eng, False)
+        p1, r1 = model(x)                                  # fp32 k_gat for every window
+        _fused(eng, True)
+        eng.set_option("conv_kernel", 0)
+        eng.set_option("gat_kernel", 0)
+    assert torch.isfinite(p2).all() and torch.isfinite(r2).all()
+    # an ordinary window's temporal layer does not see its neighbours (the feature layer and the recurrences still follow the
+    # batch-wide recorded maximum: three bf16 pieces in the mixed batch, two fp16 pieces alone -- both within 2e-6)
+    assert (p2[1:2] - small[0]).abs().max().item() <= 2e-6 and (r2[1:2] - small[1]).abs().max().item() <= 2e-6
+    tol = 5e-3 * max(1.0, r1.abs().max().item())          # (pre-activations of ~1e4 and more in the scaled windows: see test_gpu_parity)
+    ordinary = torch.ones(96, dtype=torch.bool)
+    ordinary[::5] = False
+    assert (p2[ordinary] - p1[ordinary]).abs().max().item() <= 2e-6 and (r2[ordinary] - r1[ordinary]).abs().max().item() <= 2e-6
+    assert (p2 - p1).abs().max().item() <= tol and (r2 - r1).abs().max().item() <= tol
