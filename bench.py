@@ -371,6 +371,23 @@ def sub_records(model, kw, dev, args_precision="fp32"):
             "roofline": roof4,
             "what": "BASELINE config 4: F=512, W=256, out_dim=512, H=150, 8192 windows per call (processed in chunks of chunk_windows), "
                     "fp32, random-init weights"}
+        # ... and its training step (forward + RMSE losses + HIP backward + Adam) on the wide attention kernels (round 5)
+        try:
+            m4.train()
+            opt4 = torch.optim.Adam(m4.parameters(), lr=1e-4)
+            xt4, yt4 = x4[:256].contiguous(), torch.rand(256, 512, device=dev)
+
+            def step4():
+                opt4.zero_grad()
+                p_, r_ = m4(xt4)
+                (torch.sqrt(F.mse_loss(yt4, p_)) + torch.sqrt(F.mse_loss(xt4, r_))).backward()
+                opt4.step()
+
+            tt4 = _timed(step4, dev, 2, warm=1)
+            out["config4_f512_w256"]["train_step_b256"] = {"ms": round(1e3 * tt4, 2), "windows_per_s": round(256 / tt4, 1),
+                                                           "grad_path": getattr(m4, "grad_path", None)}
+        except Exception as e:
+            out["config4_f512_w256"]["train_step_b256"] = {"error": repr(e)}
         del m4, x4
     except Exception as e:
         out["config4_f512_w256"] = {"error": repr(e)}

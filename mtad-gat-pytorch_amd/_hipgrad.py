@@ -19,6 +19,19 @@ import _torchpath
 TRAIN_CHUNK = 8192
 
 
+def _chunk_windows(eng, device):
+    """Windows per chunk of the training step: TRAIN_CHUNK, fewer when tape + backward workspace of that many windows would not
+    fit a third of the device memory (wide models: ~20 MB per window at F = 512, W = 256)."""
+    cap = getattr(eng, "_train_chunk_cap", None)
+    if cap is None:
+        probe = 64
+        per = (eng.lib.mtadgat_tape_bytes(eng.handle, probe) + eng.lib.mtadgat_backward_workspace_bytes(eng.handle, probe)) / probe
+        total = torch.cuda.get_device_properties(device).total_memory
+        cap = max(32, int((total / 3) // max(per, 1.0)) // 32 * 32)
+        eng._train_chunk_cap = cap
+    return max(1, min(TRAIN_CHUNK, cap))
+
+
 def param_order(model):
     """The model's parameters in the field order of mtadgat_params / mtadgat_grad_offsets."""
     names = ["conv.conv.weight", "conv.conv.bias"]
@@ -39,7 +52,8 @@ class _HipStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, x, p, seed, w0, *params):
         b = x.shape[0]
-        chunks = [(lo, min(lo + TRAIN_CHUNK, b)) for lo in range(0, b, TRAIN_CHUNK)] or [(0, 0)]
+        cw = _chunk_windows(eng, x.device)
+        chunks = [(lo, min(lo + cw, b)) for lo in range(0, b, cw)] or [(0, 0)]
         tape = None
         if len(chunks) == 1:
             preds, recons, tape = eng.forward_train(x, p, seed, w0)

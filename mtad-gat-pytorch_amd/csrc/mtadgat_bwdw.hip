@@ -1,0 +1,329 @@
+// Backward of a WIDE graph-attention layer (more than 128 nodes or node dimensions: the fused per-window kernels of
+// mtadgat_bwd.hip keep a whole window in LDS and stop there).  Reference: FeatureAttentionLayer.forward modules.py:65-95,
+// TemporalAttentionLayer.forward modules.py:166-193 under loss.backward(), training.py:126 -- the reference trains any shape.
+//
+// Same outputs as k_gat_bwd_att + k_gat_bwd_pair, so everything downstream is shared (mtadgat_capi.cpp: the data-gradient row
+// GEMM d V += [dL | dR] [W_l ; W_r], the weight-gradient GEMM, the batch sums of d e and d a):
+//     DE  (B, K, K)        d e_ij, the gradient of the attention scores (= of the layer's bias before the sum over windows)
+//     DV  (B*K, lddv)      the aggregation path's d V
+//     DLR (B*K, 2 Ep)      [d L | d R], the gradients of the un-scaled projections L = V W_l^T + b, R = V W_r^T
+//     DAp (B, Ep)          per-window partial sums of d a
+// but every matrix goes through HBM and the kernels are generic in K and D (<= 512), not tuned per shape:
+//     k_bw_ds        d S = d H . H (1 - H)                                      (h = sigmoid(S), modules.py:93 / :191)
+//     k_bgemm        d V = att'^T d S   (att' = dropout(att), applied while the operand is staged)        per window
+//     k_bgemm        d att' = d S V^T                                                                     per window
+//     k_bw_softmax   d e = att . (d att - sum_j att d att), d att = mask . d att'                         in place, a wave per row
+//     k_rowgemm      [L | R] = V [W_l ; W_r]^T + [b | 0]      (mtadgat_kernels.hip, the un-scaled pack of the backward plan)
+//     k_bw_pair      GATv2 scores e_ij = sum_k a_k LeakyReLU(L_ik + R_jk) (modules.py:74-77 / :174-177):
+//                        d z_ijk = d e_ij a_k [u > 0 ? 1 : alpha],  d L_ik = sum_j d z,  d R_jk = sum_i d z,
+//                        d a_k = sum_ij d e_ij LeakyReLU(u)
+//                    in two passes over a 32-column block of the embedding (the second on the transposed d e), no atomics.
+// GAT (v1) layers of this size have no HIP backward (their score backward keeps V [K][D] in LDS).
+#include "mtadgat_device.h"
+
+namespace mtadgat {
+
+namespace {
+
+// ---- d S[(win K + i) ldS + d] = d H . H . (1 - H),  H / d H at [win so_w + i so_i + d so_d]
+__global__ __launch_bounds__(256) void k_bw_ds(const float* __restrict__ H, const float* __restrict__ dH, long so_w, long so_i, long so_d,
+                                               long nwin, int K, int D, float* __restrict__ dS, int ldS) {
+    const long n = nwin * K * (long)D;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const long win = idx / ((long)K * D);
+        const int rem = (int)(idx - win * (long)K * D);
+        int i, d;
+        if (so_d == 1) { i = rem / D; d = rem - i * D; }      // the fastest thread index follows the unit stride of H
+        else { d = rem / K; i = rem - d * K; }
+        const long o = win * so_w + i * so_i + d * so_d;
+        const float h = H[o];
+        dS[(win * K + i) * (long)ldS + d] = dH[o] * h * (1.f - h);
+    }
+}
+
+// ---- batched GEMM on the fp32 matrix unit: C_b (M x N) = A_b (M x Kc) B_b (Kc x N), arbitrary element strides for A and B
+//   A_b(m, k) = A[b sAb + m sAm + k sAk]   (optionally times the dropout keep factor of attention element (k, m): A = att^T)
+//   B_b(k, n) = B[b sBb + k sBk + n sBn]
+//   C_b(m, n) = C[b sCb + m ldc + n]
+// One workgroup = a 64 x 64 block of C for one b; wave (wm, wn) owns a 32 x 32 quadrant on v_mfma_f32_32x32x2_f32; the
+// operands go through LDS 16 columns of the contraction at a time (clamped unconditional loads, zero where out of range).
+struct BGemmArgs {
+    const float* A; long sAb, sAm, sAk;
+    const float* B; long sBb, sBk, sBn;
+    float* C; long sCb, ldc;
+    int M, N, Kc;
+    long nb;
+    int adrop;                 // 1: A_b(m, k) *= keep(k * dropK + m) ? keep_scale : 0
+    int dropK;
+    DropArgs drop;
+    unsigned drop_stream;
+};
+
+__global__ __launch_bounds__(256) void k_bgemm(const BGemmArgs a) {
+    constexpr int KS = 16, AP = KS + 1, BP = 64 + 1;
+    __shared__ float As[64 * AP];
+    __shared__ float Bs[KS * BP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, g = lane >> 5;
+    const int mt = (a.M + 63) >> 6, nt = (a.N + 63) >> 6;
+    const long blk = blockIdx.x;
+    const long b = blk / (mt * nt);
+    const int t2 = (int)(blk - b * (mt * nt));
+    const int m0 = (t2 / nt) * 64, n0 = (t2 % nt) * 64;
+    const float* __restrict__ Ab = a.A + b * a.sAb;
+    const float* __restrict__ Bb = a.B + b * a.sBb;
+    unsigned key = 0;
+    if (a.adrop) key = drop_window_key(a.drop, a.drop_stream, b);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // staging maps: the thread index runs along whichever operand index has the smaller stride (coalesced either way)
+    const bool a_k_fast = a.sAk <= a.sAm, b_n_fast = a.sBn <= a.sBk;
+    for (int k0 = 0; k0 < a.Kc; k0 += KS) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int u = tid + n * 256;                   // 1024 elements of each tile
+            const int am = a_k_fast ? u / KS : u % 64, ak = a_k_fast ? u % KS : u / 64;
+            const int gm = m0 + am, gk = k0 + ak;
+            const int cm = gm < a.M ? gm : a.M - 1, ck = gk < a.Kc ? gk : a.Kc - 1;
+            float v = Ab[cm * a.sAm + ck * a.sAk];
+            if (a.adrop && a.drop.thresh) v *= drop_keep(key, (unsigned)(ck * a.dropK + cm), a.drop.thresh) ? a.drop.keep_scale : 0.f;
+            av[n] = (gm < a.M && gk < a.Kc) ? v : 0.f;
+            const int bk = b_n_fast ? u / 64 : u % KS, bn = b_n_fast ? u % 64 : u / KS;
+            const int hk = k0 + bk, hn = n0 + bn;
+            const int dk = hk < a.Kc ? hk : a.Kc - 1, dn = hn < a.N ? hn : a.N - 1;
+            const float w = Bb[dk * a.sBk + dn * a.sBn];
+            bv[n] = (hk < a.Kc && hn < a.N) ? w : 0.f;
+        }
+        __syncthreads();                                   // the previous tiles are consumed
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int u = tid + n * 256;
+            const int am = a_k_fast ? u / KS : u % 64, ak = a_k_fast ? u % KS : u / 64;
+            As[am * AP + ak] = av[n];
+            const int bk = b_n_fast ? u / 64 : u % KS, bn = b_n_fast ? u % 64 : u / KS;
+            Bs[bk * BP + bn] = bv[n];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KS; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[(wm * 32 + i) * AP + kk + g], Bs[(kk + g) * BP + wn * 32 + i], acc, 0, 0, 0);
+    }
+    // accumulator register 4 q + s of lane (i, g) = C[row 8 q + 4 g + s][column i] of the quadrant
+    float* __restrict__ Cb = a.C + b * a.sCb;
+    const int col = n0 + wn * 32 + i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int row = m0 + wm * 32 + 8 * q + 4 * g + s4;
+            if (row < a.M && col < a.N) Cb[row * a.ldc + col] = acc[4 * q + s4];
+        }
+}
+
+// ---- softmax backward, in place: DE holds d att' (the gradient of the dropped attention matrix) on entry, d e on exit.
+// One wave per row (K <= 512: eight elements per lane).
+__global__ __launch_bounds__(256) void k_bw_softmax(const float* __restrict__ ATT, float* __restrict__ DE, long nwin, int K, DropArgs drop,
+                                                    unsigned drop_stream) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nwin * K) return;
+    const long win = row / K;
+    const int i = (int)(row - win * K);
+    const unsigned key = drop_window_key(drop, drop_stream, win);
+    const float* __restrict__ ap = ATT + row * K;
+    float* __restrict__ dp = DE + row * K;
+    float av[8], dv[8];
+    float csum = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int j = lane + 64 * n;
+        const int jc = j < K ? j : K - 1;
+        float sc = 1.f;
+        if (drop.thresh) sc = drop_keep(key, (unsigned)(i * K + jc), drop.thresh) ? drop.keep_scale : 0.f;
+        av[n] = j < K ? ap[jc] : 0.f;
+        dv[n] = j < K ? dp[jc] * sc : 0.f;
+        csum += av[n] * dv[n];
+    }
+    csum = wave_sum(csum);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int j = lane + 64 * n;
+        if (j < K) dp[j] = av[n] * (dv[n] - csum);
+    }
+}
+
+// ---- (B, K, K) -> transposed per window, 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void k_bw_transpose(const float* __restrict__ src, float* __restrict__ dst, long nwin, int K) {
+    __shared__ float tile[32][33];
+    const int tk = (K + 31) >> 5;
+    const long blk = blockIdx.x;
+    const long win = blk / (tk * tk);
+    const int t2 = (int)(blk - win * (tk * tk));
+    const int r0 = (t2 / tk) * 32, c0 = (t2 % tk) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 8 rows per pass
+    const float* __restrict__ s = src + win * (long)K * K;
+    float* __restrict__ d = dst + win * (long)K * K;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + ty + 8 * p, c = c0 + tx;
+        tile[ty + 8 * p][tx] = (r < K && c < K) ? s[(long)r * K + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = c0 + ty + 8 * p, c = r0 + tx;
+        if (r < K && c < K) d[(long)r * K + c] = tile[tx][ty + 8 * p];
+    }
+}
+
+// ---- GATv2 score backward for one window and one 32-column block of the embedding.
+// 256 threads: thread (k = tid & 31, q = tid >> 5) owns column k of the block and the rows i = q, q + 8, ... (pass 1: d L, d a)
+// resp. the keys j = q, q + 8, ... (pass 2: d R).  LDS: Ls [K][32] | Rs [K][32] | des [8][K] (the d e row / column a thread
+// group is working on: written and read by the same 32 lanes, i.e. within one wave).
+struct BwPairArgs {
+    const float* LR;     // (B*K, ldlr): [L (Ep) | R (Ep)]
+    int ldlr, Ep;
+    const float* avec;   // (Ep) a, zero padded
+    const float* DE;     // (B, K, K)
+    const float* DEt;    // (B, K, K) transposed per window
+    int K;
+    float alpha;
+    float* DLR;          // (B*K, ldlr): [d L | d R]
+    float* DAp;          // (B, Ep)
+    long nwin;
+};
+
+__global__ __launch_bounds__(256) void k_bw_pair(const BwPairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int K = a.K, nkb = a.Ep >> 5;
+    const long win = blockIdx.x / nkb;
+    const int kb = (int)(blockIdx.x - win * nkb);
+    const int tid = threadIdx.x, k = tid & 31, q = tid >> 5;
+    float* __restrict__ Ls = sm;
+    float* __restrict__ Rs = Ls + K * 32;
+    float* __restrict__ des = Rs + K * 32 + q * K;
+    float* __restrict__ red = Rs + K * 32 + 8 * K;               // [8][32]
+    const float* __restrict__ lr = a.LR + (win * K) * (long)a.ldlr + 32 * kb;
+    for (int u = tid; u < K * 32; u += 256) {
+        const int r = u >> 5, c = u & 31;
+        Ls[u] = lr[(long)r * a.ldlr + c];
+        Rs[u] = lr[(long)r * a.ldlr + a.Ep + c];
+    }
+    __syncthreads();
+    const float ak = a.avec[32 * kb + k];
+    const float alpha = a.alpha;
+    float* __restrict__ dlr = a.DLR + (win * K) * (long)a.ldlr + 32 * kb;
+    float da = 0.f;
+    // pass 1: rows i of this thread group; d L_ik and the group's share of d a_k
+    const float* __restrict__ de = a.DE + win * (long)K * K;
+    for (int i = q; i < K; i += 8) {
+        __builtin_amdgcn_wave_barrier();
+        for (int j = k; j < K; j += 32) des[j] = de[(long)i * K + j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float l = Ls[i * 32 + k];
+        float dl = 0.f;
+        for (int j = 0; j < K; ++j) {
+            const float gq = des[j];
+            const float u = l + Rs[j * 32 + k];
+            const float sl = u > 0.f ? 1.f : alpha;
+            dl = __builtin_fmaf(gq * sl, ak, dl);
+            da = __builtin_fmaf(gq * sl, u, da);
+        }
+        dlr[(long)i * a.ldlr + k] = dl;
+    }
+    // pass 2: keys j of this thread group; d R_jk
+    const float* __restrict__ det = a.DEt + win * (long)K * K;
+    for (int j = q; j < K; j += 8) {
+        __builtin_amdgcn_wave_barrier();
+        for (int i = k; i < K; i += 32) des[i] = det[(long)j * K + i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float r = Rs[j * 32 + k];
+        float dr = 0.f;
+        for (int i = 0; i < K; ++i) {
+            const float u = Ls[i * 32 + k] + r;
+            dr = __builtin_fmaf(des[i] * (u > 0.f ? 1.f : alpha), ak, dr);
+        }
+        dlr[(long)j * a.ldlr + a.Ep + k] = dr;
+    }
+    red[q * 32 + k] = da;
+    __syncthreads();
+    if (tid < 32) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 8; ++g2) sacc += red[g2 * 32 + tid];
+        a.DAp[win * a.Ep + 32 * kb + tid] = sacc;
+    }
+}
+
+}  // namespace
+
+int launch_bw_ds(const float* H, const float* dH, long so_w, long so_i, long so_d, long nwin, int K, int D, float* dS, int ldS, hipStream_t s) {
+    if (nwin <= 0) return 0;
+    const long n = nwin * K * (long)D;
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_bw_ds, dim3((unsigned)(blocks > 65535 * 8 ? 65535 * 8 : blocks)), dim3(256), 0, s, H, dH, so_w, so_i, so_d, nwin, K, D, dS, ldS);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// C_b = A_b B_b for b < nb (strides in elements; see BGemmArgs); adrop: the A operand is an attention matrix read transposed,
+// A_b(m, k) = att_b[k][m], and gets the dropout keep factor of element (k, m) of window b
+int launch_bgemm(const float* A, long sAb, long sAm, long sAk, const float* B, long sBb, long sBk, long sBn, float* C, long sCb, long ldc,
+                 int M, int N, int Kc, long nb, const DropArgs* drop, unsigned drop_stream, int dropK, hipStream_t s) {
+    if (nb <= 0 || M <= 0 || N <= 0) return 0;
+    BGemmArgs a{};
+    a.A = A; a.sAb = sAb; a.sAm = sAm; a.sAk = sAk; a.B = B; a.sBb = sBb; a.sBk = sBk; a.sBn = sBn; a.C = C; a.sCb = sCb; a.ldc = ldc;
+    a.M = M; a.N = N; a.Kc = Kc; a.nb = nb;
+    if (drop) { a.adrop = 1; a.drop = *drop; a.drop_stream = drop_stream; a.dropK = dropK; }
+    const long blocks = nb * ((M + 63) / 64) * ((N + 63) / 64);
+    if (blocks > 0x7fffffffL) return -2;
+    hipLaunchKernelGGL(k_bgemm, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bw_softmax(const float* ATT, float* DE, long nwin, int K, const DropArgs& drop, unsigned drop_stream, hipStream_t s) {
+    if (nwin <= 0) return 0;
+    if (K > 512) return -2;
+    const long rows = nwin * K;
+    hipLaunchKernelGGL(k_bw_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ATT, DE, nwin, K, drop, drop_stream);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bw_transpose(const float* src, float* dst, long nwin, int K, hipStream_t s) {
+    if (nwin <= 0) return 0;
+    const long tk = (K + 31) / 32;
+    hipLaunchKernelGGL(k_bw_transpose, dim3((unsigned)(nwin * tk * tk)), dim3(256), 0, s, src, dst, nwin, K);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+size_t bw_pair_lds(int K) { return ((size_t)2 * K * 32 + (size_t)8 * K + 8 * 32) * sizeof(float); }
+
+int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const float* DE, const float* DEt, int K, float alpha, float* DLR,
+                   float* DAp, long nwin, hipStream_t s) {
+    if (nwin <= 0) return 0;
+    const size_t lds = bw_pair_lds(K);
+    if ((Ep & 31) != 0 || K > 512 || lds > 160 * 1024) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_pair), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e_ != hipSuccess) return (int)e_;
+        attr_set = true;
+    }
+    BwPairArgs a{};
+    a.LR = LR; a.ldlr = ldlr; a.Ep = Ep; a.avec = avec; a.DE = DE; a.DEt = DEt; a.K = K; a.alpha = alpha; a.DLR = DLR; a.DAp = DAp; a.nwin = nwin;
+    const long blocks = nwin * (Ep / 32);
+    if (blocks > 0x7fffffffL) return -2;
+    hipLaunchKernelGGL(k_bw_pair, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace mtadgat

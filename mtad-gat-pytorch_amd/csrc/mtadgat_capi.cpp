@@ -229,15 +229,16 @@ int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nro
 }
 
 int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, const float* v, int ldv, int64_t n, float* out,
-               long so_w, long so_i, long so_d, hipStream_t s) {
+               long so_w, long so_i, long so_d, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0) {
     Scope sc(m, S_ATTEND, s);
     if (g.K <= 512 && g.D <= 512) {
         // LDS-tiled pair grid of the fused kernel over the HBM-resident projections (BASELINE config 4 shapes)
         K_TRY(launch_gat_wide(lc, rt, g.ldl, g.rt_rows, g.Kp, g.PT, g.P8, m.packed_dev + g.bias_off, v, ldv, g.D, g.K, out, so_w,
-                              so_i, so_d, n, m.cfg.use_gatv2 ? 0 : 1, m.cfg.alpha, s),
+                              so_i, so_d, n, m.cfg.use_gatv2 ? 0 : 1, m.cfg.alpha, s, att, drop, drop_stream),
               "wide gat attention");
         return 0;
     }
+    if (att || drop) return fail(MTADGAT_ERR_UNSUPPORTED, "training forward of an attention layer with more than 512 nodes / features");
     AttendArgs a{};
     a.LC = lc; a.RT = rt; a.ldl = g.ldl; a.rt_rows = g.rt_rows; a.Kp = g.Kp; a.PT = g.PT; a.P8 = g.P8;
     a.bias = m.packed_dev + g.bias_off;
@@ -1562,8 +1563,21 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     src.x = x;
     unsigned* vmax = reinterpret_cast<unsigned*>(T + t.vmax);
     if ((rc = run_conv(m, src, 0, n, nullptr, T + t.xct, hcat, nullptr, s, vmax))) return rc;
-    if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
-    if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
+    // the two attention layers: fused per-window kernels, or -- wide layers -- projection through memory + k_gat_wide; either way
+    // the softmax rows are kept and the dropout of modules.py:90 / :189 is applied inside the kernel
+    if (use_fused(m.temp)) {
+        if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
+    } else {
+        if ((rc = run_proj(m, m.temp, hcat, m.Dp, n * W, T + t.lct, T + t.rtt, s))) return rc;
+        if ((rc = run_attend(m, m.temp, T + t.lct, T + t.rtt, hcat, m.Dp, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
+    }
+    if (use_fused(m.feat)) {
+        if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
+    } else {
+        const float* xct = T + t.xct;
+        if ((rc = run_proj(m, m.feat, xct, m.Wp, n * F, T + t.lcf, T + t.rtf, s))) return rc;
+        if ((rc = run_attend(m, m.feat, T + t.lcf, T + t.rtf, xct, m.Wp, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
+    }
     // GRU stack (modules.py:235-238): every layer keeps its gates and states; between stacked layers nn.GRU's dropout
     // (training only; reference modules.py:232-233): the dropped sequence is what the next layer reads and is kept as well
     const int Lg = (int)m.gru.size(), Ld = (int)m.rec.size();
@@ -1791,6 +1805,46 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         float* dap = ws + (which == 0 ? w.dap_f : w.dap_t);
         const int lddv = which == 0 ? m.Wp : m.Fp;
         const int colofs = which == 0 ? F : 2 * F;
+        if (gb.wide) {
+            // wide layer (mtadgat_bwdw.hip): every matrix through memory, generic in K and D
+            const long so_w = (long)W * m.Dp, so_i = which == 0 ? 1 : m.Dp, so_d = which == 0 ? m.Dp : 1;
+            const float* att = T + (which == 0 ? t.att_f : t.att_t);
+            const unsigned dstream = which == 0 ? DROP_FEAT : DROP_TEMP;
+            const float* Vn = which == 0 ? T + t.xct : hcat;          // node rows: xc^T rows (feature layer) / h_cat rows (temporal layer)
+            const long ldv = which == 0 ? m.Wp : m.Dp;
+            const int D = gp.D, ldS = round_up(D, 4), Ep = gb.Ep;
+            float* dS = ws + w.wds;
+            float* LR = ws + w.wlr;
+            float* det = ws + w.wdet;
+            K_TRY(launch_bw_ds(hcat + colofs, dhcat + colofs, so_w, so_i, so_d, n, K, D, dS, ldS, s), "attention backward (d S)");
+            // d V (aggregation path) = att'^T d S, att' = dropout(att)
+            K_TRY(launch_bgemm(att, (long)K * K, 1, K, dS, (long)K * ldS, ldS, 1, dv, (long)K * lddv, lddv, K, D, K, n, &drop, dstream, K, s),
+                  "attention backward (aggregation d V)");
+            // d att' = d S V^T, then the softmax backward in place -> d e
+            K_TRY(launch_bgemm(dS, (long)K * ldS, ldS, 1, Vn, (long)K * ldv, 1, ldv, de, (long)K * K, K, K, K, D, n, nullptr, 0, 0, s),
+                  "attention backward (d att)");
+            K_TRY(launch_bw_softmax(att, de, n, K, drop, dstream, s), "attention backward (softmax)");
+            K_TRY(launch_bw_transpose(de, det, n, K, s), "attention backward (d e transposed)");
+            // un-scaled projections [L | R] of the node rows, then the score backward
+            {
+                RowGemmArgs r{};
+                r.X = Vn; r.ldx = ldv; r.Kvalid = D; r.Q = gp.Q;
+                r.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + gb.wu_off);
+                r.bias = m.packed_dev + gb.bu_off;
+                r.Y = LR; r.ldy = 2L * Ep; r.Nvalid = 2 * Ep; r.vec_store = 1;
+                r.R = (long)n * K; r.NT = 2 * gb.NTu; r.NT_rm = 2 * gb.NTu; r.group = 1; r.relu = 0;
+                K_TRY(launch_rowgemm(r, s), "attention backward (projection)");
+            }
+            K_TRY(launch_bw_pair(LR, 2 * Ep, Ep, m.packed_dev + gb.a_off, de, det, K, m.cfg.alpha, dlr, dap, n, s), "attention backward (pairs)");
+            const long RK = (long)n * K;
+            if ((rc = run_rowgemm_T(m, gb.lrT, dlr, 2L * Ep, RK, dv, lddv, gp.D, true, nullptr, 0, 1.f, s))) return rc;
+            WgradIn in;
+            in.A = dlr; in.lda = 2L * Ep; in.R = RK; in.T = 1; in.B = Vn; in.ldb = ldv;
+            if ((rc = run_wgrad(m, gb.wg, in, wpart, grads + gl.lin_w[which], grads + gl.lin_b[which], s))) return rc;
+            K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
+            K_TRY(launch_sum_rows(dap, Ep, n, gp.E, ws + w.sums, grads + gl.a[which], s), "attention vector gradient");
+            continue;
+        }
         GatBwdAttArgs aa{};
         aa.V = hcat; aa.ldv = m.Dp; aa.D = gp.D; aa.K = K; aa.vt = which == 0 ? 1 : 0; aa.vld = gp.f_vld;
         aa.H = hcat + colofs; aa.dH = dhcat + colofs;

@@ -471,6 +471,11 @@ struct GatWideArgs {
     int nblk;            // row blocks per window
     int v1;
     float alpha;
+    // training mode (as GatArgs): the softmax rows (before dropout) are kept for the backward, dropout (modules.py:90 / :189) is
+    // applied to the attention matrix inside the kernel
+    float* ATT;          // (B, K, K) or null
+    DropArgs drop;
+    unsigned drop_stream;
 };
 
 // KP = 4 (385..512 keys) keeps 128 score registers per lane: those workgroups have 4 waves (one per SIMD, 512 VGPRs)
@@ -634,6 +639,23 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
 #pragma unroll
             for (int jj = 0; jj < JPL; ++jj) acc[kp][ii][jj] = irow < K ? acc[kp][ii][jj] * inv : 0.f;
     }
+    if (a.ATT || a.drop.thresh) {                          // training: keep the softmax rows, drop attention entries (counter-based mask)
+        const unsigned key = drop_window_key(a.drop, a.drop_stream, win);
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            const int irow = i0 + li + RI * ii;
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+                for (int jj = 0; jj < JPL; ++jj) {
+                    const int j = kp * 128 + lj + RJ * jj;
+                    if (irow < K && j < K) {
+                        if (a.ATT) a.ATT[(win * K + irow) * (long)K + j] = acc[kp][ii][jj];
+                        if (a.drop.thresh) acc[kp][ii][jj] *= drop_keep(key, (unsigned)(irow * K + j), a.drop.thresh) ? a.drop.keep_scale : 0.f;
+                    }
+                }
+        }
+    }
     // ---- aggregation h_i = sigmoid(sum_j att_ij V_j): out^T = V^T att^T on v_mfma_f32_16x16x4_f32 (as k_gat); the
     // softmax rows go through this wave's LDS slice 64 keys at a time, V through a shared LDS tile 32 keys at a time
     float* __restrict__ att = smem + wave * (IBW * GAT_APITCH);
@@ -714,7 +736,7 @@ size_t gat_wide_lds(int K, int D, int nw) {
 
 int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int Kp, int PT, int P8, const float* bias,
                     const float* V, int ldv, int D, int K, float* out, long so_w, long so_i, long so_d, long nwin, int v1,
-                    float alpha, hipStream_t s) {
+                    float alpha, hipStream_t s, float* att, const DropArgs* drop, unsigned drop_stream) {
     if (nwin <= 0) return 0;
     if (K > 512 || D > 512) return -2;
     const int KP = (K + 127) / 128;
@@ -724,6 +746,8 @@ int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int 
     a.V = V; a.ldv = ldv; a.D = D; a.K = K; a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d; a.nwin = nwin;
     a.nblk = (K + nw * 16 - 1) / (nw * 16);
     a.v1 = v1; a.alpha = alpha;
+    a.ATT = att; a.drop_stream = drop_stream;
+    if (drop) a.drop = *drop;
     const size_t lds = gat_wide_lds(K, D, nw);
     if (lds > 160 * 1024) return -2;
     const unsigned grid = (unsigned)(((nwin + 7) / 8 * 8) * a.nblk);

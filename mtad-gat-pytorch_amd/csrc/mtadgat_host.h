@@ -107,6 +107,10 @@ struct GatBwdPlan {
     LinTPlan lrT;                   // d V += [dL | dR] [W_l ; W_r]
     WgradPlan wg;                   // lin.weight / lin.bias
     size_t att_lds = 0, pair_lds = 0;
+    // wide layer (not fused: more than 128 nodes or node dimensions): the generic backward of mtadgat_bwdw.hip -- the un-scaled
+    // projection [L | R] = V [W_l ; W_r]^T + [b | 0] is a row GEMM over the pack at wu_off with the bias vector at bu_off (2 Ep)
+    bool wide = false;
+    size_t bu_off = 0;
     // GAT (v1): plain copies of lin.weight (E x D), lin.bias (E), a (2E) for the score backward
     size_t w1_off = 0, b1_off = 0;
 };
@@ -227,6 +231,7 @@ struct Workspace {
 struct Tape {
     size_t hcat, xct, att_f, att_t, hend, gates_g, seq_g, gates_d, seq_d, xdec, xp, total;
     size_t vmax;         // one word: bits of the largest convolution output (range guard of the split-operand recurrences)
+    size_t lct, rtt, lcf, rtf;   // wide attention layers: the projections L' / R'^T of the training forward (zero-sized for fused layers)
     // stacked recurrences: gates / state sequences of the layers above the first, and the (dropped-out) state sequences
     // that feed them (nn.GRU's inter-layer dropout, modules.py:233 / :253)
     std::vector<size_t> gates_gu, seq_gu, drop_g, gates_du, seq_du, drop_d;
@@ -236,6 +241,7 @@ struct Tape {
 struct BwdWorkspace {
     size_t da, dhcat, dhdec, dhend, dz0, dz1, de_f, de_t, dv_f, dv_t, dlr_f, dlr_t, dap_f, dap_t, dpre, wpart, sums, total;
     size_t v1s;          // GAT (v1): [u1 | u2 | k1 k2] and the batch sums [P1 | P2 | SC SD] of the two layers
+    size_t wds, wlr, wdet;   // wide attention layers (one layer at a time): d S (N K ldS), [L | R] (N K 2 Ep), d e transposed (N K K)
     size_t wpart_floats;
 };
 

@@ -360,7 +360,16 @@ int conv_win_pitch(int F, int Fq);
 size_t conv_win_lds(int W, int F, int Fq, int taps);
 int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int Kp, int PT, int P8, const float* bias,
                     const float* V, int ldv, int D, int K, float* out, long so_w, long so_i, long so_d, long nwin, int v1,
-                    float alpha, hipStream_t s);
+                    float alpha, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0);
+// backward of wide graph-attention layers (mtadgat_bwdw.hip)
+int launch_bw_ds(const float* H, const float* dH, long so_w, long so_i, long so_d, long nwin, int K, int D, float* dS, int ldS, hipStream_t s);
+int launch_bgemm(const float* A, long sAb, long sAm, long sAk, const float* B, long sBb, long sBk, long sBn, float* C, long sCb, long ldc,
+                 int M, int N, int Kc, long nb, const DropArgs* drop, unsigned drop_stream, int dropK, hipStream_t s);
+int launch_bw_softmax(const float* ATT, float* DE, long nwin, int K, const DropArgs& drop, unsigned drop_stream, hipStream_t s);
+int launch_bw_transpose(const float* src, float* dst, long nwin, int K, hipStream_t s);
+size_t bw_pair_lds(int K);
+int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const float* DE, const float* DEt, int K, float alpha, float* DLR,
+                   float* DAp, long nwin, hipStream_t s);
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
 bool gru_cm_supported(int ncg, int xmode, bool fc, int out_dim);

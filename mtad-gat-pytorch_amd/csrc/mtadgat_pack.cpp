@@ -341,12 +341,26 @@ std::string validate_and_plan(Model& m) {
         gl.total = go;
 
         b.supported = true;
-        if (!m.feat.fused || !m.temp.fused) { b.supported = false; b.why = "graph-attention layers beyond the fused kernel (more than 128 nodes / features)"; }
+        for (const GatPlan* g : {&m.feat, &m.temp})
+            if (!g->fused) {
+                // wide layers go through the generic kernels of mtadgat_bwdw.hip: GATv2, up to 512 nodes / node dimensions
+                if (!c.use_gatv2) { b.supported = false; b.why = "GAT (v1) attention layers beyond the fused kernel (more than 128 nodes / features)"; }
+                else if (g->K > 512 || g->D > 512) { b.supported = false; b.why = "graph-attention layers with more than 512 nodes / features"; }
+            }
         if (b.supported) {
             for (int which = 0; which < 2; ++which) {
                 const GatPlan& g = which == 0 ? m.feat : m.temp;
                 GatBwdPlan& gb = b.gat[which];
                 gb.Ep = round_up(g.E, 32); gb.NTu = gb.Ep / 32;
+                gb.wide = !g.fused;
+                if (gb.wide) {
+                    gb.wu_off = take((size_t)2 * gb.NTu * g.Q * 256);
+                    gb.bu_off = take((size_t)2 * gb.Ep);
+                    gb.a_off = take((size_t)gb.Ep);
+                    lint(gb.lrT, 2 * gb.Ep, g.D);
+                    wg(gb.wg, 2 * gb.Ep, g.D, true);
+                    continue;
+                }
                 gb.att_lds = gat_bwd_att_lds(g.K, g.D, g.f_vld, (g.K + 15) / 16);
                 if (!c.use_gatv2) {
                     // GAT (v1): the score backward is linear in the node vectors (mtadgat_bwd.hip): plain parameter copies
@@ -498,6 +512,10 @@ void plan_tape(const Model& m, int64_t n, Tape& t) {
     t.fc_act.clear();
     for (size_t i = 0; i + 1 < m.fc.size(); ++i) t.fc_act.push_back(take(N * (size_t)m.fc[i].NT * 32));
     t.vmax = take(64);
+    t.lct = take(m.temp.fused ? 0 : N * m.W * m.temp.ldl);
+    t.rtt = take(m.temp.fused ? 0 : N * m.temp.rt_rows * m.temp.Kp);
+    t.lcf = take(m.feat.fused ? 0 : N * m.F * m.feat.ldl);
+    t.rtf = take(m.feat.fused ? 0 : N * m.feat.rt_rows * m.feat.Kp);
     t.gates_gu.clear(); t.seq_gu.clear(); t.drop_g.clear(); t.gates_du.clear(); t.seq_du.clear(); t.drop_d.clear();
     for (size_t l = 1; l < m.gru.size(); ++l) {
         t.drop_g.push_back(take(N * m.W * m.gru[l - 1].Hp));
@@ -544,6 +562,17 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
     w.dap_f = take(N * b.gat[0].Ep);
     w.dap_t = take(N * b.gat[1].Ep);
     w.dpre = take(N * m.W * m.Fp);
+    {   // wide attention layers (mtadgat_bwdw.hip), one layer at a time
+        size_t ds = 0, lr = 0, det = 0;
+        for (int which = 0; which < 2; ++which) {
+            const GatPlan& gp = which == 0 ? m.feat : m.temp;
+            if (!b.gat[which].wide) continue;
+            ds = std::max(ds, N * gp.K * (size_t)round_up(gp.D, 4));
+            lr = std::max(lr, N * gp.K * 2 * (size_t)b.gat[which].Ep);
+            det = std::max(det, N * gp.K * (size_t)gp.K);
+        }
+        w.wds = take(ds); w.wlr = take(lr); w.wdet = take(det);
+    }
     // partial sums of the weight-gradient GEMMs (one at a time)
     size_t wp = 0;
     auto need = [&](const WgradPlan& p, long R) { wp = std::max(wp, (size_t)wgrad_slabs(R, p.Mp, p.Np) * p.Mp * p.Np); };
@@ -841,6 +870,8 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
                 return (k == D && side == 0) ? lb[e] : 0.f;
             });
             for (int e = 0; e < E; ++e) out[gb.a_off + e] = av[e];
+            if (gb.wide)       // (the row GEMM takes the projection bias as a vector: a wide D leaves no spare weight row for it)
+                for (int e = 0; e < E; ++e) out[gb.bu_off + e] = lb[e];
             pack_tiles(out.data() + gb.lrT.w_off, gb.lrT.NT, gb.lrT.Q, [&](int n, int k) -> float {
                 const int side = k / Ep, e = k % Ep;
                 return (n < D && e < E && side < 2) ? lw[(size_t)e * 2 * D + (size_t)side * D + n] : 0.f;

@@ -35,6 +35,17 @@ CONFIGS = {
                          forecast_n_layers=2, forecast_hid_dim=16, recon_n_layers=1, recon_hid_dim=20, dropout=0.1, alpha=0.2), 9),
     "wide_nodes": (dict(n_features=70, window_size=120, out_dim=5, kernel_size=3, gru_hid_dim=64, forecast_n_layers=1,
                         forecast_hid_dim=32, recon_hid_dim=96, dropout=0.1, alpha=0.2), 9),
+    # attention layers beyond the fused per-window kernels (more than 128 nodes or node dimensions): projections through memory +
+    # k_gat_wide in the training forward, the generic backward of csrc/mtadgat_bwdw.hip (round 5)
+    "wide_w130": (dict(n_features=20, window_size=130, out_dim=4, kernel_size=3, gru_hid_dim=48, forecast_n_layers=1,
+                       forecast_hid_dim=32, recon_hid_dim=40, dropout=0.2, alpha=0.2), 6),
+    "wide_w256": (dict(n_features=12, window_size=256, out_dim=2, kernel_size=5, feat_gat_embed_dim=40, time_gat_embed_dim=20, gru_hid_dim=40,
+                       forecast_n_layers=2, forecast_hid_dim=24, recon_hid_dim=36, dropout=0.3, alpha=0.2), 3),
+    # BASELINE config 4's shape (F = 512, W = 256, out = 512): both attention layers at the top of what the wide kernels take
+    "config4_shape": (dict(n_features=512, window_size=256, out_dim=512, kernel_size=7, gru_hid_dim=150, forecast_n_layers=3,
+                           forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 2),
+    "wide_f150": (dict(n_features=150, window_size=40, out_dim=3, kernel_size=3, feat_gat_embed_dim=33, gru_hid_dim=40, forecast_n_layers=1,
+                       forecast_hid_dim=32, recon_hid_dim=40, dropout=0.1, alpha=0.1), 5),
 }
 
 
@@ -152,7 +163,8 @@ def test_gradients_above_the_fp16_range_guard(gpu_device):
         assert model.conv(x[:64]).max().item() >= 32768.0            # the inputs do exceed the fp16 pieces' range
 
 
-@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape", "stacked", "stacked3_v1"])
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape", "stacked", "stacked3_v1", "wide_w130", "wide_w256",
+                                  "wide_f150"])
 def test_gradients_match_autograd_with_dropout(name, gpu_device):
     """train(): dropout inside the kernels; the same keep-masks (exported by the library) injected into the
     torch-op algebra must give the same outputs and gradients."""
