@@ -301,6 +301,45 @@ class Engine:
             _check(self.lib.mtadgat_params_fingerprint(ptrs, counts, n, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)), "fingerprint")
         return int(out.item())
 
+    def fingerprint_async(self, params, device):
+        """The same checksum without a host wait: the kernel and an 8-byte copy into pinned host memory are enqueued on a side
+        stream that starts where the current stream is now; returns a function that waits for THAT copy (an event, not a
+        stream: the caller's work keeps running) and returns the value."""
+        n = len(params)
+        cache = getattr(self, "_fp_cache", None)
+        key = tuple(p.data_ptr() for p in params)
+        if cache is None or cache[0] != key:
+            ptrs = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
+            counts = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+            out = torch.zeros(1, dtype=torch.int64, device=device)
+            cache = (key, ptrs, counts, out)
+            self._fp_cache = cache
+        _, ptrs, counts, out = cache
+        ring = getattr(self, "_fp_ring", None)
+        if ring is None:
+            ring = self._fp_ring = [[torch.zeros(1, dtype=torch.int64).pin_memory(), torch.cuda.Event(), torch.cuda.Event()] for _ in range(4)]
+            self._fp_slot = 0
+            self._fp_stream = torch.cuda.Stream(device)
+        self._fp_slot = (self._fp_slot + 1) % len(ring)
+        pin, ev, ev0 = ring[self._fp_slot]
+        # on a side stream that starts where the caller's stream is now: the check runs beside the call's first kernels instead of
+        # in front of them.  (The caller waits for `ev` before it returns -- _finish_weight_check -- so nothing the caller enqueues
+        # after this call can overtake the read of the parameters.)
+        with torch.cuda.device(device):
+            cur = torch.cuda.current_stream()
+            ev0.record(cur)
+            side = self._fp_stream
+            side.wait_event(ev0)
+            with torch.cuda.stream(side):
+                _check(self.lib.mtadgat_params_fingerprint(ptrs, counts, n, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(side.cuda_stream)), "fingerprint")
+                pin.copy_(out, non_blocking=True)
+                ev.record(side)
+
+        def wait():
+            ev.synchronize()
+            return int(pin[0])
+        return wait
+
     def read_packed(self, device):
         """Diagnostic: the packed weight image as a CPU tensor."""
         n = self.lib.mtadgat_packed_floats(self.handle)

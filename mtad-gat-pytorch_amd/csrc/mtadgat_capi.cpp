@@ -711,6 +711,8 @@ static void free_lane(Model& m) {
     (void)hipStreamDestroy(m.lane_stream);
     (void)hipEventDestroy(m.lane_begin);
     (void)hipEventDestroy(m.lane_end);
+    for (hipEvent_t& e : m.fork_ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (sw) (void)hipSetDevice(cur);
     m.lane_stream = nullptr;
     m.lane_begin = m.lane_end = nullptr;
@@ -1183,7 +1185,13 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
     lane_floats(m, batch, lane_need);
     bool second = false;
     for (const Piece& pc : sched) second = second || pc.lane == 1;
-    if (second) {
+    // Small calls (the reference Predictor's 256 windows, prediction.py:31): no launch fills the machine, the forward is a chain of
+    // latencies -- so the stages that do not depend on each other run side by side: the feature layer next to the temporal one
+    // (both read the convolution, mtad_gat.py:68-69), the forecasting head next to the reconstruction decoder (both read h_end,
+    // mtad_gat.py:76-77).  Same kernels, same results; the second stream joins before the call returns.
+    const bool fork = !second && sched.size() == 1 && m.lanes == 0 && sched[0].n <= FORK_MAX_WINDOWS && use_fused(m.temp) && use_fused(m.feat) &&
+                      !tband_selected(m, src, sched[0].n);
+    if (second || fork) {
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
         if (m.lane_stream && m.lane_device != dev) free_lane(m);        // the handle moved to another GPU since the lane was made
@@ -1192,7 +1200,10 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
             HIP_TRY(hipStreamCreateWithFlags(&m.lane_stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&m.lane_begin, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&m.lane_end, hipEventDisableTiming));
+            for (hipEvent_t& e : m.fork_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
+    }
+    if (second) {
         HIP_TRY(hipEventRecord(m.lane_begin, s0));            // the second lane starts after whatever the caller queued before this call
         HIP_TRY(hipStreamWaitEvent(m.lane_stream, m.lane_begin, 0));
     }
@@ -1201,7 +1212,7 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
         ~Joiner() {
             if (on && hipEventRecord(m.lane_end, m.lane_stream) == hipSuccess) (void)hipStreamWaitEvent(s0, m.lane_end, 0);
         }
-    } joiner{m, s0, second};
+    } joiner{m, s0, second || fork};
     for (const Piece& pc : sched) {
         const int64_t c0 = pc.c0, n = pc.n;
         hipStream_t s = pc.lane ? m.lane_stream : s0;
@@ -1226,11 +1237,18 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
                 conv_in_gat = true;
                 HIP_TRY(hipMemsetAsync(vmax, 0, sizeof(unsigned), s));
             } else if ((rc = run_conv(m, src, c0, n, nullptr, nullptr, hcat, nullptr, s, vmax))) return rc;
+            if (fork && !conv_in_gat) {                       // the feature layer on the second lane, beside the temporal one
+                HIP_TRY(hipEventRecord(m.fork_ev[0], s));
+                HIP_TRY(hipStreamWaitEvent(m.lane_stream, m.fork_ev[0], 0));
+                if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, m.lane_stream, nullptr, nullptr, 0, vmax))) return rc;
+                HIP_TRY(hipEventRecord(m.fork_ev[1], m.lane_stream));
+            }
             if (band) {
                 if ((rc = run_tband(m, n, ws, o, hcat, s))) return rc;
             } else if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, nullptr, nullptr, 0, vmax,
                                            conv_in_gat ? &cv : nullptr))) return rc;
-            if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, nullptr, nullptr, 0, vmax))) return rc;
+            if (fork && !conv_in_gat) HIP_TRY(hipStreamWaitEvent(s, m.fork_ev[1], 0));
+            else if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, nullptr, nullptr, 0, vmax))) return rc;
         } else {
             if ((rc = run_conv(m, src, c0, n, xc, xct, hcat, nullptr, s))) return rc;
             // temporal layer: nodes = time steps, rows of xc
@@ -1245,7 +1263,15 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
         if (hend_out)
             K_TRY(launch_copy2d(hend, ldh, hend_out + c0 * m.cfg.gru_hid_dim, m.cfg.gru_hid_dim, n, m.cfg.gru_hid_dim, s),
                   "h_end copy");
-        if (preds || recons || recons_last) {
+        if (fork && preds && (recons || recons_last)) {
+            // the forecasting head on the second lane, beside the reconstruction decoder (their scratch regions are disjoint)
+            HIP_TRY(hipEventRecord(m.fork_ev[2], s));
+            HIP_TRY(hipStreamWaitEvent(m.lane_stream, m.fork_ev[2], 0));
+            if ((rc = run_heads(m, hend, ldh, n, preds + c0 * m.cfg.out_dim, nullptr, nullptr, ws, o, m.lane_stream))) return rc;
+            if ((rc = run_heads(m, hend, ldh, n, nullptr, recons ? recons + c0 * (int64_t)W * m.cfg.out_dim : nullptr,
+                                recons_last ? recons_last + c0 * m.cfg.out_dim : nullptr, ws, o, s)))
+                return rc;
+        } else if (preds || recons || recons_last) {
             if ((rc = run_heads(m, hend, ldh, n, preds ? preds + c0 * m.cfg.out_dim : nullptr,
                                 recons ? recons + c0 * (int64_t)W * m.cfg.out_dim : nullptr,
                                 recons_last ? recons_last + c0 * m.cfg.out_dim : nullptr, ws, o, s)))

@@ -81,6 +81,7 @@ constexpr int64_t CM_MIN_WINDOWS = 4097;
 // ... of which the hidden-tile-split kernel's split-operand build takes the lower band: five waves per 32 windows instead of
 // one, a round of 8 192 windows (one workgroup per CU) in ~1.2 ms (GRU + decoder) against the 4 ms of a k_gru_cm round
 constexpr int64_t SPLIT3_MIN_WINDOWS = 2561, SPLIT3_MAX_WINDOWS = 8192;      // k_gru_cm (chunk-major recurrence, 128 windows per workgroup) from here on
+constexpr int64_t FORK_MAX_WINDOWS = 1024;   // up to here no launch of the forward fills the machine: independent stages run on two streams
 constexpr int64_t G1_MAX_WINDOWS = 1792;       // up to 7 windows per CU one after the other; beyond that 16-window groups pay
 
 // ---- backward (training) plans -------------------------------------------------------------------------
@@ -194,6 +195,7 @@ struct Model {
     // second lane of forward(): pieces of a call alternate between the caller's stream and this one (forward_schedule, mtadgat_capi.cpp)
     hipStream_t lane_stream = nullptr;
     hipEvent_t lane_begin = nullptr, lane_end = nullptr;
+    hipEvent_t fork_ev[3] = {nullptr, nullptr, nullptr};   // small calls: stage hand-offs between the caller's stream and the second lane
     int lane_device = -1;            // the device the second lane's stream and events were created on
     int lanes = 0;                   // 0 automatic, 1 everything on the caller's stream
     bool have_weights = false;

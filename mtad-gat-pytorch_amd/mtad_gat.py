@@ -228,6 +228,8 @@ class MTAD_GAT(nn.Module):
         object.__setattr__(self, "_engine", None)
         object.__setattr__(self, "_weights_key", None)
         object.__setattr__(self, "_fp_vec", None)
+        object.__setattr__(self, "_fp_pending", None)
+        object.__setattr__(self, "_fp_value", None)
         if "precision" not in self.__dict__:
             # arithmetic of GPU inference: "fp32" (<= 1e-5 of the reference: fp32 accumulation everywhere; the large-batch
             # kernels form their products from split-bf16 operands on the bf16 matrix pipe, which reproduces the
@@ -242,12 +244,11 @@ class MTAD_GAT(nn.Module):
             # arithmetic of BASELINE's "bf16 train loop" configuration)
             object.__setattr__(self, "bf16_training_recurrences", False)
         if "check_weight_contents" not in self.__dict__:
-            # True: every GPU call fingerprints the parameter *contents* (one small reduction + a host
-            # sync), so in-place edits that bypass autograd's version counter (`p.data.mul_()`,
-            # `nn.init.*_(p.data)`) are seen.  False: trust (data_ptr, _version) only -- no sync per call;
-            # call refresh_weights() after such edits.  "eval_only": fingerprint in eval() mode, trust the version
-            # counters in train() mode (optimizers bump them; saves the host sync of a training step -- but manual
-            # `p.data` edits between training steps then need refresh_weights()).  ("always" = True, kept for old callers.)
+            # True: every GPU call fingerprints the parameter *contents* (one small reduction whose 8-byte result is read after
+            # the call's kernels are enqueued: no stream synchronisation, see _sync_engine), so in-place edits that bypass
+            # autograd's version counter (`p.data.mul_()`, `nn.init.*_(p.data)`) are seen.  False: trust (data_ptr, _version)
+            # only; call refresh_weights() after such edits.  "eval_only": fingerprint in eval() mode, trust the version
+            # counters in train() mode.  ("always" = True, kept for old callers.)
             object.__setattr__(self, "check_weight_contents", True)
         if "share_series_pair_scores" not in self.__dict__:
             # forward_series / score_series over stride-1 windows (Predictor.get_score, prediction.py:51-63): the temporal
@@ -263,7 +264,7 @@ class MTAD_GAT(nn.Module):
 
     def __getstate__(self):
         d = self.__dict__.copy()
-        for k in ("_engine", "_weights_key", "_fp_vec"):
+        for k in ("_engine", "_weights_key", "_fp_vec", "_fp_pending", "_fp_value"):
             d.pop(k, None)
         return d
 
@@ -301,26 +302,58 @@ class MTAD_GAT(nn.Module):
         if self._engine is None or self._engine.device != device:
             object.__setattr__(self, "_engine", _native.Engine(self._native_cfg, device))
             object.__setattr__(self, "_weights_key", None)
+        if getattr(self, "_fp_pending", None) is not None:
+            self._finish_weight_check()                   # (a caller that took the engine directly left its check open)
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
-        # the content fingerprint is part of the key in train() and eval() mode alike (in-place `p.data` edits bump no version
-        # counter in either mode, and a key of the same shape in both modes means train() / eval() toggles force no re-pack);
-        # "eval_only" leaves it out -- in both positions of the key, as None -- while the model trains
-        fp = None
-        if self.check_weight_contents and not (self.check_weight_contents == "eval_only" and self.training):
+        # In-place edits that bypass autograd's version counters (`p.data.mul_()`, `nn.init.*_(p.data)`) are caught by a content
+        # fingerprint, in train() and eval() mode alike ("eval_only": not while the model trains).  It does not hold the call up:
+        # the kernel and an 8-byte copy to pinned memory are enqueued here, the call's kernels are enqueued behind them with the
+        # weights as packed, and _finish_weight_check() reads the value afterwards -- waiting on the copy's event only -- and has
+        # the call repeated with re-packed weights in the (rare) case that the contents changed under unchanged version counters.
+        check = bool(self.check_weight_contents) and not (self.check_weight_contents == "eval_only" and self.training)
+        pending = None
+        if check:
             if all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
-                fp = self._engine.fingerprint(params, device)
+                pending = self._engine.fingerprint_async(params, device)
             else:
-                fp = self._fingerprint(params)
-        elif self.check_weight_contents == "eval_only" and self._weights_key is not None and self._weights_key[:-1] == key:
-            fp = self._weights_key[-1]           # training under "eval_only": versions unchanged -> keep the packed weights
-        key = key + (fp,)
+                v = self._fingerprint(params)             # (odd parameter dtypes / layouts: torch ops, a host read)
+                pending = lambda: v                       # noqa: E731
         mode = 1 if bf16 else (0 if self.precision == "fp32_strict" else 2)
         self._engine.set_precision(mode)
         self._engine.set_option("series_band", {"auto": 0, False: 1, True: 2}[self.share_series_pair_scores])
-        if key != self._weights_key or (bf16 and not self._engine.bf16_ready()):
+        repack = key != self._weights_key or (bf16 and not self._engine.bf16_ready())
+        if repack:
             self._engine.load_weights(self.state_dict(), device, allow_device_pack=self.device_repack)
             object.__setattr__(self, "_weights_key", key)
+        object.__setattr__(self, "_fp_pending", (pending, repack) if pending is not None else None)
+        if not check:
+            object.__setattr__(self, "_fp_value", None)   # unknown from here on: the next checked call records, it cannot compare
         return self._engine
+
+    def _finish_weight_check(self):
+        """Second half of _sync_engine's content check, called once the call's kernels are enqueued: True when the parameters'
+        contents differ from the ones the packed weights were built from although no version counter moved -- the packed
+        weights are then marked stale and the caller repeats its launches."""
+        pend = getattr(self, "_fp_pending", None)
+        if pend is None:
+            return False
+        object.__setattr__(self, "_fp_pending", None)
+        wait, repacked = pend
+        value = wait()
+        known = getattr(self, "_fp_value", None)
+        object.__setattr__(self, "_fp_value", value)
+        if repacked or known is None or known == value:
+            return False
+        object.__setattr__(self, "_weights_key", None)
+        return True
+
+    def _checked(self, device, bf16, fn):
+        """fn(engine) with the packed weights matching the parameters: at most one repetition (see _sync_engine)."""
+        out = fn(self._sync_engine(device, bf16))
+        if self._finish_weight_check():
+            out = fn(self._sync_engine(device, bf16))
+            self._finish_weight_check()
+        return out
 
     def _use_bf16(self, x):
         if self.precision not in ("auto", "fp32", "fp32_strict", "bf16"):
@@ -345,21 +378,11 @@ class MTAD_GAT(nn.Module):
             raise NotImplementedError(
                 "stage calls run the eval-mode HIP kernels; train-mode (dropout / gradients) is supported through "
                 "MTAD_GAT.forward() -- call model.eval() for per-stage inference")
-        eng = self._sync_engine(x.device, self._use_bf16(x))
         x = x.detach().contiguous().float()
-        if name == "conv":
-            return eng.conv(x)
-        if name == "feature_gat":
-            return eng.gat(0, x)
-        if name == "temporal_gat":
-            return eng.gat(1, x)
-        if name == "gru":
-            return eng.gru(x)
-        if name == "forecast":
-            return eng.heads(x, True, False)[0]
-        if name == "recon":
-            return eng.heads(x, False, True)[1]
-        raise KeyError(name)
+        call = {"conv": lambda eng: eng.conv(x), "feature_gat": lambda eng: eng.gat(0, x), "temporal_gat": lambda eng: eng.gat(1, x),
+                "gru": lambda eng: eng.gru(x), "forecast": lambda eng: eng.heads(x, True, False)[0],
+                "recon": lambda eng: eng.heads(x, False, True)[1]}[name]
+        return self._checked(x.device, self._use_bf16(x), call)
 
     def _require_gpu(self, t, what):
         if t.device.type != "cuda":
@@ -384,18 +407,18 @@ class MTAD_GAT(nn.Module):
         # a training step computes in fp32 whatever the request (faster and more accurate than the bf16 recurrence kernels at
         # every batch size, see bf16_training_recurrences); bf16 tensors are still answered in bf16
         bf16 = self._use_bf16(x) and (not grad_step or self.bf16_training_recurrences)
-        eng = self._sync_engine(x.device, bf16)
         if grad_step:
             # training step (Trainer.fit, training.py:100-130) or any call that will be differentiated:
             # HIP forward that keeps what the HIP backward needs, dropout in the kernels
             import _hipgrad
-            preds, recons = _hipgrad.forward(self, eng, x)
+            preds, recons = self._checked(x.device, bf16, lambda eng: _hipgrad.forward(self, eng, x))
         else:
             with torch.no_grad():
                 # bfloat16 batches go to the kernels as they are (the convolution converts while staging) when the
                 # LDS-staged convolution applies; everything else is handed over as float32
                 direct = x.dtype == torch.bfloat16 and self.n_features <= 64 and self.conv.kernel_size <= 31
-                preds, recons = eng.forward(x.contiguous() if direct else x.contiguous().float())
+                xin = x.contiguous() if direct else x.contiguous().float()
+                preds, recons = self._checked(x.device, bf16, lambda eng: eng.forward(xin))
         if x.dtype in (torch.bfloat16, torch.float16):
             # reduced-precision I/O (BASELINE config "bf16 inference"): results in the caller's dtype
             return preds.to(x.dtype), recons.to(x.dtype)
@@ -409,9 +432,9 @@ class MTAD_GAT(nn.Module):
         prediction.py:43-55); consecutive windows share W-1 rows, so ~W times fewer input bytes are read.
         Returns (predictions (b, out_dim), recons (b, W, out_dim))."""
         self._require_gpu(series, "forward_series")
-        eng = self._sync_engine(series.device, self._use_bf16(series))
         with torch.no_grad():
-            p, r, _ = eng.forward_series(series.contiguous().float(), starts, start, stride, count)
+            sf = series.contiguous().float()
+            p, r, _ = self._checked(series.device, self._use_bf16(series), lambda eng: eng.forward_series(sf, starts, start, stride, count))
         return p, r
 
     def score_series(self, values):
@@ -427,9 +450,10 @@ class MTAD_GAT(nn.Module):
         n = values.shape[0] - self.window_size
         if n <= 0:
             raise RuntimeError("series shorter than window_size + 1")
-        eng = self._sync_engine(values.device, self._use_bf16(values))
         with torch.no_grad():
-            p, _, last = eng.forward_series(values.contiguous().float(), None, 0, 1, n + 1, want_recons=False, want_last=True)
+            vf = values.contiguous().float()
+            p, _, last = self._checked(values.device, self._use_bf16(values),
+                                       lambda eng: eng.forward_series(vf, None, 0, 1, n + 1, want_recons=False, want_last=True))
         return p[:n], last[1:n + 1]
 
     def anomaly_scores(self, values, target_dims=None, gamma=1.0, scale_scores=False):
