@@ -115,8 +115,9 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* params_host, vo
 /* The same for parameters that are already in device memory -- the training loop's optimizer.step() followed by a
  * forward (training.py:127 -> :110): `flat_dev` holds all parameters back to back in the field order of
  * mtadgat_params (the order of the flat gradient buffer, mtadgat_grad_offsets / mtadgat_grad_floats), and the tile
- * image is rebuilt from it by kernels on `stream`; nothing but the sign pattern of the two attention vectors `a`
- * (a few hundred bytes; it fixes the column order of the folded GATv2 projection) travels to the host.  Requires one
+ * image is rebuilt from it by kernels on `stream`; nothing travels to the host and nothing synchronises (the column order of
+ * the folded GATv2 projection follows the signs of the attention vectors `a`: derived on the device since round 5, the kernels
+ * read the sign-group boundaries from the image).  Requires one
  * earlier mtadgat_load_weights on this device and precision mode 0 or 2 (the fp32 image; the split-operand packs of mode 2
  * are re-derived from it on the device); mode 1 returns MTADGAT_ERR_UNSUPPORTED (callers then use
  * mtadgat_load_weights).  The bf16 weight streams are not maintained: mtadgat_bf16_ready turns 0. */

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64, (JPL <= 2 ? 3 : 2)) void k_attend(const AttendA
     if (win >= a.nwin) return;
     const int i0 = rb * a.rows_per_blk;
     const int nrows = min(a.rows_per_blk, a.K - i0);
-    const int K = a.K, ldl = a.ldl, PT = a.PT, Kp = a.Kp;
+    const int K = a.K, ldl = a.ldl, PT = a.ord ? a.ord[1] : a.PT, Kp = a.Kp;
     const float* __restrict__ Lrow0 = a.LC + (win * K + i0) * (long)ldl;
     const float* __restrict__ RTw = a.RT + win * (long)a.rt_rows * Kp;
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64, (JPL <= 2 ? 3 : 2)) void k_attend(const AttendA
         };
 #pragma unroll
         for (int st = 0; st < DEPTH - 1; ++st) fetch(st, st);
-        const int ptile = a.P8 >> 3;
+        const int ptile = (a.ord ? a.ord[0] : a.P8) >> 3;
         for (int t0 = 0; t0 < ntile; t0 += DEPTH) {
 #pragma unroll
             for (int st = 0; st < DEPTH; ++st) {

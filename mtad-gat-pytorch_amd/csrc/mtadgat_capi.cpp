@@ -177,7 +177,7 @@ bool tband_selected(const Model& m, const XSource& src, int64_t n) {
     if (m.taps != 2 * m.pad + 1 || m.pad < 1 || m.W < 4 * m.pad + 2 || (m.Dp & 3) != 0) return false;
     if ((size_t)(32 + m.taps - 1) * (m.Fp + 4) * sizeof(float) > 20 * 1024) return false;          // (run_conv_shared's kernel)
     const GatPlan& g = m.temp;
-    return tband_applies(g.K, g.D, g.PT, m.pad, g.ldl, g.NT * 32);
+    return tband_applies(g.K, g.D, g.PTcap, m.pad, g.ldl, g.NT * 32);     // (the bound: the device-side re-pack may move PT by a tile)
 }
 int run_tband(Model& m, int64_t n, float* ws, const Workspace& o, float* hcat, hipStream_t s) {
     const GatPlan& g = m.temp;
@@ -201,6 +201,7 @@ int run_tband(Model& m, int64_t n, float* ws, const Workspace& o, float* hcat, h
     a.BI = ws + o.band; a.bp = 2 * m.W; a.HB = m.W - 1 - 2 * m.pad;
     a.EQ = ws + o.eq; a.EK = ws + o.ek;
     a.ldp = ldp; a.ldl = g.ldl; a.PT = g.PT; a.P8 = g.P8; a.K = g.K; a.D = g.D; a.pad = m.pad;
+    a.ord = reinterpret_cast<const int*>(m.packed_dev + g.ord_off); a.PTcap = g.PTcap;
     a.n = n; a.Lrows = L;
     a.bias = m.packed_dev + g.bias_off;
     a.V = hcat; a.sv_w = (long)m.W * m.Dp; a.ldv = m.Dp;
@@ -234,13 +235,15 @@ int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, con
     if (g.K <= 512 && g.D <= 512) {
         // LDS-tiled pair grid of the fused kernel over the HBM-resident projections (BASELINE config 4 shapes)
         K_TRY(launch_gat_wide(lc, rt, g.ldl, g.rt_rows, g.Kp, g.PT, g.P8, m.packed_dev + g.bias_off, v, ldv, g.D, g.K, out, so_w,
-                              so_i, so_d, n, m.cfg.use_gatv2 ? 0 : 1, m.cfg.alpha, s, att, drop, drop_stream),
+                              so_i, so_d, n, m.cfg.use_gatv2 ? 0 : 1, m.cfg.alpha, s, att, drop, drop_stream,
+                              m.cfg.use_gatv2 ? reinterpret_cast<const int*>(m.packed_dev + g.ord_off) : nullptr),
               "wide gat attention");
         return 0;
     }
     if (att || drop) return fail(MTADGAT_ERR_UNSUPPORTED, "training forward of an attention layer with more than 512 nodes / features");
     AttendArgs a{};
     a.LC = lc; a.RT = rt; a.ldl = g.ldl; a.rt_rows = g.rt_rows; a.Kp = g.Kp; a.PT = g.PT; a.P8 = g.P8;
+    a.ord = m.cfg.use_gatv2 ? reinterpret_cast<const int*>(m.packed_dev + g.ord_off) : nullptr;
     a.bias = m.packed_dev + g.bias_off;
     a.V = v; a.ldv = ldv; a.D = g.D;
     a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d;
@@ -268,6 +271,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
     a.pbias = m.packed_dev + g.b_off;
     a.NT_L = g.NT_L; a.Q = g.Q; a.PT = g.PT; a.P8 = g.P8;
+    a.ord = m.cfg.use_gatv2 ? reinterpret_cast<const int*>(m.packed_dev + g.ord_off) : nullptr;
     if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
@@ -833,9 +837,8 @@ int mtadgat_load_weights(mtadgat_handle h, const mtadgat_params* p, void* stream
 /* Re-packs the weight image from a flat device buffer of the parameters (mtadgat_params field order = the order of
  * the flat gradient buffer, see mtadgat_grad_offsets) without a round trip through the host: the training loop's
  * optimizer.step() -> forward.  Needs one previous mtadgat_load_weights on this device (it lays down the padding
- * and the index maps) and the fp32 image (precision 0).  The only host involvement is the sign pattern of the two
- * attention vectors `a` (a few hundred bytes, one stream synchronisation): it decides the column order of the
- * folded GATv2 projection. */
+ * and the index maps) and the fp32 image (precision 0 or 2).  No host involvement: the column order of the folded GATv2
+ * projection (the sign pattern of the two attention vectors `a`) is derived by a kernel as well. */
 int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64_t n_floats, void* stream) {
     if (!h || !flat_dev) return fail(MTADGAT_ERR_INVALID, "null argument");
     Model& m = h->m;
@@ -864,41 +867,26 @@ int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.colk_dev[which]), (size_t)(g.ldl + 16) * sizeof(int)));
             t.colk[which].clear();
         }
-        t.pin_floats = (size_t)2 * (m.feat.ldl + m.temp.ldl + 64) + 2 * (size_t)(m.feat.E + m.temp.E);
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&t.pin), t.pin_floats * sizeof(float), hipHostMallocDefault));
         t.device = dev;
         t.ready = true;
     }
     if (n_floats != t.fo.total) return fail(MTADGAT_ERR_INVALID, "flat parameter buffer: wrong number of floats");
-    // column order of the GATv2 projections: the signs of a, through pinned memory
-    if (m.cfg.use_gatv2) {
-        float* a0 = t.pin;
-        float* a1 = t.pin + m.feat.E;
-        HIP_TRY(hipMemcpyAsync(a0, flat_dev + t.fo.a[0], (size_t)m.feat.E * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(a1, flat_dev + t.fo.a[1], (size_t)m.temp.E * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        int* up = reinterpret_cast<int*>(t.pin + m.feat.E + m.temp.E);
+    // column order of the GATv2 projections: from the signs of `a`, on the device (round 5: rounds 3-4 read `a` back through pinned
+    // memory and synchronised the stream here, once per optimizer step).  The kernels take [P8, PT] from the image from now on;
+    // the host's copies keep the values of the last host-side load (they only steer heuristics).
+    if (m.cfg.use_gatv2)
         for (int which = 0; which < 2; ++which) {
-            GatPlan& g = which == 0 ? m.feat : m.temp;
-            std::vector<int> colk;
-            int P8 = 0, PT = 0;
-            gat_column_order(which == 0 ? a0 : a1, g.E, m.cfg.alpha, colk, P8, PT, &g.npos);
-            if (PT >= g.ldl) return fail(MTADGAT_ERR_INVALID, "internal: sorted projection columns exceed the plan");
-            if (colk != t.colk[which] || P8 != g.P8 || PT != g.PT) {
-                g.P8 = P8; g.PT = PT;
-                std::memcpy(up, colk.data(), colk.size() * sizeof(int));
-                HIP_TRY(hipMemcpyAsync(t.colk_dev[which], up, colk.size() * sizeof(int), hipMemcpyHostToDevice, s));
-                t.colk[which] = colk;
-            }
-            up += g.ldl + 16;
+            const GatPlan& g = which == 0 ? m.feat : m.temp;
+            K_TRY(launch_gat_colorder(flat_dev + t.fo.a[which], g.E, (double)m.cfg.alpha, t.colk_dev[which], g.ldl + 16,
+                                      reinterpret_cast<int*>(m.packed_dev + g.ord_off), s), "projection column order");
         }
-    }
     K_TRY(launch_pack_gather(flat_dev, t.gidx_dev, m.packed_dev, (long)m.packed_floats, s), "weight gather");
     for (int which = 0; which < 2; ++which) {
         const GatPlan& g = which == 0 ? m.feat : m.temp;
         PackGatArgs a{};
         a.flat = flat_dev; a.lin_w = t.fo.lin_w[which]; a.lin_b = t.fo.lin_b[which]; a.a = t.fo.a[which];
-        a.E = g.E; a.D = g.D; a.KS = g.ldl; a.PT = g.PT; a.v2 = m.cfg.use_gatv2 ? 1 : 0; a.fused = g.fused ? 1 : 0;
+        a.E = g.E; a.D = g.D; a.KS = g.ldl; a.ord = reinterpret_cast<const int*>(m.packed_dev + g.ord_off);
+        a.v2 = m.cfg.use_gatv2 ? 1 : 0; a.fused = g.fused ? 1 : 0;
         a.alpha = m.cfg.alpha; a.colk = t.colk_dev[which]; a.code = t.gatcode_dev[which];
         a.n_code = g.NT * g.Q * 256; a.n_bias = g.NT * 32;
         a.w_out = m.packed_dev + g.w_off; a.b_out = m.packed_dev + g.b_off;

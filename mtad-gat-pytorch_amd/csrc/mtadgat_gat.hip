@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
     const long win = blockIdx.x;
-    const int K = a.K, D = a.D, PT = a.PT;
+    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
     const int vld = a.vld;
     const int Kp16 = (K + 15) & ~15;                   // rows of Vs: real nodes then zero rows
     const int NWA = (K + IBW - 1) / IBW;               // waves that own query rows (the rest only project)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     const int NTn = (K + 31) >> 5;                    // node tiles
     const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
     const int Q = a.Q;
-    const int ptile = a.P8 >> 3, ntile = PT >> 3;
+    const int ptile = P8 >> 3, ntile = PT >> 3;
     const int nparts = (PT >> 5) + 1;                 // the part holding column PT (c, d) is the last one with content
 
     // The weights of this wave's first task of a part are requested one phase early -- before the barrier
@@ -462,6 +462,7 @@ struct GatWideArgs {
     const float* LC;     // (B*K, ldl): [L'(PT) | c | pad]
     const float* RT;     // (B, rt_rows, Kp): rows [0, PT) = R' (key minor), row PT = d
     int ldl, rt_rows, Kp, PT, P8;
+    const int* ord;      // device-side [P8, PT] (overrides PT / P8 when set)
     const float* bias;   // (K, K) or null
     const float* V;      // (B*K, ldv) node rows
     int ldv, D, K;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
     const long win = grp * 8 + (within & 7);
     const int rb = within >> 3;
     if (win >= a.nwin) return;
-    const int K = a.K, D = a.D, PT = a.PT;
+    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
     const int i0b = rb * (NW * IBW);                       // first query row of this workgroup
     const int KJ = KP * 128;                               // key slots
     float* __restrict__ Ls = smem;                         // [NW*16][34]
@@ -519,7 +520,7 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
 #pragma unroll
             for (int jj = 0; jj < JPL; ++jj) acc[kp][ii][jj] = 0.f;
 
-    const int ntile = PT >> 3, ptile = a.P8 >> 3;
+    const int ntile = PT >> 3, ptile = P8 >> 3;
     const int nparts = (ntile + 3) >> 2;
     for (int part = 0; part < nparts; ++part) {
         // ---- stage this part: L' rows of the block (row-major source), R' columns of all keys (key-minor source).
@@ -736,7 +737,7 @@ size_t gat_wide_lds(int K, int D, int nw) {
 
 int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int Kp, int PT, int P8, const float* bias,
                     const float* V, int ldv, int D, int K, float* out, long so_w, long so_i, long so_d, long nwin, int v1,
-                    float alpha, hipStream_t s, float* att, const DropArgs* drop, unsigned drop_stream) {
+                    float alpha, hipStream_t s, float* att, const DropArgs* drop, unsigned drop_stream, const int* ord) {
     if (nwin <= 0) return 0;
     if (K > 512 || D > 512) return -2;
     const int KP = (K + 127) / 128;
@@ -746,7 +747,7 @@ int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int 
     a.V = V; a.ldv = ldv; a.D = D; a.K = K; a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d; a.nwin = nwin;
     a.nblk = (K + nw * 16 - 1) / (nw * 16);
     a.v1 = v1; a.alpha = alpha;
-    a.ATT = att; a.drop_stream = drop_stream;
+    a.ATT = att; a.drop_stream = drop_stream; a.ord = ord;
     if (drop) a.drop = *drop;
     const size_t lds = gat_wide_lds(K, D, nw);
     if (lds > 160 * 1024) return -2;

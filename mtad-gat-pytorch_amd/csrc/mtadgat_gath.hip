@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
     const long win = blockIdx.x;
-    const int K = a.K, D = a.D, PT = a.PT;
+    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
     const int pvh = a.vld;                             // piece pitch in halfs
     const int KR = K + 1;                              // rows of the pieces: the nodes and one zero row (keys past K of a 16-key group)
     // waves that own query rows (the rest only project): n_full of them 4 RI = 16 rows (IBL per lane), n_short one row per lane
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const int NTn = (K + 31) >> 5;                    // node tiles
     const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
     const int Q = a.Q;                                // 16-feature chunks incl. the ones column
-    const int ptile = a.P8 >> 3, ntile = PT >> 3;
+    const int ptile = P8 >> 3, ntile = PT >> 3;
     const int nparts = (PT >> 5) + 1;
 
     const f32x4* __restrict__ Wbase = a.Wp2;

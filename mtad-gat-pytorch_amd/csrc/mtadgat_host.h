@@ -25,6 +25,8 @@ struct GatPlan {
     int NT_L = 0;   // tiles of the query side; the key-side tiles follow (stored transposed)
     int NT = 0, Q = 0;
     size_t w_off = 0, b_off = 0, bias_off = 0;   // offsets (floats) into the packed buffer
+    size_t ord_off = 0;     // [P8, PT, npos, 0] as ints in the packed buffer: what the kernels read (the device-side re-pack rewrites it)
+    int PTcap = 0;          // upper bound of PT: E rounded up to 8, + 8
     int rows_per_blk = 0, nblk = 0, IB = 0;      // attend launch plan (un-fused path)
     // fused per-window kernel (k_gat) plan; fused == false -> k_rowgemm + k_attend through HBM
     bool fused = false;

@@ -84,6 +84,7 @@ struct AttendArgs {
     const float* LC;     // (B*K, ldl) per query node: [L'(PT) | c | pad]
     const float* RT;     // (B, rt_rows, Kp) per window, key-node-minor: rows [0,PT) = R', row PT = d
     int ldl, rt_rows, Kp, PT, P8;
+    const int* ord;      // device-side [P8, PT] (overrides PT / P8 when set)
     const float* bias;   // (K, K) or null
     const float* V;      // (B*K, ldv) node feature rows
     int ldv, D;
@@ -132,6 +133,9 @@ struct GatArgs {
     const float* scale2;
     const float* pbias;  // projection bias, 2*NT_L*32
     int NT_L, Q, PT, P8;
+    // the sign-group boundaries [P8, PT] as kept in device memory by the weight packers (the device-side re-pack derives the column
+    // order of the folded projection from the signs of `a` without telling the host): when set it overrides PT / P8 above
+    const int* ord;
     const float* bias;   // (K, K) attention bias or null
     float* out;          // out[win*so_w + i*so_i + d*so_d]
     long so_w, so_i, so_d;
@@ -308,7 +312,8 @@ inline int g1_waves(int H, int Hp, bool bwd) {
 struct PackGatArgs {
     const float* flat;
     long lin_w, lin_b, a;
-    int E, D, KS, PT;    // KS = projected columns per side (ldl); PT: see GatArgs
+    int E, D, KS;        // KS = projected columns per side (ldl)
+    const int* ord;      // [P8, PT, npos] of the layer (k_gat_colorder); PT: see GatArgs
     int v2, fused;
     double alpha;
     const int* colk;     // [PT] embedding column of sorted column n, or -1 (padding)
@@ -360,7 +365,9 @@ int conv_win_pitch(int F, int Fq);
 size_t conv_win_lds(int W, int F, int Fq, int taps);
 int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int Kp, int PT, int P8, const float* bias,
                     const float* V, int ldv, int D, int K, float* out, long so_w, long so_i, long so_d, long nwin, int v1,
-                    float alpha, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0);
+                    float alpha, hipStream_t s, float* att = nullptr, const DropArgs* drop = nullptr, unsigned drop_stream = 0,
+                    const int* ord = nullptr);
+int launch_gat_colorder(const float* a_dev, int E, double alpha, int* colk_dev, int ncolk, int* ord_dev, hipStream_t s);
 // backward of wide graph-attention layers (mtadgat_bwdw.hip)
 int launch_bw_ds(const float* H, const float* dH, long so_w, long so_i, long so_d, long nwin, int K, int D, float* dS, int ldS, hipStream_t s);
 int launch_bgemm(const float* A, long sAb, long sAm, long sAk, const float* B, long sBb, long sBk, long sBn, float* C, long sCb, long ldc,
@@ -434,6 +441,8 @@ struct TBandArgs {
     float* EQ;           // (n, 2 pad, kq) raw scores of a window's edge rows as queries against its keys, kq = (K rounded up to 4) + 4
     float* EK;           // (n, K, 2 pad + 2) raw scores of a window's queries against its edge rows as keys
     int ldp, ldl, PT, P8, K, D, pad;
+    const int* ord;      // device-side [P8, PT] of the layer (null: the host's PT / P8 above)
+    int PTcap;           // upper bound of PT (LDS sizing at launch)
     long n, Lrows;
     const float* bias;   // (K, K)
     const float* V;      // node rows of window w: V + w * sv_w + i * ldv

@@ -155,6 +155,8 @@ std::string validate_and_plan(Model& m) {
         g.w_off = take((size_t)g.NT * g.Q * 256);
         g.b_off = take((size_t)g.NT * 32);
         g.bias_off = take((size_t)K * K);
+        g.ord_off = take(16);
+        g.PTcap = ptcap;
         g.Q16 = g.fused ? (D + 1 + 15) / 16 : 0;
         if (g.fused) {      // fp16-piece build: pitch 4 x odd halfs (conflict-free 8-byte operand reads of 32 consecutive nodes)
             g.fh_IBL = g.f_IBL; g.fh_JPL = g.f_JPL; g.fh_RJ = g.f_RJ;
@@ -465,7 +467,7 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
         // (only where tband_selected, mtadgat_capi.cpp, can say yes: not for plain forward() sizes below its threshold, not with the
         // band switched off or in the bf16 mode, not -- automatic choice -- for embeddings it never picks the band for)
         const bool tb = both_fused && m.cfg.use_gatv2 && m.series_band != 1 && m.precision != 1 && n >= 1024 &&
-                        (m.series_band == 2 || g.PT >= 112) && tband_applies(g.K, g.D, g.PT, m.pad, g.ldl, (int)ldp);
+                        (m.series_band == 2 || g.PT >= 112) && tband_applies(g.K, g.D, g.PTcap, m.pad, g.ldl, (int)ldp);
         ws.pj = take(tb ? (N + m.W) * ldp : 0);
         ws.pjt = take(tb ? N * 2 * m.pad * ldp : 0);
         ws.pjb = take(tb ? N * 2 * m.pad * ldp : 0);
@@ -664,6 +666,10 @@ static void pack_gat(Model& m, GatPlan& g, const float* lin_w, const float* lin_
         });
     for (int n = 0; n < NC; ++n) out[g.b_off + n] = (float)bvec[n];
     std::memcpy(out.data() + g.bias_off, bias, sizeof(float) * (size_t)g.K * g.K);
+    {   // the sign-group boundaries the kernels read (ints in the float image)
+        int* ord = reinterpret_cast<int*>(out.data() + g.ord_off);
+        ord[0] = g.P8; ord[1] = g.PT; ord[2] = g.npos; ord[3] = 0;
+    }
 }
 
 static void pack_gru_layer(const GruPlan& g, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,

@@ -26,14 +26,15 @@ __device__ float gat_row_value(const PackGatArgs& a, int n, int k) {
     const float* __restrict__ av = a.flat + a.a;
     if (a.v2) {
         const int lin_in = 2 * D;
-        if (nn < a.PT) {
+        const int PT = a.ord[1];
+        if (nn < PT) {
             const int kk = a.colk[nn];
             if (kk < 0) return 0.f;
             const double s = fabs((1.0 - a.alpha) * 0.5 * (double)av[kk]);
             if (k < D) return (float)(s * (double)lw[(long)kk * lin_in + side * D + k]);
             return side == 0 ? (float)(s * (double)lb[kk]) : 0.f;
         }
-        if (nn == a.PT) {
+        if (nn == PT) {
             const double hl = (1.0 + a.alpha) * 0.5;
             double acc = 0.0;
             if (k < D) {
@@ -53,6 +54,31 @@ __device__ float gat_row_value(const PackGatArgs& a, int n, int k) {
         for (int e = 0; e < E; ++e) acc += (double)av[side * E + e] * (double)lb[e];
     }
     return (float)acc;
+}
+
+// Column order of a GATv2 layer's folded projection (gat_column_order, mtadgat_pack.cpp, on the device): embedding columns with
+// a'_k = (1 - alpha) / 2 a_k >= 0 first, in their own order, padded to a multiple of 8; then the negative ones, likewise.
+// colk[n] = embedding column of sorted column n or -1; ord = [P8, PT, number of non-negative columns].  One workgroup; the
+// embedding has at most a few hundred columns, so one thread walks it.
+__global__ void k_gat_colorder(const float* __restrict__ av, int E, double alpha, int* __restrict__ colk, int ncolk, int* __restrict__ ord) {
+    __shared__ int s_np;
+    const int tid = threadIdx.x;
+    for (int n = tid; n < ncolk; n += blockDim.x) colk[n] = -1;
+    if (tid == 0) {
+        int np = 0;
+        for (int k = 0; k < E; ++k) np += ((1.0 - alpha) * 0.5 * (double)av[k]) >= 0.0 ? 1 : 0;
+        s_np = np;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int np = s_np, P8 = (np + 7) / 8 * 8, N8 = (E - np + 7) / 8 * 8;
+        int ip = 0, in = 0;
+        for (int k = 0; k < E; ++k) {
+            if (((1.0 - alpha) * 0.5 * (double)av[k]) >= 0.0) colk[ip++] = k;
+            else colk[P8 + in++] = k;
+        }
+        ord[0] = P8; ord[1] = P8 + N8; ord[2] = np; ord[3] = 0;
+    }
 }
 
 __global__ void k_pack_gat(const PackGatArgs a) {
@@ -285,6 +311,11 @@ int launch_fingerprint(const FingerprintArgs& a, int n_tensors, unsigned long lo
 int launch_pack_gather(const float* flat, const int* gidx, float* img, long n, hipStream_t s) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_pack_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flat, gidx, img, n);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_gat_colorder(const float* a_dev, int E, double alpha, int* colk_dev, int ncolk, int* ord_dev, hipStream_t s) {
+    hipLaunchKernelGGL(k_gat_colorder, dim3(1), dim3(256), 0, s, a_dev, E, alpha, colk_dev, ncolk, ord_dev);
     LAUNCH_CHECK();
     return 0;
 }

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_tband_scores(const TBandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const long r0 = (long)blockIdx.x * TB_ROWS;
-    const int PT = a.PT, lp = PT + 4;                  // LDS row: L' (PT) | c | pad
+    const int PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8, lp = PT + 4;                  // LDS row: L' (PT) | c | pad
     for (int u = tid; u < TB_ROWS * (lp >> 2); u += 256) {
         const int i = u / (lp >> 2), c4 = (u - i * (lp >> 2)) * 4;
         const long r = r0 + i < a.Lrows ? r0 + i : a.Lrows - 1;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_tband_scores(const TBandArgs a) {
 #pragma unroll
         for (int i = 0; i < TB_ROWS; ++i) acc[i] = 0.f;
         int k = 0;
-        for (; k < a.P8; k += 4) {
+        for (; k < P8; k += 4) {
             const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + k);
 #pragma unroll
             for (int i = 0; i < TB_ROWS; ++i) acc[i] = abs4<false>(acc[i], *reinterpret_cast<const f32x4*>(smem + i * lp + k), rv);
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(256) void k_tband_edges(const TBandArgs a) {
     const int lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= a.n) return;
-    const int K = a.K, PT = a.PT, pad = a.pad, EW = 2 * a.pad;
+    const int K = a.K, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8, pad = a.pad, EW = 2 * a.pad;
     const int kq = ((K + 3) & ~3) + 4;
     const int half = lane >> 5, l = lane & 31;
     const int nu = PT >> 2;
     const int lc = l < nu ? l : nu - 1;
-    const float sgn = (l >= nu) ? 0.f : (4 * l >= a.P8 ? -1.f : 1.f);
+    const float sgn = (l >= nu) ? 0.f : (4 * l >= P8 ? -1.f : 1.f);
     // the edge rows' other side: half 0 (keys) needs the edge queries' L', half 1 the edge keys' R'
     const int eside = half ? a.ldl : 0, oside = half ? 0 : a.ldl;
     f32x4 e[TB_EWMAX];
@@ -321,7 +321,7 @@ bool tband_applies(int K, int D, int PT, int pad, int ldl, int ldp) {
 
 int launch_tband_scores(const TBandArgs& a, hipStream_t s) {
     if (a.Lrows <= 0) return 0;
-    const size_t lds = (size_t)TB_ROWS * (a.PT + 4) * sizeof(float);
+    const size_t lds = (size_t)TB_ROWS * ((a.PTcap > a.PT ? a.PTcap : a.PT) + 4) * sizeof(float);
     hipLaunchKernelGGL(k_tband_scores, dim3((unsigned)((a.Lrows + TB_ROWS - 1) / TB_ROWS)), dim3(256), lds, s, a);
     LAUNCH_CHECK();
     return 0;
