@@ -483,7 +483,12 @@ int wgrad_slabs(long R, int Mp, int Np) {
     // 128 x 128 output blocks (one workgroup of 4 waves each); enough row slabs for ~4 workgroups per CU
     const long tiles = (long)((Mp + 127) / 128) * ((Np + 127) / 128);
     long s = 1024 / (tiles > 0 ? tiles : 1);
-    const long rmax = (R + 127) / 128;
+    // ... of at least MTADGAT_WGRAD_ROWS rows.  Measured (SMD shape, ms per training step at 256 / 1 024 / 8 192 windows): 128 rows
+    // 2.84 / 7.79 / 33.5, 384 rows 2.80 / 6.91 / 33.6, 768 rows 3.16 / 7.12 / 34.0, 1 536 rows 3.99 / 8.49 / 34.2 -- a workgroup walks
+    // its rows serially (a latency chain of staged 16-row steps), so short slabs win until the partial blocks (Mp x Np floats per
+    // slab, written here and read back by k_wgrad_reduce) cost more than the parallelism buys
+    static const long min_rows = getenv("MTADGAT_WGRAD_ROWS") ? atol(getenv("MTADGAT_WGRAD_ROWS")) : 384;
+    const long rmax = (R + min_rows - 1) / min_rows;
     if (s > rmax) s = rmax;
     if (s > 512) s = 512;
     if (s >= 8) s = s / 8 * 8;                 // whole groups of 8 slabs: the kernel's XCD-aware block map (k_wgrad_lds)
