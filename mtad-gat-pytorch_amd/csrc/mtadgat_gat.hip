@@ -728,6 +728,264 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
     }
 }
 
+// ---------------------------------------------------------------------------
+// gat (wide), more than 256 keys, inference: the key axis in blocks of 256 with a running softmax (round 5).
+// k_gat_wide keeps ALL scores of a query row in registers -- 128 per lane at 385..512 keys, i.e. a 512-register wave, one wave
+// per SIMD: the pair grid then issues one VALU instruction per ~4.7 cycles and nothing covers the staging round trips (config 4's
+// feature layer, 512 nodes: two thirds of that shape's pair-grid work at 0.2 of the vector ALU).  Here a workgroup walks the keys in
+// blocks of 256: pair grid of the block (all embedding parts; 64 score registers per lane), then
+//     m' = max(m, max_j s_j),  l = l e^(m - m') + sum_j e^(s_j - m'),  o = o e^(m - m') + sum_j e^(s_j - m') V_j
+// (the aggregation of the block on the 16x16x4 MFMA as in k_gat_wide), and at the end h = sigmoid(o / l): eight waves per workgroup,
+// two per SIMD.  Same inputs, same output; the softmax rows never exist as a whole, so the training forward (which keeps them)
+// stays on k_gat_wide.
+// ---------------------------------------------------------------------------
+template <int DTMAX>
+__global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int IBL = 4, JPL = 8, RJ = 16, RI = 4, IBW = 16, KPB = 2, KB = KPB * 128, NW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = 512;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long blk = blockIdx.x;
+    const long grp = blk / (8 * a.nblk);
+    const int within = (int)(blk - grp * (8 * a.nblk));
+    const long win = grp * 8 + (within & 7);
+    const int rb = within >> 3;
+    if (win >= a.nwin) return;
+    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
+    const int i0b = rb * (NW * IBW);
+    float* __restrict__ Ls = smem;                         // [128][34]
+    float* __restrict__ Rs = Ls + NW * IBW * GAT_LLD;      // [256][34]
+    const int lj = lane % RJ, li = lane / RJ;
+    const float* __restrict__ LCw = a.LC + (win * K) * (long)a.ldl;
+    const float* __restrict__ RTw = a.RT + win * (long)a.rt_rows * a.Kp;
+    const int i0 = i0b + wave * IBW;
+    lds_cptr lp[IBL];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        lp[ii] = (lds_cptr)(Ls + (wave * IBW + li + RI * ii) * GAT_LLD);
+        asm volatile("" : "+v"(lp[ii]));
+    }
+    const lds_cptr rp0 = (lds_cptr)(Rs + lj * GAT_LLD);
+    const int ntile = PT >> 3, ptile = P8 >> 3;
+    const int nparts = (ntile + 3) >> 2;
+    // aggregation-side layout (as k_gat_wide): the wave's softmax rows through its LDS slice, V through a shared 32-key tile
+    const int vld2 = ((D + 15) & ~15) + 4;
+    float* __restrict__ att = smem + wave * (IBW * GAT_APITCH);
+    float* __restrict__ Vs2 = smem + NW * IBW * GAT_APITCH;
+    const int agg_floats = NW * IBW * GAT_APITCH + 32 * vld2, pair_floats = (NW * IBW + KB) * GAT_LLD;
+    float* __restrict__ scl = smem + (agg_floats > pair_floats ? agg_floats : pair_floats) + wave * IBW;     // [16] per wave: row factors
+    const int nr = lane & 15, kbq = lane >> 4;
+    const int DT = (D + 15) >> 4;
+    const float* __restrict__ Vw = a.V + (win * K) * (long)a.ldv;
+    f32x4 o[DTMAX];
+#pragma unroll
+    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrow[IBL], lrow[IBL];
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) { mrow[ii] = -INFINITY; lrow[ii] = 0.f; }
+
+    for (int kb0 = 0; kb0 < K; kb0 += KB) {
+        float acc[KPB][IBL][JPL];
+#pragma unroll
+        for (int kp = 0; kp < KPB; ++kp)
+#pragma unroll
+            for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < JPL; ++jj) acc[kp][ii][jj] = 0.f;
+        for (int part = 0; part < nparts; ++part) {
+            const int c0 = 32 * part;
+            __syncthreads();                               // the previous users of Ls / Rs (pair grid, att / V tiles) are done
+            {
+                constexpr int EL = 8;                      // (128 rows x 32 columns) / 512 threads
+                float v[EL];
+#pragma unroll
+                for (int n = 0; n < EL; ++n) {
+                    const int u = tid + n * nthr;
+                    const int r = u >> 5, c = u & 31;
+                    const int row = i0b + r;
+                    const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;
+                    v[n] = LCw[(long)rc * a.ldl + cc];
+                }
+#pragma unroll
+                for (int n = 0; n < EL; ++n) {
+                    const int u = tid + n * nthr;
+                    const int r = u >> 5, c = u & 31;
+                    Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? v[n] : 0.f;
+                }
+            }
+            {
+                constexpr int BATCH = 8;                   // (256 keys x 32 columns) / 512 threads, in two batches
+#pragma unroll 1
+                for (int hb = 0; hb < 2; ++hb) {
+                    float v[BATCH];
+#pragma unroll
+                    for (int n = 0; n < BATCH; ++n) {
+                        const int u = tid + (hb * BATCH + n) * nthr;
+                        const int c = u / KB, j = kb0 + (u - c * KB);      // key fastest: coalesced reads of the key-minor rows
+                        const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;
+                        v[n] = RTw[(long)cc * a.Kp + jc];
+                    }
+#pragma unroll
+                    for (int n = 0; n < BATCH; ++n) {
+                        const int u = tid + (hb * BATCH + n) * nthr;
+                        const int c = u / KB, jl = u - c * KB;
+                        Rs[jl * GAT_LLD + c] = (kb0 + jl < K && c0 + c < PT) ? v[n] : 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+            int ntl = ntile - 4 * part;
+            ntl = ntl > 4 ? 4 : ntl;
+            int npos = ptile - 4 * part;
+            npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
+            static_for<0, KPB>([&](auto kpc) {
+                constexpr int kp = decltype(kpc)::value;
+                if (kb0 + kp * 128 < K) {
+                    f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
+                    lds_cptr lq[IBL];
+#pragma unroll
+                    for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
+                    lds_cptr rq = rp0 + kp * 128 * GAT_LLD;
+                    gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
+                    int kt = 0;
+#pragma unroll 1
+                    for (; kt < npos; ++kt) {
+                        gat_tile<IBL, JPL, RJ, false>(acc[kp], lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                        for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                        rq += 8;
+                    }
+#pragma unroll 1
+                    for (; kt < ntl; ++kt) {
+                        gat_tile<IBL, JPL, RJ, true>(acc[kp], lA, rA, lB, rB, lq, rq);
+#pragma unroll
+                        for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                        rq += 8;
+                    }
+                }
+            });
+        }
+        // ---- scores of the block, running softmax statistics; acc becomes e^(s - m'), scl the factor of what was summed before
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            const int irow = i0 + li + RI * ii;
+            const int irc = irow < K ? irow : K - 1;
+            const float cvr = LCw[(long)irc * a.ldl + PT];
+            float mb = -INFINITY;
+#pragma unroll
+            for (int kp = 0; kp < KPB; ++kp)
+#pragma unroll
+                for (int jj = 0; jj < JPL; ++jj) {
+                    const int j = kb0 + kp * 128 + lj + RJ * jj;
+                    const int jc = j < K ? j : K - 1;
+                    float v = acc[kp][ii][jj] + cvr + RTw[(long)PT * a.Kp + jc];
+                    if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
+                    if (a.bias) v += a.bias[(long)irc * K + jc];
+                    v = j < K ? v : -INFINITY;
+                    acc[kp][ii][jj] = v;
+                    mb = fmaxf(mb, v);
+                }
+            mb = row_max<RJ>(mb);
+            const float mnew = fmaxf(mrow[ii], mb);           // (finite: the block holds at least one real key)
+            const float f = mrow[ii] == -INFINITY ? 0.f : soft_exp(mrow[ii] - mnew);
+            float sum = 0.f;
+#pragma unroll
+            for (int kp = 0; kp < KPB; ++kp)
+#pragma unroll
+                for (int jj = 0; jj < JPL; ++jj) {
+                    const int j = kb0 + kp * 128 + lj + RJ * jj;
+                    const float e = (j < K && irow < K) ? soft_exp(acc[kp][ii][jj] - mnew) : 0.f;
+                    acc[kp][ii][jj] = e;
+                    sum += e;
+                }
+            sum = row_sum<RJ>(sum);
+            lrow[ii] = lrow[ii] * f + sum;
+            mrow[ii] = mnew;
+            if (lj == 0) scl[li + RI * ii] = f;
+        }
+        __syncthreads();                                   // every wave is done with Ls / Rs; scl is visible
+        {
+            const float f = scl[nr];
+#pragma unroll
+            for (int dt = 0; dt < DTMAX; ++dt)
+                if (dt < DT) { o[dt][0] *= f; o[dt][1] *= f; o[dt][2] *= f; o[dt][3] *= f; }
+        }
+        // ---- o += e V over the block's keys (k_gat_wide's aggregation loop)
+        static_for<0, 2 * KPB>([&](auto khc) {
+            {
+                constexpr int kp = decltype(khc)::value >> 1, half = decltype(khc)::value & 1;
+                const int k0 = kb0 + kp * 128 + half * 64;
+                if (k0 < K) {
+                    __syncthreads();
+#pragma unroll
+                    for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; ++j4) att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = acc[kp][ii][4 * half + j4];
+                    for (int kq = 0; kq < 2; ++kq) {
+                        const int kv = k0 + 32 * kq;
+                        if (kq) __syncthreads();
+                        if (kv < K) {
+                            for (int u = tid; u < 32 * (vld2 >> 2); u += nthr) {
+                                const int r = u / (vld2 >> 2), c4 = (u - r * (vld2 >> 2)) * 4;
+                                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                                if (kv + r < K) {
+                                    const float* src = Vw + (long)(kv + r) * a.ldv + c4;
+#pragma unroll
+                                    for (int s4 = 0; s4 < 4; ++s4) v[s4] = (c4 + s4 < D) ? src[s4] : 0.f;
+                                }
+                                *reinterpret_cast<f32x4*>(Vs2 + r * vld2 + c4) = v;
+                            }
+                        }
+                        __syncthreads();
+                        if (kv < K) {
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2) {
+                                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 32 * kq + 16 * g2 + 4 * kbq);
+                                const float* __restrict__ vk = Vs2 + (16 * g2 + 4 * kbq) * vld2;
+#pragma unroll
+                                for (int dt = 0; dt < DTMAX; ++dt)
+                                    if (dt < DT) {
+                                        float av[4];
+#pragma unroll
+                                        for (int t = 0; t < 4; ++t) av[t] = vk[t * vld2 + 16 * dt + nr];
+#pragma unroll
+                                        for (int t = 0; t < 4; ++t) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bq[t], o[dt], 0, 0, 0);
+                                    }
+                            }
+                        }
+                    }
+                }
+            }
+        });
+    }
+    // ---- h = sigmoid(o / l)
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii)
+        if (lj == 0) scl[li + RI * ii] = soft_rcp(lrow[ii]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    {
+        const float inv = scl[nr];
+        const int row = i0 + nr;
+        float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
+#pragma unroll
+        for (int dt = 0; dt < DTMAX; ++dt)
+            if (dt < DT) {
+                const int d0 = 16 * dt + 4 * kbq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row < K && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = gate_sigmoid(o[dt][r] * inv);
+            }
+    }
+}
+
+size_t gat_wide_os_lds(int D) {
+    const size_t pair = (size_t)(8 * 16 + 256) * GAT_LLD;
+    const size_t agg = (size_t)8 * 16 * GAT_APITCH + (size_t)32 * (((D + 15) & ~15) + 4);
+    return ((pair > agg ? pair : agg) + 8 * 16) * sizeof(float);
+}
+
 size_t gat_wide_lds(int K, int D, int nw) {
     const int KP = (K + 127) / 128;
     const size_t pair = (size_t)(nw * 16 + KP * 128) * GAT_LLD;
@@ -749,10 +1007,26 @@ int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int 
     a.v1 = v1; a.alpha = alpha;
     a.ATT = att; a.drop_stream = drop_stream; a.ord = ord;
     if (drop) a.drop = *drop;
+    const int dtmax = D <= 256 ? 16 : 32;
+    static const bool os_off = getenv("MTADGAT_WIDE_OS") && atoi(getenv("MTADGAT_WIDE_OS")) == 0;     // (measurement hook)
+    if (K > 256 && dtmax == 16 && !att && !(drop && drop->thresh) && !os_off) {
+        // more than 256 keys, node dimension up to 256, inference: key blocks of 256 with a running softmax (eight waves per
+        // workgroup, two per SIMD; with 32 output tiles per lane -- D up to 512 -- the kernel spills and k_gat_wide stays)
+        a.nblk = (K + 127) / 128;
+        const size_t lds2 = gat_wide_os_lds(D);
+        if (lds2 <= 160 * 1024) {
+            const unsigned grid2 = (unsigned)(((nwin + 7) / 8 * 8) * a.nblk);
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_wide_os<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            if (e_ != hipSuccess) return (int)e_;
+            hipLaunchKernelGGL((k_gat_wide_os<16>), dim3(grid2), dim3(512), lds2, s, a);
+            LAUNCH_CHECK();
+            return 0;
+        }
+        a.nblk = (K + nw * 16 - 1) / (nw * 16);
+    }
     const size_t lds = gat_wide_lds(K, D, nw);
     if (lds > 160 * 1024) return -2;
     const unsigned grid = (unsigned)(((nwin + 7) / 8 * 8) * a.nblk);
-    const int dtmax = D <= 256 ? 16 : 32;
 #define WIDE_CASE(N, DTM)                                                                                              \
     if (KP == N && dtmax == DTM) {                                                                                     \
         if (lds > 64 * 1024) {                                                                                         \
