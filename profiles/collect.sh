@@ -18,6 +18,8 @@ rm -rf /tmp/ktt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/
 cp "$(find /tmp/ktt -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_train256.csv"
 rm -rf /tmp/ktt8 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktt8 -- python "$ROOT/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_bench_line.json" 2> /dev/null
 cp "$(find /tmp/ktt8 -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_train8192.csv"
+# (the line above was taken UNDER rocprofv3: its ms_per_step carries the tracer's overhead; the plain run is the number to quote)
+python "$ROOT/bench.py" --mode train --steps 5 --warmup 2 > "$OUT/train_bench_line_plain.json" 2> /dev/null
 rm -rf /tmp/ktf && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktf -- python "$ROOT/profiles/forward_small.py" 256 > "$OUT/forward_256.txt" 2> /dev/null
 cp "$(find /tmp/ktf -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_fwd256.csv"
 rm -rf /tmp/kts && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kts -- python "$ROOT/profiles/series_bench.py" > "$OUT/series_65536.txt" 2> /dev/null

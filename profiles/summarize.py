@@ -60,9 +60,10 @@ stats_table("kernel_stats_fwd256.csv", f"{tag}_kernel_trace_stats_fwd256.txt",
             "# rocprofv3 --kernel-trace --stats -- python profiles/forward_small.py 256   (MSL shape, 55 eval forwards of 256 windows)")
 stats_table("kernel_stats_series.csv", f"{tag}_kernel_trace_stats_series.txt",
             "# rocprofv3 --kernel-trace --stats -- python profiles/series_bench.py   (MSL shape, score_series over 65 536 stride-1 windows, 8 calls)")
-for extra in ("train_step_256.txt", "forward_256.txt", "train_bench_line.json", "series_65536.txt", "batch_sweep.txt"):
+for extra, out in (("train_step_256.txt", None), ("forward_256.txt", None), ("train_bench_line.json", "train_bench_line_under_rocprof.json"),
+                   ("train_bench_line_plain.json", None), ("series_65536.txt", None), ("batch_sweep.txt", None)):
     if os.path.exists(os.path.join(d, extra)):
-        open(os.path.join(d, f"{tag}_{extra}"), "w").write(open(os.path.join(d, extra)).read())
+        open(os.path.join(d, f"{tag}_{out or extra}"), "w").write(open(os.path.join(d, extra)).read())
 
 
 def pmc(path):
