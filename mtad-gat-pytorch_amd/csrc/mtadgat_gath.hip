@@ -484,9 +484,15 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * RJ * GAT_LLD + col];
     }
     __syncthreads();
-    if (!rows_owner) return;                           // no barrier below this point
-    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.out[0] = cv[0] + dv[0]; return; }
-
+    if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.out[0] = cv[0] + dv[0]; return; }       // (uniform)
+    static_assert(IBW == 16, "one 16-row MFMA group per wave");
+    constexpr int DTMAX = 8;                           // D <= 128 (plan)
+    const int DT = (D + 15) >> 4;
+    const int nr = lane & 15, kb = lane >> 4;
+    f32x4 o[DTMAX];
+#pragma unroll
+    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rows_owner) {                                  // (the waves that only project wait at the barrier below)
     // ---- scores -> softmax over j (reference modules.py:85-89 / :184-188); S leaves the scores here
     const float sinv = a.scale2[1];
 #pragma unroll
@@ -527,17 +533,10 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) as out^T = V^T att^T on v_mfma_f32_16x16x16_f16, three terms per product
     // (k_gat); the softmax rows go through this wave's slice of the (now free) Ls / Rs region 64 keys at a time and are split per
     // 16-key group, the node values come as packed fp16 pieces straight from LDS
-    static_assert(IBW == 16, "one 16-row MFMA group per wave");
-    constexpr int DTMAX = 8;                           // D <= 128 (plan)
     constexpr int APP = 36;                            // pitch of the restaged rows: 32 keys per pass
     float* __restrict__ att = Ls + wave * (IBW * APP);
-    const int DT = (D + 15) >> 4;
-    const int nr = lane & 15, kb = lane >> 4;
     constexpr int JPP = 32 / RJ;                       // key registers per 32-key pass
     constexpr int PASSES = (JPL + JPP - 1) / JPP;
-    f32x4 o[DTMAX];
-#pragma unroll
-    for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int lo_off = (int)(Vl - Vh);
 #pragma unroll
@@ -591,26 +590,38 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             }
         }
     }
+    }   // rows_owner
+    // ---- output.  The layer's K x D result leaves through LDS (round 5): every wave drops its sigmoid values into one tile laid
+    // out like the destination -- rows along the output's long stride, the unit-stride index inside a row -- and the workgroup
+    // then writes whole rows, 256 consecutive bytes per wave instruction.  Before, a lane stored the four values it held: 16-byte
+    // pieces that start 56 bytes into a 64-byte sector for the temporal layer (45 KB written for a 22 KB output) and, for the
+    // feature layer -- whose node index is the output's unit-stride index -- four separate 4-byte stores 704 bytes apart.
+    // The tile takes the L' / R' region and runs on into the pieces: nobody reads either after the barrier.
+    __syncthreads();
     {
-        const int row = i0 + nr;
-        const bool rv = nr < RI * iblw && row < K;
-        float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
+        float* __restrict__ otile = smem;
+        const bool nodes_minor = a.so_i == 1;            // feature layer: out[.. + node + d * so_d]; temporal: out[.. + node * so_i + d]
+        const int R = nodes_minor ? D : K, C = nodes_minor ? K : D;      // rows x unit-stride columns of the destination block
+        if (rows_owner) {
+            const int row = i0 + nr;
+            const bool rv = nr < RI * iblw && row < K;
 #pragma unroll
-        for (int dt = 0; dt < DTMAX; ++dt)
-            if (dt < DT) {
-                const int d0 = 16 * dt + 4 * kb;
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = gate_sigmoid(o[dt][r]);
-                if (a.so_d == 1 && rv && d0 + 3 < D) {
-                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-                    *reinterpret_cast<f32x4_a4*>(orow + d0) = y;
-                } else {
+            for (int dt = 0; dt < DTMAX; ++dt)
+                if (dt < DT) {
+                    const int d0 = 16 * dt + 4 * kb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (rv && d0 + r < D) orow[(long)(d0 + r) * a.so_d] = y[r];
+                        if (rv && d0 + r < D) otile[nodes_minor ? (d0 + r) * C + row : row * C + d0 + r] = gate_sigmoid(o[dt][r]);
                 }
-            }
+        }
+        __syncthreads();
+        const long rstride = nodes_minor ? a.so_d : a.so_i;
+        float* __restrict__ obase = a.out + win * a.so_w;
+        const float cinv = 1.0f / (float)C;
+        for (int u = tid; u < R * C; u += nthr) {
+            const int r = (int)(((float)u + 0.5f) * cinv), c = u - r * C;
+            obase[(long)r * rstride + c] = otile[u];
+        }
     }
 }
 

@@ -231,17 +231,19 @@ class MTAD_GAT(nn.Module):
         object.__setattr__(self, "_fp_pending", None)
         object.__setattr__(self, "_fp_value", None)
         if "precision" not in self.__dict__:
-            # arithmetic of GPU inference: "fp32" (<= 1e-5 of the reference: fp32 accumulation everywhere; the large-batch
-            # kernels form their products from split-bf16 operands on the bf16 matrix pipe, which reproduces the
-            # fp32-MFMA result to ~2e-7 -- DESIGN.md section 4), "fp32_strict" (v_mfma_f32 / fp32 VALU only), "bf16"
-            # (bf16 MFMA operands, fp32 accumulation / state / softmax, <= 2e-2), "auto" = bf16 exactly when the
-            # caller hands over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
+            # arithmetic of GPU inference: "fp32" (<= 1e-5 of the reference: fp32 accumulation, state, gates and softmax
+            # everywhere; the large-batch kernels form their products from split 16-bit operands on the 16-bit matrix pipe --
+            # two fp16 pieces per operand where its range is bounded or recorded (recurrent state, attention outputs, the
+            # convolution's outputs below 2^15, weights under a per-layer power of two), three bf16 pieces otherwise -- which
+            # reproduces the fp32-MFMA result to ~2e-7: DESIGN.md section 4), "fp32_strict" (v_mfma_f32 / fp32 VALU only),
+            # "bf16" (bf16 MFMA operands, fp32 accumulation / state / softmax, <= 2e-2), "auto" = bf16 exactly when the caller
+            # hands over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
             object.__setattr__(self, "precision", "auto")
         if "bf16_training_recurrences" not in self.__dict__:
-            # False (default): a training step always runs the fp32 step (split-operand / small-batch recurrences), also
-            # when bf16 is requested -- it is the faster one at every batch size (batch 256: 3.2 vs 8.5 ms, 8 192: 46.7 vs
-            # 47.9 ms) and the more accurate one.  True: the four recurrences of the step on bf16 MFMA operands (the
-            # arithmetic of BASELINE's "bf16 train loop" configuration)
+            # False (default): a training step always runs the fp32 step (split-operand / small-batch recurrences), also when
+            # bf16 is requested -- it is the faster one at every batch size (round 5, SMD shape: batch 256 2.8 vs 8.4 ms, batch
+            # 8 192 33.7 vs 36.6 ms) and the more accurate one.  True: the four recurrences of the step on bf16 MFMA operands
+            # (the arithmetic of BASELINE's "bf16 train loop" configuration)
             object.__setattr__(self, "bf16_training_recurrences", False)
         if "check_weight_contents" not in self.__dict__:
             # True: every GPU call fingerprints the parameter *contents* (one small reduction whose 8-byte result is read after
