@@ -74,10 +74,15 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         w[u][0] = wp[((long)q * 2) * 64];
         w[u][1] = wp[((long)q * 2 + 1) * 64];
     };
+    auto fresh_lane = [&]() -> int {                  // the lane id, recomputed where it is used: see the note at the tail
+        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(l));
+        return l;
+    };
     auto prefetch = [&](int part) {
         if (wave < ntask) {
             const int wtile = wave >= NTn ? a.NT_L + part : part;
-            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + lane;
+            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + fresh_lane();
 #pragma unroll
             for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
         }
@@ -379,10 +384,12 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             const bool keyside = task >= NTn;
             const int nt = keyside ? task - NTn : task;
             const int wtile = keyside ? a.NT_L + part : part;
+            const int lane_p = fresh_lane();
+            const int i = lane_p & 31, g = lane_p >> 5;          // MFMA roles
             const int node = nt * 32 + i;
             const unsigned short* __restrict__ vrh = Vh + (node < K ? node : K - 1) * pvh + 4 * g;
             const unsigned short* __restrict__ vrl = Vl + (node < K ? node : K - 1) * pvh + 4 * g;
-            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + lane;
+            const f32x4* __restrict__ wp = Wbase + ((long)wtile * Q) * (64 * 2) + lane_p;
             if (task != wave) {
 #pragma unroll
                 for (int u = 0; u < QB; ++u) wfetch(wp, u, u < Q ? u : Q - 1);
@@ -488,7 +495,13 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     static_assert(IBW == 16, "one 16-row MFMA group per wave");
     constexpr int DTMAX = 8;                           // D <= 128 (plan)
     const int DT = (D + 15) >> 4;
-    const int nr = lane & 15, kb = lane >> 4;
+    // The lane's roles for the tail, from a fresh lane id: held across the pair grid they cost registers the 128-VGPR budget does
+    // not have -- the compiler spilled them (11 dwords per lane = 22 KB of scratch writes per window, which the round-4 counters
+    // showed as "45 KB written for a 22 KB output")
+    int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_t));
+    const int ljt = lane_t % RJ, lit = lane_t / RJ;
+    const int nr = lane_t & 15, kb = lane_t >> 4;
     f32x4 o[DTMAX];
 #pragma unroll
     for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -497,14 +510,14 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const float sinv = a.scale2[1];
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) {
-        const int irow = i0 + li + RI * ii;
+        const int irow = i0 + lit + RI * ii;
         const bool rowok = ii < iblw && irow < K;
         const int irc = irow < K ? irow : K - 1;
         float e[JPL];
         float m = -INFINITY;
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
-            const int j = lj + RJ * jj;
+            const int j = ljt + RJ * jj;
             const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
             float v;
             if (a.v1) {
@@ -521,7 +534,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         float sum = 0.f;
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
-            e[jj] = (lj + RJ * jj < K) ? gath_exp(e[jj] - m) : 0.f;
+            e[jj] = (ljt + RJ * jj < K) ? gath_exp(e[jj] - m) : 0.f;
             sum += e[jj];
         }
         sum = row_sum<RJ>(sum);
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
                 for (int j4 = 0; j4 < JPP; ++j4)
-                    att[(li + RI * ii) * APP + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
+                    att[(lit + RI * ii) * APP + ljt + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const int jn = min(32, K - pass * 32);
@@ -617,11 +630,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         __syncthreads();
         const long rstride = nodes_minor ? a.so_d : a.so_i;
         float* __restrict__ obase = a.out + win * a.so_w;
-        const float cinv = 1.0f / (float)C;
-        for (int u = tid; u < R * C; u += nthr) {
-            const int r = (int)(((float)u + 0.5f) * cinv), c = u - r * C;
-            obase[(long)r * rstride + c] = otile[u];
-        }
+        // a wave instruction stays inside one destination row (its 64-byte sectors are touched by one request each)
+        for (int r = wave; r < R; r += NW)
+            for (int c = lane_t; c < C; c += 64) obase[(long)r * rstride + c] = otile[r * C + c];
     }
 }
 
