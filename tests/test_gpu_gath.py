@@ -282,3 +282,34 @@ def test_fused_convolution_range_guard_is_per_window(gpu_device):
     ordinary[::5] = False
     assert (p2[ordinary] - p1[ordinary]).abs().max().item() <= 2e-6 and (r2[ordinary] - r1[ordinary]).abs().max().item() <= 2e-6
     assert (p2 - p1).abs().max().item() <= tol and (r2 - r1).abs().max().item() <= tol
+
+
+def test_fused_convolution_reads_bfloat16_windows_and_series_views(gpu_device):
+    """The convolution inside the temporal workgroup takes its window the ways k_conv_win does: float32 or bfloat16 elements,
+    materialised windows or views of a device-resident series (arithmetic progression or explicit starts).  Each must equal the
+    two-launch path bit for bit."""
+    case = Case("smd_1_1")
+    model = case.build_model().to(gpu_device)
+    model.precision = "fp32"
+    model.check_weight_contents = False
+    eng = _engine(model, gpu_device)
+    W, F = case.kwargs["window_size"], case.kwargs["n_features"]
+    g = torch.Generator().manual_seed(41)
+    series = torch.rand(400 + W - 1, F, generator=g).to(gpu_device)
+    starts = torch.randperm(400, generator=g)[:77].to(gpu_device)
+    xb = torch.rand(65, W, F, generator=g).to(gpu_device).to(torch.bfloat16)
+    model.share_series_pair_scores = False
+    with torch.no_grad():
+        eng.set_option("conv_kernel", 2)
+        eng.set_option("gat_kernel", 3)
+        outs = {}
+        for fused in (True, False):
+            _fused(eng, fused)
+            outs[fused] = (model(xb), model.forward_series(series, start=3, stride=2, count=150), model.forward_series(series, starts=starts))
+        _fused(eng, True)
+        eng.set_option("conv_kernel", 0)
+        eng.set_option("gat_kernel", 0)
+        ref = model(torch.stack([series[s:s + W] for s in starts.tolist()]))
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert (outs[True][2][0] - ref[0]).abs().max().item() <= 2e-6 and (outs[True][2][1] - ref[1]).abs().max().item() <= 2e-6
