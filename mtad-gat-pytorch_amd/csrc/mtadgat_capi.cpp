@@ -299,7 +299,8 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     // (inference, node values below 2^15 -- decided on the device from the convolution's recorded maximum: of the two launches
     // exactly one does the work)
     const int scols = vt ? g.K : g.D;
-    if (a.bf16 == 2 && vmax && !att && (m.gat_kernel == 0 || m.gat_kernel == 3) && g.fh_lds_bytes <= 160 * 1024 && aligned16(v) &&
+    // (training forward -- att set -- from 4096 windows as well: k_gath keeps the softmax rows and applies the dropout)
+    if (a.bf16 == 2 && vmax && (!att || n >= 4096) && (m.gat_kernel == 0 || m.gat_kernel == 3) && g.fh_lds_bytes <= 160 * 1024 && aligned16(v) &&
         (ldv & 3) == 0 && ((scols + 3) & ~3) <= ldv) {
         GatArgs b = a;
         b.vld = g.fh_vld; b.lr_floats = g.fh_lr; b.n_full = g.fh_full; b.n_short = g.fh_short;
@@ -1580,13 +1581,13 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
     // the two attention layers: fused per-window kernels, or -- wide layers -- projection through memory + k_gat_wide; either way
     // the softmax rows are kept and the dropout of modules.py:90 / :189 is applied inside the kernel
     if (use_fused(m.temp)) {
-        if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
+        if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP, vmax))) return rc;
     } else {
         if ((rc = run_proj(m, m.temp, hcat, m.Dp, n * W, T + t.lct, T + t.rtt, s))) return rc;
         if ((rc = run_attend(m, m.temp, T + t.lct, T + t.rtt, hcat, m.Dp, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, T + t.att_t, &drop, DROP_TEMP))) return rc;
     }
     if (use_fused(m.feat)) {
-        if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT))) return rc;
+        if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, T + t.att_f, &drop, DROP_FEAT, vmax))) return rc;
     } else {
         const float* xct = T + t.xct;
         if ((rc = run_proj(m, m.feat, xct, m.Wp, n * F, T + t.lcf, T + t.rtf, s))) return rc;

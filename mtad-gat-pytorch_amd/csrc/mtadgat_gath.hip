@@ -16,7 +16,8 @@ namespace mtadgat {
 //     (ds_read_b64_tr_b16, round 5; rounds 3-4 gathered it with eight 16-bit reads and four merges per tile);
 //     the softmax rows are split per 16-key group as before;
 //   * staging: one index computation per 16-byte unit, exp with one rounding-error term.
-// Same LDS budget as k_gat (pieces: 2 x 2 bytes per value), same pair grid (gat_tile), same launch geometry.
+// Same LDS budget as k_gat (pieces: 2 x 2 bytes per value), same pair grid (gat_tile), same launch geometry.  Round 5: also the
+// training forward's kernel from 4096 windows (keeps the softmax rows in a.ATT, applies the attention dropout).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float gath_exp(float x) {      // e^x, x <= 0 (or -inf): the product x log2(e) in two pieces
     const float c_hi = 1.4426950216293335f;
@@ -543,6 +544,25 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = rowok ? e[jj] * inv : 0.f;
     }
 
+    if (a.ATT || a.drop.thresh) {                      // training forward: keep the softmax rows, drop attention entries (counter-based mask)
+        const unsigned key = drop_window_key(a.drop, a.drop_stream, win);
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            const int irow = i0 + lit + RI * ii;
+            if (ii < iblw && irow < K) {
+                float* __restrict__ ap = a.ATT ? a.ATT + (win * K + irow) * (long)K : nullptr;
+#pragma unroll
+                for (int jj = 0; jj < JPL; ++jj) {
+                    const int j = ljt + RJ * jj;
+                    if (j < K) {
+                        if (ap) ap[j] = acc[ii][jj];
+                        if (a.drop.thresh) acc[ii][jj] *= drop_keep(key, (unsigned)(irow * K + j), a.drop.thresh) ? a.drop.keep_scale : 0.f;
+                    }
+                }
+            }
+        }
+    }
+
     // ---- aggregation h_i = sigmoid(sum_j att_ij V_j) as out^T = V^T att^T on v_mfma_f32_16x16x16_f16, three terms per product
     // (k_gat); the softmax rows go through this wave's slice of the (now free) Ls / Rs region 64 keys at a time and are split per
     // 16-key group, the node values come as packed fp16 pieces straight from LDS
@@ -663,7 +683,7 @@ bool gath_conv_applies(const GatArgs& a, int nw, int F, int W) {
 // conv: the workgroup computes the window's convolution first (a.cv; a.V is not read)
 int launch_gath(const GatArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, bool conv, hipStream_t s) {
     if (a.nwin <= 0) return 0;
-    if (rj * JPL < a.K || nw > 8 || a.ATT || a.n_full + a.n_short > nw || a.n_full * 16 + a.n_short * (16 - 64 / rj) < a.K) return -2;
+    if (rj * JPL < a.K || nw > 8 || a.n_full + a.n_short > nw || a.n_full * 16 + a.n_short * (16 - 64 / rj) < a.K) return -2;
     if (conv && !gath_conv_applies(a, nw, a.D, a.K)) return -2;
     const unsigned grid = (unsigned)a.nwin;
     bool launched = false;
