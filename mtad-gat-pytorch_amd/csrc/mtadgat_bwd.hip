@@ -71,6 +71,11 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
+    // tiles of this wave that lie wholly in the padding of d W (M, N rounded up to 32, the block to 128) issue nothing: with
+    // N = 166 + 1 the second 128-column block holds two real 32-column tiles of four, with M = 480 the fourth block row three of
+    // four -- at the GRU layer's shapes 30 % of the 2 x 2 x (blocks) tiles (wave-uniform predicates: no divergence)
+    const bool mval[2] = {128 * mb + 64 * wm < a.Mp, 128 * mb + 64 * wm + 32 < a.Mp};
+    const bool nval[2] = {128 * nb + 64 * wn < a.Np, 128 * nb + 64 * wn + 32 < a.Np};
     float av[8], bv[8];
     // vector staging role: thread -> float4 (tid & 31) of rows (tid >> 5) + 8 e, e = 0..1
     const int vc4 = (tid & 31) * 4, vrow0 = tid >> 5;
@@ -149,7 +154,10 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
         }
     };
 
-    if (rbeg < rend) {
+    // the main loop for NX x NY real tiles of this wave (the valid tiles are the leading ones), chosen once outside the loop: a
+    // predicate inside it costs the software pipeline its counted waits (21 % slower at 256 windows when tried that way)
+    auto main_loop = [&](auto nx_tag, auto ny_tag) {
+        constexpr int NX = decltype(nx_tag)::value, NY = decltype(ny_tag)::value;
         gload(rbeg);
         sstore(0);
         __syncthreads();
@@ -163,17 +171,23 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 lo, hi;
+                    if constexpr (NY > 0)
+                        if (u < NX) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = As[buf][4 * kk + s4][64 * wm + 32 * u + c]; hi[s4] = As[buf][8 + 4 * kk + s4][64 * wm + 32 * u + c]; }
-                    split3(lo, hi, ap[u][0], ap[u][1], ap[u][2]);
+                            for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = As[buf][4 * kk + s4][64 * wm + 32 * u + c]; hi[s4] = As[buf][8 + 4 * kk + s4][64 * wm + 32 * u + c]; }
+                            split3(lo, hi, ap[u][0], ap[u][1], ap[u][2]);
+                        }
+                    if constexpr (NX > 0)
+                        if (u < NY) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = Bs[buf][4 * kk + s4][64 * wn + 32 * u + c]; hi[s4] = Bs[buf][8 + 4 * kk + s4][64 * wn + 32 * u + c]; }
-                    split3(lo, hi, bp[u][0], bp[u][1], bp[u][2]);
+                            for (int s4 = 0; s4 < 4; ++s4) { lo[s4] = Bs[buf][4 * kk + s4][64 * wn + 32 * u + c]; hi[s4] = Bs[buf][8 + 4 * kk + s4][64 * wn + 32 * u + c]; }
+                            split3(lo, hi, bp[u][0], bp[u][1], bp[u][2]);
+                        }
                 }
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+                for (int x = 0; x < NX; ++x)
 #pragma unroll
-                    for (int y = 0; y < 2; ++y) acc[x][y] = mfma_s3(ap[x], bp[y], acc[x][y]);
+                    for (int y = 0; y < NY; ++y) acc[x][y] = mfma_s3(ap[x], bp[y], acc[x][y]);
             } else
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -187,14 +201,25 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
                         bf[u] = Bs[buf][lr][64 * wn + 32 * u + c];
                     }
 #pragma unroll
-                    for (int x = 0; x < 2; ++x)
+                    for (int x = 0; x < NX; ++x)
 #pragma unroll
-                        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x], bf[y], acc[x][y], 0, 0, 0);
+                        for (int y = 0; y < NY; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x], bf[y], acc[x][y], 0, 0, 0);
                 }
             if (more) sstore(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
+    };
+    if (rbeg < rend) {
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        const int nx = a.noskip ? 2 : (mval[0] ? 1 : 0) + (mval[1] ? 1 : 0), ny = a.noskip ? 2 : (nval[0] ? 1 : 0) + (nval[1] ? 1 : 0);
+        if (nx == 2 && ny == 2) main_loop(I2{}, I2{});
+        else if (nx == 0 || ny == 0) main_loop(I0{}, I0{});
+        else if (nx == 2) main_loop(I2{}, I1{});
+        else if (ny == 2) main_loop(I1{}, I2{});
+        else main_loop(I1{}, I1{});
     }
     float* __restrict__ P = a.P + (long)slab * a.Mp * a.Np;
 #pragma unroll
@@ -233,6 +258,8 @@ int launch_wgrad(const WgradArgs& a, hipStream_t s) {
     {
         static const int plain = getenv("MTADGAT_WGRAD_PLAIN") ? 1 : 0;       // measurement hook: the (tile, slab) grid as launched
         const_cast<WgradArgs&>(a).plain_map = plain;
+        static const int noskip = getenv("MTADGAT_WGRAD_NOSKIP") ? 1 : 0;    // measurement hook: issue the all-padding tiles as well
+        const_cast<WgradArgs&>(a).noskip = noskip;
         const dim3 grid((unsigned)(((a.Mp + 127) / 128) * ((a.Np + 127) / 128)), (unsigned)a.nslab);
         const bool vec = a.bmode == 0 && (a.lda & 3) == 0 && (a.ldb & 3) == 0 && a.lda >= 4 && a.ldb >= 4 &&
                          (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0;

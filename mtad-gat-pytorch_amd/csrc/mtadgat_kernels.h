@@ -220,6 +220,7 @@ struct WgradArgs {
     int Mp, Np;
     int x3;              // 1: products from three bf16 pieces per operand on the 16-bit matrix pipe (fp32-class sums)
     int plain_map;       // measurement hook: 1 = no XCD-aware tile / slab remap
+    int noskip;          // measurement hook: 1 = the tiles that lie wholly in the padding of d W are issued as well
 };
 
 // out[rowmap[m] + colmap[n]] += sum_slab P[slab][m][n];  column N (ones) -> outB[rowmapB[m]]
