@@ -1178,6 +1178,8 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
     // latencies -- so the stages that do not depend on each other run side by side: the feature layer next to the temporal one
     // (both read the convolution, mtad_gat.py:68-69), the forecasting head next to the reconstruction decoder (both read h_end,
     // mtad_gat.py:76-77).  Same kernels, same results; the second stream joins before the call returns.
+    // (large calls gain nothing from it: with the convolution as its own launch and both attention layers side by side, 65 536
+    // windows take 21.0-21.2 ms against 21.1-21.3 one after the other -- the layers compete for the same vector ALUs)
     const bool fork = !second && sched.size() == 1 && m.lanes == 0 && sched[0].n <= FORK_MAX_WINDOWS && use_fused(m.temp) && use_fused(m.feat) &&
                       !tband_selected(m, src, sched[0].n);
     if (second || fork) {
