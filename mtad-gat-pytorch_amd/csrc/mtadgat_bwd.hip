@@ -29,7 +29,7 @@ constexpr int WG_ROWS = 16;
 // tile instead of eight v_mfma_f32_32x32x2_f32: 2.7x less matrix time, fp32-class sums -- mtadgat_device.h); the 16 rows of a
 // staging step are exactly one chunk, a lane gathers its eight rows of a column from the fp32 tile and splits them
 template <int BMODE, bool VEC, bool X3 = false>
-__global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
+__global__ __launch_bounds__(256, (VEC || BMODE == 1) ? 3 : 2) void k_wgrad_lds(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][WG_ROWS][128];
     __shared__ __attribute__((aligned(16))) float Bs[2][WG_ROWS][128];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -76,36 +76,65 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
     // four -- at the GRU layer's shapes 30 % of the 2 x 2 x (blocks) tiles (wave-uniform predicates: no divergence)
     const bool mval[2] = {128 * mb + 64 * wm < a.Mp, 128 * mb + 64 * wm + 32 < a.Mp};
     const bool nval[2] = {128 * nb + 64 * wn < a.Np, 128 * nb + 64 * wn + 32 < a.Np};
+    // The loads of a piece are issued raw (clamped addresses, nothing looks at the values) and masked only when they are
+    // written to LDS, after the MFMAs of the piece before: a select right behind the load made the compiler fold the load
+    // into the select's control flow and wait for each one in turn (four serial memory round trips per staging step).
     float av[8], bv[8];
     // vector staging role: thread -> float4 (tid & 31) of rows (tid >> 5) + 8 e, e = 0..1
     const int vc4 = (tid & 31) * 4, vrow0 = tid >> 5;
+    const int colA = 128 * mb + vc4, colB = 128 * nb + vc4;
+    const int ccA = colA + 3 < (int)a.lda ? colA : (int)a.lda - 4;
+    const int ccB = colB + 3 < (int)a.ldb ? colB : (int)a.ldb - 4;
     auto gload = [&](long r0) {
+        if (VEC) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const long row = r0 + vrow0 + 8 * e;
+                const long rowc = row < rend ? row : a.R - 1;
+                long br = rowc - (a.bshift ? 1 : 0);
+                br = br < 0 ? 0 : br;
+                const f32x4 va = *reinterpret_cast<const f32x4*>(a.A + rowc * a.lda + ccA);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(a.B + br * a.ldb + ccB);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { av[4 * e + s4] = va[s4]; bv[4 * e + s4] = vb[s4]; }
+            }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long row = r0 + srow0 + 2 * e;
+            const long rowc = row < rend ? row : a.R - 1;
+            av[e] = a.A[rowc * a.lda + mc];
+            if (BMODE == 1) {
+                long xr = rowc + tapn - a.pad;
+                xr = xr < 0 ? 0 : (xr < a.R ? xr : a.R - 1);
+                bv[e] = a.B[xr * a.F + chn];
+            } else {
+                long br = rowc - (a.bshift ? 1 : 0);
+                br = br < 0 ? 0 : br;
+                bv[e] = a.B[br * a.ldb + nc];
+            }
+        }
+    };
+    // r0: the first row of the piece held in av / bv
+    auto sstore = [&](int buf, long r0) {
         if (VEC) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const long row = r0 + vrow0 + 8 * e;
                 const bool rok = row < rend;
                 const long rowc = rok ? row : a.R - 1;
-                {
-                    const int col = 128 * mb + vc4;
-                    const int cc = col + 3 < (int)a.lda ? col : (int)a.lda - 4;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + rowc * a.lda + cc);
+                const bool tok = !(a.bshift && ((unsigned)rowc % (unsigned)T) == 0);
+                const bool aok = rok && ccA == colA, bok = rok && tok && ccB == colB;
+                f32x4 va, vb;
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) av[4 * e + s4] = (rok && cc == col && col + s4 < a.M) ? v[s4] : 0.f;
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    va[s4] = (aok && colA + s4 < a.M) ? av[4 * e + s4] : 0.f;
+                    const float x = (bok && colB + s4 < a.N) ? bv[4 * e + s4] : 0.f;
+                    vb[s4] = (rok && colB + s4 == a.N) ? 1.f : x;               // the all-ones column
                 }
-                {
-                    const int col = 128 * nb + vc4;
-                    const int cc = col + 3 < (int)a.ldb ? col : (int)a.ldb - 4;
-                    long br = rowc - (a.bshift ? 1 : 0);
-                    br = br < 0 ? 0 : br;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(a.B + br * a.ldb + cc);
-                    const bool tok = !(a.bshift && ((unsigned)rowc % (unsigned)T) == 0);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const float x = (rok && tok && cc == col && col + s4 < a.N) ? v[s4] : 0.f;
-                        bv[4 * e + s4] = (rok && col + s4 == a.N) ? 1.f : x;       // the all-ones column
-                    }
-                }
+                *reinterpret_cast<f32x4*>(&As[buf][vrow0 + 8 * e][vc4]) = va;
+                *reinterpret_cast<f32x4*>(&Bs[buf][vrow0 + 8 * e][vc4]) = vb;
             }
             return;
         }
@@ -114,43 +143,16 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
             const long row = r0 + srow0 + 2 * e;
             const bool rok = row < rend;
             const long rowc = rok ? row : a.R - 1;
-            const float va = a.A[rowc * a.lda + mc];
-            av[e] = (rok && mcol < a.M) ? va : 0.f;
-            float vb;
             bool ok = rok && ncol < a.N;
             if (BMODE == 1) {
                 const int t = (int)((unsigned)rowc % (unsigned)T);      // R = windows * steps fits 32 bits
                 const int tt = t + tapn - a.pad;
-                long xr = rowc + tapn - a.pad;
-                xr = xr < 0 ? 0 : (xr < a.R ? xr : a.R - 1);
-                vb = a.B[xr * a.F + chn];
                 ok = ok && tt >= 0 && tt < T;
-            } else {
-                long br = rowc - (a.bshift ? 1 : 0);
-                br = br < 0 ? 0 : br;
-                vb = a.B[br * a.ldb + nc];
-                if (need_t) ok = ok && !(a.bshift && ((unsigned)rowc % (unsigned)T) == 0);
-            }
-            vb = ok ? vb : 0.f;
-            bv[e] = (rok && ncol == a.N) ? 1.f : vb;            // the all-ones column: bias gradients
-        }
-    };
-    auto sstore = [&](int buf) {
-        if (VEC) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                f32x4 va, vb;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) { va[s4] = av[4 * e + s4]; vb[s4] = bv[4 * e + s4]; }
-                *reinterpret_cast<f32x4*>(&As[buf][vrow0 + 8 * e][vc4]) = va;
-                *reinterpret_cast<f32x4*>(&Bs[buf][vrow0 + 8 * e][vc4]) = vb;
-            }
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            As[buf][srow0 + 2 * e][scol] = av[e];
-            Bs[buf][srow0 + 2 * e][scol] = bv[e];
+            } else if (need_t)
+                ok = ok && !(a.bshift && ((unsigned)rowc % (unsigned)T) == 0);
+            As[buf][srow0 + 2 * e][scol] = (rok && mcol < a.M) ? av[e] : 0.f;
+            const float vb = ok ? bv[e] : 0.f;
+            Bs[buf][srow0 + 2 * e][scol] = (rok && ncol == a.N) ? 1.f : vb;        // the all-ones column: bias gradients
         }
     };
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
     auto main_loop = [&](auto nx_tag, auto ny_tag) {
         constexpr int NX = decltype(nx_tag)::value, NY = decltype(ny_tag)::value;
         gload(rbeg);
-        sstore(0);
+        sstore(0, rbeg);
         __syncthreads();
         int buf = 0;
         for (long r = rbeg; r < rend; r += WG_ROWS) {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void k_wgrad_lds(const WgradArgs a) {
 #pragma unroll
                         for (int y = 0; y < NY; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x], bf[y], acc[x][y], 0, 0, 0);
                 }
-            if (more) sstore(buf ^ 1);
+            if (more) sstore(buf ^ 1, r + WG_ROWS);
             __syncthreads();
             buf ^= 1;
         }
