@@ -150,17 +150,39 @@ __device__ __forceinline__ f32x16 mfma_s3(const f32x4 (&w)[3], const f32x4 (&x)[
 template <bool BF>
 __device__ __forceinline__ void mfma_x3(const f32x4 (&w)[3], const f32x4 x, f32x16& a0, f32x16& a1, f32x16& a2);
 
-// four features k0..k0+3 of a row; zero beyond kvalid.  vec_ok: row base and k0 are 16-byte aligned
-__device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ row, int k0, int kvalid, bool vec_ok) {
+// four features k0..k0+3 of a row; zero beyond kvalid.  Branch-free: the loads are unconditional from addresses inside the row's
+// valid features and masked afterwards -- with a guarded load per lane (the two halves of a wave hold different k0) every call was
+// a divergent branch whose loads waited for everything in flight before them (the weight words of the same chunk), one memory
+// round trip after another.  XV (kvalid >= 4, k0 a multiple of 4): one 16-byte load; the group that straddles kvalid is read as
+// the row's last four valid features and shifted into place.
+// Two halves, so that a software-pipelined loop can issue the raw load one chunk ahead and look at the values only when it uses them
+// (feat4_fix right behind the load would wait for it, and for every load issued before it).
+template <bool XV>
+__device__ __forceinline__ f32x4 feat4_raw(const float* __restrict__ row, int k0, int kvalid) {
     f32x4 v;
-    if (vec_ok && k0 + 3 < kvalid) {
-        v = *reinterpret_cast<const f32x4*>(row + k0);
+    if constexpr (XV) {
+        v = *reinterpret_cast<const f32x4*>(row + (k0 + 3 < kvalid ? k0 : kvalid - 4));
     } else {
-        v[0] = (k0 + 0 < kvalid) ? row[k0 + 0] : 0.f;
-        v[1] = (k0 + 1 < kvalid) ? row[k0 + 1] : 0.f;
-        v[2] = (k0 + 2 < kvalid) ? row[k0 + 2] : 0.f;
-        v[3] = (k0 + 3 < kvalid) ? row[k0 + 3] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = row[k0 + e < kvalid ? k0 + e : kvalid - 1];
     }
+    return v;
+}
+template <bool XV>
+__device__ __forceinline__ f32x4 feat4_fix(const f32x4 w, int k0, int kvalid) {
+    f32x4 v = w;
+    if constexpr (XV) {
+        if (kvalid & 3) {                                   // wave-uniform: a straddling group exists
+            const int sh = (k0 + 3 < kvalid) ? 0 : (k0 - kvalid) & 3;      // = k0 - (kvalid - 4): 1..3 for the straddling group
+            const bool s1 = sh & 1, s2 = sh & 2;
+            const float a0 = s1 ? w[1] : w[0], a1 = s1 ? w[2] : w[1], a2 = s1 ? w[3] : w[2];
+            v[0] = s2 ? a2 : a0;
+            v[1] = s2 ? w[3] : a1;
+            v[2] = a2;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (k0 + e < kvalid) ? v[e] : 0.f;
     return v;
 }
 

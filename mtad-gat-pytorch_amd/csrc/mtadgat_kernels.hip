@@ -33,19 +33,23 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemmArgs& a, const f32
 #pragma unroll
                 for (int s = 0; s < 4; ++s) v[s] = drop_keep(key, (unsigned)(col + s), a.drop_thresh) ? v[s] * a.keep_scale : 0.f;
             }
+            // (the loads below are unconditional from clamped addresses and masked afterwards: guarded element loads were a
+            // branch and a full memory round trip each, up to 32 in series per lane)
             if (a.gate) {             // backward through ReLU (+ dropout): the kept activation tells which units were live
                 const float* gp = a.gate + rowc * a.ldg;
+                float gv[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float gv = (col + s < a.Nvalid) ? gp[col + s] : 0.f;
-                    v[s] = gv > 0.f ? v[s] * a.gate_scale : 0.f;
-                }
+                for (int s = 0; s < 4; ++s) gv[s] = gp[col + s < a.Nvalid ? col + s : a.Nvalid - 1];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[s] = (col + s < a.Nvalid && gv[s] > 0.f) ? v[s] * a.gate_scale : 0.f;
             }
-            if (a.accumulate && row < a.R && !transposed) {
-                const float* yo = a.Y + row * a.ldy + col;
+            if (a.accumulate && !transposed) {
+                const float* yo = a.Y + rowc * a.ldy;
+                float yv[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (col + s < a.Nvalid) v[s] += yo[s];
+                for (int s = 0; s < 4; ++s) yv[s] = yo[col + s < a.Nvalid ? col + s : a.Nvalid - 1];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v[s] += (col + s < a.Nvalid) ? yv[s] : 0.f;
             }
             if (row < a.R) {
                 if (transposed) {   // lanes i <-> consecutive group members: coalesced 4-byte stores
@@ -67,14 +71,15 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemmArgs& a, const f32
     }
 }
 
-template <int NTB>
+// XV: the rows are read with 16-byte loads (row stride a multiple of 4 floats) -- a template parameter, not a run-time flag: with
+// both loaders in one body the compiler serialises the chunk's loads on the registers the two paths share
+template <int NTB, bool XV>
 __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
     const int lane = threadIdx.x;
     const int i = lane & 31, g = lane >> 5;
     const long row = (long)blockIdx.x * 32 + i;
     const long rowc = row < a.R ? row : a.R - 1;
     const float* __restrict__ xrow = a.X + rowc * a.ldx;
-    const bool xvec = (a.ldx & 3) == 0;
     const f32x4* __restrict__ Wp = a.Wp;
     const int Q = a.Q;
 
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-        f32x4 xv = load_feat4(xrow, 4 * g, a.Kvalid, xvec);
+        f32x4 xr = feat4_raw<XV>(xrow, 4 * g, a.Kvalid);
         f32x4 w[NTB];
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
@@ -95,7 +100,8 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
         }
         for (int q = 0; q < Q; ++q) {
             const int qn = (q + 1 < Q) ? q + 1 : q;
-            const f32x4 xn = load_feat4(xrow, 8 * qn + 4 * g, a.Kvalid, xvec);
+            const f32x4 xn = feat4_raw<XV>(xrow, 8 * qn + 4 * g, a.Kvalid);        // raw: looked at one chunk later
+            const f32x4 xv = feat4_fix<XV>(xr, 8 * q + 4 * g, a.Kvalid);
             f32x4 wn[NTB];
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) {
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
             }
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) acc[nb] = mfma4(w[nb], xv, acc[nb]);
-            xv = xn;
+            xr = xn;
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) w[nb] = wn[nb];
         }
@@ -117,14 +123,13 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
 // v_mfma_f32_32x32x16_bf16 per chunk and tile (mfma_s3): 2.7 x less matrix time than the four fp32 MFMAs of two 8-feature
 // chunks, products of 24-bit significands.  Used by the data-gradient products of mtadgat_backward (d X = d Y W over all
 // (window, step) rows), which ran at the fp32-MFMA rate.
-template <int NTB>
+template <int NTB, bool XV>
 __global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
     const int lane = threadIdx.x;
     const int i = lane & 31, g = lane >> 5;
     const long row = (long)blockIdx.x * 32 + i;
     const long rowc = row < a.R ? row : a.R - 1;
     const float* __restrict__ xrow = a.X + rowc * a.ldx;
-    const bool xvec = (a.ldx & 3) == 0;
     const f32x4* __restrict__ Wp = a.Wp3;
     const int Q = a.Q16;
     for (int n0 = blockIdx.y * NTB; n0 < a.NT; n0 += NTB * gridDim.y) {
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
         for (int nb = 0; nb < NTB; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-        f32x4 xa = load_feat4(xrow, 4 * g, a.Kvalid, xvec), xb = load_feat4(xrow, 8 + 4 * g, a.Kvalid, xvec);
+        f32x4 ra = feat4_raw<XV>(xrow, 4 * g, a.Kvalid), rb = feat4_raw<XV>(xrow, 8 + 4 * g, a.Kvalid);
         f32x4 w[NTB][3];
 #pragma unroll
         for (int nb = 0; nb < NTB; ++nb) {
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
         }
         for (int q = 0; q < Q; ++q) {
             const int qn = (q + 1 < Q) ? q + 1 : q;
-            const f32x4 xan = load_feat4(xrow, 16 * qn + 4 * g, a.Kvalid, xvec), xbn = load_feat4(xrow, 16 * qn + 8 + 4 * g, a.Kvalid, xvec);
+            const f32x4 ran = feat4_raw<XV>(xrow, 16 * qn + 4 * g, a.Kvalid), rbn = feat4_raw<XV>(xrow, 16 * qn + 8 + 4 * g, a.Kvalid);    // raw
+            const f32x4 xa = feat4_fix<XV>(ra, 16 * q + 4 * g, a.Kvalid), xb = feat4_fix<XV>(rb, 16 * q + 8 + 4 * g, a.Kvalid);
             f32x4 xp[3];
             split3(xa, xb, xp[0], xp[1], xp[2]);
 #pragma unroll
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) w[nb][pc] = Wp[(((long)n * Q + qn) * 3 + pc) * 64 + lane];       // the next chunk's words, behind this tile's MFMAs
             }
-            xa = xan; xb = xbn;
+            ra = ran; rb = rbn;
         }
         rowgemm_epilogue<NTB>(a, acc, n0, row, rowc, g);
     }
@@ -636,33 +642,39 @@ __global__ void k_transpose_win(const float* __restrict__ src, long lds, float* 
         dst[(b * C + c) * ldd + r] = src[(b * R + r) * lds + c];
     }
 }
-int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
-    if (a.R <= 0) return 0;
+template <bool XV>
+static void launch_rowgemm_xv(const RowGemmArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.R + 31) / 32);
     const long groups4 = (a.NT + 3) / 4;
     if (a.x3) {
         if (a.NT >= 4) {
             const long want = (4096 + grid - 1) / grid;
             const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
-            hipLaunchKernelGGL(k_rowgemm_x3<4>, dim3(grid, split), dim3(64), 0, s, a);
+            hipLaunchKernelGGL((k_rowgemm_x3<4, XV>), dim3(grid, split), dim3(64), 0, s, a);
         } else if (a.NT >= 2)
-            hipLaunchKernelGGL(k_rowgemm_x3<2>, dim3(grid), dim3(64), 0, s, a);
+            hipLaunchKernelGGL((k_rowgemm_x3<2, XV>), dim3(grid), dim3(64), 0, s, a);
         else
-            hipLaunchKernelGGL(k_rowgemm_x3<1>, dim3(grid), dim3(64), 0, s, a);
-        LAUNCH_CHECK();
-        return 0;
+            hipLaunchKernelGGL((k_rowgemm_x3<1, XV>), dim3(grid), dim3(64), 0, s, a);
+        return;
     }
     if (a.NT >= 2 && (long)grid * groups4 < 1024) {
         // a latency chain on a few waves (a head Linear on 256 rows): one output tile per wave
-        hipLaunchKernelGGL(k_rowgemm<1>, dim3(grid, (unsigned)a.NT), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_rowgemm<1, XV>), dim3(grid, (unsigned)a.NT), dim3(64), 0, s, a);
     } else if (a.NT >= 4) {
         const long want = (4096 + grid - 1) / grid;                 // ~4 waves per SIMD
         const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
-        hipLaunchKernelGGL(k_rowgemm<4>, dim3(grid, split), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_rowgemm<4, XV>), dim3(grid, split), dim3(64), 0, s, a);
     } else if (a.NT >= 2)
-        hipLaunchKernelGGL(k_rowgemm<2>, dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_rowgemm<2, XV>), dim3(grid), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL(k_rowgemm<1>, dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_rowgemm<1, XV>), dim3(grid), dim3(64), 0, s, a);
+}
+int launch_rowgemm(const RowGemmArgs& a, hipStream_t s) {
+    if (a.R <= 0) return 0;
+    if ((a.ldx & 3) == 0 && a.Kvalid >= 4)
+        launch_rowgemm_xv<true>(a, s);
+    else
+        launch_rowgemm_xv<false>(a, s);
     LAUNCH_CHECK();
     return 0;
 }
