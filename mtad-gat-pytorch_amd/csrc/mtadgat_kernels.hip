@@ -91,6 +91,25 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
+        if constexpr (NTB == 1) {
+            // one tile per wave: the launches that use this build are latency chains (a head Linear on 256 rows: a few waves, nothing
+            // else on their SIMD), so the chunks go four at a time -- every load of the four issued before the first MFMA, one
+            // memory round trip per four chunks instead of one per chunk (19 chunks of a 150-wide layer: 20 -> 8 us per launch)
+            constexpr int U = 4;
+            const int n = n0 < a.NT ? n0 : a.NT - 1;
+            for (int q = 0; q < Q; q += U) {
+                f32x4 xr[U], w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int qq = q + u < Q ? q + u : Q - 1;
+                    xr[u] = feat4_raw<XV>(xrow, 8 * qq + 4 * g, a.Kvalid);
+                    w[u] = Wp[((long)n * Q + qq) * 64 + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (q + u < Q) acc[0] = mfma4(w[u], feat4_fix<XV>(xr[u], 8 * (q + u) + 4 * g, a.Kvalid), acc[0]);
+            }
+        } else {
         f32x4 xr = feat4_raw<XV>(xrow, 4 * g, a.Kvalid);
         f32x4 w[NTB];
 #pragma unroll
@@ -113,6 +132,7 @@ __global__ __launch_bounds__(64) void k_rowgemm(const RowGemmArgs a) {
             xr = xn;
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) w[nb] = wn[nb];
+        }
         }
         rowgemm_epilogue<NTB>(a, acc, n0, row, rowc, g);
     }
