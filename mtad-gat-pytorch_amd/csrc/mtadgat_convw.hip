@@ -50,29 +50,49 @@ __global__ __launch_bounds__(256 / CW_RT, CW_RT == 1 ? 4 : 3) void k_conv_win(co
     f32x4 v[MAXU];
     const int nunit = (total + 3) >> 2;
     float mx = 0.f;
+    // the loader is picked once (wave-uniform) and issues all of a thread's units before anything looks at them: with the choice
+    // inside the unit loop each unit was a load, a wait for it, and its maximum -- MAXU memory round trips in a row per window
+    const bool whole = vec && (total & 3) == 0;        // every unit is one aligned 16-byte (bf16 input: 8-byte) word
+    if (whole && !a.x_bf16) {
 #pragma unroll
-    for (int n = 0; n < MAXU; ++n) {
-        const int u = tid + n * NTHR;
-        const int uc = u < nunit ? u : nunit - 1;
-        if (a.x_bf16) {
-            typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
-            if (vec && 4 * uc + 3 < total) {
-                const u32x2_ w2 = *reinterpret_cast<const u32x2_*>(xw16 + 4 * uc);
-                v[n] = f32x4{__uint_as_float(w2[0] << 16), __uint_as_float(w2[0] & 0xffff0000u), __uint_as_float(w2[1] << 16), __uint_as_float(w2[1] & 0xffff0000u)};
-            } else {
+        for (int n = 0; n < MAXU; ++n) {
+            const int u = tid + n * NTHR;
+            v[n] = *reinterpret_cast<const f32x4*>(xw + 4 * (u < nunit ? u : nunit - 1));
+        }
+    } else if (whole) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        u32x2_ w2[MAXU];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[n][e] = __uint_as_float((unsigned)xw16[4 * uc + e < total ? 4 * uc + e : total - 1] << 16);
-            }
-        } else if (vec && 4 * uc + 3 < total) {
-            v[n] = *reinterpret_cast<const f32x4*>(xw + 4 * uc);
-        } else {
+        for (int n = 0; n < MAXU; ++n) {
+            const int u = tid + n * NTHR;
+            w2[n] = *reinterpret_cast<const u32x2_*>(xw16 + 4 * (u < nunit ? u : nunit - 1));
+        }
+#pragma unroll
+        for (int n = 0; n < MAXU; ++n)
+            v[n] = f32x4{__uint_as_float(w2[n][0] << 16), __uint_as_float(w2[n][0] & 0xffff0000u), __uint_as_float(w2[n][1] << 16), __uint_as_float(w2[n][1] & 0xffff0000u)};
+    } else if (a.x_bf16) {
+#pragma unroll
+        for (int n = 0; n < MAXU; ++n) {
+            const int u = tid + n * NTHR, uc = u < nunit ? u : nunit - 1;
+            unsigned short h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = xw16[4 * uc + e < total ? 4 * uc + e : total - 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[n][e] = __uint_as_float((unsigned)h[e] << 16);
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < MAXU; ++n) {
+            const int u = tid + n * NTHR, uc = u < nunit ? u : nunit - 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[n][e] = xw[4 * uc + e < total ? 4 * uc + e : total - 1];
         }
-        if (u < nunit) {
+    }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, (4 * u + e < total) ? fabsf(v[n][e]) : 0.f);
-        }
+    for (int n = 0; n < MAXU; ++n) {
+        const int u = tid + n * NTHR;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, (4 * u + e < total) ? fabsf(v[n][e]) : 0.f);
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;

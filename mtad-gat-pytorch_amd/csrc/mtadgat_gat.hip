@@ -57,7 +57,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
     const long win = blockIdx.x;
-    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
+    const int K = a.K, D = a.D;
+    int P8, PT;
+    gat_load_order(a.ord, a.P8, a.PT, P8, PT);
     const int vld = a.vld;
     const int Kp16 = (K + 15) & ~15;                   // rows of Vs: real nodes then zero rows
     const int NWA = (K + IBW - 1) / IBW;               // waves that own query rows (the rest only project)
@@ -495,7 +497,9 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
     const long win = grp * 8 + (within & 7);
     const int rb = within >> 3;
     if (win >= a.nwin) return;
-    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
+    const int K = a.K, D = a.D;
+    int P8, PT;
+    gat_load_order(a.ord, a.P8, a.PT, P8, PT);
     const int i0b = rb * (NW * IBW);                       // first query row of this workgroup
     const int KJ = KP * 128;                               // key slots
     float* __restrict__ Ls = smem;                         // [NW*16][34]
@@ -751,7 +755,9 @@ __global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
     const long win = grp * 8 + (within & 7);
     const int rb = within >> 3;
     if (win >= a.nwin) return;
-    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
+    const int K = a.K, D = a.D;
+    int P8, PT;
+    gat_load_order(a.ord, a.P8, a.PT, P8, PT);
     const int i0b = rb * (NW * IBW);
     float* __restrict__ Ls = smem;                         // [128][34]
     float* __restrict__ Rs = Ls + NW * IBW * GAT_LLD;      // [256][34]

@@ -17,6 +17,19 @@ typedef const __attribute__((address_space(3))) float* lds_cptr;      // explici
 constexpr int GAT_LLD = 34;     // 32 columns + 2: rows 8-byte aligned, 16 consecutive rows start on 16 distinct bank pairs
 constexpr int GAT_APITCH = 68;
 
+// The layer's column-order record {P8, PT} (k_gat_colorder writes it on the device when the weights change): both words in ONE
+// scalar load.  Written as asm because the compiler does not know that nothing writes the record while the kernel runs and
+// reads it with two vector loads, each waited for in turn -- two memory round trips at the head of every workgroup.
+__device__ __forceinline__ void gat_load_order(const int* ord, int P8_host, int PT_host, int& P8, int& PT) {
+    P8 = P8_host; PT = PT_host;
+    if (ord) {
+        typedef int i32x2_ __attribute__((ext_vector_type(2)));
+        i32x2_ pr;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr) : "s"(ord) : "memory");
+        P8 = pr[0]; PT = pr[1];
+    }
+}
+
 // lp[ii]: one base pointer per query row.  The pointers are made opaque to the compiler on purpose:
 // with a common base it merges row pairs into ds_read2_b64, which runs at half the LDS rate of two
 // ds_read_b64 (MI355X: 8 vs 2 x 2 LDS cycles per wave instruction).

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
     const long win = blockIdx.x;
-    const int K = a.K, D = a.D, PT = a.ord ? a.ord[1] : a.PT, P8 = a.ord ? a.ord[0] : a.P8;
+    const int K = a.K, D = a.D;
+    int P8, PT;
+    gat_load_order(a.ord, a.P8, a.PT, P8, PT);
     const int pvh = a.vld;                             // piece pitch in halfs
     const int KR = K + 1;                              // rows of the pieces: the nodes and one zero row (keys past K of a 16-key group)
     // waves that own query rows (the rest only project): n_full of them 4 RI = 16 rows (IBL per lane), n_short one row per lane
