@@ -183,6 +183,10 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   columns, where it was measured to win), 1 off, 2 wherever the kernels apply (<= 128 time steps, <= 64 features, kernel_size <= 7).
  * "rowgemm_kernel": the data-gradient products d X = d Y W of mtadgat_backward: 0 automatic (three bf16 pieces per operand from
  *   4096 rows in precision mode 2), 1 fp32 MFMA, 2 the split-bf16 build always.
+ * "gemm_lds" (process-wide, not per handle): the split-bf16 row GEMMs and the wide models' convolution on launches of >= 131 072
+ *   rows (Linear / Conv1d layers: modules.py:18-22, :76-81, :176-181; the data gradients of training.py:126): 0 automatic -- a
+ *   workgroup of four waves owns 256 rows and shares each chunk's weight words through LDS; 1 the one-wave kernels everywhere
+ *   (results are bit-identical either way).
  * "lanes": 0 automatic: mtadgat_forward / _forward_series walk calls of 8 193 .. 16 384 and of more than 32 768 windows per chunk in
  *   pieces that alternate between `stream` and a second stream owned by the handle (each with its own half of the workspace;
  *   `stream` waits for the second lane before the call's work on it counts as complete, so the caller's ordering rules do not

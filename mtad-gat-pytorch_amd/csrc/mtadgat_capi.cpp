@@ -1058,6 +1058,7 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (std::strcmp(name, "wgrad_kernel") == 0 && value >= 0 && value <= 2) { h->m.wgrad_kernel = value; return 0; }
     if (std::strcmp(name, "conv_kernel") == 0 && value >= 0 && value <= 2) { h->m.conv_kernel = value; return 0; }
     if (std::strcmp(name, "rowgemm_kernel") == 0 && value >= 0 && value <= 2) { h->m.rowgemm_kernel = value; return 0; }
+    if (std::strcmp(name, "gemm_lds") == 0 && value >= 0 && value <= 1) { set_gemm_lds_off(value); return 0; }      // process-wide; 1 = off
     if (std::strcmp(name, "conv_shared") == 0 && value >= 0 && value <= 1) { h->m.conv_shared = value; return 0; }
     if (std::strcmp(name, "conv_fused") == 0 && value >= 0 && value <= 1) { h->m.conv_fused = value; return 0; }
     if (std::strcmp(name, "series_band") == 0 && value >= 0 && value <= 2) { h->m.series_band = value; return 0; }

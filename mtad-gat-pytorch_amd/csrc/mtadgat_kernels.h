@@ -354,6 +354,9 @@ inline int cu_count() {
 }
 
 int launch_rowgemm(const RowGemmArgs& a, hipStream_t s);
+// measurement / test hook (process-wide): 1 = the many-row launches of the split-bf16 row GEMM and wide convolution use the one-wave
+// kernels (k_rowgemm_x3 / k_conv_x3) instead of the workgroup kernels that share the weight words through LDS
+void set_gemm_lds_off(int off);
 int launch_conv(const ConvArgs& a, hipStream_t s);
 bool conv_win_applies(const ConvArgs& a);
 int launch_conv_win(const ConvArgs& a, hipStream_t s);

@@ -1,4 +1,5 @@
 // k_rowgemm (Linear layers), k_conv / k_conv_lds (ConvLayer), small copy kernels + launchers
+#include <cstdlib>
 #include "mtadgat_device.h"
 
 namespace mtadgat {
@@ -182,6 +183,88 @@ __global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
             ra = ran; rb = rbn;
         }
         rowgemm_epilogue<NTB>(a, acc, n0, row, rowc, g);
+    }
+}
+
+// Many rows: a workgroup of four waves owns 256 rows (two row tiles per wave) x four output tiles and shares the weight words of a
+// chunk through LDS.  In k_rowgemm_x3 every wave pulls every weight word through the CU's vector L1 itself: 12 KB per 24 MFMAs,
+// measured (TCP_TOTAL_CACHE_ACCESSES / TCP_TCC_READ_REQ on the data-gradient GEMMs of an 8 192-window training step) 427 M line
+// accesses per launch, three quarters of them weight words -- 0.7 ms of the 1.3 ms launch at the L1's 64 bytes per clock.  Here
+// the chunk's 12 KB are loaded once per workgroup (coalesced, double buffered in LDS, one barrier per chunk) and each word a wave
+// reads from LDS feeds two MFMAs: 1.32 -> 0.95 ms per launch.  (Taking the rows through a wave-private LDS tile as well -- 32
+// features = 128 contiguous bytes per row, every line read once -- was built and is no faster: 0.99 ms with 27 spilled registers;
+// what is left is the one-chunk prefetch distance of both operands.)  Rows with a stride of whole 16-byte words only.  Same
+// chunk order and terms per output element: results are bit-identical to k_rowgemm_x3.
+__global__ __launch_bounds__(256, 2) void k_rowgemm_x3s(const RowGemmArgs a) {
+    constexpr bool XV = true;
+    constexpr int NTB = 4, WWORDS = NTB * 3 * 64;         // 16-byte words of a chunk: [tile][piece][lane]
+    __shared__ __attribute__((aligned(16))) f32x4 wsh[2][WWORDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    long row[2], rowc[2];
+    const float* __restrict__ xrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        row[t] = (long)blockIdx.x * 256 + 64 * wave + 32 * t + i;
+        rowc[t] = row[t] < a.R ? row[t] : a.R - 1;
+        xrow[t] = a.X + rowc[t] * a.ldx;
+    }
+    const f32x4* __restrict__ Wp = a.Wp3;
+    const int Q = a.Q16;
+    for (int n0 = blockIdx.y * NTB; n0 < a.NT; n0 += NTB * gridDim.y) {
+        // this thread's three words of a chunk: flat word idx = tid + 256 e -> (tile, piece, lane); 192 consecutive words per tile
+        const f32x4* __restrict__ wsrc[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int idx = tid + 256 * e, nb = idx / 192, rem = idx - nb * 192;
+            const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
+            wsrc[e] = Wp + ((long)n * Q) * 192 + rem;
+        }
+        f32x16 acc[2][NTB];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][nb][r] = 0.f;
+        f32x4 ra[2], rb[2], wr[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { ra[t] = feat4_raw<XV>(xrow[t], 4 * g, a.Kvalid); rb[t] = feat4_raw<XV>(xrow[t], 8 + 4 * g, a.Kvalid); }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) wsh[0][tid + 256 * e] = wr[e];
+        __syncthreads();
+        int buf = 0;
+        for (int q = 0; q < Q; ++q) {
+            const int qn = (q + 1 < Q) ? q + 1 : q;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][(long)qn * 192];                  // the next chunk: in flight during the MFMAs
+            f32x4 ran[2], rbn[2], xp[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ran[t] = feat4_raw<XV>(xrow[t], 16 * qn + 4 * g, a.Kvalid);
+                rbn[t] = feat4_raw<XV>(xrow[t], 16 * qn + 8 + 4 * g, a.Kvalid);
+                split3(feat4_fix<XV>(ra[t], 16 * q + 4 * g, a.Kvalid), feat4_fix<XV>(rb[t], 16 * q + 8 + 4 * g, a.Kvalid), xp[t][0], xp[t][1], xp[t][2]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) {
+                f32x4 w[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) w[pc] = wsh[buf][(nb * 3 + pc) * 64 + lane];
+                acc[0][nb] = mfma_s3(w, xp[0], acc[0][nb]);
+                acc[1][nb] = mfma_s3(w, xp[1], acc[1][nb]);
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) wsh[buf ^ 1][tid + 256 * e] = wr[e];
+            __syncthreads();
+            buf ^= 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { ra[t] = ran[t]; rb[t] = rbn[t]; }
+        }
+        rowgemm_epilogue<NTB>(a, acc[0], n0, row[0], rowc[0], g);
+        rowgemm_epilogue<NTB>(a, acc[1], n0, row[1], rowc[1], g);
     }
 }
 
@@ -374,6 +457,127 @@ __global__ __launch_bounds__(64) void k_conv_x3(const ConvArgs a) {
                 }
             }
         }
+    }
+}
+
+// k_conv_x3 for many rows, as k_rowgemm_x3s: a workgroup of four waves owns 256 output rows (two row tiles per wave) x four
+// output tiles, the weight words of a chunk go through LDS once per workgroup and feed two MFMAs per LDS read.  F a multiple of 4.
+// Same chunk order and terms per output element: results are bit-identical to k_conv_x3.
+__global__ __launch_bounds__(256, 2) void k_conv_x3s(const ConvArgs a) {
+    constexpr int NTB = 4, WWORDS = NTB * 3 * 64;
+    __shared__ __attribute__((aligned(16))) f32x4 wsh[2][WWORDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, g = lane >> 5;
+    const long R = a.B * a.W;
+    long row[2], win[2];
+    int t[2];
+    const float* __restrict__ xwin[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        row[rt] = (long)blockIdx.x * 256 + 64 * wave + 32 * rt + i;
+        const long rowc = row[rt] < R ? row[rt] : R - 1;
+        win[rt] = rowc / a.W;
+        t[rt] = (int)(rowc - win[rt] * a.W);
+        xwin[rt] = a.gather ? a.X + (a.starts ? a.starts[win[rt]] : a.start0 + win[rt] * a.stride) * (long)a.F
+                            : a.X + win[rt] * (long)a.W * a.F;
+        if (a.HCAT && row[rt] < R && g == 0)
+            for (int c = 3 * a.F; c < a.Dp; ++c) a.HCAT[row[rt] * a.Dp + c] = 0.f;
+    }
+    const int QF = a.Fq >> 4;
+    const int Q = a.taps * QF;
+    const f32x4* __restrict__ Wp = a.Wp3;
+    // channels 16 cb + 8 half + 4 g .. + 3 of input row t + tap - pad: the raw 16 bytes (clamped address), masked where they are used
+    auto rawx = [&](int rt, int tap, int cb, int half) -> f32x4 {
+        const int tt = t[rt] + tap - a.pad;
+        const int c0 = 16 * cb + 8 * half + 4 * g;
+        const int ttc = tt < 0 ? 0 : (tt < a.W ? tt : a.W - 1);
+        return *reinterpret_cast<const f32x4*>(xwin[rt] + (long)ttc * a.F + (c0 + 3 < a.F ? c0 : a.F - 4));
+    };
+    auto fixx = [&](f32x4 v, int rt, int tap, int cb, int half) -> f32x4 {
+        const int tt = t[rt] + tap - a.pad;
+        const int c0 = 16 * cb + 8 * half + 4 * g;
+        const bool ok = tt >= 0 && tt < a.W && c0 + 3 < a.F;       // F % 4 == 0: a group is whole or beyond the row
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) v[s4] = ok ? v[s4] : 0.f;
+        return v;
+    };
+    for (int n0 = 0; n0 < a.NT; n0 += NTB) {
+        const f32x4* __restrict__ wsrc[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int idx = tid + 256 * e, nb = idx / 192, rem = idx - nb * 192;
+            const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
+            wsrc[e] = Wp + ((long)n * Q) * 192 + rem;
+        }
+        f32x16 acc[2][NTB];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][nb][r] = 0.f;
+        f32x4 ra[2], rb[2], wr[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][0];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) { ra[rt] = rawx(rt, 0, 0, 0); rb[rt] = rawx(rt, 0, 0, 1); }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) wsh[0][tid + 256 * e] = wr[e];
+        __syncthreads();
+        int buf = 0, tap = 0, cb = 0;                     // chunk q = tap * QF + cb
+        for (int q = 0; q < Q; ++q) {
+            int tapn = tap, cbn = cb + 1;
+            if (cbn == QF) { cbn = 0; ++tapn; }
+            const bool more = q + 1 < Q;
+            if (!more) { tapn = tap; cbn = cb; }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][(long)(more ? q + 1 : q) * 192];
+            f32x4 ran[2], rbn[2], xp[2][3];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                ran[rt] = rawx(rt, tapn, cbn, 0);
+                rbn[rt] = rawx(rt, tapn, cbn, 1);
+                split3(fixx(ra[rt], rt, tap, cb, 0), fixx(rb[rt], rt, tap, cb, 1), xp[rt][0], xp[rt][1], xp[rt][2]);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) {
+                f32x4 w[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) w[pc] = wsh[buf][(nb * 3 + pc) * 64 + lane];
+                acc[0][nb] = mfma_s3(w, xp[0], acc[0][nb]);
+                acc[1][nb] = mfma_s3(w, xp[1], acc[1][nb]);
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) wsh[buf ^ 1][tid + 256 * e] = wr[e];
+            __syncthreads();
+            buf ^= 1;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) { ra[rt] = ran[rt]; rb[rt] = rbn[rt]; }
+            tap = tapn; cb = cbn;
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nb = 0; nb < NTB; ++nb) {
+                if (n0 + nb >= a.NT) break;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int col = 32 * (n0 + nb) + 8 * m + 4 * g;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int o = col + s4;
+                        const float v = fmaxf(acc[rt][nb][4 * m + s4] + bv[s4], 0.f);
+                        if (row[rt] < R && o < a.F) {
+                            if (a.XC) a.XC[row[rt] * a.Fp + o] = v;
+                            if (a.XCT) a.XCT[(win[rt] * a.F + o) * (long)a.Wpad + t[rt]] = v;
+                            if (a.HCAT) a.HCAT[row[rt] * a.Dp + o] = v;
+                            if (a.Y) a.Y[row[rt] * a.F + o] = v;
+                        }
+                    }
+                }
+            }
     }
 }
 
@@ -662,12 +866,22 @@ __global__ void k_transpose_win(const float* __restrict__ src, long lds, float* 
         dst[(b * C + c) * ldd + r] = src[(b * R + r) * lds + c];
     }
 }
+static int g_gemm_lds_off = getenv("MTADGAT_ROWGEMM_NOLDS") ? 1 : 0;
+void set_gemm_lds_off(int off) { g_gemm_lds_off = off; }
+
 template <bool XV>
 static void launch_rowgemm_xv(const RowGemmArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.R + 31) / 32);
     const long groups4 = (a.NT + 3) / 4;
     if (a.x3) {
-        if (a.NT >= 4) {
+        const int s_off = g_gemm_lds_off;
+        if (XV && a.NT >= 4 && a.R >= 64 * 2048 && !s_off) {
+            // plenty of rows of whole 16-byte words: 256 per workgroup, the chunk's weight words through LDS (k_rowgemm_x3s)
+            const unsigned gridw = (unsigned)((a.R + 255) / 256);
+            const long want = (2048 + gridw - 1) / gridw;
+            const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
+            hipLaunchKernelGGL(k_rowgemm_x3s, dim3(gridw, split), dim3(256), 0, s, a);
+        } else if (a.NT >= 4) {
             const long want = (4096 + grid - 1) / grid;
             const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
             hipLaunchKernelGGL((k_rowgemm_x3<4, XV>), dim3(grid, split), dim3(64), 0, s, a);
@@ -726,7 +940,10 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         // the straight-from-memory kernel does not record the output range: mark it unknown (a NaN pattern)
         if (a.vmax && hipMemsetAsync(a.vmax, 0xFF, sizeof(unsigned), s) != hipSuccess) return -3;
         if (a.Wp3) {                 // split-bf16 operands (precision mode 2, large launches: run_conv)
-            if (a.NT >= 4)
+            const int s_off = g_gemm_lds_off;
+            if (a.NT >= 4 && R >= 64 * 2048 && (a.F & 3) == 0 && a.F >= 4 && !s_off)
+                hipLaunchKernelGGL(k_conv_x3s, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, a);
+            else if (a.NT >= 4)
                 hipLaunchKernelGGL(k_conv_x3<4>, dim3(grid), dim3(64), 0, s, a);
             else if (a.NT >= 2)
                 hipLaunchKernelGGL(k_conv_x3<2>, dim3(grid), dim3(64), 0, s, a);

@@ -172,3 +172,43 @@ def test_config4_chunked_batch_against_the_oracle(gpu_device):
     gate(p2, p_ref, what="config 4 preds, split-bf16 convolution / projections")
     gate(r2, r_ref, what="config 4 recons, split-bf16 convolution / projections")
     assert (p2 - p1).abs().max().item() <= 2e-6 * max(1.0, p1.abs().max().item()) and (r2 - r1).abs().max().item() <= 2e-6 * max(1.0, r1.abs().max().item())
+
+
+def test_many_row_gemms_share_weight_words_through_lds(gpu_device):
+    """Launches of >= 131 072 rows of the split-bf16 row GEMM and of the wide models' convolution run as workgroups of four
+    waves that share each chunk's weight words through LDS (k_rowgemm_x3s / k_conv_x3s, csrc/mtadgat_kernels.hip; the Linear
+    / Conv1d layers modules.py:18-22, :176-181).  A wide model (W = 256 > 128 nodes: projections through memory; F = 136: the
+    straight-from-memory convolution) on 1 024 windows = 262 144 (window, step) rows: bit-equal to the one-wave kernels
+    (engine option "gemm_lds" = 1), and the first windows against the oracle."""
+    from mtad_gat import MTAD_GAT
+    kw = dict(n_features=136, window_size=256, out_dim=136, kernel_size=7, gru_hid_dim=64, forecast_n_layers=1, forecast_hid_dim=64,
+              recon_hid_dim=64)
+    torch.manual_seed(3)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1024, 256, 136, generator=g)
+    with torch.no_grad():
+        p_ref, r_ref = oracle.forward_chunked(x[:4], model.state_dict(), alpha=0.2, chunk=2)
+        m = model.to(gpu_device)
+        eng = m._sync_engine(gpu_device)
+        eng.set_chunk_windows(1024)
+        xd = x.to(gpu_device)
+        p, r = m(xd)
+        eng.set_option("gemm_lds", 1)
+        try:
+            p1, r1 = m(xd)
+            eng.set_option("conv_kernel", 1)
+            eng.set_option("rowgemm_kernel", 1)
+            p2, r2 = m(xd)                               # fp32-MFMA convolution / projections: a different arithmetic
+        finally:
+            eng.set_option("gemm_lds", 0)
+            eng.set_option("conv_kernel", 0)
+            eng.set_option("rowgemm_kernel", 0)
+    assert torch.equal(p, p1) and torch.equal(r, r1)
+    assert not (torch.equal(p2, p1) and torch.equal(r2, r1)), "the split-bf16 kernels did not run"
+    assert (p2 - p1).abs().max().item() <= 2e-6 * max(1.0, p1.abs().max().item()) and (r2 - r1).abs().max().item() <= 2e-6 * max(1.0, r1.abs().max().item())
+    gate(p[:4], p_ref, what="wide model preds, 1 024 windows per chunk")
+    gate(r[:4], r_ref, what="wide model recons, 1 024 windows per chunk")
