@@ -187,7 +187,8 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   rows (Linear / Conv1d layers: modules.py:18-22, :76-81, :176-181; the data gradients of training.py:126): 0 automatic -- a
  *   workgroup of four waves owns 256 rows and shares each chunk's weight words through LDS; 1 the one-wave kernels everywhere
  *   (results are bit-identical either way).
- * "lanes": 0 automatic: mtadgat_forward / _forward_series walk calls of 8 193 .. 16 384 and of more than 32 768 windows per chunk in
+ * "lanes": 0 automatic: mtadgat_forward / _forward_series walk calls of 8 193 .. 16 384 (two halves; 8 192 + the rest when the rest
+ *   is at most 1 536 windows) and of more than 32 768 windows per chunk (whole 32 768-window pieces, then the rest) in
  *   pieces that alternate between `stream` and a second stream owned by the handle (each with its own half of the workspace;
  *   `stream` waits for the second lane before the call's work on it counts as complete, so the caller's ordering rules do not
  *   change); results = those of the call on each piece.  1: everything on `stream`.

@@ -1086,6 +1086,8 @@ static void forward_schedule(const Model& m, int64_t batch, std::vector<Piece>& 
         if (two && n > SPLIT3_MAX_WINDOWS && n <= 2 * SPLIT3_MAX_WINDOWS) {                // two halves for the hidden-tile-split kernel
             k = 2;
             base = n / 2 / 32 * 32;                                                        // (whole 32-window groups, the last piece takes the rest)
+            // a short tail rides beside a full piece instead (9 216 windows: 5.15 -> 4.77 ms; from 10 240 on the halves are as fast)
+            if (n - SPLIT3_MAX_WINDOWS <= 1536) base = SPLIT3_MAX_WINDOWS;
         } else if (two && n > 32768 && n % 32768 != 0) {                                   // full k_gru_cm rounds (256 workgroups of 128 windows), then the rest
             // (whole multiples of 32 768 gain nothing from the second lane -- every round is full -- and stay one piece on the caller's stream)
             k = (n + 32767) / 32768;

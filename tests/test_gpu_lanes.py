@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _pieces(n):
     if 8192 < n <= 16384:
-        h = n // 2 // 32 * 32
+        h = 8192 if n - 8192 <= 1536 else n // 2 // 32 * 32      # (a short tail rides beside a full 8 192-window piece)
         return [h, n - h]
     if n > 32768 and n % 32768:
         k = (n + 32767) // 32768
