@@ -895,7 +895,8 @@ static size_t pair_lds_base(int K, int vld) {
     if (nj8 < 0) return (size_t)1 << 30;
     const int njq = (nj8 + 3) / 4;
     const int NTn = (K + 31) >> 5;
-    return ((size_t)Kp16 * vld + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)32 * njq * 32 + 32 * njq + 64) * sizeof(float);
+    const size_t sums = (size_t)4 * K + (size_t)8 * 32 * njq;          // rsq [K][4], csw [8 waves][key slots]
+    return ((size_t)Kp16 * vld + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)32 * njq * 32 + 32 * njq + 64 + sums) * sizeof(float);
 }
 // the window's d e in LDS: row r = four blocks (one per 16-lane quarter of the keys) of 8 NJQ + 4 floats -- the quarters then
 // read different banks (the plain [K][K] layout put all four on the same ones: 47 % of the kernel's wave cycles were spent
@@ -933,7 +934,9 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
     float* __restrict__ cs = NS + KJ * 32;
     float* __restrict__ daS = cs + KJ;
     constexpr int DBS = 8 * NJQ + 4;                // floats per quarter block of a staged d e row
-    float* __restrict__ des = daS + 64;             // DES: [K][4][DBS]
+    float* __restrict__ rsq = daS + 64;             // [K][4]: sums of a d e row over each quarter's keys
+    float* __restrict__ csw = rsq + 4 * K;          // [8][KJ]: sums of a d e column over the rows of each wave
+    float* __restrict__ des = csw + 8 * KJ;         // DES: [K][4][DBS]
     const int i = lane & 31, g = lane >> 5;
 
     // ---- stage V (+ the ones column D: the projection bias is weight row D), d e, clear the accumulators
@@ -970,17 +973,34 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
         }
         __syncthreads();
     }
+    // Sums of d e the pair phase needs per embedding column k only through L and R (both linear in them):
+    //   s1_k = sum_{r,j} d_rj (L_rk + R_jk)        = sum_r L_rk rs_r + sum_j R_jk cs_j
+    //   A_k  = sum_{r,j} d_rj max(L_rk + R_jk, 0)  = sum_r L_rk M_rk + sum_j R_jk N_jk     (M, N: the d L / d R sums of the pair phase)
+    // and d a_k = alpha s1_k + (1 - alpha) A_k: no product per pair is needed for it.  rsq: row sums per quarter of the keys (a lane
+    // owns one quarter), csw: column sums per wave (a wave owns the rows r = wave, wave + NW, ...); cs = sum over the waves.
+    auto de_at = [&](int r, int j) -> float {
+        if (j >= K) return 0.f;
+        if constexpr (DES) return des[(r * 4 + j / (DBS - 4)) * DBS + (j % (DBS - 4))];
+        else return deg[(long)r * K + j];
+    };
+    for (int u = tid; u < 4 * K; u += nthr) {
+        const int r = u >> 2, q = u & 3;
+        float sum = 0.f;
+        for (int pq = 0; pq < DBS - 4; ++pq) sum += de_at(r, q * (DBS - 4) + pq);
+        rsq[u] = sum;
+    }
+    for (int u = tid; u < 8 * KJ; u += nthr) {
+        const int w = u / KJ, j = u - w * KJ;
+        float sum = 0.f;
+        if (w < NW)
+            for (int r = w; r < K; r += NW) sum += de_at(r, j);
+        csw[u] = sum;
+    }
+    __syncthreads();
     for (int j = tid; j < KJ; j += nthr) {           // column sums of d e
-        float s = 0.f;
-        if (j < K) {
-            if constexpr (DES) {
-                const int q = j / (DBS - 4), pq = j - q * (DBS - 4);
-                for (int r = 0; r < K; ++r) s += des[(r * 4 + q) * DBS + pq];
-            } else {
-                for (int r = 0; r < K; ++r) s += deg[(long)r * K + j];
-            }
-        }
-        cs[j] = s;
+        float sum = 0.f;
+        for (int w = 0; w < 8; ++w) sum += csw[w * KJ + j];
+        cs[j] = sum;
     }
     __syncthreads();
 
@@ -1029,12 +1049,14 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
             float Nacc[8 * NJQ];
 #pragma unroll
             for (int j = 0; j < 8 * NJQ; ++j) Nacc[j] = 0.f;
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = 0.f, s2 = 0.f;                  // this lane's share of s1_k and A_k (see above)
             const float* __restrict__ rsp = Rs + j0 * GP_LLD + k;
             // the keys' R values of this column do not depend on the query row: registers, not one LDS read per pair
             float Rv[8 * NJQ];
 #pragma unroll
             for (int j = 0; j < 8 * NJQ; ++j) Rv[j] = rsp[j * GP_LLD];
+#pragma unroll
+            for (int j = 0; j < 8 * NJQ; ++j) s1 = __builtin_fmaf(Rv[j], csw[wave * KJ + j0 + j], s1);
             for (int r = wave; r < K; r += NW) {
                 const float L = Ls[r * GP_LLD + k];
                 // the row's d e values of this quarter's keys: its block of the staged row (aligned, conflict free, zeros past K), or
@@ -1062,9 +1084,9 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
                     const float mm = t > 0.f ? d : 0.f;
                     Macc += mm;
                     Nacc[j] += mm;
-                    s1 = __builtin_fmaf(d, t, s1);
-                    s2 = __builtin_fmaf(d, fabsf(t), s2);
                 }
+                s1 = __builtin_fmaf(L, rsq[4 * r + quarter], s1);
+                s2 = __builtin_fmaf(L, Macc, s2);          // (this lane's keys only: the quarters are summed with s2 below)
                 Macc += __shfl_xor(Macc, 16);
                 Macc += __shfl_xor(Macc, 32);
                 if (quarter == 0) a.DLR[(win * K + r) * (long)(2 * Ep) + col] = cl * Macc;
@@ -1072,6 +1094,8 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
             // the waves' partial sums into NS / daS, one wave after the other (plain read-add-write between barriers): LDS float
             // atomics from all eight waves at once cost 5.6 of this kernel's 9.0 ms at 100 keys (~180 cycles per wave instruction);
             // the order of the sums is fixed as well
+#pragma unroll
+            for (int j = 0; j < 8 * NJQ; ++j) s2 = __builtin_fmaf(Rv[j], Nacc[j], s2);
             for (int wq = 0; wq < NW; ++wq) {
                 if (wave == wq) {
 #pragma unroll
@@ -1093,7 +1117,7 @@ __global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const
         }
         if (tid < 32) {
             const int col = 32 * part + tid;
-            a.DApart[win * Ep + col] = 0.5f * (1.f + a.alpha) * daS[tid] + 0.5f * (1.f - a.alpha) * daS[32 + tid];
+            a.DApart[win * Ep + col] = a.alpha * daS[tid] + (1.f - a.alpha) * daS[32 + tid];
         }
         __syncthreads();
         for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
