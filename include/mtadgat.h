@@ -153,6 +153,8 @@ int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, voi
  *   1            bf16 MFMA operands (weights packed to bf16 once per load_weights, activations rounded on the
  *                way into the matrix unit), fp32 accumulation, fp32 recurrent state / gates / softmax:
  *                <= 2e-2 of the fp32 reference on outputs of scale ~1 (BASELINE configs "bf16 inference").
+ *                From 4 096 windows per chunk the convolution and the two attention layers run on mode 2's two-fp16-piece
+ *                kernels instead (faster than their bf16 builds and closer to fp32); the recurrences and heads stay bf16.
  * The training entry points follow the same switch for their four recurrences (GRU layer and decoder, forward and
  * back-propagation through time: bf16 MFMA operands, fp32 accumulation / state / gate arithmetic); convolution,
  * attention, the Linear layers and every weight-gradient GEMM stay fp32. */

@@ -73,8 +73,11 @@ struct XSource {
 };
 
 // the batch sizes / options at which the fused front end's convolution is the window-per-workgroup kernel on fp16 pieces
+// (precision mode 1 -- bf16 operands -- takes the same front end from 4096 windows: its fp16-piece kernels are faster than the bf16
+// builds of k_conv_lds / k_gat, 10.5 against 12.3 ms per 65 536 windows, and closer to the fp32 results; the recurrences stay bf16)
+static bool split_front(const Model& m, int64_t n) { return m.precision == 1 && n >= 4096 && m.conv_kernel == 0 && m.gat_kernel == 0; }
 static bool conv_win_selected(const Model& m, int64_t n) {
-    return m.precision == 2 && m.conv_kernel != 1 && (n >= 4096 || m.conv_kernel == 2);
+    return (m.precision == 2 || split_front(m, n)) && m.conv_kernel != 1 && (n >= 4096 || m.conv_kernel == 2);
 }
 
 // geo (optional): the rows are cut into `geo_W`-row windows instead of the model's W-row ones (run_conv_shared)
@@ -97,7 +100,8 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
     a.Fq = m.Fp;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w_off);
     // bf16 operand build: inference forward only (hcat / y outputs), when the LDS-staged kernel applies
-    if (m.precision == 1 && !xc && !xct && (size_t)(32 + m.taps - 1) * (m.Fp16 + 4) * sizeof(float) <= 20 * 1024) {
+    if (m.precision == 1 && !xc && !xct && (size_t)(32 + m.taps - 1) * (m.Fp16 + 4) * sizeof(float) <= 20 * 1024 &&
+        !(conv_win_selected(m, n) && !geo_W && hcat && !y)) {
         a.bf16 = 1; a.Fq = m.Fp16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w16_off);
     }
@@ -272,10 +276,10 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     a.pbias = m.packed_dev + g.b_off;
     a.NT_L = g.NT_L; a.Q = g.Q; a.PT = g.PT; a.P8 = g.P8;
     a.ord = m.cfg.use_gatv2 ? reinterpret_cast<const int*>(m.packed_dev + g.ord_off) : nullptr;
-    if (m.precision == 1 && !att) {       // bf16 operand build of the projection (inference)
+    if (m.precision == 1 && !att && !(split_front(m, n) && vmax)) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w16_off);
-    } else if (m.precision == 2 && (n >= 4096 || (m.gat_kernel == 3 && !att))) {
+    } else if ((m.precision == 2 || (split_front(m, n) && !att)) && (n >= 4096 || (m.gat_kernel == 3 && !att))) {
         // large batches: split-bf16 operands for the projection -- fp32-class L' / R' on the bf16 matrix pipe, which runs
         // beside the pair grid of the other waves (the fp32 MFMA does not: profiles/r02_mfma_valu_overlap.txt).  Measured at
         // (W=100, F=55): feature layer 5.90 -> 5.09 ms, temporal layer 7.40 -> 6.94 ms (two weight chunks in registers; with
@@ -320,7 +324,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
 // conditions of k_conv_win and of k_gath's launch in run_gat_fused, and the staged input must fit the L' / R' region.  Fills `cv`.
 bool fused_conv_args(const Model& m, const XSource& src, int64_t c0, int64_t n, float* hcat, unsigned* vmax, unsigned char* flag, GatConvIn& cv) {
     const GatPlan& g = m.temp;
-    if (m.conv_fused == 1 || m.precision != 2 || !conv_win_selected(m, n) || !g.fused || !m.feat.fused) return false;
+    if (m.conv_fused == 1 || !(m.precision == 2 || split_front(m, n)) || !conv_win_selected(m, n) || !g.fused || !m.feat.fused) return false;
     if (!(n >= 4096 || m.gat_kernel == 3) || !(m.gat_kernel == 0 || m.gat_kernel == 3) || g.fh_lds_bytes > 160 * 1024) return false;
     if (g.K != m.W || g.D != m.F || !aligned16(hcat) || (m.Dp & 3) != 0 || ((g.D + 3) & ~3) > m.Dp) return false;
     cv = GatConvIn{};

@@ -236,13 +236,14 @@ class MTAD_GAT(nn.Module):
             # two fp16 pieces per operand where its range is bounded or recorded (recurrent state, attention outputs, the
             # convolution's outputs below 2^15, weights under a per-layer power of two), three bf16 pieces otherwise -- which
             # reproduces the fp32-MFMA result to ~2e-7: DESIGN.md section 4), "fp32_strict" (v_mfma_f32 / fp32 VALU only),
-            # "bf16" (bf16 MFMA operands, fp32 accumulation / state / softmax, <= 2e-2), "auto" = bf16 exactly when the caller
+            # "bf16" (bf16 MFMA operands, fp32 accumulation / state / softmax, <= 2e-2; from 4 096 windows per call the convolution
+            # and attention layers take the faster two-fp16-piece kernels of "fp32"), "auto" = bf16 exactly when the caller
             # hands over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
             object.__setattr__(self, "precision", "auto")
         if "bf16_training_recurrences" not in self.__dict__:
             # False (default): a training step always runs the fp32 step (split-operand / small-batch recurrences), also when
-            # bf16 is requested -- it is the faster one at every batch size (round 5, SMD shape: batch 256 2.8 vs 8.4 ms, batch
-            # 8 192 33.7 vs 36.6 ms) and the more accurate one.  True: the four recurrences of the step on bf16 MFMA operands
+            # bf16 is requested -- it is the faster one at every batch size (round 5, SMD shape: batch 256 2.5 vs 8.2 ms, batch
+            # 8 192 29.5 vs 34.5 ms) and the more accurate one.  True: the four recurrences of the step on bf16 MFMA operands
             # (the arithmetic of BASELINE's "bf16 train loop" configuration)
             object.__setattr__(self, "bf16_training_recurrences", False)
         if "check_weight_contents" not in self.__dict__:
