@@ -239,13 +239,26 @@ __global__ __launch_bounds__(256, (VEC || BMODE == 1) ? 3 : 2) void k_wgrad_lds(
         }
 }
 
-__global__ void k_wgrad_reduce(const WgradReduceArgs a) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// 64 outputs per workgroup, four threads per output (slabs g, g + 4, ...; the four partial sums are added in a fixed order through
+// LDS): with one thread per output the 64 .. 128 slab reads of an element were one chain on a launch of ~1 workgroup per CU
+// (14 us for 20 MB at 256 windows, twelve launches per training step)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduceArgs a) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + e;
     const int NN = a.N + 1;
-    if (idx >= (long)a.M * NN) return;
-    const int m = (int)(idx / NN), n = (int)(idx - (long)m * NN);
+    const bool ok = idx < (long)a.M * NN;
+    int m = 0, n = 0;
     float v = 0.f;
-    for (int s = 0; s < a.nslab; ++s) v += a.P[((long)s * a.Mp + m) * a.Np + n];
+    if (ok) {
+        m = (int)(idx / NN);
+        n = (int)(idx - (long)m * NN);
+        for (int s = g; s < a.nslab; s += 4) v += a.P[((long)s * a.Mp + m) * a.Np + n];
+    }
+    part[g][e] = v;
+    __syncthreads();
+    if (g != 0 || !ok) return;
+    v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
     if (n < a.N) {
         const int ro = a.rowmapW[m], co = a.colmap[n];
         if (ro >= 0 && co >= 0) a.outW[ro + co] += v;
@@ -286,7 +299,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t s) {
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s) {
     const long total = (long)a.M * (a.N + 1);
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return 0;
 }
@@ -306,12 +319,17 @@ __global__ void k_sum_rows1(const float* __restrict__ src, long ld, long R, int 
     for (long r = r0; r < r1; ++r) v += src[r * ld + n];
     part[(long)blockIdx.y * N + n] = v;
 }
-__global__ void k_sum_rows2(const float* __restrict__ part, int nslab, int N, float* __restrict__ dst) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// (four threads per output, as k_wgrad_reduce: the slab reads of an element are four short chains instead of one)
+__global__ __launch_bounds__(256) void k_sum_rows2(const float* __restrict__ part, int nslab, int N, float* __restrict__ dst) {
+    __shared__ float ps[4][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + e;
     float v = 0.f;
-    for (int s = 0; s < nslab; ++s) v += part[(long)s * N + n];
-    dst[n] += v;
+    if (n < N)
+        for (int s = g; s < nslab; s += 4) v += part[(long)s * N + n];
+    ps[g][e] = v;
+    __syncthreads();
+    if (g == 0 && n < N) dst[n] += (ps[0][e] + ps[1][e]) + (ps[2][e] + ps[3][e]);
 }
 int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, float* dst, hipStream_t s) {
     if (R <= 0 || N <= 0) return 0;
@@ -319,7 +337,7 @@ int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, fl
     const long rps = (R + S - 1) / S;
     hipLaunchKernelGGL(k_sum_rows1, dim3((unsigned)((N + 255) / 256), (unsigned)S), dim3(256), 0, s, src, ld, R, N, rps, scratch);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_rows2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, scratch, S, N, dst);
+    hipLaunchKernelGGL(k_sum_rows2, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, scratch, S, N, dst);
     LAUNCH_CHECK();
     return 0;
 }
