@@ -894,6 +894,11 @@ static void launch_rowgemm_xv(const RowGemmArgs& a, hipStream_t s) {
     if (a.NT >= 2 && (long)grid * groups4 < 1024) {
         // a latency chain on a few waves (a head Linear on 256 rows): one output tile per wave
         hipLaunchKernelGGL((k_rowgemm<1, XV>), dim3(grid, (unsigned)a.NT), dim3(64), 0, s, a);
+    } else if (a.NT >= 4 && (long)grid * groups4 < 8192) {
+        // mid-size launches (the GRU input projection of a 256-window batch: 800 row blocks x 15 tiles): two tiles per wave (108
+        // registers, four waves per SIMD, instead of 172 and two) spread over gridDim.y -- 256-window forward 0.456 -> 0.429 ms
+        const long groups2 = (a.NT + 1) / 2;
+        hipLaunchKernelGGL((k_rowgemm<2, XV>), dim3(grid, (unsigned)groups2), dim3(64), 0, s, a);
     } else if (a.NT >= 4) {
         const long want = (4096 + grid - 1) / grid;                 // ~4 waves per SIMD
         const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
