@@ -13,9 +13,12 @@ runs its own batch), timing is bracketed by barrier + synchronize and the maximu
 over ranks is used.  Rank 0 prints ONE JSON line.
 
 Also in the line:
-  roofline      -- the launch family that dominates the step, timed with HIP events on
-                   the launch stream inside the timed region (C ABI: mtadgat_profile_*),
-                   algorithmic FLOPs per launch / average duration vs the fp32 MFMA peak;
+  roofline      -- the launch family that takes most of the step, timed with HIP events on
+                   the launch stream inside the timed region (C ABI: mtadgat_profile_*): the
+                   attention family (k_gath, pair grid on the vector ALU) against the VALU
+                   lane-op rate, or the recurrences (k_gru_cm) against the guide's 2 500 TF dense
+                   16-bit MFMA peak (`alg_frac` algorithmic, `issued_frac` incl. the three split
+                   terms and padding); both families always under `roofline_valu` / `roofline_mfma`;
                    plus `hbm` with the algorithmic-bytes rate vs 8 TB/s that BASELINE.json
                    asks for (this path is compute-bound by ~100x).
   cpu_baseline  -- the unmodified reference module (imported from $MTADGAT_REFERENCE or /root/reference,
@@ -28,7 +31,8 @@ Also in the line:
                    SMAP weights) and `config4_f512_w256` (config 4, batch 8192); each names the code path that ran.
 
 --mode train times the data-parallel TRAINING step instead (BASELINE config 5's exchange step: sharding.dp_training_step =
-forward + global-batch RMSE losses through a 4-scalar all-reduce + backward + one flat gradient all-reduce on RCCL + Adam;
+forward + global-batch RMSE losses through one small statistics all-reduce + backward + one flat gradient all-reduce on RCCL + Adam
+-- two collectives per step, no host read before the backward is enqueued;
 reference training.py:106-127) at the MSL shape, `--batch` windows per GPU (default 8192); the two collectives are timed
 separately with HIP events on the stream they run on.  Works at N = 1 (the collectives are skipped).
 """
@@ -331,7 +335,29 @@ def sub_records(model, kw, dev, args_precision="fp32"):
     x2 = torch.rand(4096, kw2["window_size"], 25, generator=g).to(dev).to(torch.bfloat16)
     with torch.no_grad():
         t = _timed(lambda: m2(x2), dev, 10)
-    out["smap_bf16_b4096"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(4096 / t, 1),
+        e2 = m2._sync_engine(dev, bf16=True)
+        e2.profile_enable(True)
+        for _ in range(5):
+            m2(x2)
+        torch.cuda.synchronize(dev)
+        p2 = e2.profile_read()
+        e2.profile_enable(False)
+    # config 2's roofline: the launch family that takes most of this (latency-class) call, priced on the pipe it runs on
+    km2 = {k: round(v[0] / 5, 4) for k, v in p2.items() if v[1]}
+    dom2 = max(km2, key=km2.get)
+    if dom2 in ("attend", "proj"):
+        fam_ms = km2.get("attend", 0.0) + km2.get("proj", 0.0)
+        tl2 = valu_lane_ops(kw2)["attend"] * 4096 / (fam_ms * 1e-3) / 1e12
+        roof2 = {"kernel": "attention family (k_gath: projection + pair grid + aggregation, both layers)", "bound": "valu",
+                 "achieved": round(tl2, 2), "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "T lane-op/s", "frac": round(tl2 / VALU_PEAK_TLANEOPS, 4),
+                 "ms": round(fam_ms, 4)}
+    else:
+        tf2 = algorithmic_flops(kw2)[dom2] * 4096 / (km2[dom2] * 1e-3) / 1e12
+        roof2 = {"kernel": dom2, "bound": "mfma", "achieved": round(tf2, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(tf2 / BF16_MFMA_PEAK_TFLOPS, 4), "ms": km2[dom2],
+                 "note": "algorithmic matrix FLOPs of the family / its time vs the dense 16-bit MFMA peak; at 4 096 windows the "
+                         "recurrences are a 100-step latency chain on 128 workgroups, not a throughput kernel"}
+    out["smap_bf16_b4096"] = {"ms": round(1e3 * t, 3), "windows_per_s": round(4096 / t, 1), "kernel_ms": km2, "roofline": roof2,
                               "what": f"SMAP shape (F=25), batch 4096, bf16 in / bf16 out, {w2}"}
     del m2, x2
     # BASELINE config 4: synthetic F=512, W=256, out=512, H=150, batch 8192 (chunked by the library), fp32, random init

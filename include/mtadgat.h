@@ -17,8 +17,10 @@
  *     negative mtadgat_status; mtadgat_last_error() gives the message
  *     (thread-local).  Nothing throws across the boundary.
  *   - all tensors are float32, row-major contiguous, in the reference's own
- *     shapes; `*_dev` pointers are device (HBM) pointers owned by the caller,
- *     `*_host` pointers are host pointers.
+ *     shapes -- with one exception: mtadgat_forward_xbf16 takes its input
+ *     windows as bfloat16 (BASELINE config 2's "bf16 inference"); its outputs
+ *     are float32 like everyone else's.  `*_dev` pointers are device (HBM)
+ *     pointers owned by the caller, `*_host` pointers are host pointers.
  *   - every launch goes to the HIP stream the caller passes (a hipStream_t cast
  *     to void*; NULL = the null stream) and nothing synchronises the device.
  *   - the library keeps no per-call state besides the packed weights held by

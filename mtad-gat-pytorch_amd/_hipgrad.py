@@ -111,8 +111,21 @@ class _HipStep(torch.autograd.Function):
 _warned = set()      # reasons already reported (one warning per reason and process)
 
 
-def forward(model, eng, x):
-    """(preds, recons) with autograd history when grad is enabled; dropout active iff model.training."""
+def draw_dropout_stream(model):
+    """(seed, first global window) of this call's counter-based dropout masks.  One seed per call from torch's (CPU) generator:
+    runs are reproducible under torch.manual_seed.  A caller that shards one logical batch over several ranks sets
+    `model.dropout_stream = (seed, first_global_window)` for the call (sharding.dp_training_step does): the masks are keyed by
+    the global window index, so the shards draw exactly the masks the single-process step over the whole batch would."""
+    override = getattr(model, "dropout_stream", None)
+    if override is not None:
+        return int(override[0]), int(override[1])
+    p = float(model.dropout_p) if model.training else 0.0
+    return (int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0), 0
+
+
+def forward(model, eng, x, stream=None):
+    """(preds, recons) with autograd history when grad is enabled; dropout active iff model.training.
+    stream: draw_dropout_stream(model) when the caller drew it already (MTAD_GAT.forward does, once per call)."""
     why = None
     if not eng.backward_supported():
         why = eng.why_not()
@@ -120,25 +133,19 @@ def forward(model, eng, x):
         # Not silent: the torch-op route materialises the (b, K, K, 2E) attention tensors and runs MIOpen's GRU -- a caller
         # who expects the HIP training step must learn that this configuration does not have one.
         object.__setattr__(model, "grad_path", "torch-ops: " + why)
-        if getattr(model, "strict_hip_training", False):
-            raise RuntimeError("MTAD_GAT.strict_hip_training is set and this training step cannot run on the HIP kernels: " + why)
+        if getattr(model, "strict_hip_training", True):
+            raise RuntimeError("this training step cannot run on the HIP kernels: " + why + ".  The inference forward of this "
+                               "configuration is unaffected.  MTAD_GAT.strict_hip_training = False evaluates such a step "
+                               "by torch ops on the GPU instead (rocBLAS / MIOpen through autograd, much slower).")
         if why not in _warned:
             _warned.add(why)
             warnings.warn("MTAD_GAT training step on the GPU runs through torch ops (autograd), not the HIP backward: " + why +
-                          ".  The inference forward of this configuration is unaffected.  Set model.strict_hip_training = True "
-                          "to make this an error.", RuntimeWarning, stacklevel=3)
+                          ".  The inference forward of this configuration is unaffected (model.strict_hip_training = False "
+                          "opted into this route).", RuntimeWarning, stacklevel=3)
         return _torchpath.forward(model, x.float())
     object.__setattr__(model, "grad_path", "hip")
     p = float(model.dropout_p) if model.training else 0.0
-    # one seed per call from torch's (CPU) generator: runs are reproducible under torch.manual_seed.  A caller that
-    # shards one logical batch over several ranks sets `model.dropout_stream = (seed, first_global_window)` for the
-    # call (sharding.dp_training_step does): the masks are keyed by the global window index, so the shards draw
-    # exactly the masks the single-process step over the whole batch would.
-    override = getattr(model, "dropout_stream", None)
-    if override is not None:
-        seed, w0 = int(override[0]), int(override[1])
-    else:
-        seed, w0 = (int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0), 0
+    seed, w0 = stream if stream is not None else draw_dropout_stream(model)
     params = param_order(model)
     # (x keeps its autograd history: when it requires a gradient the backward also returns d x -- mtadgat_backward_input)
     return _HipStep.apply(eng, x.contiguous().float(), p, seed, w0, *params)

@@ -311,11 +311,9 @@ int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const f
     if (nwin <= 0) return 0;
     const size_t lds = bw_pair_lds(K);
     if ((Ep & 31) != 0 || K > 512 || lds > 160 * 1024) return -2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_pair), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 64 * 1024) {      // per device and cheap: set on every launch that needs it (as launch_gat_wide does), no process-wide flag
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e_ != hipSuccess) return (int)e_;
-        attr_set = true;
     }
     BwPairArgs a{};
     a.LR = LR; a.ldlr = ldlr; a.Ep = Ep; a.avec = avec; a.DE = DE; a.DEt = DEt; a.K = K; a.alpha = alpha; a.DLR = DLR; a.DAp = DAp; a.nwin = nwin;

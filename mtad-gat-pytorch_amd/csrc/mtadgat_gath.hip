@@ -25,6 +25,20 @@ __device__ __forceinline__ float gath_exp(float x) {      // e^x, x <= 0 (or -in
     const float lo = __builtin_fmaf(x, c_hi, -hi);
     return __builtin_amdgcn_exp2f(hi) * __builtin_fmaf(0.6931471805599453f, lo, 1.0f);
 }
+// Developer build -DMTADGAT_GATH_STAMP (profiles/gath_timeline.py): lane 0 of every wave of GATH_STAMP_WINS mid-launch workgroups
+// records s_memtime at the phase boundaries below; read back through mtadgat_debug_gath_stamps.  Not in the regular build.
+#ifdef MTADGAT_GATH_STAMP
+constexpr int GATH_STAMP_WINS = 64;
+__device__ unsigned long long g_gath_stamp[2 * GATH_STAMP_WINS * 8 * 32];
+#define GATH_STAMP(id)                                                                                                   \
+    do {                                                                                                                 \
+        const long sw_ = (long)blockIdx.x - (long)(a.nwin >> 1);                                                         \
+        if (sw_ >= 0 && sw_ < GATH_STAMP_WINS && (threadIdx.x & 63) == 0)                                                \
+            g_gath_stamp[(((CONV ? 0 : GATH_STAMP_WINS) + sw_) * 8 + (threadIdx.x >> 6)) * 32 + (id)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GATH_STAMP(id) do { } while (0)
+#endif
 // (A <= 80-VGPR build with one operand register set -- three 8-wave workgroups per CU -- was measured at 12.0 against 9.6 ms for
 // the two layers and is gone; so are staggered workgroup starts, which changed nothing: DESIGN.md section 4.)
 //
@@ -53,6 +67,19 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     // the chains get their few instructions at once and the pair grid soaks up the rest.  Measured, both layers per 65 536
     // windows, same process: 10.65 -> 10.43 ms (8 runs each way); the reverse assignment 10.42 -> 10.79.
     __builtin_amdgcn_s_setprio(3);
+    GATH_STAMP(0);
+#ifdef MTADGAT_GATH_STAMP
+    {
+        const long sw_ = (long)blockIdx.x - (long)(a.nwin >> 1);
+        if (sw_ >= 0 && sw_ < GATH_STAMP_WINS && (threadIdx.x & 63) == 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_gath_stamp[(((CONV ? 0 : GATH_STAMP_WINS) + sw_) * 8 + (threadIdx.x >> 6)) * 32 + 31] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
@@ -167,6 +194,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         }
         mx = wave_max(mx);
         if (lane == 0) red[wave] = mx;
+        GATH_STAMP(1);
         {   // zero halo rows, the two spare rows behind them and the channel padding [F, Fq) of the window's rows
             const int hw = pvx >> 1;                   // dwords per row
             for (int u = tid; u < 2 * pad * hw; u += nthr) {
@@ -198,6 +226,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             red[9] = __uint_as_float((254u - ec) << 23);
         }
         __syncthreads();
+        GATH_STAMP(2);
         const float sx = red[8], sxi = red[9];
         {
             const float finv = 1.0f / (float)F;
@@ -223,6 +252,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             }
         }
         __syncthreads();
+        GATH_STAMP(3);
         // out[t][o] = sum_{tap, ch} w[o][tap][ch] x[t + tap - pad][ch]: A = weights (32 output channels), B = input rows (lane (i, g):
         // row of the tile + i, channels 16 cb + 4 g .. + 3 and + 8 .. -- mtadgat_device.h), K runs over taps x 16-channel chunks
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -276,6 +306,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                 }
             }
             // epilogue: 1 / (S sx), bias, ReLU -> h_cat[:, :F] (+ the zero alignment padding of the row) and the window's pieces
+            GATH_STAMP(4);
             if (t < W) {
                 float* __restrict__ hrow = c.HCAT + (win * W + t) * (long)c.Dp;
                 if (nb == 0 && g == 0)
@@ -311,6 +342,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         }
         vmx = wave_max(vmx);
         if (lane == 0) red[10 + wave] = vmx;
+        GATH_STAMP(5);
         __syncthreads();                               // every wave is done with the staged input: the region is the projection's now
         float wmax = red[10];
         for (int w2 = 1; w2 < NW; ++w2) wmax = fmaxf(wmax, red[10 + w2]);
@@ -319,6 +351,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             if (c.vmax && !(wmax <= __uint_as_float(*c.vmax))) atomicMax(c.vmax, __float_as_uint(wmax));
             if (c.flag) c.flag[win] = big ? 1 : 0;
         }
+        GATH_STAMP(6);
         if (big) return;                               // (uniform) k_gat's bf16-piece build, enqueued behind this kernel, takes the window
         f0 = FPc;
     } else {
@@ -391,6 +424,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     }
     prefetch(0);
     __syncthreads();
+    GATH_STAMP(7);
 
     const bool rows_owner = wave < NWA;
     const bool full = wave < a.n_full;
@@ -456,7 +490,9 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                 }
             }
         }
+        GATH_STAMP(8 + 3 * (part < 5 ? part : 4));
         __syncthreads();
+        GATH_STAMP(9 + 3 * (part < 5 ? part : 4));
         // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
         int ntl = ntile - 4 * part;
         ntl = ntl > 4 ? 4 : ntl;
@@ -511,6 +547,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             }
         }
         __builtin_amdgcn_s_setprio(3);
+        GATH_STAMP(10 + 3 * (part < 5 ? part : 4));
         if (part + 1 < nparts) {
             prefetch(part + 1);
             __syncthreads();
@@ -525,6 +562,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         for (int jj = 0; jj < JPL; ++jj) dv[jj] = rp[jj * RJ * GAT_LLD + col];
     }
     __syncthreads();
+    GATH_STAMP(23);
     if (a.dbg & 4) { if (acc[0][0] == 12345.f) a.out[0] = cv[0] + dv[0]; return; }       // (uniform)
     static_assert(IBW == 16, "one 16-row MFMA group per wave");
     constexpr int DTMAX = 8;                           // D <= 128 (plan)
@@ -577,6 +615,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         for (int jj = 0; jj < JPL; ++jj) acc[ii][jj] = rowok ? e[jj] * inv : 0.f;
     }
 
+    GATH_STAMP(24);
     if (a.ATT || a.drop.thresh) {                      // training forward: keep the softmax rows, drop attention entries (counter-based mask)
         const unsigned key = drop_window_key(a.drop, a.drop_stream, win);
 #pragma unroll
@@ -657,6 +696,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         }
     }
     }   // rows_owner
+    GATH_STAMP(25);
     // ---- output.  The layer's K x D result leaves through LDS (round 5): every wave drops its sigmoid values into one tile laid
     // out like the destination -- rows along the output's long stride, the unit-stride index inside a row -- and the workgroup
     // then writes whole rows, 256 consecutive bytes per wave instruction.  Before, a lane stored the four values it held: 16-byte
@@ -680,14 +720,24 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                         if (rv && d0 + r < D) otile[nodes_minor ? (d0 + r) * C + row : row * C + d0 + r] = gate_sigmoid(o[dt][r]);
                 }
         }
+        GATH_STAMP(26);
         __syncthreads();
+        GATH_STAMP(27);
         const long rstride = nodes_minor ? a.so_d : a.so_i;
         float* __restrict__ obase = a.out + win * a.so_w;
         // a wave instruction stays inside one destination row (its 64-byte sectors are touched by one request each)
         for (int r = wave; r < R; r += NW)
             for (int c = lane_t; c < C; c += 64) obase[(long)r * rstride + c] = otile[r * C + c];
     }
+    GATH_STAMP(28);
 }
+
+#ifdef MTADGAT_GATH_STAMP
+extern "C" int mtadgat_debug_gath_stamps(unsigned long long* dst, size_t n) {
+    if (n > sizeof(g_gath_stamp) / sizeof(unsigned long long)) n = sizeof(g_gath_stamp) / sizeof(unsigned long long);
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gath_stamp), n * sizeof(unsigned long long));
+}
+#endif
 
 #define GATH_CASE(I, J, RJ)                                                                     \
     if (IBL == I && JPL == J && rj == RJ) {                                                     \

@@ -18,13 +18,15 @@ Device contract.  Tensors on the GPU ('cuda' = HIP on PyTorch-ROCm) always run t
 HIP kernels in inference (no grad) and raise if `libmtadgat.so` is missing: there is no
 fallback for the inference forward of GPU tensors.  When gradients are wanted, the HIP
 training step (forward that keeps a tape + HIP backward behind a `torch.autograd.Function`)
-runs for the configurations it covers: GATv2 and GAT (v1) attention, any number of GRU and
-decoder layers (nn.GRU's inter-layer dropout included), attention layers of at most 128 nodes
-(window_size, n_features <= 128); parameter gradients, and the input's when `x.requires_grad`
-(mtadgat_backward_input).  Outside of that (wider layers) the step is evaluated by torch ops on the GPU
-(`_torchpath.py`, autograd): `model.grad_path` names the route and the reason, a
-RuntimeWarning is raised once per reason, and `model.strict_hip_training = True` turns it
-into an error.  A model and input left on the CPU (the reference's
+runs for the configurations it covers: GATv2 attention layers of up to 512 nodes / features
+(fused kernels up to 128, the wide kernels of csrc/mtadgat_bwdw.hip above), GAT (v1) layers of
+up to 128, any number of GRU and decoder layers (nn.GRU's inter-layer dropout included);
+parameter gradients, and the input's when `x.requires_grad` (mtadgat_backward_input).
+Outside of that (GAT v1 above 128 nodes, anything above 512) there is no HIP training step and
+the call RAISES (`model.strict_hip_training`, default True): nothing on the GPU runs rocBLAS /
+MIOpen behind the caller's back.  `model.strict_hip_training = False` opts into evaluating
+such a step by torch ops on the GPU (`_torchpath.py`, autograd), with `model.grad_path`
+naming the route and the reason and a RuntimeWarning once per reason.  A model and input left on the CPU (the reference's
 `--use_cuda False` / no-GPU branch, predict.py:122, training.py:60; BASELINE config 1)
 are evaluated by the package's own torch-op algebra (`_torchpath.py`), chosen by the
 caller through the tensors' device.
@@ -293,7 +295,14 @@ class MTAD_GAT(nn.Module):
 
     def _sync_engine(self, device, bf16=False):
         """Engine (on `device`) whose packed weights match the current parameters (repacked when any changed), with
-        the requested arithmetic selected (the bf16 weight streams are packed on first use only)."""
+        the requested arithmetic selected (the bf16 weight streams are packed on first use only).
+
+        The content check is split in two: this half enqueues the fingerprint, `_finish_weight_check()` reads it once the
+        call's kernels are enqueued (its `event.synchronize()` blocks the host until the side stream's 8-byte copy has landed --
+        the main stream is not synchronised).  `_checked()` does both and repeats the call when the contents changed under
+        unchanged version counters.  A caller that takes the engine from here directly (bench.py, profiles/, tests) leaves the
+        check open: it is finished at the top of the next `_sync_engine`, i.e. such a caller sees a `p.data` edit one call late
+        -- use `_checked` or set `check_weight_contents = False` and call `refresh_weights()`."""
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
@@ -325,6 +334,11 @@ class MTAD_GAT(nn.Module):
         self._engine.set_precision(mode)
         self._engine.set_option("series_band", {"auto": 0, False: 1, True: 2}[self.share_series_pair_scores])
         repack = key != self._weights_key or (bf16 and not self._engine.bf16_ready())
+        if check and getattr(self, "_fp_value", None) is None:
+            # the contents the packed weights were built from are not on record (first call, or unchecked calls in between:
+            # "eval_only" while training, the flag toggled): a `p.data` edit made meanwhile could not be seen by comparing, so
+            # this call re-packs and records the fingerprint of what it packed
+            repack = True
         if repack:
             self._engine.load_weights(self.state_dict(), device, allow_device_pack=self.device_repack)
             object.__setattr__(self, "_weights_key", key)
@@ -414,7 +428,8 @@ class MTAD_GAT(nn.Module):
             # training step (Trainer.fit, training.py:100-130) or any call that will be differentiated:
             # HIP forward that keeps what the HIP backward needs, dropout in the kernels
             import _hipgrad
-            preds, recons = self._checked(x.device, bf16, lambda eng: _hipgrad.forward(self, eng, x))
+            stream = _hipgrad.draw_dropout_stream(self)   # once: a repetition by _checked must not consume the generator twice
+            preds, recons = self._checked(x.device, bf16, lambda eng: _hipgrad.forward(self, eng, x, stream))
         else:
             with torch.no_grad():
                 # bfloat16 batches go to the kernels as they are (the convolution converts while staging) when the

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from helpers import ALL_CASES, SHIPPED_CASES, Case, gate
+from oracle import mtad_gat_oracle as oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -189,6 +190,30 @@ def test_full_machine_batch_matches(name, precision, gpu_device):
     assert (r_big[40000:40100] - r_small).abs().max().item() <= 2e-6
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32_strict"])
+def test_headline_batch_random_windows_against_the_oracle(precision, gpu_device):
+    """The headline workload itself (bench.py: 65 536 MSL windows, x ~ U[0,1) seed 1234, the shipped MSL checkpoint, eval): 64
+    windows drawn at random from the whole batch -- both rounds of the large-batch recurrence, every chunk -- against the oracle
+    (the reference's algorithm on the CPU, mtad_gat.py:64-79), not only the fixture windows at the tail."""
+    from bench import load_msl_state_dict
+    from mtad_gat import MTAD_GAT
+    sd, kw = load_msl_state_dict()
+    model = MTAD_GAT(**kw)
+    model.load_state_dict(sd)
+    model = model.eval()
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(65536, kw["window_size"], kw["n_features"], generator=g)
+    pick = torch.randperm(65536, generator=torch.Generator().manual_seed(7))[:64].sort().values
+    with torch.no_grad():
+        p_ref, r_ref = oracle.forward_chunked(x[pick], sd, alpha=kw.get("alpha", 0.2), chunk=16)
+        m = model.to(gpu_device)
+        m.precision = precision
+        p, r = m(x.to(gpu_device))
+    pk = pick.to(gpu_device)
+    gate(p[pk], p_ref, what=f"preds, 64 random windows of the 65 536-window bench batch, {precision}")
+    gate(r[pk], r_ref, what=f"recons, 64 random windows of the 65 536-window bench batch, {precision}")
+
+
 def test_bf16_io_smap_batch_4096(gpu_device):
     """BASELINE config 2 (SMAP, F=25, W=100, bf16 inference, batch 4096): bf16 tensors in and out.
     precision "auto" (default) answers bf16 tensors with the bf16-operand kernels; precision "fp32" keeps fp32
@@ -244,6 +269,33 @@ def test_weight_update_is_seen(gpu_device):
         bias.data.copy_(orig)
         assert torch.equal(model(x)[0], p3)
         model.refresh_weights()
+        assert torch.equal(model(x)[0], p0)
+
+
+def test_data_edit_behind_an_unchecked_call_is_seen(gpu_device):
+    """check_weight_contents = "eval_only": a train-mode call runs unchecked (the contents on record are dropped), a `p.data`
+    edit follows (no version counter moves, the packed-weight key is unchanged), then the first checked call has nothing to
+    compare with -- it must re-pack instead of serving the old weights.  Same when the flag is toggled off and on."""
+    a = Case("smap")
+    model = a.build_model().to(gpu_device)
+    model.check_weight_contents = "eval_only"
+    x = a.x.to(gpu_device)
+    bias = model.forecasting_model.layers[3].bias
+    with torch.no_grad():
+        p0, _ = model(x)
+    model.train()
+    model(x)                                           # unchecked (training): hip training forward, weights as packed
+    model.eval()
+    v = bias._version
+    bias.data.add_(0.75)
+    assert bias._version == v
+    with torch.no_grad():
+        p1, _ = model(x)
+        assert torch.allclose(p1, p0 + 0.75, atol=1e-6)
+        model.check_weight_contents = False
+        model(x)
+        bias.data.sub_(0.75)
+        model.check_weight_contents = True
         assert torch.equal(model(x)[0], p0)
 
 

@@ -174,6 +174,36 @@ def test_config4_chunked_batch_against_the_oracle(gpu_device):
     assert (p2 - p1).abs().max().item() <= 2e-6 * max(1.0, p1.abs().max().item()) and (r2 - r1).abs().max().item() <= 2e-6 * max(1.0, r1.abs().max().item())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp32_strict"])
+def test_config4_bench_chunk_against_the_oracle(precision, gpu_device):
+    """BASELINE config 4 at the dispatch bench.py's `config4_f512_w256` number runs on: ONE call of 896 windows (the library's own
+    chunk at this shape: F = 512, W = 256, out_dim = 512) with every engine option at its default, so the chunk goes through the
+    LDS-shared split-bf16 GEMMs (k_conv_x3s, k_rowgemm_x3s: 229 376 rows per launch), k_gat_wide / k_gat_wide_os and the
+    896-window recurrences.  The first two, two mid-chunk and the last two windows against oracle.forward_chunked (the reference's
+    algorithm, modules.py:65-95, :166-193, mtad_gat.py:64-79), in both fp32 arithmetics."""
+    from mtad_gat import MTAD_GAT
+    kw = dict(n_features=512, window_size=256, out_dim=512, kernel_size=7, gru_hid_dim=150, forecast_n_layers=3, forecast_hid_dim=150,
+              recon_hid_dim=150)
+    torch.manual_seed(0)
+    model = MTAD_GAT(**kw).eval()
+    with torch.no_grad():
+        model.feature_gat.bias.normal_()
+        model.temporal_gat.bias.normal_()
+    n = 896
+    g = torch.Generator().manual_seed(47)
+    x = torch.rand(n, 256, 512, generator=g)
+    pick = torch.tensor([0, 1, 447, 448, n - 2, n - 1])
+    with torch.no_grad():
+        p_ref, r_ref = oracle.forward_chunked(x[pick], model.state_dict(), alpha=0.2, chunk=2)
+        m = model.to(gpu_device)
+        m.precision = precision
+        eng = m._sync_engine(gpu_device)
+        assert eng.chunk_windows() >= n, "the library no longer takes 896 windows of this shape in one chunk: update the test and bench.py"
+        p, r = m(x.to(gpu_device))
+    gate(p[pick.to(gpu_device)], p_ref, what=f"config 4 preds, one 896-window chunk, {precision}")
+    gate(r[pick.to(gpu_device)], r_ref, what=f"config 4 recons, one 896-window chunk, {precision}")
+
+
 def test_many_row_gemms_share_weight_words_through_lds(gpu_device):
     """Launches of >= 131 072 rows of the split-bf16 row GEMM and of the wide models' convolution run as workgroups of four
     waves that share each chunk's weight words through LDS (k_rowgemm_x3s / k_conv_x3s, csrc/mtadgat_kernels.hip; the Linear

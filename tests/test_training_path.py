@@ -110,6 +110,72 @@ def test_data_parallel_step_equals_global_batch(tmp_path):
         assert (prm.grad - res["grads"][n]).abs().max().item() <= 2e-6, n
 
 
+def _dp_count_worker(rank, world, port, out_path):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "mtad-gat-pytorch_amd"), root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import sharding
+    from sharding import dp_training_step, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    kw = KW[0]
+    m = _model(kw)
+    frozen = m.forecasting_model.layers[0].bias
+    frozen.requires_grad_(False)                           # a parameter without a gradient: stays without one (copy path)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(7, kw["window_size"], kw["n_features"], generator=g)
+    y = torch.rand(7, 1, kw["n_features"], generator=g)
+    lo, hi = shard_range(7, rank, world)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    log = []                                               # ("coll", name) / ("item",) / ("backward",) in call order
+    real = {n: getattr(dist, n) for n in ("all_reduce", "broadcast", "all_gather", "reduce", "all_gather_into_tensor", "barrier")}
+    for n, fn in real.items():
+        setattr(dist, n, (lambda n, fn: lambda *a, **k: (log.append(("coll", n)), fn(*a, **k))[1])(n, fn))
+    real_item, real_float, real_bwd = torch.Tensor.item, torch.Tensor.__float__, torch.Tensor.backward
+    torch.Tensor.item = lambda self: (log.append(("item",)), real_item(self))[1]
+    torch.Tensor.__float__ = lambda self: (log.append(("item",)), real_float(self))[1]
+    torch.Tensor.backward = lambda self, *a, **k: (log.append(("backward",)), real_bwd(self, *a, **k))[1]
+    per_step = []
+    try:
+        for step in range(3):
+            del log[:]
+            dp_training_step(m, x[lo:hi], y[lo:hi], opt)
+            per_step.append(list(log))
+    finally:
+        for n, fn in real.items():
+            setattr(dist, n, fn)
+        torch.Tensor.item, torch.Tensor.__float__, torch.Tensor.backward = real_item, real_float, real_bwd
+    if rank == 0:
+        torch.save(dict(per_step=per_step, frozen_grad_is_none=frozen.grad is None, state=dict(m._dp_state, pinned=None)), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_talks_twice(tmp_path):
+    """SURVEY section 8e / reference training.py:122-127: the steady-state data-parallel step is TWO collectives (statistics,
+    gradient bucket); what the ranks must agree on rides in the first, the run's seed / shard sizes are settled once in step 0;
+    nothing reads a device value on the host before backward() has been enqueued."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dpc.pt")
+    mp.spawn(_dp_count_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    first, steady = res["per_step"][0], res["per_step"][1:]
+    assert [e[1] for e in first if e[0] == "coll"] == ["all_gather", "all_reduce", "all_reduce"]
+    for log in steady:
+        assert [e[1] for e in log if e[0] == "coll"] == ["all_reduce", "all_reduce"], log
+        b = log.index(("backward",))
+        assert ("item",) not in log[:b], "a host read in front of backward()"
+        assert [e for e in log[:b] if e[0] == "coll"] == [("coll", "all_reduce")]       # the statistics go first, the bucket after
+    assert res["frozen_grad_is_none"]
+    assert res["state"]["counts"] == [4, 3] and res["state"]["step"] == 3 and res["state"]["layout_refreshed"] == 0
+
+
 @pytest.mark.parametrize("name", ["grads_msl_eval", "grads_msl_masks", "grads_smd_eval", "grads_smd_masks"])
 def test_torch_op_algebra_matches_the_reference_held_gradients(name):
     """_torchpath.forward (the CPU route of the training step and the other side of tests/test_gpu_backward.py) against
