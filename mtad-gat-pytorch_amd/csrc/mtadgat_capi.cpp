@@ -1067,7 +1067,7 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (std::strcmp(name, "conv_fused") == 0 && value >= 0 && value <= 1) { h->m.conv_fused = value; return 0; }
     if (std::strcmp(name, "series_band") == 0 && value >= 0 && value <= 2) { h->m.series_band = value; return 0; }
     if (std::strcmp(name, "lanes") == 0 && value >= 0 && value <= 1) { h->m.lanes = value; return 0; }
-    if (std::strcmp(name, "gath_dbg") == 0 && value >= 0 && value <= 7) { h->m.gath_dbg = value; return 0; }
+    if (std::strcmp(name, "gath_dbg") == 0 && value >= 0 && value <= 63) { h->m.gath_dbg = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
 }
 

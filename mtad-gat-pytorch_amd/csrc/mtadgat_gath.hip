@@ -57,7 +57,14 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
     constexpr int IBW = RI * IBL;                      // query rows per wave
-    constexpr int QB = MTADGAT_GAT_QB3;                // weight chunks held in registers per task batch
+#ifndef MTADGAT_GATH_QB2
+#define MTADGAT_GATH_QB2 2
+#endif
+    // weight chunks held in registers per task batch (requested before the pair grid of the previous part, so they are there when
+    // the projection phase begins).  The 4-row blocking (temporal layer at the flagship shape) has 128 registers in use with two;
+    // the 2-row blocking (feature layer: 91 registers, 7 chunks per tile at W = 100) has room for six, but six measured slower than
+    // two (both layers 10.70 vs 10.55 ms per 65 536 windows, same box: -DMTADGAT_GATH_QB2=6).
+    constexpr int QB = IBL == 2 ? MTADGAT_GATH_QB2 : MTADGAT_GAT_QB3;
     if constexpr (!CONV)
         if (!(a.vmax != nullptr && __uint_as_float(*a.vmax) < 32768.f)) return;     // k_gat's bf16-piece build serves this launch
     // Wave priorities by phase (round 5): the kernel's waves share a SIMD's issue slots with the other workgroup's, and the
@@ -105,16 +112,21 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const int ptile = P8 >> 3, ntile = PT >> 3;
     const int nparts = (PT >> 5) + 1;
 
-    const f32x4* __restrict__ Wbase = a.Wp2;
-    f32x4 w[QB][2];
-    auto wfetch = [&](const f32x4* __restrict__ wp, int u, int q) {
-        w[u][0] = wp[((long)q * 2) * 64];
-        w[u][1] = wp[((long)q * 2 + 1) * 64];
-    };
     auto fresh_lane = [&]() -> int {                  // the lane id, recomputed where it is used: see the note at the tail
         int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(l));
         return l;
+    };
+    const f32x4* __restrict__ Wbase = a.Wp2;
+    f32x4 w[QB][2];
+    const bool rows_owner = wave < NWA;
+    const bool full = wave < a.n_full;
+    const int i0 = !rows_owner ? 0 : (full ? wave * IBW : a.n_full * IBW + (wave - a.n_full) * (IBW - RI));
+    const int iblw = full ? IBL : IBL - 1;             // rows per lane of this wave
+    float acc[IBL][JPL];
+    auto wfetch = [&](const f32x4* __restrict__ wp, int u, int q) {
+        w[u][0] = wp[((long)q * 2) * 64];
+        w[u][1] = wp[((long)q * 2 + 1) * 64];
     };
     auto prefetch = [&](int part) {
         if (wave < ntask) {
@@ -262,44 +274,68 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         const float osc = c.wscale[1] * sxi;           // both factors are powers of two
         const int FPc = FP < 32 * c.NT ? FP : 32 * c.NT;
         float vmx = 0.f;
-        for (int ctask = wave; ctask < RT * c.NT; ctask += NW) {
-            const int nb = ctask / RT, rt = ctask - nb * RT;
-            const int t = 32 * rt + i;
-            const int xoff = (t < W ? t : nrows - taps + 1) * pvx + 4 * g;       // rows past the window read the spare zero rows
-            const f32x4* __restrict__ Wc = c.Wp + ((long)nb * QC) * (2 * 64) + lane;      // [tile][QC][2 pieces][64]
-            f32x16 acc;
+#ifndef MTADGAT_GATH_CONV_RPW
+#define MTADGAT_GATH_CONV_RPW 1
+#endif
+        // A wave takes RPW row tiles of one 32-channel output tile (each tile's sum keeps its order: same bits).  RPW = 2 halves the
+        // weight words the workgroup pulls from L2 (448 -> 224 KB per window) with four waves working -- and changes nothing: the
+        // phase is a latency chain per wave (28 chunks, three in flight), 13.1 k cycles with RPW = 1 and 14.9 k with RPW = 2 in the
+        // stamped build; both layers 10.51-10.54 (RPW 1) vs 10.55-10.61 ms (RPW 2) per 65 536 windows, same box; a ring of seven
+        // chunks instead of four: 10.52-10.62 (profiles/r06_gath_experiments.txt).
+        constexpr int RPW = MTADGAT_GATH_CONV_RPW;
+        const int RTP = (RT + RPW - 1) / RPW;
+        for (int ctask = wave; ctask < RTP * c.NT; ctask += NW) {
+            const int nb = ctask / RTP, rtp = ctask - nb * RTP;
+            int tt[RPW], xoff[RPW];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < RPW; ++r) {
+                tt[r] = 32 * (RPW * rtp + r) + i;
+                xoff[r] = (tt[r] < W ? tt[r] : nrows - taps + 1) * pvx + 4 * g;       // rows past the window read the spare zero rows
+            }
+            const f32x4* __restrict__ Wc = c.Wp + ((long)nb * QC) * (2 * 64) + lane;      // [tile][QC][2 pieces][64]
+            f32x16 acc[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+            f32x4 cbias[4];                            // the epilogue's bias words, requested ahead of the weight stream
+#pragma unroll
+            for (int m = 0; m < 4; ++m) cbias[m] = *reinterpret_cast<const f32x4*>(c.bias + 32 * nb + 8 * m + 4 * g);
             // a ring of four chunks: the words of chunk q + 3 are requested before the MFMAs of chunk q (mtadgat_convw.hip)
-            constexpr int RING = 4;
+#ifndef MTADGAT_GATH_CONV_RING
+#define MTADGAT_GATH_CONV_RING 4
+#endif
+            constexpr int RING = MTADGAT_GATH_CONV_RING;
             f32x4 wr[RING][2];
             auto wload = [&](f32x4 (&wq)[2], int q) {
                 const int qc = q < QC ? q : QC - 1;
                 wq[0] = Wc[((long)qc * 2) * 64];
                 wq[1] = Wc[((long)qc * 2 + 1) * 64];
             };
-            wload(wr[0], 0);
-            wload(wr[1], 1);
-            wload(wr[2], 2);
+#pragma unroll
+            for (int u = 0; u < RING - 1; ++u) wload(wr[u], u);
             int tap = 0, cb = 0;
 #pragma unroll 1
             for (int q0 = 0; q0 < QC; q0 += RING) {
 #pragma unroll
                 for (int u = 0; u < RING; ++u) {
                     const int q = q0 + u;
-                    wload(wr[(u + 3) % RING], q + 3);
+                    wload(wr[(u + RING - 1) % RING], q + RING - 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (q < QC) {
                         const int ko = tap * pvx + 16 * cb;
-                        const unsigned short* __restrict__ ph = Xh + xoff + ko;
-                        const unsigned short* __restrict__ pl = Xl + xoff + ko;
-                        const u32x2 ha = *reinterpret_cast<const u32x2*>(ph), hb = *reinterpret_cast<const u32x2*>(ph + 8);
-                        const u32x2 la = *reinterpret_cast<const u32x2*>(pl), lb = *reinterpret_cast<const u32x2*>(pl + 8);
-                        const f32x4 xh = __builtin_bit_cast(f32x4, u4{ha[0], ha[1], hb[0], hb[1]});
-                        const f32x4 xl = __builtin_bit_cast(f32x4, u4{la[0], la[1], lb[0], lb[1]});
-                        acc = mfma_h(wr[u][0], xl, acc);
-                        acc = mfma_h(wr[u][1], xh, acc);
-                        acc = mfma_h(wr[u][0], xh, acc);
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) {
+                            const unsigned short* __restrict__ ph = Xh + xoff[r] + ko;
+                            const unsigned short* __restrict__ pl = Xl + xoff[r] + ko;
+                            const u32x2 ha = *reinterpret_cast<const u32x2*>(ph), hb = *reinterpret_cast<const u32x2*>(ph + 8);
+                            const u32x2 la = *reinterpret_cast<const u32x2*>(pl), lb = *reinterpret_cast<const u32x2*>(pl + 8);
+                            const f32x4 xh = __builtin_bit_cast(f32x4, u4{ha[0], ha[1], hb[0], hb[1]});
+                            const f32x4 xl = __builtin_bit_cast(f32x4, u4{la[0], la[1], lb[0], lb[1]});
+                            acc[r] = mfma_h(wr[u][0], xl, acc[r]);
+                            acc[r] = mfma_h(wr[u][1], xh, acc[r]);
+                            acc[r] = mfma_h(wr[u][0], xh, acc[r]);
+                        }
                         if (++cb == QF) { cb = 0; ++tap; }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -307,35 +343,39 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             }
             // epilogue: 1 / (S sx), bias, ReLU -> h_cat[:, :F] (+ the zero alignment padding of the row) and the window's pieces
             GATH_STAMP(4);
-            if (t < W) {
-                float* __restrict__ hrow = c.HCAT + (win * W + t) * (long)c.Dp;
-                if (nb == 0 && g == 0)
-                    for (int cc = 3 * F; cc < c.Dp; ++cc) hrow[cc] = 0.f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int col = 32 * nb + 8 * m + 4 * g;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(c.bias + col);
-                    f32x4 y;
+            for (int r = 0; r < RPW; ++r) {
+                const int t = tt[r];
+                if (t < W) {
+                    float* __restrict__ hrow = c.HCAT + (win * W + t) * (long)c.Dp;
+                    if (nb == 0 && g == 0)
+                        for (int cc = 3 * F; cc < c.Dp; ++cc) hrow[cc] = 0.f;
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        y[s4] = fmaxf(__builtin_fmaf(acc[4 * m + s4], osc, bv[s4]), 0.f);
-                        vmx = (col + s4 < F) ? fmaxf(vmx, y[s4]) : vmx;
-                    }
-                    if (col + 3 < F) {
-                        *reinterpret_cast<f32x4*>(hrow + col) = y;
-                    } else {
+                    for (int m = 0; m < 4; ++m) {
+                        const int col = 32 * nb + 8 * m + 4 * g;
+                        const f32x4 bv = cbias[m];
+                        f32x4 y;
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4)
-                            if (col + s4 < F) hrow[col + s4] = y[s4];
-                    }
-                    if (col < FPc) {
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            y[s4] = fmaxf(__builtin_fmaf(acc[r][4 * m + s4], osc, bv[s4]), 0.f);
+                            vmx = (col + s4 < F) ? fmaxf(vmx, y[s4]) : vmx;
+                        }
+                        if (col + 3 < F) {
+                            *reinterpret_cast<f32x4*>(hrow + col) = y;
+                        } else {
 #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) y[s4] = col + s4 < D ? y[s4] : (col + s4 == D ? 1.f : 0.f);
-                        unsigned h0, l0, h1, l1;
-                        split_pair_h(y[0], y[1], h0, l0);
-                        split_pair_h(y[2], y[3], h1, l1);
-                        *reinterpret_cast<u32x2*>(Vh + t * pvh + col) = u32x2{h0, h1};
-                        *reinterpret_cast<u32x2*>(Vl + t * pvh + col) = u32x2{l0, l1};
+                            for (int s4 = 0; s4 < 4; ++s4)
+                                if (col + s4 < F) hrow[col + s4] = y[s4];
+                        }
+                        if (col < FPc) {
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) y[s4] = col + s4 < D ? y[s4] : (col + s4 == D ? 1.f : 0.f);
+                            unsigned h0, l0, h1, l1;
+                            split_pair_h(y[0], y[1], h0, l0);
+                            split_pair_h(y[2], y[3], h1, l1);
+                            *reinterpret_cast<u32x2*>(Vh + t * pvh + col) = u32x2{h0, h1};
+                            *reinterpret_cast<u32x2*>(Vl + t * pvh + col) = u32x2{l0, l1};
+                        }
                     }
                 }
             }
@@ -426,10 +466,6 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     __syncthreads();
     GATH_STAMP(7);
 
-    const bool rows_owner = wave < NWA;
-    const bool full = wave < a.n_full;
-    const int i0 = !rows_owner ? 0 : (full ? wave * IBW : a.n_full * IBW + (wave - a.n_full) * (IBW - RI));
-    const int iblw = full ? IBL : IBL - 1;             // rows per lane of this wave
     lds_cptr lp[IBL];
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) {
@@ -437,7 +473,6 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         asm volatile("" : "+v"(lp[ii]));
     }
     const lds_cptr rp = (lds_cptr)(Rs + lj * GAT_LLD);
-    float acc[IBL][JPL];
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
@@ -496,6 +531,16 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
         int ntl = ntile - 4 * part;
         ntl = ntl > 4 ? 4 : ntl;
+        if ((a.dbg & 16) && part == 0) {                      // sensitivity probe: 1 000 extra vector-ALU instructions per wave (results unchanged)
+            float d0 = (float)part, d1 = 1.f, d2 = 2.f, d3 = 3.f;
+#pragma unroll 1
+            for (int it = 0; it < 250; ++it) {
+                asm volatile("v_add_f32_e32 %0, %0, %0\n\tv_add_f32_e32 %1, %1, %1\n\tv_add_f32_e32 %2, %2, %2\n\tv_add_f32_e32 %3, %3, %3"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+            }
+            if (d0 + d1 + d2 + d3 == 12345.f) a.out[0] = d0;
+        }
+        if ((a.dbg & 32) && part == 0) __builtin_amdgcn_s_sleep(78);      // ~5 k idle cycles in front of the first pair grid
         if (ntl > 0 && rows_owner && !(a.dbg & 1)) {
             __builtin_amdgcn_s_setprio(0);                       // the pair grid takes the issue slots nobody else wants (see the kernel's head)
             int npos = ptile - 4 * part;
@@ -553,6 +598,25 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             __syncthreads();
         }
     }
+    // Round 6: the (K, K) attention bias (modules.py:85 / :184), all 4 x JPL words of the lane requested HERE in one batch -- the
+    // pair grid's operand registers are free now -- so that they travel while the c / d columns are read and the workgroup meets
+    // at the barrier below.  Requested inside the softmax's row loop (rounds 1-5) the compiler waited for them row by row: the
+    // r06a timeline (profiles/gath_timeline.py) put 13.7 k (temporal) / 6.3 k (feature) cycles on the softmax phase.
+    float bv[IBL][JPL];
+    if (rows_owner) {
+        const int lb = fresh_lane();                   // (roles from a fresh lane id: held across the pair grid they would spill)
+        const int lj = lb % RJ, li = lb / RJ;
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            const int irow = i0 + li + RI * ii;
+            const int irc = irow < K ? irow : K - 1;
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = lj + RJ * jj;
+                bv[ii][jj] = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
+            }
+        }
+    }
     float cv[IBL], dv[JPL];
     {
         const int col = PT & 31;
@@ -590,7 +654,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
 #pragma unroll
         for (int jj = 0; jj < JPL; ++jj) {
             const int j = ljt + RJ * jj;
-            const float b = a.bias ? a.bias[(long)irc * K + (j < K ? j : K - 1)] : 0.f;
+            const float b = bv[ii][jj];
             float v;
             if (a.v1) {
                 v = (acc[ii][jj] + cv[ii] + dv[jj]) * sinv;

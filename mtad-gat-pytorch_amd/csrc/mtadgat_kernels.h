@@ -148,7 +148,9 @@ struct GatArgs {
     DropArgs drop;
     unsigned drop_stream;
     int n_full, n_short; // k_gath: waves owning 16 query rows / 16 - 64 / RJ query rows (the rest of the workgroup only projects)
-    int dbg;             // k_gath measurement hook (bit 0: no pair grid, 1: no projection, 2: return before the softmax); results invalid
+    int dbg;             // k_gath measurement hooks: knock-outs (bit 0: no pair grid, 1: no projection, 2: return before the softmax; results invalid) and
+                         // sensitivity probes (bit 3: ~5 k idle cycles ahead of the convolution, 4: 1 000 extra VALU instructions per wave ahead of
+                         // the first pair grid, 5: ~5 k idle cycles there; results unchanged) -- profiles/r06_gath_experiments.txt
     int skip_h;          // 1: return at once when *vmax < 2^15 -- k_gath (launched ahead of this kernel) serves that case
     const unsigned char* winflag;   // k_gat behind a CONV launch of k_gath: serve exactly the windows whose flag is set
     GatConvIn cv;        // k_gath, CONV build

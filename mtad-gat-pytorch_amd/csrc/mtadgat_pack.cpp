@@ -182,6 +182,8 @@ std::string validate_and_plan(Model& m) {
             const int orows = (g.fh_full + g.fh_short) * 16;     // rows of L' the owning waves address
             g.fh_lr = (int)round_up((int)std::max((size_t)(orows + K) * 34, (size_t)orows * 36), 4);
             g.fh_lds_bytes = (size_t)g.fh_lr * sizeof(float) + (size_t)2 * ((K + 1) * g.fh_vld + 16) * 2;
+            // measurement hook (profiles/gath_timeline.py): more LDS per workgroup = fewer resident workgroups per CU
+            if (const char* e_ = getenv("MTADGAT_GATH_PADLDS")) g.fh_lds_bytes = std::max<size_t>(g.fh_lds_bytes, (size_t)atoi(e_) * 1024);
         }
         g.w16_off = take((size_t)g.NT * g.Q16 * 256);
         g.w3_off = take((size_t)g.NT * g.Q16 * 3 * 256);
