@@ -1084,6 +1084,25 @@ struct Piece { int64_t c0, n; int lane; };
 static void forward_schedule(const Model& m, int64_t batch, std::vector<Piece>& out) {
     out.clear();
     const bool two = m.lanes == 0 && m.precision == 2 && m.temp.fused && m.feat.fused;
+    // Round 6: models on the un-fused (wide) attention path walk a call of several chunks with the chunks ALTERNATING between the
+    // lanes.  Their chunks are a few hundred windows (projections through HBM: ~7 MB of scratch per window at F = 512, W = 256), so the
+    // recurrences of a chunk are small-batch latency chains on a quarter of the CUs (896 windows: ~56 workgroups; GRU layer + decoder
+    // 68.7 of config 4's 273 ms in round 5, strictly behind the chunk's front end) -- on the other lane the next chunk's convolution,
+    // projections and attention fill the rest of the machine meanwhile.  Each lane has its own workspace (lane_floats).
+    const bool alt = m.lanes == 0 && !(m.temp.fused && m.feat.fused) && batch > m.chunk && !getenv("MTADGAT_PIECES");
+    if (alt) {
+        // the first piece is HALF a chunk: with equal pieces the lanes run in lock step (both front ends side by side, then both
+        // recurrences on 2 x 56 CUs: 258 vs 268 ms for one lane); offset by half a chunk, one lane's recurrences sit under the other's
+        // front end
+        int64_t c0 = 0, ci = 0;
+        const int64_t half = std::max<int64_t>(32, m.chunk / 2 / 32 * 32);
+        while (c0 < batch) {
+            const int64_t n = std::min<int64_t>(ci == 0 ? half : m.chunk, batch - c0);
+            out.push_back({c0, n, (int)(ci & 1)});
+            c0 += n; ++ci;
+        }
+        return;
+    }
     for (int64_t c0 = 0; c0 < batch; c0 += m.chunk) {
         const int64_t n = std::min<int64_t>(m.chunk, batch - c0);
         int64_t k = 1, base = n;
