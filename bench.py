@@ -253,17 +253,13 @@ def sub_records(model, kw, dev, args_precision="fp32"):
                     "where a bf16 build of the kernel exists, fp32 accumulation, state, gates and softmax; <= 2e-2 of the fp32 reference"}
         del xb
         # the same 65 536 windows as stride-1 windows of one series (Predictor.get_score's access
-        # pattern, prediction.py:51-63), gathered on the GPU; with and without the temporal pair scores shared between windows
+        # pattern, prediction.py:51-63), gathered on the GPU (no (b, W, F) batch is materialised)
         try:
             series = torch.rand(65536 + kw["window_size"] - 1, kw["n_features"], generator=g).to(dev)
-            rec = {}
-            for name, share in (("per_window_pair_grid", False), ("shared_pair_scores", True)):
-                model.share_series_pair_scores = share
-                tser = _timed(lambda: model.forward_series(series, start=0, stride=1, count=65536), dev, 3, warm=1)
-                rec[name] = {"ms": round(1e3 * tser, 3), "windows_per_s": round(65536 / tser, 1)}
-            model.share_series_pair_scores = "auto"
-            rec["what"] = ("forward_series over 65 536 stride-1 windows of one (65 635, F) series: no (b, W, F) batch is materialised; "
-                           "shared_pair_scores = k_tband (the temporal layer's interior pair scores once per pair of series rows)")
+            tser = _timed(lambda: model.forward_series(series, start=0, stride=1, count=65536), dev, 3, warm=1)
+            rec = {"ms": round(1e3 * tser, 3), "windows_per_s": round(65536 / tser, 1),
+                   "what": "forward_series over 65 536 stride-1 windows of one (65 635, F) series: every window is read out of the series by the "
+                           "fused front end (per-window pair grids; the shared-score band of rounds 4-5 is gone: it bought 0.5 %)"}
             out["series_b65536"] = rec
             del series
         except Exception as e:

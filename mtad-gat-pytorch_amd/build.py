@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["mtadgat_kernels.hip", "mtadgat_attend.hip", "mtadgat_convw.hip", "mtadgat_gat.hip", "mtadgat_gath.hip", "mtadgat_tband.hip", "mtadgat_gru.hip", "mtadgat_gru_f32.hip", "mtadgat_gru_bf16.hip", "mtadgat_gru_x3.hip", "mtadgat_gru_x3b.hip", "mtadgat_gru_cm.hip", "mtadgat_gru16.hip", "mtadgat_packdev.hip", "mtadgat_bwd.hip", "mtadgat_bwdw.hip", "mtadgat_eval.hip", "mtadgat_pack.cpp", "mtadgat_capi.cpp"]
+SOURCES = ["mtadgat_kernels.hip", "mtadgat_attend.hip", "mtadgat_convw.hip", "mtadgat_gat.hip", "mtadgat_gath.hip", "mtadgat_gru.hip", "mtadgat_gru_f32.hip", "mtadgat_gru_bf16.hip", "mtadgat_gru_x3.hip", "mtadgat_gru_x3b.hip", "mtadgat_gru_cm.hip", "mtadgat_gru16.hip", "mtadgat_packdev.hip", "mtadgat_bwd.hip", "mtadgat_bwdw.hip", "mtadgat_eval.hip", "mtadgat_pack.cpp", "mtadgat_capi.cpp"]
 HEADERS = ["mtadgat_kernels.h", "mtadgat_device.h", "mtadgat_host.h", "mtadgat_gru_impl.h", "mtadgat_gat_impl.h", os.path.join("..", "..", "include", "mtadgat.h")]
 LIB = os.path.join(HERE, "libmtadgat.so")
 OBJDIR = os.path.join(HERE, "build")          # object files (git-ignored)

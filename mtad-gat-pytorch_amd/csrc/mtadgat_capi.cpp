@@ -168,54 +168,6 @@ int run_conv_shared(Model& m, const XSource& src, int64_t c0, int64_t n, float* 
     return 0;
 }
 
-// Temporal attention of n stride-1 windows with the pair scores shared between them (mtadgat_tband.hip; SURVEY section 8f
-// row 3, second half): the temporal layer's projections of the segment's rows and of the windows' own edge rows (the rows
-// run_conv_shared left in cf / el / er), the band of raw scores between series rows, then one workgroup per window for its
-// edge pairs, bias, softmax and aggregation.  GATv2 only (v1 has no pair grid to share).
-bool tband_selected(const Model& m, const XSource& src, int64_t n) {
-    if (m.series_band == 1 || !m.cfg.use_gatv2 || !m.temp.fused || !m.feat.fused) return false;
-    // automatic: where it was measured to win against k_gath's own pair grid -- wide embeddings (MSL: 110 columns, 20.3 against
-    // 20.5 ms per 65 536 windows; at 76 columns, SMD, 19.8 against 19.1: DESIGN.md section 4)
-    if (m.series_band == 0 && m.temp.PT < 112) return false;
-    if (!src.gather || src.starts || src.stride != 1 || n < 1024 || m.precision == 1 || src.x_bf16) return false;
-    if (m.taps != 2 * m.pad + 1 || m.pad < 1 || m.W < 4 * m.pad + 2 || (m.Dp & 3) != 0) return false;
-    if ((size_t)(32 + m.taps - 1) * (m.Fp + 4) * sizeof(float) > 20 * 1024) return false;          // (run_conv_shared's kernel)
-    const GatPlan& g = m.temp;
-    return tband_applies(g.K, g.D, g.PTcap, m.pad, g.ldl, g.NT * 32);     // (the bound: the device-side re-pack may move PT by a tile)
-}
-int run_tband(Model& m, int64_t n, float* ws, const Workspace& o, float* hcat, hipStream_t s) {
-    const GatPlan& g = m.temp;
-    Scope sc(m, S_ATTEND, s);
-    const int ldp = g.NT * 32, EW = 2 * m.pad;
-    const int64_t L = n + m.W - 1;
-    auto project = [&](const float* rows, int64_t nrows, float* y) {
-        RowGemmArgs r{};
-        r.X = rows; r.ldx = m.Fp; r.Kvalid = g.D; r.Q = g.Q;
-        r.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
-        r.bias = m.packed_dev + g.b_off;
-        r.Y = y; r.ldy = ldp; r.Nvalid = ldp; r.vec_store = 1;
-        r.R = nrows; r.NT = g.NT; r.NT_rm = g.NT; r.group = 1; r.relu = 0;
-        return launch_rowgemm(r, s);
-    };
-    K_TRY(project(ws + o.cf, L, ws + o.pj), "temporal projection (series rows)");
-    K_TRY(project(ws + o.el, n * EW, ws + o.pjt), "temporal projection (first rows)");
-    K_TRY(project(ws + o.er, n * EW, ws + o.pjb), "temporal projection (last rows)");
-    TBandArgs a{};
-    a.PJ = ws + o.pj; a.PJT = ws + o.pjt; a.PJB = ws + o.pjb;
-    a.BI = ws + o.band; a.bp = 2 * m.W; a.HB = m.W - 1 - 2 * m.pad;
-    a.EQ = ws + o.eq; a.EK = ws + o.ek;
-    a.ldp = ldp; a.ldl = g.ldl; a.PT = g.PT; a.P8 = g.P8; a.K = g.K; a.D = g.D; a.pad = m.pad;
-    a.ord = reinterpret_cast<const int*>(m.packed_dev + g.ord_off); a.PTcap = g.PTcap;
-    a.n = n; a.Lrows = L;
-    a.bias = m.packed_dev + g.bias_off;
-    a.V = hcat; a.sv_w = (long)m.W * m.Dp; a.ldv = m.Dp;
-    a.out = hcat + 2 * m.F; a.so_w = (long)m.W * m.Dp; a.so_i = m.Dp; a.so_d = 1;
-    K_TRY(launch_tband_scores(a, s), "temporal score band");
-    K_TRY(launch_tband_edges(a, s), "temporal edge scores");
-    K_TRY(launch_tband_att(a, s), "temporal attention (shared scores)");
-    return 0;
-}
-
 int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nrows, float* lc, float* rt, hipStream_t s) {
     Scope sc(m, S_PROJ, s);
     RowGemmArgs a{};
@@ -1065,7 +1017,6 @@ int mtadgat_set_option(mtadgat_handle h, const char* name, int value) {
     if (std::strcmp(name, "gemm_lds") == 0 && value >= 0 && value <= 1) { set_gemm_lds_off(value); return 0; }      // process-wide; 1 = off
     if (std::strcmp(name, "conv_shared") == 0 && value >= 0 && value <= 1) { h->m.conv_shared = value; return 0; }
     if (std::strcmp(name, "conv_fused") == 0 && value >= 0 && value <= 1) { h->m.conv_fused = value; return 0; }
-    if (std::strcmp(name, "series_band") == 0 && value >= 0 && value <= 2) { h->m.series_band = value; return 0; }
     if (std::strcmp(name, "lanes") == 0 && value >= 0 && value <= 1) { h->m.lanes = value; return 0; }
     if (std::strcmp(name, "gath_dbg") == 0 && value >= 0 && value <= 63) { h->m.gath_dbg = value; return 0; }
     return fail(MTADGAT_ERR_INVALID, "unknown option or value");
@@ -1206,8 +1157,7 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
     // mtad_gat.py:76-77).  Same kernels, same results; the second stream joins before the call returns.
     // (large calls gain nothing from it: with the convolution as its own launch and both attention layers side by side, 65 536
     // windows take 21.0-21.2 ms against 21.1-21.3 one after the other -- the layers compete for the same vector ALUs)
-    const bool fork = !second && sched.size() == 1 && m.lanes == 0 && sched[0].n <= FORK_MAX_WINDOWS && use_fused(m.temp) && use_fused(m.feat) &&
-                      !tband_selected(m, src, sched[0].n);
+    const bool fork = !second && sched.size() == 1 && m.lanes == 0 && sched[0].n <= FORK_MAX_WINDOWS && use_fused(m.temp) && use_fused(m.feat);
     if (second || fork) {
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
@@ -1243,10 +1193,9 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
             // fused front: conv writes only h_cat[:, :F]; each layer's workgroup stages its window from
             // there (the feature layer transposes on the way into LDS) -- no xc / xc^T / L' / R' in HBM
             unsigned* vmax = reinterpret_cast<unsigned*>(ws + o.vmax);
-            const bool band = tband_selected(m, src, n);
             GatConvIn cv{};
             bool conv_in_gat = false;
-            if (band || conv_shared_applies(m, src, n)) {
+            if (conv_shared_applies(m, src, n)) {
                 if ((rc = run_conv_shared(m, src, c0, n, hcat, ws + o.cf, ws + o.el, ws + o.er, s, vmax))) return rc;
             } else if (fused_conv_args(m, src, c0, n, hcat, vmax, reinterpret_cast<unsigned char*>(ws + o.winflag), cv)) {
                 // the temporal layer's workgroups compute the convolution of their windows themselves: no convolution launch,
@@ -1260,9 +1209,7 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
                 if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, m.lane_stream, nullptr, nullptr, 0, vmax))) return rc;
                 HIP_TRY(hipEventRecord(m.fork_ev[1], m.lane_stream));
             }
-            if (band) {
-                if ((rc = run_tband(m, n, ws, o, hcat, s))) return rc;
-            } else if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, nullptr, nullptr, 0, vmax,
+            if ((rc = run_gat_fused(m, m.temp, hcat, m.Dp, 0, n, hcat + 2 * F, (long)W * m.Dp, m.Dp, 1, s, nullptr, nullptr, 0, vmax,
                                            conv_in_gat ? &cv : nullptr))) return rc;
             if (fork && !conv_in_gat) HIP_TRY(hipStreamWaitEvent(s, m.fork_ev[1], 0));
             else if ((rc = run_gat_fused(m, m.feat, hcat, m.Dp, 1, n, hcat + F, (long)W * m.Dp, 1, m.Dp, s, nullptr, nullptr, 0, vmax))) return rc;

@@ -205,7 +205,6 @@ struct Model {
     int precision = 0;               // 0: fp32 operands (default, <= 1e-5 parity); 1: bf16 MFMA operands, fp32 accumulate / state
     int64_t chunk = 65536;
     int wgrad_kernel = 0;            // weight-gradient GEMMs of the training step (testing hook): 0 automatic (split-bf16 operands in mode 2), 1 fp32 MFMA, 2 split-bf16 always
-    int series_band = 0;             // stride-1 series scoring, temporal pair scores shared between the windows (k_tband): 0 automatic (embeddings of >= 100 columns), 1 off, 2 wherever it applies
     int conv_shared = 0;             // series scoring (testing hook): 1 keeps the shared-row convolution where the window-per-workgroup kernel would run
     uint64_t weights_version = 0;    // counts weight uploads / device-side re-packs
     int rowgemm_kernel = 0;          // data-gradient row GEMMs of mtadgat_backward in mode 2 (testing hook): 0 automatic (split-bf16 operands from 4096 rows), 1 fp32 MFMA, 2 split-bf16 always
@@ -228,7 +227,6 @@ struct Workspace {
     size_t vmax;         // one word: bits of the largest convolution output of the chunk (range guard of the fp16 operand pieces)
     size_t winflag;      // one byte per window: the fused convolution's per-window range flag (k_gath CONV build -> k_gat)
     size_t cf, el, er;   // convolution rows shared by stride-1 windows of a series (run_conv_shared): segment rows, edge rows
-    size_t pj, pjt, pjb, band, eq, ek;   // shared temporal pair scores of stride-1 windows (run_tband): projections of the segment / edge rows, score band
 };
 
 // activations kept between the training forward and the backward (caller-owned "tape"), offsets in floats

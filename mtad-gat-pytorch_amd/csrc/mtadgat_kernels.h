@@ -437,31 +437,6 @@ int launch_dropmask(const DropArgs& d, unsigned stream, long nwin, long n_per_wi
 // nn.GRU's dropout between stacked layers on a (nwin * T, ld) state sequence (columns >= H are written as zero); also its adjoint
 int launch_seq_dropout(const float* src, float* dst, long nwin, int T, int H, int ld, const DropArgs& d, unsigned stream, hipStream_t s);
 int launch_copy2d(const float* src, long lds, float* dst, long ldd, long R, int ncols, hipStream_t s);
-// temporal attention of stride-1 windows with shared pair scores (mtadgat_tband.hip)
-struct TBandArgs {
-    const float* PJ;     // (Lrows, ldp) projections of the segment's rows (interior convolution): [L'(PT) | c | pad](ldl) [R'(PT) | d | pad]
-    const float* PJT;    // (n * 2 pad, ldp) of the windows' first 2 pad rows as their own windows (first pad rows of each: its top edge rows)
-    const float* PJB;    // (n * 2 pad, ldp) of the last 2 pad rows (last pad rows of each: its bottom edge rows)
-    float* BI;           // (Lrows, bp) band of raw scores: BI[r][t - r + HB], |t - r| <= HB
-    int bp, HB;
-    float* EQ;           // (n, 2 pad, kq) raw scores of a window's edge rows as queries against its keys, kq = (K rounded up to 4) + 4
-    float* EK;           // (n, K, 2 pad + 2) raw scores of a window's queries against its edge rows as keys
-    int ldp, ldl, PT, P8, K, D, pad;
-    const int* ord;      // device-side [P8, PT] of the layer (null: the host's PT / P8 above)
-    int PTcap;           // upper bound of PT (LDS sizing at launch)
-    long n, Lrows;
-    const float* bias;   // (K, K)
-    const float* V;      // node rows of window w: V + w * sv_w + i * ldv
-    long sv_w;
-    int ldv;
-    float* out;          // out[w * so_w + i * so_i + d * so_d]
-    long so_w, so_i, so_d;
-    int dbg;             // measurement hook (MTADGAT_TB_DBG): knock-outs of k_tband_att's phases, wrong results
-};
-bool tband_applies(int K, int D, int PT, int pad, int ldl, int ldp);
-int launch_tband_scores(const TBandArgs& a, hipStream_t s);
-int launch_tband_edges(const TBandArgs& a, hipStream_t s);
-int launch_tband_att(const TBandArgs& a, hipStream_t s);
 int launch_conv_scatter(const float* cf, const float* el, const float* er, float* hcat, long n, int W, int F, int Fp, int Dp, int pad,
                         hipStream_t s);
 int launch_transpose_win(const float* src, long lds, float* dst, long ldd, long B, int R, int C, hipStream_t s);

@@ -186,6 +186,19 @@ __global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
     }
 }
 
+// workgroup barrier for an LDS hand-off: this wave's LDS traffic is done, vector-memory requests stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS-DMA of three consecutive KiB (global_load_lds_dwordx4: 16 bytes per lane from uniform base + per-lane byte offset to LDS byte
+// address M0 + 16 lane; the immediate offset moves source and destination alike -- as in k_gru_cm).  M0 is written and restored here.
+__device__ __forceinline__ void glds3(const void* sbase, unsigned voff, unsigned ldsdst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldsdst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // Many rows: a workgroup of four waves owns 256 rows (two row tiles per wave) x four output tiles and shares the weight words of a
 // chunk through LDS.  In k_rowgemm_x3 every wave pulls every weight word through the CU's vector L1 itself: 12 KB per 24 MFMAs,
 // measured (TCP_TOTAL_CACHE_ACCESSES / TCP_TCC_READ_REQ on the data-gradient GEMMs of an 8 192-window training step) 427 M line
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(64) void k_rowgemm_x3(const RowGemmArgs a) {
 __global__ __launch_bounds__(256, 2) void k_rowgemm_x3s(const RowGemmArgs a) {
     constexpr bool XV = true;
     constexpr int NTB = 4, WWORDS = NTB * 3 * 64;         // 16-byte words of a chunk: [tile][piece][lane]
-    __shared__ __attribute__((aligned(16))) f32x4 wsh[2][WWORDS];
+    __shared__ __attribute__((aligned(16))) f32x4 wsh[3][WWORDS];      // ring of three chunks, filled by LDS-DMA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
@@ -213,14 +226,15 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_x3s(const RowGemmArgs a) {
     const f32x4* __restrict__ Wp = a.Wp3;
     const int Q = a.Q16;
     for (int n0 = blockIdx.y * NTB; n0 < a.NT; n0 += NTB * gridDim.y) {
-        // this thread's three words of a chunk: flat word idx = tid + 256 e -> (tile, piece, lane); 192 consecutive words per tile
-        const f32x4* __restrict__ wsrc[3];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int idx = tid + 256 * e, nb = idx / 192, rem = idx - nb * 192;
-            const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
-            wsrc[e] = Wp + ((long)n * Q) * 192 + rem;
-        }
+        // Round 6 (DESIGN section 8.4 of round 5): both operands two chunks ahead.  The weight words of chunk q + 2 travel by LDS-DMA
+        // into a ring of three slots -- wave w brings tile w's three KiB, no staging registers, nothing for the compiler's vmcnt
+        // accounting to wait on -- the rows' raw words of chunk q + 2 into registers; the chunk barrier is s_waitcnt lgkmcnt(0) +
+        // s_barrier (__syncthreads() also drains vmcnt: it waited for the requests issued at the top of the same iteration, so
+        // one chunk of MFMAs, ~1.5 k cycles, had to cover a loaded HBM round trip).  A wave's own requests retire in order:
+        // vmcnt(7) at the end of iteration q leaves only the 3 + 4 requests of chunk q + 2 outstanding, i.e. chunk q + 1 has landed.
+        const f32x4* __restrict__ wtile = Wp + ((long)((n0 + wave < a.NT) ? n0 + wave : a.NT - 1) * Q) * 192;      // this wave's tile: 192 words per chunk
+        const unsigned wlds = (unsigned)(uintptr_t)&wsh[0][0] + (unsigned)wave * 3072u;
+        const unsigned voff = (unsigned)lane << 4;
         f32x16 acc[2][NTB];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -228,41 +242,44 @@ __global__ __launch_bounds__(256, 2) void k_rowgemm_x3s(const RowGemmArgs a) {
             for (int nb = 0; nb < NTB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][nb][r] = 0.f;
-        f32x4 ra[2], rb[2], wr[3];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][0];
+        f32x4 ra[2], rb[2], ra1[2], rb1[2];
+        const int q1 = Q > 1 ? 1 : 0;
+        lds_barrier();                                   // (a previous pass's readers are done with the ring)
+        glds3(wtile, voff, wlds);
 #pragma unroll
         for (int t = 0; t < 2; ++t) { ra[t] = feat4_raw<XV>(xrow[t], 4 * g, a.Kvalid); rb[t] = feat4_raw<XV>(xrow[t], 8 + 4 * g, a.Kvalid); }
+        glds3(wtile + (long)q1 * 192, voff, wlds + (unsigned)(WWORDS * 16));
 #pragma unroll
-        for (int e = 0; e < 3; ++e) wsh[0][tid + 256 * e] = wr[e];
-        __syncthreads();
-        int buf = 0;
+        for (int t = 0; t < 2; ++t) { ra1[t] = feat4_raw<XV>(xrow[t], 16 * q1 + 4 * g, a.Kvalid); rb1[t] = feat4_raw<XV>(xrow[t], 16 * q1 + 8 + 4 * g, a.Kvalid); }
+        wait_vmcnt<7>();
+        lds_barrier();
+        int slot = 0;
         for (int q = 0; q < Q; ++q) {
-            const int qn = (q + 1 < Q) ? q + 1 : q;
-#pragma unroll
-            for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][(long)qn * 192];                  // the next chunk: in flight during the MFMAs
+            const int qnn = (q + 2 < Q) ? q + 2 : Q - 1;
+            const int slot2 = slot == 0 ? 2 : slot - 1;                                   // (q + 2) % 3
+            glds3(wtile + (long)qnn * 192, voff, wlds + (unsigned)slot2 * (unsigned)(WWORDS * 16));
             f32x4 ran[2], rbn[2], xp[2][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                ran[t] = feat4_raw<XV>(xrow[t], 16 * qn + 4 * g, a.Kvalid);
-                rbn[t] = feat4_raw<XV>(xrow[t], 16 * qn + 8 + 4 * g, a.Kvalid);
+                ran[t] = feat4_raw<XV>(xrow[t], 16 * qnn + 4 * g, a.Kvalid);
+                rbn[t] = feat4_raw<XV>(xrow[t], 16 * qnn + 8 + 4 * g, a.Kvalid);
                 split3(feat4_fix<XV>(ra[t], 16 * q + 4 * g, a.Kvalid), feat4_fix<XV>(rb[t], 16 * q + 8 + 4 * g, a.Kvalid), xp[t][0], xp[t][1], xp[t][2]);
             }
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) {
                 f32x4 w[3];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) w[pc] = wsh[buf][(nb * 3 + pc) * 64 + lane];
+                for (int pc = 0; pc < 3; ++pc) w[pc] = wsh[slot][(nb * 3 + pc) * 64 + lane];
                 acc[0][nb] = mfma_s3(w, xp[0], acc[0][nb]);
                 acc[1][nb] = mfma_s3(w, xp[1], acc[1][nb]);
             }
+            wait_vmcnt<7>();
+            lds_barrier();
+            slot = slot == 2 ? 0 : slot + 1;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) wsh[buf ^ 1][tid + 256 * e] = wr[e];
-            __syncthreads();
-            buf ^= 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { ra[t] = ran[t]; rb[t] = rbn[t]; }
+            for (int t = 0; t < 2; ++t) { ra[t] = ra1[t]; rb[t] = rb1[t]; ra1[t] = ran[t]; rb1[t] = rbn[t]; }
         }
+        wait_vmcnt<0>();
         rowgemm_epilogue<NTB>(a, acc[0], n0, row[0], rowc[0], g);
         rowgemm_epilogue<NTB>(a, acc[1], n0, row[1], rowc[1], g);
     }
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(64) void k_conv_x3(const ConvArgs a) {
 // Same chunk order and terms per output element: results are bit-identical to k_conv_x3.
 __global__ __launch_bounds__(256, 2) void k_conv_x3s(const ConvArgs a) {
     constexpr int NTB = 4, WWORDS = NTB * 3 * 64;
-    __shared__ __attribute__((aligned(16))) f32x4 wsh[2][WWORDS];
+    __shared__ __attribute__((aligned(16))) f32x4 wsh[3][WWORDS];      // ring of three chunks, filled by LDS-DMA (k_rowgemm_x3s)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, g = lane >> 5;
@@ -503,13 +520,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_x3s(const ConvArgs a) {
         return v;
     };
     for (int n0 = 0; n0 < a.NT; n0 += NTB) {
-        const f32x4* __restrict__ wsrc[3];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int idx = tid + 256 * e, nb = idx / 192, rem = idx - nb * 192;
-            const int n = (n0 + nb < a.NT) ? n0 + nb : a.NT - 1;
-            wsrc[e] = Wp + ((long)n * Q) * 192 + rem;
-        }
+        // (round 6, as k_rowgemm_x3s: weight words two chunks ahead by LDS-DMA into a ring of three slots, input words two chunks
+        // ahead in registers, chunk barrier without the vector-memory drain)
+        const f32x4* __restrict__ wtile = Wp + ((long)((n0 + wave < a.NT) ? n0 + wave : a.NT - 1) * Q) * 192;
+        const unsigned wlds = (unsigned)(uintptr_t)&wsh[0][0] + (unsigned)wave * 3072u;
+        const unsigned voff = (unsigned)lane << 4;
         f32x16 acc[2][NTB];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -517,45 +532,50 @@ __global__ __launch_bounds__(256, 2) void k_conv_x3s(const ConvArgs a) {
             for (int nb = 0; nb < NTB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][nb][r] = 0.f;
-        f32x4 ra[2], rb[2], wr[3];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][0];
+        f32x4 ra[2], rb[2], ra1[2], rb1[2];
+        int tap = 0, cb = 0;                              // chunk q = tap * QF + cb
+        int tap1 = 0, cb1 = Q > 1 ? 1 : 0;                // chunk q + 1
+        if (cb1 == QF) { cb1 = 0; tap1 = 1; }
+        lds_barrier();                                    // (a previous pass's readers are done with the ring)
+        glds3(wtile, voff, wlds);
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) { ra[rt] = rawx(rt, 0, 0, 0); rb[rt] = rawx(rt, 0, 0, 1); }
+        glds3(wtile + (long)(Q > 1 ? 1 : 0) * 192, voff, wlds + (unsigned)(WWORDS * 16));
 #pragma unroll
-        for (int e = 0; e < 3; ++e) wsh[0][tid + 256 * e] = wr[e];
-        __syncthreads();
-        int buf = 0, tap = 0, cb = 0;                     // chunk q = tap * QF + cb
+        for (int rt = 0; rt < 2; ++rt) { ra1[rt] = rawx(rt, tap1, cb1, 0); rb1[rt] = rawx(rt, tap1, cb1, 1); }
+        wait_vmcnt<7>();
+        lds_barrier();
+        int slot = 0;
         for (int q = 0; q < Q; ++q) {
-            int tapn = tap, cbn = cb + 1;
-            if (cbn == QF) { cbn = 0; ++tapn; }
-            const bool more = q + 1 < Q;
-            if (!more) { tapn = tap; cbn = cb; }
-#pragma unroll
-            for (int e = 0; e < 3; ++e) wr[e] = wsrc[e][(long)(more ? q + 1 : q) * 192];
+            int tap2 = tap1, cb2 = cb1 + 1;               // chunk q + 2 (clamped to the last one)
+            if (cb2 == QF) { cb2 = 0; ++tap2; }
+            if (q + 2 >= Q) { tap2 = tap1; cb2 = cb1; }
+            const int qnn = (q + 2 < Q) ? q + 2 : Q - 1;
+            const int slot2 = slot == 0 ? 2 : slot - 1;
+            glds3(wtile + (long)qnn * 192, voff, wlds + (unsigned)slot2 * (unsigned)(WWORDS * 16));
             f32x4 ran[2], rbn[2], xp[2][3];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                ran[rt] = rawx(rt, tapn, cbn, 0);
-                rbn[rt] = rawx(rt, tapn, cbn, 1);
+                ran[rt] = rawx(rt, tap2, cb2, 0);
+                rbn[rt] = rawx(rt, tap2, cb2, 1);
                 split3(fixx(ra[rt], rt, tap, cb, 0), fixx(rb[rt], rt, tap, cb, 1), xp[rt][0], xp[rt][1], xp[rt][2]);
             }
 #pragma unroll
             for (int nb = 0; nb < NTB; ++nb) {
                 f32x4 w[3];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) w[pc] = wsh[buf][(nb * 3 + pc) * 64 + lane];
+                for (int pc = 0; pc < 3; ++pc) w[pc] = wsh[slot][(nb * 3 + pc) * 64 + lane];
                 acc[0][nb] = mfma_s3(w, xp[0], acc[0][nb]);
                 acc[1][nb] = mfma_s3(w, xp[1], acc[1][nb]);
             }
+            wait_vmcnt<7>();
+            lds_barrier();
+            slot = slot == 2 ? 0 : slot + 1;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) wsh[buf ^ 1][tid + 256 * e] = wr[e];
-            __syncthreads();
-            buf ^= 1;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) { ra[rt] = ran[rt]; rb[rt] = rbn[rt]; }
-            tap = tapn; cb = cbn;
+            for (int rt = 0; rt < 2; ++rt) { ra[rt] = ra1[rt]; rb[rt] = rb1[rt]; ra1[rt] = ran[rt]; rb1[rt] = rbn[rt]; }
+            tap = tap1; cb = cb1; tap1 = tap2; cb1 = cb2;
         }
+        wait_vmcnt<0>();
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll

@@ -462,21 +462,6 @@ void plan_workspace(const Model& m, int64_t n, Workspace& ws) {
     ws.cf = take(both_fused ? (N + m.W) * m.Fp : 0);
     ws.el = take(both_fused ? N * 2 * m.pad * m.Fp : 0);
     ws.er = take(both_fused ? N * 2 * m.pad * m.Fp : 0);
-    // ... and the temporal layer's projections of those rows and the band of pair scores the windows share (run_tband)
-    {
-        const GatPlan& g = m.temp;
-        const size_t ldp = (size_t)g.NT * 32;
-        // (only where tband_selected, mtadgat_capi.cpp, can say yes: not for plain forward() sizes below its threshold, not with the
-        // band switched off or in the bf16 mode, not -- automatic choice -- for embeddings it never picks the band for)
-        const bool tb = both_fused && m.cfg.use_gatv2 && m.series_band != 1 && m.precision != 1 && n >= 1024 &&
-                        (m.series_band == 2 || g.PT >= 112) && tband_applies(g.K, g.D, g.PTcap, m.pad, g.ldl, (int)ldp);
-        ws.pj = take(tb ? (N + m.W) * ldp : 0);
-        ws.pjt = take(tb ? N * 2 * m.pad * ldp : 0);
-        ws.pjb = take(tb ? N * 2 * m.pad * ldp : 0);
-        ws.band = take(tb ? (N + m.W) * 2 * m.W : 0);
-        ws.eq = take(tb ? N * 2 * m.pad * (((g.K + 3) & ~3) + 4) : 0);
-        ws.ek = take(tb ? N * g.K * (2 * m.pad + 2) : 0);
-    }
     ws.total = off;
 }
 

@@ -255,13 +255,6 @@ class MTAD_GAT(nn.Module):
             # only; call refresh_weights() after such edits.  "eval_only": fingerprint in eval() mode, trust the version
             # counters in train() mode.  ("always" = True, kept for old callers.)
             object.__setattr__(self, "check_weight_contents", True)
-        if "share_series_pair_scores" not in self.__dict__:
-            # forward_series / score_series over stride-1 windows (Predictor.get_score, prediction.py:51-63): the temporal
-            # layer's pair scores of interior rows computed once per pair of SERIES rows instead of once per window (SURVEY
-            # section 8f row 3).  "auto": where it was measured to win (embeddings of >= 100 columns), True: wherever the
-            # kernels apply, False: never (every window computes its own pair grid; outputs then equal forward() on the
-            # materialised windows bit for bit)
-            object.__setattr__(self, "share_series_pair_scores", "auto")
         if "device_repack" not in self.__dict__:
             # True: after the first load, changed fp32 weights (an optimizer step) are re-packed on the GPU
             # (mtadgat_update_weights_device); False: every load goes through the host packer
@@ -332,7 +325,6 @@ class MTAD_GAT(nn.Module):
                 pending = lambda: v                       # noqa: E731
         mode = 1 if bf16 else (0 if self.precision == "fp32_strict" else 2)
         self._engine.set_precision(mode)
-        self._engine.set_option("series_band", {"auto": 0, False: 1, True: 2}[self.share_series_pair_scores])
         repack = key != self._weights_key or (bf16 and not self._engine.bf16_ready())
         if check and getattr(self, "_fp_value", None) is None:
             # the contents the packed weights were built from are not on record (first call, or unchecked calls in between:

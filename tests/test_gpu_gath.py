@@ -298,7 +298,6 @@ def test_fused_convolution_reads_bfloat16_windows_and_series_views(gpu_device):
     series = torch.rand(400 + W - 1, F, generator=g).to(gpu_device)
     starts = torch.randperm(400, generator=g)[:77].to(gpu_device)
     xb = torch.rand(65, W, F, generator=g).to(gpu_device).to(torch.bfloat16)
-    model.share_series_pair_scores = False
     with torch.no_grad():
         eng.set_option("conv_kernel", 2)
         eng.set_option("gat_kernel", 3)

@@ -57,14 +57,13 @@ def test_two_lane_forward_equals_forward_on_the_pieces(n, gpu_device):
     gate(r[-3:], r_o, what="two-lane forward, reconstructions of the last piece")
     if n < 20000:
         with torch.no_grad():
-            model.share_series_pair_scores = False
             ps, rs = model.forward_series(series, start=0, stride=1, count=n)
         assert torch.equal(ps, p) and torch.equal(rs, r)
 
 
-def test_chunks_pieces_and_shared_scores_compose(gpu_device):
-    """A call larger than the chunk size walks chunk by chunk, every chunk by its own piece schedule, and -- for a stride-1
-    series -- every piece builds its own score band: whatever the combination, the outputs stay within 2e-6 of the single-chunk
+def test_chunks_and_pieces_compose(gpu_device):
+    """A call larger than the chunk size walks chunk by chunk, every chunk by its own piece schedule -- here the stride-1 windows
+    of a series, read out of it by the fused front end: whatever the combination, the outputs stay within 2e-6 of the single-chunk
     call (other recurrence kernels per size class) and the first / last windows match the oracle."""
     case = Case("msl")
     model = case.build_model().to(gpu_device)
@@ -74,7 +73,6 @@ def test_chunks_pieces_and_shared_scores_compose(gpu_device):
     n = 23000
     series = torch.rand(n + W - 1, F, generator=g).to(gpu_device)
     with torch.no_grad():
-        model.share_series_pair_scores = True
         p0, r0 = model.forward_series(series, start=0, stride=1, count=n)
         eng = model._engine
         default_chunk = eng.chunk_windows()
@@ -86,7 +84,6 @@ def test_chunks_pieces_and_shared_scores_compose(gpu_device):
                 assert (p1 - p0).abs().max().item() <= tol and (r1 - r0).abs().max().item() <= tol, chunk
         finally:
             eng.set_chunk_windows(default_chunk)
-            model.share_series_pair_scores = "auto"
         x = torch.stack([series[i:i + W] for i in (0, 1, n - 2, n - 1)]).cpu()
         p_o, r_o = oracle.forward(x, case.state_dict(), alpha=case.kwargs["alpha"])
     sel = torch.tensor([0, 1, n - 2, n - 1], device=gpu_device)

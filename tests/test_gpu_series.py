@@ -126,7 +126,6 @@ def test_shared_convolution_rows_of_stride_one_windows_are_bit_equal(gpu_device)
     series_s = torch.rand(24 + 2100, 11, device=gpu_device)
     with torch.no_grad():
         for m, sr, ww in ((model, series, w), (small, series_s, 24)):
-            m.share_series_pair_scores = False          # (the shared pair scores have their own test below)
             n = sr.shape[0] - ww + 1
             x = torch.stack([sr[i:i + ww] for i in range(n)])
             for prec in ("fp32", "fp32_strict"):
@@ -143,47 +142,3 @@ def test_shared_convolution_rows_of_stride_one_windows_are_bit_equal(gpu_device)
         xw = torch.stack([series[i:i + w] for i in range(series.shape[0] - w + 1)])
         pw, rw = model(xw)
         assert torch.equal(preds, pw[:-1]) and torch.equal(last, rw[1:, -1, :])
-
-
-def test_shared_temporal_pair_scores_of_stride_one_windows(gpu_device):
-    """SURVEY section 8f row 3, second half: from 1 024 stride-1 windows on the temporal layer's pair scores of interior rows are
-    computed once per pair of series rows (k_tband_scores) and shared by the windows that contain both; the windows' own
-    edge rows, the bias, softmax and aggregation stay per window (k_tband_edges / k_tband_att).  Against the per-window pair
-    grid (same model, sharing off: itself bit-equal to forward() on the materialised windows) <= 1e-6 of the output scale --
-    kernel sizes 7, 5, 3 (3, 2, 1 edge rows per side), a segment that does not start at row 0, the shipped MSL weights with
-    their exploded attention biases, both fp32 arithmetics -- and the first windows against the oracle."""
-    from mtad_gat import MTAD_GAT
-    case = Case("msl")
-    msl = case.build_model().to(gpu_device)
-    g = torch.Generator().manual_seed(11)
-    shapes = [(msl, case.kwargs["window_size"], case.kwargs["n_features"], 2300, case.state_dict(), case.kwargs["alpha"])]
-    for (F, W, ks, n, od) in ((38, 100, 7, 1500, 38), (9, 30, 3, 3000, 1), (21, 64, 5, 1200, 3), (5, 17, 3, 1100, 5), (48, 128, 7, 1024, 2)):
-        torch.manual_seed(F + W)
-        m = MTAD_GAT(n_features=F, window_size=W, out_dim=od, kernel_size=ks, gru_hid_dim=48, recon_hid_dim=40).eval()
-        with torch.no_grad():
-            m.temporal_gat.bias.normal_()
-            m.feature_gat.bias.normal_()
-        shapes.append((m.to(gpu_device), W, F, n, {k: v.detach().cpu() for k, v in m.state_dict().items()}, 0.2))
-    with torch.no_grad():
-        for m, W, F, n, sd, alpha in shapes:
-            series = (torch.rand(W + n + 6, F, generator=g) * 3 - 1).to(gpu_device)
-            for prec in ("fp32", "fp32_strict"):
-                m.precision = prec
-                m.share_series_pair_scores = False
-                p0, r0 = m.forward_series(series, start=5, stride=1, count=n)
-                m.share_series_pair_scores = True
-                p1, r1 = m.forward_series(series, start=5, stride=1, count=n)
-                assert not (torch.equal(p0, p1) and torch.equal(r0, r1)), "the shared-score kernels did not run"
-                tol = 1e-6 * max(1.0, r0.abs().max().item(), p0.abs().max().item())
-                assert (p1 - p0).abs().max().item() <= tol and (r1 - r0).abs().max().item() <= tol, (W, F, prec)
-            m.precision = "auto"
-            x = torch.stack([series[5 + i:5 + i + W] for i in range(4)]).cpu()
-            p_o, r_o = oracle.forward(x, sd, alpha=alpha)
-            gate(p1[:4], p_o, what=f"shared pair scores, forecasts (W={W}, F={F})")
-            gate(r1[:4], r_o, what=f"shared pair scores, reconstructions (W={W}, F={F})")
-            # strided / listed windows and short calls do not qualify: they run the per-window kernels whatever the switch says
-            pa, ra = m.forward_series(series, start=0, stride=2, count=40)
-            m.share_series_pair_scores = False
-            pb, rb = m.forward_series(series, start=0, stride=2, count=40)
-            assert torch.equal(pa, pb) and torch.equal(ra, rb)
-            m.share_series_pair_scores = "auto"

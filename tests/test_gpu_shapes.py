@@ -117,7 +117,6 @@ def test_recurrence_kernel_bands_on_random_shapes(idx, gpu_device):
         x_head = torch.stack([series[i:i + W] for i in range(6)])
         p_ref, r_ref = oracle.forward(x_head, model.state_dict(), alpha=kw["alpha"])
         m = model.to(gpu_device)
-        m.share_series_pair_scores = False          # (per-window pair grids: the series outputs are compared bit for bit below)
         sd = series.to(gpu_device)
         for n in (3000, 8192, 9000):
             x = torch.stack([sd[i:i + W] for i in range(n)])

@@ -162,10 +162,11 @@ def test_create_validates_and_plans_without_a_gpu():
     assert lib.mtadgat_set_option(h, b"lanes", 1) == 0
     assert lib.mtadgat_workspace_bytes(h, 36864) < lib.mtadgat_workspace_bytes(h, 32768) * 1.2
     assert lib.mtadgat_set_option(h, b"lanes", 0) == 0 and lib.mtadgat_set_option(h, b"lanes", 2) != 0
-    for name, top in ((b"series_band", 2), (b"rowgemm_kernel", 2), (b"wgrad_kernel", 2), (b"conv_kernel", 2), (b"gat_kernel", 3)):
+    for name, top in ((b"rowgemm_kernel", 2), (b"wgrad_kernel", 2), (b"conv_kernel", 2), (b"gat_kernel", 3)):
         assert lib.mtadgat_set_option(h, name, top) == 0 and lib.mtadgat_set_option(h, name, top + 1) != 0
         assert lib.mtadgat_set_option(h, name, 0) == 0
     assert lib.mtadgat_set_option(h, b"gat_kernel", 2) != 0                       # (round 4's column-sliced kernel is gone)
+    assert lib.mtadgat_set_option(h, b"series_band", 0) != 0                      # (... and so is the shared-score band of rounds 4-5)
     assert lib.mtadgat_set_option(h, b"no_such_option", 0) != 0
     # arithmetic switch: 0 fp32 MFMA, 1 bf16 operands, 2 fp32 through split 16-bit operands; anything else is refused
     for mode, ok in ((0, True), (1, True), (2, True), (3, False), (-1, False)):
