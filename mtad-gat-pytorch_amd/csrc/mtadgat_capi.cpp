@@ -316,6 +316,22 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 // the part of run_gru_layer's `cm_fit` that does not depend on the call: can the split-operand kernels (k_gru_cm / the X3H
 // build of k_gru_split) serve this layer at all?  (hidden sizes above 160, wide windows, input packs that need the range guard
 // without a fused front end cannot: such layers keep k_gru16 up to G16_MAX_WINDOWS)
+// A Linear over (window, step) rows in the default fp32 arithmetic: from 65 536 rows on the products come from three bf16 pieces per
+// operand on the 16-bit matrix pipe (k_rowgemm_x3 / _x3s: 2.7 x less matrix time than the fp32 MFMA, results <= 2e-7 apart), with the
+// split pack derived on first use after an upload -- as the wide attention layers' projections and the backward's data gradients
+// do.  Round 6: the GRU's hoisted input projection and recon_model.fc ran on the fp32 MFMA whatever the size (config 4: two 2.3 ms
+// launches per 896-window chunk, 42 of its 268 ms per 8 192 windows).
+int lin_split_operands(Model& m, const LinPlan& p, long rows, RowGemmArgs& a, hipStream_t s) {
+    if (!p.w3_off || p.Q16 <= 0 || m.precision != 2 || m.rowgemm_kernel == 1 || !(rows >= 65536 || m.rowgemm_kernel == 2)) return 0;
+    if (p.w3_version != m.weights_version) {
+        K_TRY(launch_split3(m.packed_dev + p.w_off, m.packed_dev + p.w3_off, p.NT, p.Q, p.Q16, 1, nullptr, s), "split-bf16 Linear weights");
+        p.w3_version = m.weights_version;
+    }
+    a.x3 = 1; a.Q16 = p.Q16;
+    a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + p.w3_off);
+    return 0;
+}
+
 bool split_kernels_fit(const Model& m, const GruPlan& g) {
     if (m.W > 512 || !(g.Qxp16 == 1 || g.Qxp16 % 2 == 0)) return false;
     if (g.xmode == 1) return g.Qxp16 == 1 && gru_cm_supported(g.NCG, 1, false, 0);
@@ -355,6 +371,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
             r.bias = m.packed_dev + g.xproj.b_off;
             r.Y = xp; r.ldy = 3L * g.Hp; r.Nvalid = 3 * g.Hp; r.vec_store = 1;
             r.R = n * m.W; r.NT = g.xproj.NT; r.NT_rm = g.xproj.NT; r.group = 1; r.relu = 0;
+            if (int rc_ = lin_split_operands(m, g.xproj, r.R, r, s)) return rc_;
             K_TRY(launch_rowgemm(r, s), "gru input projection");
         } else {
             K_TRY(launch_xproj_dec(x, ldx, kx, m.packed_dev + g.fold_off, reinterpret_cast<const int*>(m.packed_dev + g.m0_off),
@@ -404,6 +421,7 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         r.bias = m.packed_dev + g.xproj.b_off;
         r.Y = xp; r.ldy = 3L * g.Hp; r.Nvalid = 3 * g.Hp; r.vec_store = 1;
         r.R = n * m.W; r.NT = g.xproj.NT; r.NT_rm = g.xproj.NT; r.group = 1; r.relu = 0;
+        if (int rc_ = lin_split_operands(m, g.xproj, r.R, r, s)) return rc_;
         K_TRY(launch_rowgemm(r, s), "gru input projection");
         x = xp; ldx = 3L * g.Hp; xmode = 3;
     }
@@ -556,6 +574,7 @@ int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, fl
             a.Y = y; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
             a.vec_store = (p.out_dim % 4 == 0 && aligned16(y)) ? 1 : 0;
             a.R = recons ? n * (int64_t)m.W : n; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
+            if (int rc_ = lin_split_operands(m, p, a.R, a, s)) return rc_;
             K_TRY(launch_rowgemm(a, s), "reconstruction Linear");
             if (recons && recons_last)
                 K_TRY(launch_copy2d(recons + (int64_t)(m.W - 1) * p.out_dim, (long)m.W * p.out_dim, recons_last, p.out_dim, n, p.out_dim, s),
@@ -582,6 +601,7 @@ int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, fl
             a.Y = recons; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
             a.vec_store = (p.out_dim % 4 == 0 && aligned16(recons)) ? 1 : 0;
             a.R = n * (int64_t)m.W; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
+            if (int rc_ = lin_split_operands(m, p, a.R, a, s)) return rc_;
             K_TRY(launch_rowgemm(a, s), "reconstruction Linear");
             if (recons_last)
                 K_TRY(launch_copy2d(recons + (int64_t)(m.W - 1) * p.out_dim, (long)m.W * p.out_dim, recons_last, p.out_dim, n, p.out_dim, s),
@@ -919,6 +939,9 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
         add(m.bw.recfcT.w3_off, (size_t)m.bw.recfcT.NT * m.bw.recfcT.Q16 * 3 * 256);
         for (int k = 0; k < 2; ++k) add(m.bw.gat[k].lrT.w3_off, (size_t)m.bw.gat[k].lrT.NT * m.bw.gat[k].lrT.Q16 * 3 * 256);
     }
+    for (const GruPlan& g : m.gru)
+        if (g.has_xproj && g.xproj.w3_off) add(g.xproj.w3_off, (size_t)g.xproj.NT * g.xproj.Q16 * 3 * 256);
+    if (m.rec_fc.w3_off) add(m.rec_fc.w3_off, (size_t)m.rec_fc.NT * m.rec_fc.Q16 * 3 * 256);
     add(m.conv_w3_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 3 * 256);
     for (const GatPlan* g : {&m.feat, &m.temp}) add(g->uw3_off, (size_t)g->NT * g->uQ16 * 3 * 256);
     add(m.conv_w2h_off, (size_t)m.convNT * (m.taps * m.Fp16 / 16) * 2 * 256);

@@ -51,6 +51,12 @@ struct GatPlan {
 struct LinPlan {
     int in_dim = 0, out_dim = 0, NT = 0, Q = 0;
     size_t w_off = 0, b_off = 0;
+    // split-bf16 pack [tile][Q16][3 pieces][64] for launches of many rows (k_rowgemm_x3 / _x3s), derived on the device on first use
+    // after an upload; only planned for the Linears that run over (window, step) rows: the GRU's hoisted input projection and
+    // recon_model.fc
+    int Q16 = 0;
+    size_t w3_off = 0;
+    mutable uint64_t w3_version = 0;
 };
 
 struct GruPlan {

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_x3s(const ConvArgs a) {
         for (int s4 = 0; s4 < 4; ++s4) v[s4] = ok ? v[s4] : 0.f;
         return v;
     };
-    for (int n0 = 0; n0 < a.NT; n0 += NTB) {
+    for (int n0 = blockIdx.y * NTB; n0 < a.NT; n0 += NTB * gridDim.y) {
         // (round 6, as k_rowgemm_x3s: weight words two chunks ahead by LDS-DMA into a ring of three slots, input words two chunks
         // ahead in registers, chunk barrier without the vector-memory drain)
         const f32x4* __restrict__ wtile = Wp + ((long)((n0 + wave < a.NT) ? n0 + wave : a.NT - 1) * Q) * 192;
@@ -967,7 +967,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         if (a.Wp3) {                 // split-bf16 operands (precision mode 2, large launches: run_conv)
             const int s_off = g_gemm_lds_off;
             if (a.NT >= 4 && R >= 64 * 2048 && (a.F & 3) == 0 && a.F >= 4 && !s_off)
-                hipLaunchKernelGGL(k_conv_x3s, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, a);
+                {
+                    // groups of four output tiles spread over gridDim.y until the launch has >= 2 048 workgroups: a chunk of config 4
+                    // (229 376 rows) was 896 workgroups of four passes each on 512 slots -- 1.75 rounds of very long workgroups
+                    const unsigned gridw = (unsigned)((R + 255) / 256);
+                    const long groups4 = (a.NT + 3) / 4, want = (2048 + gridw - 1) / gridw;
+                    const unsigned split = (unsigned)(want < 1 ? 1 : (want > groups4 ? groups4 : want));
+                    hipLaunchKernelGGL(k_conv_x3s, dim3(gridw, split), dim3(256), 0, s, a);
+                }
             else if (a.NT >= 4)
                 hipLaunchKernelGGL(k_conv_x3<4>, dim3(grid), dim3(64), 0, s, a);
             else if (a.NT >= 2)

@@ -235,6 +235,8 @@ std::string validate_and_plan(Model& m) {
             g.xproj.NT = 3 * g.Hp / 32; g.xproj.Q = (g.in_dim + 7) / 8;
             g.xproj.w_off = take((size_t)g.xproj.NT * g.xproj.Q * 256);
             g.xproj.b_off = take((size_t)3 * g.Hp);
+            g.xproj.Q16 = (g.in_dim + 15) / 16;
+            g.xproj.w3_off = take((size_t)g.xproj.NT * g.xproj.Q16 * 3 * 256);
             plan16(g);
         }
     }
@@ -296,6 +298,8 @@ std::string validate_and_plan(Model& m) {
         p.Q = m.rec.back().Hp / 8;
         p.w_off = take((size_t)p.NT * p.Q * 256);
         p.b_off = take((size_t)p.NT * 32);
+        p.Q16 = (p.Q + 1) / 2;
+        p.w3_off = take((size_t)p.NT * p.Q16 * 3 * 256);
     }
 
     // ---- backward (training) plans: transposed packs, un-scaled attention projections, gradient index maps

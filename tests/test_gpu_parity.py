@@ -281,6 +281,7 @@ def test_data_edit_behind_an_unchecked_call_is_seen(gpu_device):
     model.check_weight_contents = "eval_only"
     x = a.x.to(gpu_device)
     bias = model.forecasting_model.layers[3].bias
+    orig = bias.detach().clone()
     with torch.no_grad():
         p0, _ = model(x)
     model.train()
@@ -294,7 +295,7 @@ def test_data_edit_behind_an_unchecked_call_is_seen(gpu_device):
         assert torch.allclose(p1, p0 + 0.75, atol=1e-6)
         model.check_weight_contents = False
         model(x)
-        bias.data.sub_(0.75)
+        bias.data.copy_(orig)
         model.check_weight_contents = True
         assert torch.equal(model(x)[0], p0)
 
