@@ -80,6 +80,81 @@ static bool conv_win_selected(const Model& m, int64_t n) {
     return (m.precision == 2 || split_front(m, n)) && m.conv_kernel != 1 && (n >= 4096 || m.conv_kernel == 2);
 }
 
+// Round 6: the split packs are derived LAZILY, by the first launch that reads them after an upload.  Rounds 2-5 re-derived all of
+// them behind every upload -- ~30 launches of a few microseconds each (ranges, scales, splits) after every optimizer step, although a
+// training step of the reference's batch size (256 windows) reads none of them: 0.15-0.2 ms of a 2.3 ms step.  An upload now only
+// bumps weights_version; ensure_*_split() derive on the stream of the consumer.  Calls that fork onto the second lane derive
+// everything on the caller's stream first (ensure_all_split in forward_impl), so the lanes never race for a derivation.
+int ensure_gru_split(Model& m, const GruPlan& g, hipStream_t s) {
+    if (g.split_ver == m.weights_version) return 0;
+    // the layer's power-of-two weight scale (fp16 range of the recurrent pieces), from the largest weight, on the device
+    const long outer_x = (long)(g.xmode == 1 ? m.W : 1) * g.NCG;
+    float* sc = m.packed_dev + g.scale_off;
+    HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
+    K_TRY(launch_absmax(m.packed_dev + g.wx_off, outer_x * g.Qxp * 3 * 256, sc, s), "weight range");
+    K_TRY(launch_absmax(m.packed_dev + g.wh_off, (long)g.NCG * (4 * g.NCG + 2) * 3 * 256, sc, s), "weight range");
+    K_TRY(launch_scale_from_max(sc, s), "weight scale");
+    K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, g.qb3, sc + 1, s), "split input weights");
+    if (g.wx2_off && g.qb3 > 0)
+        K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx2_off, outer_x, g.Qxp, g.Qxp16, 0, sc + 1, s), "split input weights (fp16)");
+    K_TRY(launch_split2h(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, sc + 1, s),
+          "split-fp16 recurrent weights");
+    if (g.wxq_off)       // chunk-major copy of the two-piece input pack (k_gru_cm)
+        K_TRY(launch_reorder_xq(m.packed_dev + ((g.wx2_off && g.qb3 > 0) ? g.wx2_off : g.wx3_off), m.packed_dev + g.wxq_off, g.NCG, g.Qxp16, s),
+              "chunk-major input weights");
+    g.split_ver = m.weights_version;
+    return 0;
+}
+int ensure_conv_split(Model& m, hipStream_t s) {
+    if (m.split_ver_conv == m.weights_version) return 0;
+    // the window convolution's pack: two fp16 pieces of S * W in the 16-channel geometry; three bf16 pieces for the wide models' k_conv_x3
+    float* sc = m.packed_dev + m.conv_scale_off;
+    const int q8 = m.taps * m.Fp16 / 8;
+    HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
+    K_TRY(launch_absmax(m.packed_dev + m.conv_wf16_off, (long)m.convNT * q8 * 256, sc, s), "convolution weight range");
+    K_TRY(launch_scale_from_max(sc, s), "convolution weight scale");
+    K_TRY(launch_split2h(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w2h_off, m.convNT, q8, q8 / 2, 1, sc + 1, s), "split-fp16 convolution weights");
+    K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, nullptr, s),
+          "split-bf16 convolution weights");
+    m.split_ver_conv = m.weights_version;
+    return 0;
+}
+int ensure_gat_split(Model& m, const GatPlan& g, hipStream_t s) {
+    const int which = &g == &m.feat ? 0 : 1;
+    if (m.split_ver_gat[which] == m.weights_version) return 0;
+    if (!g.fused && g.uQ16 > 0)
+        K_TRY(launch_split3(m.packed_dev + g.w_off, m.packed_dev + g.uw3_off, g.NT, g.Q, g.uQ16, 1, nullptr, s), "split-bf16 projection weights (row GEMM)");
+    if (g.fused) {
+        K_TRY(launch_split3(m.packed_dev + g.w_off, m.packed_dev + g.w3_off, g.NT, g.Q, g.Q16, 1, nullptr, s), "split-bf16 projection weights");
+        float* sc = m.packed_dev + g.gscale_off;
+        HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
+        K_TRY(launch_absmax(m.packed_dev + g.w_off, (long)g.NT * g.Q * 256, sc, s), "projection weight range");
+        K_TRY(launch_scale_from_max(sc, s), "projection weight scale");
+        K_TRY(launch_split2h(m.packed_dev + g.w_off, m.packed_dev + g.w2h_off, g.NT, g.Q, g.Q16, 1, sc + 1, s), "split-fp16 projection weights");
+    }
+    m.split_ver_gat[which] = m.weights_version;
+    return 0;
+}
+int ensure_lin_split(Model& m, const LinPlan& p, hipStream_t s) {
+    if (!p.w3_off || p.Q16 <= 0 || p.w3_version == m.weights_version) return 0;
+    K_TRY(launch_split3(m.packed_dev + p.w_off, m.packed_dev + p.w3_off, p.NT, p.Q, p.Q16, 1, nullptr, s), "split-bf16 Linear weights");
+    p.w3_version = m.weights_version;
+    return 0;
+}
+// everything an inference call may read, on ONE stream (no-ops while the weights are unchanged)
+int ensure_all_split(Model& m, hipStream_t s) {
+    int rc;
+    for (const GruPlan& g : m.gru) {
+        if ((rc = ensure_gru_split(m, g, s))) return rc;
+        if (g.has_xproj && (rc = ensure_lin_split(m, g.xproj, s))) return rc;
+    }
+    for (const GruPlan& g : m.rec)
+        if ((rc = ensure_gru_split(m, g, s))) return rc;
+    if ((rc = ensure_lin_split(m, m.rec_fc, s))) return rc;
+    if ((rc = ensure_conv_split(m, s))) return rc;
+    if ((rc = ensure_gat_split(m, m.feat, s)) || (rc = ensure_gat_split(m, m.temp, s))) return rc;
+    return 0;
+}
 // geo (optional): the rows are cut into `geo_W`-row windows instead of the model's W-row ones (run_conv_shared)
 int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, float* xct, float* hcat, float* y, hipStream_t s,
              unsigned* vmax = nullptr, int64_t geo_W = 0, bool keep_vmax = false) {
@@ -118,6 +193,7 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
     if (conv_win_selected(m, n) && !geo_W && hcat && !xc && !xct && !y) {
         ConvArgs b = a;
         b.Fq = m.Fp16;
+        if (int rc_ = ensure_conv_split(m, s)) return rc_;
         b.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w2h_off);
         b.wscale = m.packed_dev + m.conv_scale_off + 1;
         if (conv_win_applies(b)) {
@@ -128,6 +204,7 @@ int run_conv(Model& m, const XSource& src, int64_t c0, int64_t n, float* xc, flo
     // wide models (rows too long for the LDS-staged kernels): the straight-from-memory kernel on three bf16 pieces per operand
     if (m.precision == 2 && !a.bf16 && !src.x_bf16 && m.conv_kernel != 1 && (n * Wk >= 65536 || m.conv_kernel == 2) &&
         (size_t)(32 + m.taps - 1) * (m.Fp + 4) * sizeof(float) > 20 * 1024) {
+        if (int rc_ = ensure_conv_split(m, s)) return rc_;
         a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + m.conv_w3_off);
         a.Fq = m.Fp16;
     }
@@ -178,6 +255,7 @@ int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nro
     a.R = nrows; a.NT = g.NT; a.relu = 0;
     a.NT_rm = g.NT_L; a.YT = rt; a.group = g.K; a.YT_rows = g.rt_rows; a.YT_ld = g.Kp;
     if (m.precision == 2 && g.uw3_off && g.uQ16 > 0 && m.rowgemm_kernel != 1 && (nrows >= 65536 || m.rowgemm_kernel == 2)) {       // wide layers: three bf16 pieces per operand
+        if (int rc_ = ensure_gat_split(m, g, s)) return rc_;
         a.x3 = 1; a.Q16 = g.uQ16;
         a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + g.uw3_off);
     }
@@ -236,6 +314,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
         // beside the pair grid of the other waves (the fp32 MFMA does not: profiles/r02_mfma_valu_overlap.txt).  Measured at
         // (W=100, F=55): feature layer 5.90 -> 5.09 ms, temporal layer 7.40 -> 6.94 ms (two weight chunks in registers; with
         // four the temporal layer's larger pair-grid block spilled and lost)
+        if (int rc_ = ensure_gat_split(m, g, s)) return rc_;
         a.bf16 = 2; a.Q = g.Q16;
         a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w3_off);
         // two fp16 pieces instead when the convolution that produced the node values recorded a maximum below 2^15
@@ -323,10 +402,7 @@ int run_gat_layer(Model& m, const GatPlan& g, const float* v, int ldv, int64_t n
 // launches per 896-window chunk, 42 of its 268 ms per 8 192 windows).
 int lin_split_operands(Model& m, const LinPlan& p, long rows, RowGemmArgs& a, hipStream_t s) {
     if (!p.w3_off || p.Q16 <= 0 || m.precision != 2 || m.rowgemm_kernel == 1 || !(rows >= 65536 || m.rowgemm_kernel == 2)) return 0;
-    if (p.w3_version != m.weights_version) {
-        K_TRY(launch_split3(m.packed_dev + p.w_off, m.packed_dev + p.w3_off, p.NT, p.Q, p.Q16, 1, nullptr, s), "split-bf16 Linear weights");
-        p.w3_version = m.weights_version;
-    }
+    if (int rc_ = ensure_lin_split(m, p, s)) return rc_;
     a.x3 = 1; a.Q16 = p.Q16;
     a.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + p.w3_off);
     return 0;
@@ -438,6 +514,9 @@ int run_gru_layer(Model& m, int slot, const GruPlan& g, const float* x, long ldx
         a.whs = 2 * g.NCG + 2;
         a.Qxp = g.Qxp16;
         a.bf16 = 1;
+    }
+    if (x3 || sp_train) {
+        if (int rc_ = ensure_gru_split(m, g, s)) return rc_;
     }
     if (x3) {
         a.Wx = reinterpret_cast<const f32x4*>(m.packed_dev + g.wx3_off);
@@ -574,7 +653,9 @@ int run_heads(Model& m, const float* hend, long ldh, int64_t n, float* preds, fl
             a.Y = y; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
             a.vec_store = (p.out_dim % 4 == 0 && aligned16(y)) ? 1 : 0;
             a.R = recons ? n * (int64_t)m.W : n; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
-            if (int rc_ = lin_split_operands(m, p, a.R, a, s)) return rc_;
+            // (the arithmetic is chosen by the size of the whole reconstruction, also when only its last step is wanted: score_series
+            // equals forward() on the same windows bit for bit)
+            if (int rc_ = lin_split_operands(m, p, n * (int64_t)m.W, a, s)) return rc_;
             K_TRY(launch_rowgemm(a, s), "reconstruction Linear");
             if (recons && recons_last)
                 K_TRY(launch_copy2d(recons + (int64_t)(m.W - 1) * p.out_dim, (long)m.W * p.out_dim, recons_last, p.out_dim, n, p.out_dim, s),
@@ -720,50 +801,9 @@ int mtadgat_destroy(mtadgat_handle h) {
 }
 
 // split-bf16 packs of the large-batch recurrences, derived on the device from the fp32 packs of the image
-static int run_split3(Model& m, hipStream_t s) {
-    auto one = [&](const GruPlan& g) -> int {
-        // the layer's power-of-two weight scale (fp16 range of the recurrent pieces), from the largest weight, on the device
-        const long outer_x = (long)(g.xmode == 1 ? m.W : 1) * g.NCG;
-        float* sc = m.packed_dev + g.scale_off;
-        HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
-        K_TRY(launch_absmax(m.packed_dev + g.wx_off, outer_x * g.Qxp * 3 * 256, sc, s), "weight range");
-        K_TRY(launch_absmax(m.packed_dev + g.wh_off, (long)g.NCG * (4 * g.NCG + 2) * 3 * 256, sc, s), "weight range");
-        K_TRY(launch_scale_from_max(sc, s), "weight scale");
-        K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx3_off, outer_x, g.Qxp, g.Qxp16, g.qb3, sc + 1, s), "split input weights");
-        if (g.wx2_off && g.qb3 > 0)
-            K_TRY(launch_split_x(m.packed_dev + g.wx_off, m.packed_dev + g.wx2_off, outer_x, g.Qxp, g.Qxp16, 0, sc + 1, s), "split input weights (fp16)");
-        K_TRY(launch_split2h(m.packed_dev + g.wh_off, m.packed_dev + g.wh3_off, g.NCG, 4 * g.NCG + 2, 2 * g.NCG + 2, 3, sc + 1, s),
-              "split-fp16 recurrent weights");
-        if (g.wxq_off)       // chunk-major copy of the two-piece input pack (k_gru_cm)
-            K_TRY(launch_reorder_xq(m.packed_dev + ((g.wx2_off && g.qb3 > 0) ? g.wx2_off : g.wx3_off), m.packed_dev + g.wxq_off, g.NCG, g.Qxp16, s),
-                  "chunk-major input weights");
-        return 0;
-    };
-    for (const GruPlan& g : m.gru) { int rc = one(g); if (rc) return rc; }
-    for (const GruPlan& g : m.rec) { int rc = one(g); if (rc) return rc; }
-    {   // the window convolution's pack: two fp16 pieces of S * W in the 16-channel geometry
-        float* sc = m.packed_dev + m.conv_scale_off;
-        const int q8 = m.taps * m.Fp16 / 8;
-        HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
-        K_TRY(launch_absmax(m.packed_dev + m.conv_wf16_off, (long)m.convNT * q8 * 256, sc, s), "convolution weight range");
-        K_TRY(launch_scale_from_max(sc, s), "convolution weight scale");
-        K_TRY(launch_split2h(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w2h_off, m.convNT, q8, q8 / 2, 1, sc + 1, s), "split-fp16 convolution weights");
-    }
-    ++m.weights_version;                 // (the transposed packs of the backward's data-gradient products are split on first use: run_rowgemm_T)
-    K_TRY(launch_split3(m.packed_dev + m.conv_wf16_off, m.packed_dev + m.conv_w3_off, m.convNT, m.taps * m.Fp16 / 8, m.taps * m.Fp16 / 16, 1, nullptr, s),
-          "split-bf16 convolution weights");
-    for (const GatPlan* g : {&m.feat, &m.temp})
-        if (!g->fused && g->uQ16 > 0)
-            K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->uw3_off, g->NT, g->Q, g->uQ16, 1, nullptr, s), "split-bf16 projection weights (row GEMM)");
-    for (const GatPlan* g : {&m.feat, &m.temp})
-        if (g->fused) {
-            K_TRY(launch_split3(m.packed_dev + g->w_off, m.packed_dev + g->w3_off, g->NT, g->Q, g->Q16, 1, nullptr, s), "split-bf16 projection weights");
-            float* sc = m.packed_dev + g->gscale_off;
-            HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
-            K_TRY(launch_absmax(m.packed_dev + g->w_off, (long)g->NT * g->Q * 256, sc, s), "projection weight range");
-            K_TRY(launch_scale_from_max(sc, s), "projection weight scale");
-            K_TRY(launch_split2h(m.packed_dev + g->w_off, m.packed_dev + g->w2h_off, g->NT, g->Q, g->Q16, 1, sc + 1, s), "split-fp16 projection weights");
-        }
+// an upload happened: every derived pack is stale from here on
+static int run_split3(Model& m, hipStream_t) {
+    ++m.weights_version;
     return 0;
 }
 
@@ -1012,6 +1052,7 @@ int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, voi
     Model& m = h->m;
     if (!m.have_weights || !m.packed_dev) return fail(MTADGAT_ERR_NOWEIGHTS, "no weights loaded");
     if (n_floats != (int64_t)m.packed_floats) return fail(MTADGAT_ERR_INVALID, "wrong size");
+    if (int rc_ = ensure_all_split(m, (hipStream_t)stream)) return rc_;      // the image as the kernels would see it
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(dst_host, m.packed_dev, m.packed_floats * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
@@ -1168,6 +1209,7 @@ static int forward_impl(mtadgat_handle h, const XSource& src, int64_t batch, flo
     Model& m = h->m;
     hipStream_t s0 = (hipStream_t)stream;
     const int F = m.F, W = m.W;
+    if ((rc = ensure_all_split(m, s0))) return rc;        // (no-ops while the weights are unchanged; before any lane forks off)
     std::vector<Piece> sched;
     forward_schedule(m, batch, sched);
     size_t lane_need[2];

@@ -67,6 +67,7 @@ struct GruPlan {
     // rows (b*T, in_dim) -> (b*T, 3*Hp) [W_ir x + b_ir + b_hr | W_iz x + b_iz + b_hz | W_in x + b_in]
     bool has_xproj = false;
     LinPlan xproj;
+    mutable uint64_t split_ver = 0;   // Model::weights_version the layer's split packs (scale, wx3, wx2, wh3, wxq) were derived from
     // bf16 operand packs (16-feature chunks, element order of mtadgat_device.h): same streams, half the bytes per feature
     int Qxp16 = 0;          // packed input chunks (1, or a multiple of 3)
     size_t wx16_off = 0, wh16_off = 0;
@@ -213,6 +214,9 @@ struct Model {
     int wgrad_kernel = 0;            // weight-gradient GEMMs of the training step (testing hook): 0 automatic (split-bf16 operands in mode 2), 1 fp32 MFMA, 2 split-bf16 always
     int conv_shared = 0;             // series scoring (testing hook): 1 keeps the shared-row convolution where the window-per-workgroup kernel would run
     uint64_t weights_version = 0;    // counts weight uploads / device-side re-packs
+    // the split packs (two-fp16-piece / three-bf16-piece copies of the fp32 packs, power-of-two scales) are derived on the device
+    // on first use after an upload: the upload each of them was last derived from (ensure_*_split, mtadgat_capi.cpp)
+    uint64_t split_ver_conv = 0, split_ver_gat[2] = {0, 0};
     int rowgemm_kernel = 0;          // data-gradient row GEMMs of mtadgat_backward in mode 2 (testing hook): 0 automatic (split-bf16 operands from 4096 rows), 1 fp32 MFMA, 2 split-bf16 always
     int conv_kernel = 0;             // convolution of the fused front end in mode 2 (testing hook): 0 automatic (k_conv_win from 4096 windows), 1 k_conv_lds, 2 k_conv_win at any batch size
     int gath_dbg = 0;                // measurement hook: GatArgs::dbg of k_gath (knock-out bits, profiles/gath_knockout.py)
