@@ -352,10 +352,10 @@ int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, fl
 // transposed recurrent product on the MFMA (same chunk / lane mapping as the forward).  d a_* of every step
 // are written out for the weight-gradient GEMMs and the input-gradient rowgemm.
 // ---------------------------------------------------------------------------
-// BF: bf16 operand build of the transposed recurrent product (the gate-gradient blocks are converted once by the
-// publishing wave, W_hh^T comes as a bf16 pack of 16-feature chunks); fp32 accumulation and gate arithmetic.
-template <bool BF>
+// (Rounds 2-5 carried a bf16-operand build of the transposed recurrent product as an opt-in "bf16 training step"; it lost to this
+// fp32 step at every batch size -- 7.98 vs 2.32 ms at 256 windows, 33.9 vs 28.5 at 8 192 -- and is gone: a bf16 request trains here.)
 __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
+    constexpr bool BF = false;
     extern __shared__ __attribute__((aligned(16))) float gsm[];
     f32x4* __restrict__ das = reinterpret_cast<f32x4*>(gsm);          // fp32: [3][NCG][4][64] float4; bf16: [3][NCG][2][64] containers
     const int lane = threadIdx.x & 63;
@@ -472,14 +472,11 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)3 * a.NCG * 4 * 64 * sizeof(f32x4);
     if (a.NCG < 1 || a.NCG > 8 || lds > 160 * 1024) return -2;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(a.bf16 ? reinterpret_cast<const void*>(&k_gru_bwd<true>) : reinterpret_cast<const void*>(&k_gru_bwd<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (a.bf16)
-        hipLaunchKernelGGL(k_gru_bwd<true>, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
-    else
-        hipLaunchKernelGGL(k_gru_bwd<false>, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
+    if (a.bf16) return -2;
+    hipLaunchKernelGGL(k_gru_bwd, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1483,8 +1483,9 @@ int check_train(mtadgat_handle h, int64_t batch, float p) {
     if (!h->m.have_weights) return fail(MTADGAT_ERR_NOWEIGHTS, "mtadgat_load_weights has not been called");
     if (!h->m.bw.supported) return fail(MTADGAT_ERR_UNSUPPORTED, "no HIP backward for this configuration: " + h->m.bw.why);
     if (!(p >= 0.f && p < 1.f)) return fail(MTADGAT_ERR_INVALID, "dropout probability must be in [0, 1)");
-    if (h->m.precision == 1 && !h->m.bf16_packed)
-        return fail(MTADGAT_ERR_NOWEIGHTS, "bf16 precision selected after the weights were loaded: call mtadgat_load_weights again");
+    if (h->m.precision == 1)
+        return fail(MTADGAT_ERR_UNSUPPORTED, "the training step computes in fp32 (mtadgat_set_precision 0 or 2): the bf16-operand recurrences of "
+                                             "rounds 2-5 were slower than it at every batch size and are gone");
     return 0;
 }
 
@@ -1792,7 +1793,6 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
             ga.Gates = gates; ga.Seq = seq; ga.DHseq = dhseq; ga.lddh = q.Hp; ga.DHend = dhend_; ga.ldde = q.Hp;
             ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + qb.whT_off);
             ga.DA = da; ga.Hp = q.Hp; ga.H = q.H; ga.T = W; ga.NCG = q.NCG; ga.B = n;
-            if (m.precision == 1) { ga.bf16 = 1; ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + qb.whT16_off); }
             K_TRY(launch_gru_bwd(ga, s), what);
         }
         int rc2;

@@ -242,12 +242,6 @@ class MTAD_GAT(nn.Module):
             # and attention layers take the faster two-fp16-piece kernels of "fp32"), "auto" = bf16 exactly when the caller
             # hands over bfloat16 tensors (BASELINE "bf16 inference" configs), fp32 otherwise
             object.__setattr__(self, "precision", "auto")
-        if "bf16_training_recurrences" not in self.__dict__:
-            # False (default): a training step always runs the fp32 step (split-operand / small-batch recurrences), also when
-            # bf16 is requested -- it is the faster one at every batch size (round 5, SMD shape: batch 256 2.5 vs 8.2 ms, batch
-            # 8 192 29.5 vs 34.5 ms) and the more accurate one.  True: the four recurrences of the step on bf16 MFMA operands
-            # (the arithmetic of BASELINE's "bf16 train loop" configuration)
-            object.__setattr__(self, "bf16_training_recurrences", False)
         if "check_weight_contents" not in self.__dict__:
             # True: every GPU call fingerprints the parameter *contents* (one small reduction whose 8-byte result is read after
             # the call's kernels are enqueued: no stream synchronisation, see _sync_engine), so in-place edits that bypass
@@ -413,9 +407,10 @@ class MTAD_GAT(nn.Module):
             preds, recons = _torchpath.forward(self, x.float())
             return (preds.to(x.dtype), recons.to(x.dtype)) if x.dtype != torch.float32 else (preds, recons)
         grad_step = self.training or self._wants_grad(x)
-        # a training step computes in fp32 whatever the request (faster and more accurate than the bf16 recurrence kernels at
-        # every batch size, see bf16_training_recurrences); bf16 tensors are still answered in bf16
-        bf16 = self._use_bf16(x) and (not grad_step or self.bf16_training_recurrences)
+        # a training step computes in fp32 whatever the request (BASELINE config 3's "bf16 train loop": the bf16 recurrence kernels
+        # of rounds 2-5 were slower AND less accurate than the fp32 step at every batch size and were removed in round 6); bf16
+        # tensors are still answered in bf16
+        bf16 = self._use_bf16(x) and not grad_step
         if grad_step:
             # training step (Trainer.fit, training.py:100-130) or any call that will be differentiated:
             # HIP forward that keeps what the HIP backward needs, dropout in the kernels

@@ -288,15 +288,14 @@ def test_backward_stage_diagnostics(gpu_device):
 
 
 @pytest.mark.parametrize("name", ["odd_shapes", "smd_shape"])
-def test_bf16_training_step_tracks_the_fp32_step(name, gpu_device):
-    """precision = "bf16" in train() with model.bf16_training_recurrences = True (opt-in; by default a bf16 request trains on
-    the fp32 step, which is faster and more accurate): the four recurrences (GRU layer and decoder, forward and BPTT) run on
-    bf16 MFMA operands with fp32 accumulation / state / gate arithmetic (BASELINE config 3: bf16 train loop); everything
-    else is fp32.  Outputs stay within the bf16 inference gate (2e-2); every parameter gradient stays within a few
-    percent of the fp32 step's in norm; a few Adam steps still learn."""
+def test_bf16_request_trains_on_the_fp32_step(name, gpu_device):
+    """BASELINE config 3 names a "bf16 train loop": precision = "bf16" (or bf16 tensors) in train() is served by the fp32 HIP
+    training step -- the bf16-operand recurrence kernels of rounds 2-5 were slower and less accurate than it at every batch size
+    and were removed in round 6.  Same outputs bit for bit, same gradients up to the backward's summation order; bf16 tensors are
+    answered in bf16; a few Adam steps learn; the C ABI refuses a bf16-mode training call."""
+    import _native
     kw, b = CONFIGS[name]
     model = _model(kw, gpu_device).train()
-    model.bf16_training_recurrences = True
     g = torch.Generator().manual_seed(14)
     x = torch.rand(b, kw["window_size"], kw["n_features"], generator=g).to(gpu_device)
     y = torch.rand(b, kw["out_dim"], generator=g).to(gpu_device)
@@ -312,22 +311,21 @@ def test_bf16_training_step_tracks_the_fp32_step(name, gpu_device):
         return pr.detach(), rc.detach(), {n: p.grad.clone() for n, p in model.named_parameters()}
 
     p32, r32, g32 = step("fp32")
-    model.bf16_training_recurrences = False
-    pd, rd, gd = step("bf16")                                 # default: the bf16 request trains on the fp32 step
+    pd, rd, gd = step("bf16")
     assert torch.equal(pd, p32) and torch.equal(rd, r32)      # (the backward sums through float atomics: not bit-reproducible)
     assert all((gd[n] - g32[n]).abs().max().item() <= 1e-6 + 1e-5 * g32[n].abs().max().item() for n in g32)
-    model.bf16_training_recurrences = True
-    p16, r16, g16 = step("bf16")
-    assert (p16 - p32).abs().max().item() <= 2e-2 and (r16 - r32).abs().max().item() <= 2e-2
-    assert not torch.equal(r16, r32)
-    worst = 0.0
-    for n in g32:
-        rel = ((g16[n] - g32[n]).norm() / (g32[n].norm() + 1e-12)).item()
-        worst = max(worst, rel)
-        assert rel <= 6e-2, (n, rel)
-    print(f"{name}: worst relative gradient deviation of the bf16 step {worst:.2e}")
+    model.precision = "auto"
+    torch.manual_seed(9)
+    pb, rb = model(x.to(torch.bfloat16))
+    assert pb.dtype == torch.bfloat16 and rb.dtype == torch.bfloat16
+    eng = model._engine
+    eng.set_precision(1)
+    with pytest.raises(RuntimeError, match="computes in fp32"):
+        eng.forward_train(x, 0.0, 0, 0)
+    eng.set_precision(2)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     losses = []
+    model.precision = "bf16"
     for _ in range(6):
         opt.zero_grad()
         pr, rc = model(x)
