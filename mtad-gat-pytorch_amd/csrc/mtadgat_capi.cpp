@@ -339,6 +339,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
         (ldv & 3) == 0 && ((scols + 3) & ~3) <= ldv) {
         GatArgs b = a;
         b.vld = g.fh_vld; b.lr_floats = g.fh_lr; b.n_full = g.fh_full; b.n_short = g.fh_short;
+        b.lr_buf = g.fh_lr_buf;
         b.dbg = m.gath_dbg;              // (measurement hook: mtadgat_set_option "gath_dbg", profiles/gath_knockout.py)
         if (cv) b.cv = *cv;
         K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, cv != nullptr, s), cv ? "fused convolution + gat (fp16 pieces)" : "fused gat (fp16 pieces)");

@@ -99,8 +99,16 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     // waves that own query rows (the rest only project): n_full of them 4 RI = 16 rows (IBL per lane), n_short one row per lane
     // less (IBL - 1: 12 rows, or 8 with 8 lanes along the keys) -- 100 rows = 4 x 16 + 3 x 12, 55 = 3 x 16 + 8: no padded rows
     const int NWA = a.n_full + a.n_short;
+    // Round 6, "run-ahead projection" (a.lr_buf > 0: the launcher found an idle wave, Q <= 4 and room for a second L' / R' buffer):
+    // part p's pair grid reads buffer p & 1 while the workgroup's last wave -- it owns no query rows and used to wait at the
+    // barrier -- projects part p + 1 into the other buffer, with the part's weight words (2 x Q chunks x 2 pieces = 64 registers
+    // at Q = 4) fetched once per part instead of once per 32-node tile.  Parts 1 .. nparts - 1 lose their projection phase and one
+    // of their two barriers: 3 x (2.6-3.1 k + ~0.3 k) of the temporal workgroup's ~114 k cycles per window (r06 timelines).
+    const int lr_buf = CONV ? a.lr_buf : 0;            // (the projector's code only exists in the CONV build: the temporal layer's inference launch)
+    const bool ahead = lr_buf > 0;
+    const int Lrows = ahead ? K : NWA * IBW;           // (two buffers only fit with K rows of L': padded rows are never read by the pair grid)
     float* __restrict__ Ls = smem;
-    float* __restrict__ Rs = Ls + NWA * IBW * GAT_LLD;
+    float* __restrict__ Rs = Ls + Lrows * GAT_LLD;
     unsigned short* __restrict__ Vh = reinterpret_cast<unsigned short*>(smem + a.lr_floats);
     unsigned short* __restrict__ Vl = Vh + KR * pvh + 16;          // (+ 16 zero halfs: chunk reads of the last row run past its end when the pitch is below 16 Q)
     const int i = lane & 31, g = lane >> 5;            // MFMA roles
@@ -282,6 +290,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         // phase is a latency chain per wave (28 chunks, three in flight), 13.1 k cycles with RPW = 1 and 14.9 k with RPW = 2 in the
         // stamped build; both layers 10.51-10.54 (RPW 1) vs 10.55-10.61 ms (RPW 2) per 65 536 windows, same box; a ring of seven
         // chunks instead of four: 10.52-10.62 (profiles/r06_gath_experiments.txt).
+        if (a.dbg & 8) __builtin_amdgcn_s_sleep(78);          // sensitivity probe: ~5 k idle cycles ahead of the convolution (results unchanged)
         constexpr int RPW = MTADGAT_GATH_CONV_RPW;
         const int RTP = (RT + RPW - 1) / RPW;
         for (int ctask = wave; ctask < RTP * c.NT; ctask += NW) {
@@ -480,7 +489,8 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
 
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     for (int part = 0; part < nparts; ++part) {
-        // ---- MFMA phase: project this part's 32 + 32 columns for all nodes into Ls / Rs (scaled by S: the weights carry it)
+        // ---- MFMA phase: project this part's 32 + 32 columns for all nodes into L' / R' (scaled by S: the weights carry it)
+        if (!ahead || part == 0) {
         for (int task = wave; task < ntask && !(a.dbg & 2); task += NW) {
             const bool keyside = task >= NTn;
             const int nt = keyside ? task - NTn : task;
@@ -525,9 +535,65 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                 }
             }
         }
+        }
         GATH_STAMP(8 + 3 * (part < 5 ? part : 4));
-        __syncthreads();
+        if (!ahead || part == 0) __syncthreads();
         GATH_STAMP(9 + 3 * (part < 5 ? part : 4));
+        const int boff = ahead ? (part & 1) * lr_buf : 0;        // this part's L' / R' buffer (floats)
+        if constexpr (CONV) {
+        if (ahead && wave == NW - 1 && part + 1 < nparts && !(a.dbg & 2)) {
+            // (the projector keeps priority 3 like every latency phase: 0 / 1 / 2 measured the same, 9.96-10.11 vs 10.07-10.11 ms)
+            // the run-ahead projector: all 2 NTn tiles of part + 1 into the other buffer -- a side at a time with that side's weight
+            // words of the whole part in registers (Q x 2 pieces: 32 at Q = 4), every tile's products in the order of the projection
+            // phase (same bits).  ~100 MFMAs + the LDS traffic of eight tiles: well inside a pair-grid part (10-16 k cycles)
+            const int lane_p = fresh_lane();
+            const int i = lane_p & 31, g = lane_p >> 5;
+            constexpr int QA = 4;                      // (launcher: Q <= 4)
+#pragma unroll 1
+            for (int side = 0; side < 2; ++side) {
+                float* __restrict__ Db = (side ? Rs : Ls) + ((part + 1) & 1) * lr_buf;
+                const f32x4* __restrict__ wsd = Wbase + ((long)((side ? a.NT_L : 0) + part + 1) * Q) * (64 * 2) + lane_p;
+                f32x4 wS[QA][2];
+#pragma unroll
+                for (int q = 0; q < QA; ++q) {
+                    const int qc = q < Q ? q : Q - 1;
+                    wS[q][0] = wsd[((long)qc * 2) * 64];
+                    wS[q][1] = wsd[((long)qc * 2 + 1) * 64];
+                }
+#pragma unroll 1
+                for (int nt = 0; nt < NTn; ++nt) {
+                    const int node = nt * 32 + i;
+                    const unsigned short* __restrict__ vrh = Vh + (node < K ? node : K - 1) * pvh + 4 * g;
+                    const unsigned short* __restrict__ vrl = Vl + (node < K ? node : K - 1) * pvh + 4 * g;
+                    f32x16 o;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < QA; ++q)
+                        if (q < Q) {
+                            const u32x2 ha = *reinterpret_cast<const u32x2*>(vrh + 16 * q), hb = *reinterpret_cast<const u32x2*>(vrh + 16 * q + 8);
+                            const u32x2 la = *reinterpret_cast<const u32x2*>(vrl + 16 * q), lb = *reinterpret_cast<const u32x2*>(vrl + 16 * q + 8);
+                            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                            const f32x4 xh = __builtin_bit_cast(f32x4, u4{ha[0], ha[1], hb[0], hb[1]});
+                            const f32x4 xl = __builtin_bit_cast(f32x4, u4{la[0], la[1], lb[0], lb[1]});
+                            o = mfma_h(wS[q][0], xl, o);
+                            o = mfma_h(wS[q][1], xh, o);
+                            o = mfma_h(wS[q][0], xh, o);
+                        }
+                    if (node < K) {
+                        float* __restrict__ dst = Db + node * GAT_LLD + 4 * g;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            f32x2 v0, v1;
+                            v0[0] = o[4 * m + 0]; v0[1] = o[4 * m + 1]; v1[0] = o[4 * m + 2]; v1[1] = o[4 * m + 3];
+                            *reinterpret_cast<f32x2*>(dst + 8 * m) = v0;
+                            *reinterpret_cast<f32x2*>(dst + 8 * m + 2) = v1;
+                        }
+                    }
+                }
+            }
+        }
+        }
         // ---- VALU phase: pairwise term over this part's k tiles (positive group first, then negative)
         int ntl = ntile - 4 * part;
         ntl = ntl > 4 ? 4 : ntl;
@@ -540,18 +606,18 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
             }
             if (d0 + d1 + d2 + d3 == 12345.f) a.out[0] = d0;
         }
-        if ((a.dbg & 32) && part == 0) __builtin_amdgcn_s_sleep(78);      // ~5 k idle cycles in front of the first pair grid
+        if ((a.dbg & 32) && part == 0) __builtin_amdgcn_s_sleep(78);      // sensitivity probe: ~5 k idle cycles in front of the first pair grid
         if (ntl > 0 && rows_owner && !(a.dbg & 1)) {
             __builtin_amdgcn_s_setprio(0);                       // the pair grid takes the issue slots nobody else wants (see the kernel's head)
             int npos = ptile - 4 * part;
             npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
-            lds_cptr rq = rp;
+            lds_cptr rq = rp + boff;
             int kt = 0;
             if (full) {
                 f32x2 lA[IBL], rA[JPL], lB[IBL], rB[JPL];
                 lds_cptr lq[IBL];
 #pragma unroll
-                for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii];
+                for (int ii = 0; ii < IBL; ++ii) lq[ii] = lp[ii] + boff;
                 gat_load<IBL, JPL, RJ>(lA, rA, lq, rq, 0);
 #pragma unroll 1
                 for (; kt < npos; ++kt) {
@@ -573,7 +639,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                 f32x2 lA[IS], rA[JPL], lB[IS], rB[JPL];
                 lds_cptr lq[IS];
 #pragma unroll
-                for (int ii = 0; ii < IS; ++ii) lq[ii] = lp[ii];
+                for (int ii = 0; ii < IS; ++ii) lq[ii] = lp[ii] + boff;
                 gat_load<IS, JPL, RJ>(lA, rA, lq, rq, 0);
 #pragma unroll 1
                 for (; kt < npos; ++kt) {
@@ -594,7 +660,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         __builtin_amdgcn_s_setprio(3);
         GATH_STAMP(10 + 3 * (part < 5 ? part : 4));
         if (part + 1 < nparts) {
-            prefetch(part + 1);
+            if (!ahead) prefetch(part + 1);
             __syncthreads();
         }
     }
@@ -619,7 +685,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     }
     float cv[IBL], dv[JPL];
     {
-        const int col = PT & 31;
+        const int col = (PT & 31) + (ahead ? ((nparts - 1) & 1) * lr_buf : 0);
 #pragma unroll
         for (int ii = 0; ii < IBL; ++ii) cv[ii] = lp[ii][col];
 #pragma unroll

@@ -35,6 +35,7 @@ struct GatPlan {
     int fh_full = 0, fh_short = 0;   // k_gath: row-owning waves with 16 rows / with 16 - 64 / RJ rows
     int fh_JPL = 0, fh_RJ = 16, fh_IBL = 4;   // k_gath's pair-grid blocking (8 lanes along the keys whenever that pads them less)
     int fh_lr = 0;          // k_gath: LDS floats of the L' / R' (and attention-row) region
+    int fh_lr_buf = 0;      // k_gath run-ahead projection: floats per L' / R' buffer (two of them in fh_lr), 0 = one buffer
     int fh_vld = 0;         // k_gath (fp16-piece build of the fused kernel): piece pitch in halfs, LDS bytes
     size_t fh_lds_bytes = 0;
     int Q16 = 0;            // bf16 build of the fused projection: 16-feature chunks incl. the bias row

@@ -151,6 +151,7 @@ struct GatArgs {
     int dbg;             // k_gath measurement hooks: knock-outs (bit 0: no pair grid, 1: no projection, 2: return before the softmax; results invalid) and
                          // sensitivity probes (bit 3: ~5 k idle cycles ahead of the convolution, 4: 1 000 extra VALU instructions per wave ahead of
                          // the first pair grid, 5: ~5 k idle cycles there; results unchanged) -- profiles/r06_gath_experiments.txt
+    int lr_buf;          // k_gath: > 0 = floats per L' / R' buffer of the run-ahead projection (two buffers inside lr_floats, K rows of L' each); 0 = one buffer
     int skip_h;          // 1: return at once when *vmax < 2^15 -- k_gath (launched ahead of this kernel) serves that case
     const unsigned char* winflag;   // k_gat behind a CONV launch of k_gath: serve exactly the windows whose flag is set
     GatConvIn cv;        // k_gath, CONV build

@@ -182,6 +182,19 @@ std::string validate_and_plan(Model& m) {
             const int orows = (g.fh_full + g.fh_short) * 16;     // rows of L' the owning waves address
             g.fh_lr = (int)round_up((int)std::max((size_t)(orows + K) * 34, (size_t)orows * 36), 4);
             g.fh_lds_bytes = (size_t)g.fh_lr * sizeof(float) + (size_t)2 * ((K + 1) * g.fh_vld + 16) * 2;
+            {   // run-ahead projection (k_gath): a second L' / R' buffer when the workgroup has a wave that owns no query rows, the
+                // part's weight words fit the projector's registers (Q <= 4) and the LDS does not cost a resident workgroup
+                // (160 KB per CU; 16 waves per CU at the kernel's 128 registers).  Two buffers only fit with K rows of L' each.
+                g.fh_lr_buf = 0;
+                const size_t buf = (size_t)round_up((K + K) * 34, 4);
+                const size_t pieces = (size_t)2 * ((K + 1) * g.fh_vld + 16) * 2;
+                const size_t total = 2 * buf * sizeof(float) + pieces;
+                auto resident = [&](size_t bytes) { return std::min<size_t>((size_t)160 * 1024 / bytes, (size_t)16 / g.f_nw); };
+                if (g.f_nw == 8 && g.fh_full + g.fh_short <= 7 && g.Q16 <= 4 && ptcap >= 32 && (size_t)orows * 36 <= 2 * buf &&
+                    total <= 160 * 1024 && resident(total) == resident(g.fh_lds_bytes) && !getenv("MTADGAT_GATH_NOAHEAD")) {
+                    g.fh_lr_buf = (int)buf; g.fh_lr = (int)(2 * buf); g.fh_lds_bytes = total;
+                }
+            }
             // measurement hook (profiles/gath_timeline.py): more LDS per workgroup = fewer resident workgroups per CU
             if (const char* e_ = getenv("MTADGAT_GATH_PADLDS")) g.fh_lds_bytes = std::max<size_t>(g.fh_lds_bytes, (size_t)atoi(e_) * 1024);
         }
