@@ -130,7 +130,11 @@ int ensure_gat_split(Model& m, const GatPlan& g, hipStream_t s) {
         HIP_TRY(hipMemsetAsync(sc, 0, 4 * sizeof(float), s));
         K_TRY(launch_absmax(m.packed_dev + g.w_off, (long)g.NT * g.Q * 256, sc, s), "projection weight range");
         K_TRY(launch_scale_from_max(sc, s), "projection weight scale");
-        K_TRY(launch_split2h(m.packed_dev + g.w_off, m.packed_dev + g.w2h_off, g.NT, g.Q, g.Q16, 1, sc + 1, s), "split-fp16 projection weights");
+        if (m.cfg.use_gatv2)     // k_gath's pack: the compact column order (non-negative group padded to 2, not 8)
+            K_TRY(launch_split2h_gath(m.packed_dev + g.w_off, m.packed_dev + g.w2h_off, g.NT_L, g.Q, g.Q16,
+                                      reinterpret_cast<const int*>(m.packed_dev + g.ord_off), g.E, sc + 1, s), "split-fp16 projection weights (compact)");
+        else
+            K_TRY(launch_split2h(m.packed_dev + g.w_off, m.packed_dev + g.w2h_off, g.NT, g.Q, g.Q16, 1, sc + 1, s), "split-fp16 projection weights");
     }
     m.split_ver_gat[which] = m.weights_version;
     return 0;
@@ -340,6 +344,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
         GatArgs b = a;
         b.vld = g.fh_vld; b.lr_floats = g.fh_lr; b.n_full = g.fh_full; b.n_short = g.fh_short;
         b.lr_buf = g.fh_lr_buf;
+        b.E = m.cfg.use_gatv2 ? g.E : 0;
         b.dbg = m.gath_dbg;              // (measurement hook: mtadgat_set_option "gath_dbg", profiles/gath_knockout.py)
         if (cv) b.cv = *cv;
         K_TRY(launch_gath(b, g.fh_IBL, g.fh_JPL, g.fh_RJ, g.f_nw, g.fh_lds_bytes, cv != nullptr, s), cv ? "fused convolution + gat (fp16 pieces)" : "fused gat (fp16 pieces)");

@@ -30,6 +30,14 @@ __device__ __forceinline__ void gat_load_order(const int* ord, int P8_host, int 
     }
 }
 
+// ... and with the number of non-negative columns (k_gath's compact order): [P8, PT, npos, 0] in ONE 16-byte scalar load
+__device__ __forceinline__ void gat_load_order3(const int* ord, int& P8, int& PT, int& npos) {
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    i32x4_ pr;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr) : "s"(ord) : "memory");
+    P8 = pr[0]; PT = pr[1]; npos = pr[2];
+}
+
 // lp[ii]: one base pointer per query row.  The pointers are made opaque to the compiler on purpose:
 // with a common base it merges row pairs into ds_read2_b64, which runs at half the LDS rate of two
 // ds_read_b64 (MI355X: 8 vs 2 x 2 LDS cycles per wave instruction).
@@ -90,6 +98,51 @@ __device__ __forceinline__ void gat_tile(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL
     gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 8);
     __builtin_amdgcn_sched_barrier(0);
     gat_step<IBL, JPL, NEG>(acc, lB, rB);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// k_gath's tile (round 6): the sign of a 2-column step is a wave-uniform scalar (+1 / -1) that rides in the accumulate --
+// v_fma_f32 acc, |t|, sgn, acc is the same one full-rate instruction as v_add / v_sub with the |t| modifier and rounds the same --
+// so one loop serves non-negative, negative and the tile on the sign boundary of the compact column order (whose first steps add
+// and whose last steps subtract), without a third copy of the unrolled tile body in the kernel.
+template <int IBL, int JPL>
+__device__ __forceinline__ void gat_step_s(float (&acc)[IBL][JPL], const f32x2 (&l)[IBL], const f32x2 (&r)[JPL], float sgn) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            float t[JPL];
+            const float lv = l[ii][e];
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const float rv = r[jj][e];
+                asm volatile("v_add_f32_e32 %0, %1, %2" : "=v"(t[jj]) : "v"(lv), "v"(rv));
+            }
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj)
+                asm volatile("v_fma_f32 %0, |%1|, %2, %0" : "+v"(acc[ii][jj]) : "v"(t[jj]), "s"(sgn));
+        }
+}
+// one 8-column tile; npl = its non-negative 2-column steps (4: all add, 0: all subtract)
+template <int IBL, int JPL, int RJ>
+__device__ __forceinline__ void gat_tile_s(float (&acc)[IBL][JPL], f32x2 (&lA)[IBL], f32x2 (&rA)[JPL], f32x2 (&lB)[IBL],
+                                           f32x2 (&rB)[JPL], const lds_cptr (&lp)[IBL], lds_cptr rp, int npl) {
+    const float s0 = npl > 0 ? 1.f : -1.f, s1 = npl > 1 ? 1.f : -1.f, s2 = npl > 2 ? 1.f : -1.f, s3 = npl > 3 ? 1.f : -1.f;
+    gat_load<IBL, JPL, RJ>(lB, rB, lp, rp, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step_s<IBL, JPL>(acc, lA, rA, s0);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step_s<IBL, JPL>(acc, lB, rB, s1);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL, RJ>(lB, rB, lp, rp, 6);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step_s<IBL, JPL>(acc, lA, rA, s2);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_load<IBL, JPL, RJ>(lA, rA, lp, rp, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    gat_step_s<IBL, JPL>(acc, lB, rB, s3);
     __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -92,8 +92,17 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const int NW = blockDim.x >> 6;
     const long win = blockIdx.x;
     const int K = a.K, D = a.D;
-    int P8, PT;
-    gat_load_order(a.ord, a.P8, a.PT, P8, PT);
+    // the column order of the pack: GATv2 layers come in k_gath's compact order (a.E > 0: the non-negative group padded to 2 columns,
+    // PB = the boundary, a multiple of 2; mtadgat_packdev.hip), everything else in whole 8-column tiles of one sign (PB = P8)
+    int PB, PT;
+    if (a.E > 0 && a.ord) {
+        int P8_, PT_, npos_;
+        gat_load_order3(a.ord, P8_, PT_, npos_);
+        PB = (npos_ + 1) & ~1;
+        PT = (PB + (a.E - npos_) + 7) & ~7;
+    } else {
+        gat_load_order(a.ord, a.P8, a.PT, PB, PT);
+    }
     const int pvh = a.vld;                             // piece pitch in halfs
     const int KR = K + 1;                              // rows of the pieces: the nodes and one zero row (keys past K of a 16-key group)
     // waves that own query rows (the rest only project): n_full of them 4 RI = 16 rows (IBL per lane), n_short one row per lane
@@ -117,7 +126,8 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
     const int NTn = (K + 31) >> 5;                    // node tiles
     const int ntask = 2 * NTn;                        // per part: query-side tiles then key-side tiles
     const int Q = a.Q;                                // 16-feature chunks incl. the ones column
-    const int ptile = P8 >> 3, ntile = PT >> 3;
+    const int ptile = PB >> 3, ntile = PT >> 3;        // whole non-negative tiles (the next one may be mixed: PB & 7 columns of it)
+    const int pmix = (PB & 7) >> 1;                    // non-negative 2-column steps of the mixed tile, 0 = there is none
     const int nparts = (PT >> 5) + 1;
 
     auto fresh_lane = [&]() -> int {                  // the lane id, recomputed where it is used: see the note at the tail
@@ -610,6 +620,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
         if (ntl > 0 && rows_owner && !(a.dbg & 1)) {
             __builtin_amdgcn_s_setprio(0);                       // the pair grid takes the issue slots nobody else wants (see the kernel's head)
             int npos = ptile - 4 * part;
+            const bool mixed_here = pmix != 0 && npos >= 0 && npos < ntl;      // tile `ptile` lies in this part
             npos = npos < 0 ? 0 : (npos > ntl ? ntl : npos);
             lds_cptr rq = rp + boff;
             int kt = 0;
@@ -625,6 +636,13 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
 #pragma unroll
                     for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
                     rq += 8;
+                }
+                if (mixed_here) {                                // the tile on the sign boundary (compact order): sign per step, as a scalar
+                    gat_tile_s<IBL, JPL, RJ>(acc, lA, rA, lB, rB, lq, rq, pmix);
+#pragma unroll
+                    for (int ii = 0; ii < IBL; ++ii) lq[ii] += 8;
+                    rq += 8;
+                    ++kt;
                 }
 #pragma unroll 1
                 for (; kt < ntl; ++kt) {
@@ -647,6 +665,13 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
 #pragma unroll
                     for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
                     rq += 8;
+                }
+                if (mixed_here) {
+                    gat_tile_s<IS, JPL, RJ>(accs, lA, rA, lB, rB, lq, rq, pmix);
+#pragma unroll
+                    for (int ii = 0; ii < IS; ++ii) lq[ii] += 8;
+                    rq += 8;
+                    ++kt;
                 }
 #pragma unroll 1
                 for (; kt < ntl; ++kt) {

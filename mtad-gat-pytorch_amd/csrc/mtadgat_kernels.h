@@ -151,6 +151,7 @@ struct GatArgs {
     int dbg;             // k_gath measurement hooks: knock-outs (bit 0: no pair grid, 1: no projection, 2: return before the softmax; results invalid) and
                          // sensitivity probes (bit 3: ~5 k idle cycles ahead of the convolution, 4: 1 000 extra VALU instructions per wave ahead of
                          // the first pair grid, 5: ~5 k idle cycles there; results unchanged) -- profiles/r06_gath_experiments.txt
+    int E;               // k_gath: > 0 = embedding columns of a GATv2 layer whose Wp2 pack is in the compact column order (sign per 2-column step)
     int lr_buf;          // k_gath: > 0 = floats per L' / R' buffer of the run-ahead projection (two buffers inside lr_floats, K rows of L' each); 0 = one buffer
     int skip_h;          // 1: return at once when *vmax < 2^15 -- k_gath (launched ahead of this kernel) serves that case
     const unsigned char* winflag;   // k_gat behind a CONV launch of k_gath: serve exactly the windows whose flag is set
@@ -396,6 +397,8 @@ int launch_fingerprint(const FingerprintArgs& a, int n_tensors, unsigned long lo
 int launch_split3(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s);
 int launch_split_x(const float* src, float* dst, long n_outer, int Qs, int Qd, int qb, const float* scale, hipStream_t s);
 int launch_split2h(const float* src, float* dst, long n_outer, int Qs, int Qd, int G, const float* scale, hipStream_t s);
+// k_gath's pack of a GATv2 projection: two fp16 pieces in the compact column order (mtadgat_packdev.hip)
+int launch_split2h_gath(const float* src, float* dst, int NT_L, int Qs, int Qd, const int* ord, int E, const float* scale, hipStream_t s);
 int launch_absmax(const float* src, long n, float* sc, hipStream_t s);
 int launch_scale_from_max(float* sc, hipStream_t s);
 int launch_pack_gather(const float* flat, const int* gidx, float* img, long n, hipStream_t s);

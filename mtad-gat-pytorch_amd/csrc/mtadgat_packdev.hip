@@ -192,6 +192,50 @@ __global__ void k_split2h(const f32x4* __restrict__ src, f32x4* __restrict__ dst
     d[0] = hi; d[64] = lo;
 }
 
+// k_gath's two-fp16-piece pack of a GATv2 projection in the COMPACT column order (round 6).  The fp32 pack keeps the sign-sorted
+// columns with each group padded to 8 -- [non-negative a' (npos) | pad to P8 | negative | pad to PT | c / d at PT] -- because the tile
+// loops of k_gat / k_gat_wide / k_attend walk whole 8-column tiles of one sign.  k_gath's pair grid takes the sign per 2-column STEP,
+// so its pack pads the non-negative group to 2 only: [npos | pad to P2 | negative | pad to PT2 | c / d at PT2], P2 = round_up(npos, 2),
+// PT2 = round_up(P2 + nneg, 8) -- one 8-column tile less whenever the two paddings add up to 8 or more (E = 110: 120 -> 112 columns,
+// 15 -> 14 tiles of the temporal pair grid at the flagship shape).  ord = [P8, PT, npos] as k_gat_colorder / the host packer wrote it.
+// src: fp32 tiles [2 NT_L][Qs][64] (query-side tiles then key-side tiles), dst: [2 NT_L][Qd][2 pieces][64].
+__device__ __forceinline__ int gath_compact_src(int c, int npos, int nneg, int P8, int PT) {
+    const int P2 = (npos + 1) & ~1, PT2 = (P2 + nneg + 7) & ~7;
+    if (c < npos) return c;
+    if (c < P2) return -1;
+    if (c < P2 + nneg) return P8 + (c - P2);
+    if (c == PT2) return PT;
+    return -1;
+}
+__global__ void k_split2h_gath(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int NT_L, int Qs, int Qd, const int* __restrict__ ord, int E,
+                               const float* __restrict__ scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)2 * NT_L * Qd * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long r = idx >> 6;
+    const int qd = (int)(r % Qd);
+    const int o = (int)(r / Qd);                        // destination tile
+    const int side = o >= NT_L ? 1 : 0, n = o - side * NT_L;
+    const int i = lane & 31;
+    const int P8 = ord[0], PT = ord[1], npos = ord[2];
+    const int cs = gath_compact_src(32 * n + i, npos, E - npos, P8, PT);
+    const float S = scale[0];
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (cs >= 0) {
+        const long so = (long)side * NT_L + (cs >> 5);
+        const int sl = (lane & 32) | (cs & 31);
+        if (2 * qd < Qs) a = src[(so * Qs + 2 * qd) * 64 + sl];
+        if (2 * qd + 1 < Qs) b = src[(so * Qs + 2 * qd + 1) * 64 + sl];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] *= S; b[e] *= S; }
+    f32x4 hi, lo;
+    split2h(a, b, hi, lo);
+    f32x4* __restrict__ d = dst + (((long)o * Qd + qd) * 2) * 64 + lane;
+    d[0] = hi; d[64] = lo;
+}
+
 // input-part weights of a recurrent layer, three gates per chunk: chunks below qb as three bf16 pieces (9 words), the
 // others as two fp16 pieces (6 words), all of S * W
 __global__ void k_split_x(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n_outer, int Qs, int Qd, int qb, const float* __restrict__ scale) {
@@ -268,6 +312,14 @@ int launch_split2h(const float* src, float* dst, long n_outer, int Qs, int Qd, i
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_split2h, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
                        reinterpret_cast<f32x4*>(dst), n_outer, Qs, Qd, G, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+int launch_split2h_gath(const float* src, float* dst, int NT_L, int Qs, int Qd, const int* ord, int E, const float* scale, hipStream_t s) {
+    const long total = (long)2 * NT_L * Qd * 64;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_split2h_gath, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), NT_L, Qs, Qd, ord, E, scale);
     LAUNCH_CHECK();
     return 0;
 }
