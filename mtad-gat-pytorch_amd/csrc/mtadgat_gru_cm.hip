@@ -627,12 +627,10 @@ template <int NCG, int XMODE, bool FC>
 int launch_cm_one(const CmArgs& a, hipStream_t s) {
     using GEO = CmGeom<NCG, XMODE>;
     const size_t lds = (size_t)GEO::L_END;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // (per device, and cheap: set on every launch -- a process-wide "done" flag would leave a second GPU of the process without it)
         hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_cm<NCG, XMODE, FC>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e_ != hipSuccess) return (int)e_;
-        attr_set = true;
     }
     const unsigned grid = (unsigned)((a.B + 127) / 128);
     hipLaunchKernelGGL((k_gru_cm<NCG, XMODE, FC>), dim3(grid), dim3(256), lds, s, a);
