@@ -92,7 +92,11 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // workgroup barrier without the vmcnt(0) drain of __syncthreads(): the DMA of later granules stays in flight across it.
 // lgkmcnt(0): this wave's LDS reads of the slot that is recycled after the barrier have returned.
+#ifdef MTADGAT_CM_NOBARRIER     // knock-out (results invalid: the waves race for the ring): what the granule barriers cost
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 #define CM_SB() __builtin_amdgcn_sched_barrier(0)
 
