@@ -151,15 +151,16 @@ int mtadgat_read_packed(mtadgat_handle h, float* dst_host, int64_t n_floats, voi
  *                construction -- recurrent state, attention outputs, weights scaled by a per-layer power of two --, of
  *                two fp16 pieces (three terms): within ~2e-7 of mode 0, same 1e-5 gate, 2.7-5x less matrix-pipe time
  *                on the pipe that runs beside the VALU (the Python module's default).
- *                The split weight packs are derived on the device at every load; switching needs no reload.
+ *                The split weight packs are derived on the device by the first launch that reads them after a load
+ *                (round 6; rounds 2-5: at every load); switching needs no reload.
  *   1            bf16 MFMA operands (weights packed to bf16 once per load_weights, activations rounded on the
  *                way into the matrix unit), fp32 accumulation, fp32 recurrent state / gates / softmax:
  *                <= 2e-2 of the fp32 reference on outputs of scale ~1 (BASELINE configs "bf16 inference").
  *                From 4 096 windows per chunk the convolution and the two attention layers run on mode 2's two-fp16-piece
  *                kernels instead (faster than their bf16 builds and closer to fp32); the recurrences and heads stay bf16.
- * The training entry points follow the same switch for their four recurrences (GRU layer and decoder, forward and
- * back-propagation through time: bf16 MFMA operands, fp32 accumulation / state / gate arithmetic); convolution,
- * attention, the Linear layers and every weight-gradient GEMM stay fp32. */
+ * The training entry points (mtadgat_forward_train / mtadgat_backward) compute in fp32 -- modes 0 and 2 -- and REFUSE mode 1
+ * (MTADGAT_ERR_UNSUPPORTED): the bf16-operand recurrences of rounds 2-5 were slower than the fp32 step at every batch size and
+ * were removed in round 6. */
 int mtadgat_set_precision(mtadgat_handle h, int mode);
 /* The bf16 weight streams are packed by mtadgat_load_weights only while mode 1 is selected (select first, or load
  * again after switching); 1 when they are present. */
@@ -181,10 +182,7 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   per window.  1: always two launches.
  * "conv_shared": stride-1 series scoring in precision mode 2: 0 automatic (k_conv_win reads each window out of the series where it
  *   applies, the shared-row convolution of k_conv_lds otherwise), 1 the shared-row convolution wherever it applies.
- * "series_band": stride-1 series scoring (mtadgat_forward_series without `starts`, stride 1, >= 1024 windows per chunk, GATv2):
- *   the temporal layer's pair scores of interior rows are computed once per pair of SERIES rows and shared by the windows that
- *   contain both (prediction.py:51-63 scores every stride-1 window; modules.py:174-191): 0 automatic (embeddings of >= 100
- *   columns, where it was measured to win), 1 off, 2 wherever the kernels apply (<= 128 time steps, <= 64 features, kernel_size <= 7).
+ * ("series_band", the shared temporal pair scores of rounds 4-5, is gone: the option is refused.)
  * "rowgemm_kernel": the data-gradient products d X = d Y W of mtadgat_backward: 0 automatic (three bf16 pieces per operand from
  *   4096 rows in precision mode 2), 1 fp32 MFMA, 2 the split-bf16 build always.
  * "gemm_lds" (process-wide, not per handle): the split-bf16 row GEMMs and the wide models' convolution on launches of >= 131 072
@@ -195,7 +193,9 @@ int mtadgat_bf16_ready(mtadgat_handle h);
  *   is at most 1 536 windows) and of more than 32 768 windows per chunk (whole 32 768-window pieces, then the rest) in
  *   pieces that alternate between `stream` and a second stream owned by the handle (each with its own half of the workspace;
  *   `stream` waits for the second lane before the call's work on it counts as complete, so the caller's ordering rules do not
- *   change); results = those of the call on each piece.  1: everything on `stream`.
+ *   change); results = those of the call on each piece.  Models on the un-fused (wide) attention path alternate the CHUNKS of a call
+ *   between the two streams (first piece: half a chunk).  1: everything on `stream`.
+ * "gath_dbg": measurement hooks of k_gath (knock-outs: results invalid; sensitivity probes: results unchanged), csrc/mtadgat_kernels.h.
  * "wgrad_kernel": the weight-gradient GEMMs of mtadgat_backward (training.py:126): 0 automatic (three bf16 pieces per operand on
  *   the 16-bit matrix pipe in precision mode 2), 1 fp32 MFMA, 2 the split-bf16 build in every mode. */
 int mtadgat_set_option(mtadgat_handle h, const char* name, int value);
