@@ -18,7 +18,9 @@
 //                        d z_ijk = d e_ij a_k [u > 0 ? 1 : alpha],  d L_ik = sum_j d z,  d R_jk = sum_i d z,
 //                        d a_k = sum_ij d e_ij LeakyReLU(u)
 //                    in two passes over a 32-column block of the embedding (the second on the transposed d e), no atomics.
-// GAT (v1) layers of this size have no HIP backward (their score backward keeps V [K][D] in LDS).
+// GAT (v1) layers of this size (round 6): the score backward e_ij = LeakyReLU(c_i + d_j) is linear in the node vectors below d s
+// (mtadgat_bwd.hip: k_gat_v1_prep / k_gat_bwd_v1 / k_gat_v1_finish); k_bw_v1 is k_gat_bwd_v1 with the node rows read from memory
+// instead of an LDS copy of the window -- same outputs (d V +=, per-window partials [p1 | p2 | sc sd]), so prep and finish are shared.
 #include "mtadgat_device.h"
 
 namespace mtadgat {
@@ -260,6 +262,71 @@ __global__ __launch_bounds__(256) void k_bw_pair(const BwPairArgs a) {
     }
 }
 
+// ---- GAT (v1) score backward of a wide layer, one workgroup (256 threads) per window.  Vn: node rows (win K + node) ldv, D columns.
+//   c_i = u1 . v_i + ub1, d_j = u2 . v_j + ub2;  d s_ij = d e_ij [c_i + d_j > 0 ? 1 : alpha];  dc_i = sum_j d s_ij, dd_j = sum_i d s_ij
+//   d V[node] += dc u1 + dd u2;  part = [sum_i dc_i v_i | sum_j dd_j v_j | sum dc, sum dd]
+// LDS: cq[K] | dk[K] | dc[K] | dd[K] (K <= 512)
+__global__ __launch_bounds__(256) void k_bw_v1(const float* __restrict__ Vn, long ldv, int D, int K, const float* __restrict__ u,
+                                               const float* __restrict__ DE, float alpha, float* __restrict__ DV, int lddv,
+                                               float* __restrict__ part) {
+    __shared__ float cq[512], dk[512], dc[512], dd[512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long win = blockIdx.x;
+    const float* __restrict__ vw = Vn + win * K * ldv;
+    for (int x = tid; x < K; x += 256) { dc[x] = 0.f; dd[x] = 0.f; }
+    // c / d of every node: a wave per node, lanes over the columns (coalesced row reads)
+    for (int i = wave; i < K; i += 4) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int col = lane; col < D; col += 64) { const float v = vw[(long)i * ldv + col]; s1 += u[col] * v; s2 += u[D + col] * v; }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { cq[i] = s1 + u[2 * D]; dk[i] = s2 + u[2 * D + 1]; }
+    }
+    __syncthreads();
+    // d s: a wave per query row, lanes over the keys; row sums by a wave reduction, column sums per lane (keys lane + 64 h)
+    const float* __restrict__ de = DE + win * (long)K * K;
+    float colacc[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) colacc[h] = 0.f;
+    for (int i = wave; i < K; i += 4) {
+        const float ci = cq[i];
+        float rs = 0.f;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int j = lane + 64 * h;
+            if (j < K) {
+                const float ds = de[(long)i * K + j] * (ci + dk[j] > 0.f ? 1.f : alpha);
+                rs += ds; colacc[h] += ds;
+            }
+        }
+        rs = wave_sum(rs);
+        if (lane == 0) dc[i] = rs;
+    }
+    // the four waves add their column sums one after the other (fixed order, no float atomics)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int h = 0; h < 8; ++h)
+                if (lane + 64 * h < K) dd[lane + 64 * h] += colacc[h];
+        }
+        __syncthreads();
+    }
+    for (long x = tid; x < (long)K * D; x += 256) {
+        const int node = (int)(x / D), col = (int)(x - (long)node * D);
+        DV[(win * K + node) * (long)lddv + col] += dc[node] * u[col] + dd[node] * u[D + col];
+    }
+    float* __restrict__ po = part + win * (long)(2 * D + 2);
+    for (int col = tid; col < D; col += 256) {
+        float p1 = 0.f, p2 = 0.f;
+        for (int i = 0; i < K; ++i) { const float v = vw[(long)i * ldv + col]; p1 += dc[i] * v; p2 += dd[i] * v; }
+        po[col] = p1; po[D + col] = p2;
+    }
+    if (tid == 255) {
+        float sc = 0.f, sd = 0.f;
+        for (int i = 0; i < K; ++i) { sc += dc[i]; sd += dd[i]; }
+        po[2 * D] = sc; po[2 * D + 1] = sd;
+    }
+}
+
 }  // namespace
 
 int launch_bw_ds(const float* H, const float* dH, long so_w, long so_i, long so_d, long nwin, int K, int D, float* dS, int ldS, hipStream_t s) {
@@ -320,6 +387,15 @@ int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const f
     const long blocks = nwin * (Ep / 32);
     if (blocks > 0x7fffffffL) return -2;
     hipLaunchKernelGGL(k_bw_pair, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bw_v1(const float* Vn, long ldv, int D, int K, const float* u, const float* DE, float alpha, float* DV, int lddv, float* part,
+                 long nwin, hipStream_t s) {
+    if (nwin <= 0) return 0;
+    if (K > 512 || D < 1) return -2;
+    hipLaunchKernelGGL(k_bw_v1, dim3((unsigned)nwin), dim3(256), 0, s, Vn, ldv, D, K, u, DE, alpha, DV, lddv, part);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1885,6 +1885,24 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
             K_TRY(launch_bgemm(dS, (long)K * ldS, ldS, 1, Vn, (long)K * ldv, 1, ldv, de, (long)K * K, K, K, K, D, n, nullptr, 0, 0, s),
                   "attention backward (d att)");
             K_TRY(launch_bw_softmax(att, de, n, K, drop, dstream, s), "attention backward (softmax)");
+            if (!m.cfg.use_gatv2) {
+                // GAT (v1), round 6: the score backward is linear in the node vectors below d s -- k_gat_bwd_v1's algebra with the
+                // node rows read from memory (k_bw_v1); prep and finish are the fused path's
+                const int E = gp.E, PV = 2 * D + 2;
+                float* u = ws + w.v1s + (size_t)which * 2 * (2 * std::max(m.F, m.W) + 2);
+                float* P = u + (2 * std::max(m.F, m.W) + 2);
+                const float* Wm = m.packed_dev + gb.w1_off;
+                const float* bv = m.packed_dev + gb.b1_off;
+                const float* av = m.packed_dev + gb.a_off;
+                K_TRY(launch_gat_v1_prep(Wm, bv, av, E, D, u, s), "attention backward (v1 vectors)");
+                K_TRY(launch_bw_v1(Vn, ldv, D, K, u, de, m.cfg.alpha, dv, lddv, dlr, n, s), "attention backward (v1 scores, wide)");
+                HIP_TRY(hipMemsetAsync(P, 0, (size_t)PV * sizeof(float), s));
+                K_TRY(launch_sum_rows(dlr, PV, n, PV, ws + w.sums, P, s), "attention backward (v1 sums)");
+                K_TRY(launch_gat_v1_finish(P, Wm, bv, av, E, D, grads + gl.lin_w[which], grads + gl.lin_b[which], grads + gl.a[which], s),
+                      "attention parameter gradients (v1)");
+                K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
+                continue;
+            }
             K_TRY(launch_bw_transpose(de, det, n, K, s), "attention backward (d e transposed)");
             // un-scaled projections [L | R] of the node rows, then the score backward
             {

@@ -364,9 +364,8 @@ std::string validate_and_plan(Model& m) {
         b.supported = true;
         for (const GatPlan* g : {&m.feat, &m.temp})
             if (!g->fused) {
-                // wide layers go through the generic kernels of mtadgat_bwdw.hip: GATv2, up to 512 nodes / node dimensions
-                if (!c.use_gatv2) { b.supported = false; b.why = "GAT (v1) attention layers beyond the fused kernel (more than 128 nodes / features)"; }
-                else if (g->K > 512 || g->D > 512) { b.supported = false; b.why = "graph-attention layers with more than 512 nodes / features"; }
+                // wide layers go through the generic kernels of mtadgat_bwdw.hip: GATv2 and (round 6) GAT v1, up to 512 nodes / node dimensions
+                if (g->K > 512 || g->D > 512) { b.supported = false; b.why = "graph-attention layers with more than 512 nodes / features"; }
             }
         if (b.supported) {
             for (int which = 0; which < 2; ++which) {
@@ -374,6 +373,12 @@ std::string validate_and_plan(Model& m) {
                 GatBwdPlan& gb = b.gat[which];
                 gb.Ep = round_up(g.E, 32); gb.NTu = gb.Ep / 32;
                 gb.wide = !g.fused;
+                if (gb.wide && !c.use_gatv2) {       // GAT (v1), wide: plain parameter copies for k_gat_v1_prep / k_bw_v1 / k_gat_v1_finish
+                    gb.w1_off = take((size_t)g.E * g.D);
+                    gb.b1_off = take((size_t)g.E);
+                    gb.a_off = take((size_t)2 * g.E);
+                    continue;
+                }
                 if (gb.wide) {
                     gb.wu_off = take((size_t)2 * gb.NTu * g.Q * 256);
                     gb.bu_off = take((size_t)2 * gb.Ep);

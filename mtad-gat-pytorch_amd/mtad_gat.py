@@ -18,12 +18,12 @@ Device contract.  Tensors on the GPU ('cuda' = HIP on PyTorch-ROCm) always run t
 HIP kernels in inference (no grad) and raise if `libmtadgat.so` is missing: there is no
 fallback for the inference forward of GPU tensors.  When gradients are wanted, the HIP
 training step (forward that keeps a tape + HIP backward behind a `torch.autograd.Function`)
-runs for the configurations it covers: GATv2 attention layers of up to 512 nodes / features
-(fused kernels up to 128, the wide kernels of csrc/mtadgat_bwdw.hip above), GAT (v1) layers of
-up to 128, any number of GRU and decoder layers (nn.GRU's inter-layer dropout included);
-parameter gradients, and the input's when `x.requires_grad` (mtadgat_backward_input).
-Outside of that (GAT v1 above 128 nodes, anything above 512) there is no HIP training step and
-the call RAISES (`model.strict_hip_training`, default True): nothing on the GPU runs rocBLAS /
+runs for every configuration the forward takes: GATv2 and GAT (v1) attention layers of up to
+512 nodes / features (fused kernels up to 128, the wide kernels of csrc/mtadgat_bwdw.hip above;
+round 6: GAT v1 there too), any number of GRU and decoder layers (nn.GRU's inter-layer dropout
+included); parameter gradients, and the input's when `x.requires_grad` (mtadgat_backward_input).
+Should the library report a configuration without a HIP training step (attention backward tiles
+that exceed the LDS), the call RAISES (`model.strict_hip_training`, default True): nothing on the GPU runs rocBLAS /
 MIOpen behind the caller's back.  `model.strict_hip_training = False` opts into evaluating
 such a step by torch ops on the GPU (`_torchpath.py`, autograd), with `model.grad_path`
 naming the route and the reason and a RuntimeWarning once per reason.  A model and input left on the CPU (the reference's
