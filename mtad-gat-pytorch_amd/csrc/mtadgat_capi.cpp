@@ -249,6 +249,13 @@ int run_conv_shared(Model& m, const XSource& src, int64_t c0, int64_t n, float* 
     return 0;
 }
 
+// The sign-group boundaries handed to the attention kernels by VALUE: GATv2 layers keep the authoritative [P8, PT] in the packed image
+// (the device-side re-pack moves them without telling the host), every kernel reads them through its `ord` pointer, and the by-value
+// copies are poisoned so that a path that forgot `ord` fails its parity tests instead of using a stale order; GAT (v1) has no
+// sign groups (0, 0).
+static int pt_by_value(const Model& m, const GatPlan& g) { return m.cfg.use_gatv2 ? -1 : g.PT; }
+static int p8_by_value(const Model& m, const GatPlan& g) { return m.cfg.use_gatv2 ? -1 : g.P8; }
+
 int run_proj(Model& m, const GatPlan& g, const float* rows, long ld, int64_t nrows, float* lc, float* rt, hipStream_t s) {
     Scope sc(m, S_PROJ, s);
     RowGemmArgs a{};
@@ -272,7 +279,7 @@ int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, con
     Scope sc(m, S_ATTEND, s);
     if (g.K <= 512 && g.D <= 512) {
         // LDS-tiled pair grid of the fused kernel over the HBM-resident projections (BASELINE config 4 shapes)
-        K_TRY(launch_gat_wide(lc, rt, g.ldl, g.rt_rows, g.Kp, g.PT, g.P8, m.packed_dev + g.bias_off, v, ldv, g.D, g.K, out, so_w,
+        K_TRY(launch_gat_wide(lc, rt, g.ldl, g.rt_rows, g.Kp, pt_by_value(m, g), p8_by_value(m, g), m.packed_dev + g.bias_off, v, ldv, g.D, g.K, out, so_w,
                               so_i, so_d, n, m.cfg.use_gatv2 ? 0 : 1, m.cfg.alpha, s, att, drop, drop_stream,
                               m.cfg.use_gatv2 ? reinterpret_cast<const int*>(m.packed_dev + g.ord_off) : nullptr),
               "wide gat attention");
@@ -280,7 +287,7 @@ int run_attend(Model& m, const GatPlan& g, const float* lc, const float* rt, con
     }
     if (att || drop) return fail(MTADGAT_ERR_UNSUPPORTED, "training forward of an attention layer with more than 512 nodes / features");
     AttendArgs a{};
-    a.LC = lc; a.RT = rt; a.ldl = g.ldl; a.rt_rows = g.rt_rows; a.Kp = g.Kp; a.PT = g.PT; a.P8 = g.P8;
+    a.LC = lc; a.RT = rt; a.ldl = g.ldl; a.rt_rows = g.rt_rows; a.Kp = g.Kp; a.PT = pt_by_value(m, g); a.P8 = p8_by_value(m, g);
     a.ord = m.cfg.use_gatv2 ? reinterpret_cast<const int*>(m.packed_dev + g.ord_off) : nullptr;
     a.bias = m.packed_dev + g.bias_off;
     a.V = v; a.ldv = ldv; a.D = g.D;
@@ -308,7 +315,7 @@ int run_gat_fused(Model& m, const GatPlan& g, const float* v, int ldv, int vt, i
     a.V = v; a.ldv = ldv; a.vt = vt; a.D = g.D; a.K = g.K; a.vld = g.f_vld; a.lr_floats = g.f_lr;
     a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + g.w_off);
     a.pbias = m.packed_dev + g.b_off;
-    a.NT_L = g.NT_L; a.Q = g.Q; a.PT = g.PT; a.P8 = g.P8;
+    a.NT_L = g.NT_L; a.Q = g.Q; a.PT = pt_by_value(m, g); a.P8 = p8_by_value(m, g);
     a.ord = m.cfg.use_gatv2 ? reinterpret_cast<const int*>(m.packed_dev + g.ord_off) : nullptr;
     if (m.precision == 1 && !att && !(split_front(m, n) && vmax)) {       // bf16 operand build of the projection (inference)
         a.bf16 = 1; a.Q = g.Q16;
