@@ -450,6 +450,138 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
 }
 
 
+// ---- aggregation o += att V of the wide kernels, software-pipelined (round 6).  The V rows of the window go through LDS in
+// tiles of VK keys (32; 16 when the node dimension exceeds 256 so that two tiles fit beside the softmax slices), TWO tile
+// buffers filled by LDS-DMA (global_load_lds_dwordx4: a 1-KiB piece of a V row per wave instruction, no staging registers):
+// while the workgroup's waves run the MFMAs of tile t, tile t + 1 is on its way from memory into the other buffer; ONE
+// s_waitcnt + barrier per tile publishes it.  Before: every tile was loaded element by element behind guards (a branch and a
+// memory round trip per 16 bytes and thread, 4..9 in a row) between two barriers, with the matrix pipe idle.
+// `fast` (uniform): V rows 16-byte aligned with a pitch and a node dimension that are multiples of four; otherwise the tile is
+// staged by guarded scalar loads in front of its barrier as before (no prefetch).
+template <int DTMAX>
+struct WideAgg {
+    static constexpr int VK = DTMAX > 16 ? 16 : 32;                     // keys per V tile
+};
+
+// 16 bytes per lane from (uniform base + per-lane byte offset) to LDS byte address ldsdst + 16 * lane (M0 is compiler-reserved:
+// written and restored inside the statement; as mtadgat_gru_cm.hip's glds_burst)
+__device__ __forceinline__ void gat_glds16(const void* sbase, unsigned voff, unsigned ldsdst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(ldsdst) : "memory");
+}
+
+// request tile kv .. kv + VK - 1 into Vt ([VK][vld2]); rows past K are zero-filled with ordinary stores.  Not waited for.
+template <int DTMAX, int NTHR>
+__device__ __forceinline__ void wide_vtile_dma(float* __restrict__ Vt, const float* __restrict__ Vw, int ldv, int kv, int K, int D, int vld2,
+                                               int wave, int lane, bool fast) {
+    if (!fast) return;
+    constexpr int VK = WideAgg<DTMAX>::VK, NWV = NTHR / 64;
+    const int npc = (D + 255) >> 8;                                     // 1-KiB pieces per row
+    const int col = lane * 4;
+    // the window's V base as an SGPR pair (it is uniform, but a 64-bit product computed on the vector ALU does not satisfy the
+    // "s" constraint by itself); the row and piece go into the 32-bit lane offset
+    const unsigned long vb = reinterpret_cast<unsigned long>(Vw);
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+    const void* sbase = reinterpret_cast<const void*>(((unsigned long)bhi << 32) | blo);
+    for (int r = wave; r < VK; r += NWV)                                // (wave-uniform)
+        for (int pc = 0; pc < npc; ++pc) {
+            float* __restrict__ dst = Vt + r * vld2 + pc * 256;
+            if (pc * 256 + col < D) {
+                if (kv + r < K) gat_glds16(sbase, (unsigned)(((kv + r) * ldv + pc * 256 + col) * 4), (unsigned)(size_t)(lds_cptr)dst);
+                else *reinterpret_cast<f32x4*>(dst + col) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+}
+// the slow path of a tile (not `fast`): guarded scalar loads, stored at once
+template <int DTMAX, int NTHR>
+__device__ __forceinline__ void wide_vtile_slow(float* __restrict__ Vt, const float* __restrict__ Vw, int ldv, int kv, int K, int D, int vld2, int tid) {
+    constexpr int VK = WideAgg<DTMAX>::VK;
+    const int vq = vld2 >> 2;
+    for (int u = tid; u < VK * vq; u += NTHR) {
+        const int r = u / vq, c4 = (u - r * vq) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (kv + r < K) {
+            const float* src = Vw + (long)(kv + r) * ldv + c4;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) v[s4] = (c4 + s4 < D) ? src[s4] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(Vt + r * vld2 + c4) = v;
+    }
+}
+
+// o += att V over the keys [kbeg, kbeg + 128 NKP) of the window (those below K).  acc: the (dropped-out) softmax rows of this
+// wave's 16 query rows, pair-grid layout; att: this wave's private LDS slice [16][GAT_APITCH]; Vs2: two tile buffers of
+// VK x vld2 floats shared by the workgroup, the first tile (keys kbeg ..) already requested into buffer 0 by wide_vtile_dma.
+// On entry every wave of the workgroup is past its last use of the LDS that att aliases (the caller's barrier).
+template <int NKP, int DTMAX, int NTHR>
+__device__ __forceinline__ void wide_aggregate(const float (&acc)[NKP][4][8], f32x4 (&o)[DTMAX], float* __restrict__ att,
+                                               float* __restrict__ Vs2, const float* __restrict__ Vw, int ldv, int kbeg, int K, int D,
+                                               int vld2, int tid, int wave, bool fast) {
+    constexpr int RJ = 16, RI = 4, VK = WideAgg<DTMAX>::VK, TPH = 64 / VK;          // V tiles per 64-key half
+    const int lane = tid & 63, lj = lane % RJ, li = lane / RJ;
+    const int nr = lane & 15, kb = lane >> 4;
+    const int DT = (D + 15) >> 4;
+    const int kend = kbeg + 128 * NKP < K ? kbeg + 128 * NKP : K;
+    int buf = 0;
+    static_for<0, 2 * NKP>([&](auto khc) {
+        constexpr int kp = decltype(khc)::value >> 1, half = decltype(khc)::value & 1;
+        const int k0 = kbeg + kp * 128 + half * 64;                 // 64 keys of att at a time
+        if (k0 < kend) {
+            // this wave's slice: its own earlier reads are behind it in program order (LDS operations of a wave complete in order)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = acc[kp][ii][4 * half + j4];
+#pragma unroll 1
+            for (int kq = 0; kq < TPH; ++kq) {
+                const int kv = k0 + VK * kq;
+                if (kv < kend) {                                    // (uniform)
+                    float* __restrict__ Vt = Vs2 + buf * (VK * vld2);
+                    if (!fast) wide_vtile_slow<DTMAX, NTHR>(Vt, Vw, ldv, kv, K, D, vld2, tid);
+                    // tile t has landed for every wave; every wave is done with the MFMAs of tile t - 1, i.e. with the other buffer
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (kv + VK < kend) wide_vtile_dma<DTMAX, NTHR>(Vs2 + (buf ^ 1) * (VK * vld2), Vw, ldv, kv + VK, K, D, vld2, wave, lane, fast);
+#pragma unroll
+                    for (int grp = 0; grp < VK / 16; ++grp) {       // 16 keys per MFMA group
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + VK * kq + 16 * grp + 4 * kb);
+                        const float* __restrict__ vk = Vt + (16 * grp + 4 * kb) * vld2 + nr;
+                        // Output tiles in pairs behind ONE uniform branch each (no second code path: two versions of the loop
+                        // made the compiler shuffle all of o between two register assignments); the four V words of tile
+                        // dt + 1 are requested before the MFMAs of tile dt (left alone the compiler waits for each word right
+                        // in front of its MFMA: an LDS round trip per 32-cycle instruction).  An odd DT computes one tile of
+                        // finite garbage (the next row's first words) into an o that is never stored.
+                        const float* __restrict__ vk1 = vk + vld2;
+                        const float* __restrict__ vk2 = vk1 + vld2;
+                        const float* __restrict__ vk3 = vk2 + vld2;
+                        float avA[4], avB[4];
+                        avA[0] = vk[0]; avA[1] = vk1[0]; avA[2] = vk2[0]; avA[3] = vk3[0];
+                        static_for<0, DTMAX / 2>([&](auto dc) {
+                            constexpr int d0 = 2 * decltype(dc)::value;
+                            if (d0 < DT) {
+                                avB[0] = vk[16 * (d0 + 1)]; avB[1] = vk1[16 * (d0 + 1)]; avB[2] = vk2[16 * (d0 + 1)]; avB[3] = vk3[16 * (d0 + 1)];
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) o[d0] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[t], bq[t], o[d0], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (d0 + 2 < DTMAX) {
+                                    avA[0] = vk[16 * (d0 + 2)]; avA[1] = vk1[16 * (d0 + 2)]; avA[2] = vk2[16 * (d0 + 2)]; avA[3] = vk3[16 * (d0 + 2)];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) o[d0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[t], bq[t], o[d0 + 1], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                    }
+                    buf ^= 1;
+                }
+            }
+        }
+    });
+}
+
 // ---------------------------------------------------------------------------
 // gat (wide): graph attention for node counts beyond the per-window fused kernel (128 < K <= 512, BASELINE
 // config 4: 512 features / 256 time steps).  The projected L', R' come from k_rowgemm through HBM (LC row-major
@@ -532,24 +664,20 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
         // store: one memory round trip per batch (a guarded load costs one per element)
         const int c0 = 32 * part;
         {
+            // the block's L' loads are issued ahead of the first batch of R' loads and stored behind them: one memory round trip
+            // for both (a batch = one round trip: all its loads before its first LDS store)
             constexpr int EL = 8;                                  // (NW*16 rows x 32 columns) / (NW*64 threads)
-            float v[EL];
+            float vl[EL];
+            int tl = tid;                                          // (opaque per part: the unit indices are not kept -- and spilled -- as loop invariants)
+            asm volatile("" : "+v"(tl));
 #pragma unroll
             for (int n = 0; n < EL; ++n) {
-                const int u = tid + n * nthr;
+                const int u = tl + n * nthr;
                 const int r = u >> 5, c = u & 31;
                 const int row = i0b + r;
                 const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;       // column PT (c_i) exists in every row
-                v[n] = LCw[(long)rc * a.ldl + cc];
+                vl[n] = LCw[(unsigned)(rc * a.ldl + cc)];
             }
-#pragma unroll
-            for (int n = 0; n < EL; ++n) {
-                const int u = tid + n * nthr;
-                const int r = u >> 5, c = u & 31;
-                Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? v[n] : 0.f;
-            }
-        }
-        {
             constexpr int KJC = KP * 128;
             constexpr int BATCH = 16;
             const int total = KJC * 32;
@@ -557,15 +685,23 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
                 float v[BATCH];
 #pragma unroll
                 for (int n = 0; n < BATCH; ++n) {
-                    const int u = base + tid + n * nthr;
+                    const int u = base + tl + n * nthr;
                     const int uc = u < total ? u : total - 1;
                     const int c = uc / KJC, j = uc - c * KJC;      // key fastest: coalesced reads of the key-minor rows
                     const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;       // row PT (d_j) exists
-                    v[n] = RTw[(long)cc * a.Kp + jc];
+                    v[n] = RTw[(unsigned)(cc * a.Kp + jc)];
+                }
+                if (base == 0) {
+#pragma unroll
+                    for (int n = 0; n < EL; ++n) {
+                        const int u = tl + n * nthr;
+                        const int r = u >> 5, c = u & 31;
+                        Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? vl[n] : 0.f;
+                    }
                 }
 #pragma unroll
                 for (int n = 0; n < BATCH; ++n) {
-                    const int u = base + tid + n * nthr;
+                    const int u = base + tl + n * nthr;
                     if (u < total) {
                         const int c = u / KJC, j = u - c * KJC;
                         Rs[j * GAT_LLD + c] = (j < K && c0 + c < PT) ? v[n] : 0.f;
@@ -606,22 +742,56 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
         });
         __syncthreads();
     }
+    // ---- the first V tile of the aggregation is requested here (the part loop ended with a barrier: every wave is done with
+    // Ls / Rs, which the tile buffers alias): its round trip runs under the softmax
+    constexpr int NTHRC = KP == 4 ? 256 : 512;
+    const int vld2 = ((D + 15) & ~15) + 4;
+    const float* __restrict__ Vw = a.V + (win * K) * (long)a.ldv;
+    const bool vfast = (a.ldv & 3) == 0 && (D & 3) == 0 && (reinterpret_cast<size_t>(a.V) & 15) == 0;
+    float* __restrict__ Vs2 = smem + NW * IBW * GAT_APITCH;      // 2 x [VK][vld2]
+    wide_vtile_dma<DTMAX, NTHRC>(Vs2, Vw, a.ldv, 0, K, D, vld2, wave, lane, vfast);
     // ---- scores -> softmax over all K keys of a row (16 lanes x KP*8 registers)
+    // The score's rank-1 terms and the bias are loaded in BATCHES, unconditionally from clamped addresses: the keys' d_j once
+    // (they do not depend on the row), the rows' c_i together, a row's KP*8 bias values together.  (Left as `acc + c + RT[..]`
+    // and `if (bias) v += bias[..]` per element, each score waited for two memory round trips of its own -- a guarded load is a
+    // branch with s_waitcnt vmcnt(0) at the join: 2 x KP*32 serial round trips per lane.)
+    float dv[KP][JPL], cvr[IBL];
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+        for (int jj = 0; jj < JPL; ++jj) {
+            const int j = kp * 128 + lj + RJ * jj;
+            dv[kp][jj] = RTw[(unsigned)(PT * a.Kp + (j < K ? j : K - 1))];
+        }
+#pragma unroll
+    for (int ii = 0; ii < IBL; ++ii) {
+        const int irow = i0 + li + RI * ii;
+        cvr[ii] = LCw[(unsigned)((irow < K ? irow : K - 1) * a.ldl + PT)];
+    }
+    const bool has_bias = a.bias != nullptr;
+    const float* __restrict__ bsrc = has_bias ? a.bias : LCw;          // (no bias: every lane reads one valid word and drops it)
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) {
         const int irow = i0 + li + RI * ii;
         const int irc = irow < K ? irow : K - 1;
-        const float cv = LCw[(long)irc * a.ldl + PT];
+        const float cv = cvr[ii];
+        float bv[KP][JPL];
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = kp * 128 + lj + RJ * jj;
+                bv[kp][jj] = bsrc[has_bias ? (unsigned)(irc * K + (j < K ? j : K - 1)) : 0u];
+            }
         float m = -INFINITY;
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp)
 #pragma unroll
             for (int jj = 0; jj < JPL; ++jj) {
                 const int j = kp * 128 + lj + RJ * jj;
-                const int jc = j < K ? j : K - 1;
-                float v = acc[kp][ii][jj] + cv + RTw[(long)PT * a.Kp + jc];
+                float v = acc[kp][ii][jj] + cv + dv[kp][jj];
                 if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
-                if (a.bias) v += a.bias[(long)irc * K + jc];
+                v += has_bias ? bv[kp][jj] : 0.f;
                 v = j < K ? v : -INFINITY;
                 acc[kp][ii][jj] = v;
                 m = fmaxf(m, v);
@@ -662,62 +832,14 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
         }
     }
     // ---- aggregation h_i = sigmoid(sum_j att_ij V_j): out^T = V^T att^T on v_mfma_f32_16x16x4_f32 (as k_gat); the
-    // softmax rows go through this wave's LDS slice 64 keys at a time, V through a shared LDS tile 32 keys at a time
+    // softmax rows go through this wave's LDS slice 64 keys at a time, V through two shared LDS tiles (wide_aggregate)
     float* __restrict__ att = smem + wave * (IBW * GAT_APITCH);
-    const int vld2 = ((D + 15) & ~15) + 4;
-    float* __restrict__ Vs2 = smem + NW * IBW * GAT_APITCH;      // [32][vld2]
     const int nr = lane & 15, kb = lane >> 4;
     const int DT = (D + 15) >> 4;
     f32x4 o[DTMAX];
 #pragma unroll
     for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* __restrict__ Vw = a.V + (win * K) * (long)a.ldv;
-    static_for<0, 2 * KP>([&](auto khc) {
-        {
-            constexpr int kp = decltype(khc)::value >> 1, half = decltype(khc)::value & 1;
-            const int k0 = kp * 128 + half * 64;                 // 64 keys of att at a time
-            if (k0 < K) {
-                __syncthreads();                                 // everybody is done with the previous att / V tiles
-#pragma unroll
-                for (int ii = 0; ii < IBL; ++ii)
-#pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4) att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = acc[kp][ii][4 * half + j4];
-                for (int kq = 0; kq < 2; ++kq) {                 // V tiles of 32 keys
-                    const int kv = k0 + 32 * kq;
-                    if (kq) __syncthreads();
-                    if (kv < K) {
-                        for (int u = tid; u < 32 * (vld2 >> 2); u += nthr) {
-                            const int r = u / (vld2 >> 2), c4 = (u - r * (vld2 >> 2)) * 4;
-                            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                            if (kv + r < K) {
-                                const float* src = Vw + (long)(kv + r) * a.ldv + c4;
-#pragma unroll
-                                for (int s4 = 0; s4 < 4; ++s4) v[s4] = (c4 + s4 < D) ? src[s4] : 0.f;
-                            }
-                            *reinterpret_cast<f32x4*>(Vs2 + r * vld2 + c4) = v;
-                        }
-                    }
-                    __syncthreads();
-                    if (kv < K) {
-#pragma unroll
-                        for (int grp = 0; grp < 2; ++grp) {      // 16 keys per MFMA group
-                            const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 32 * kq + 16 * grp + 4 * kb);
-                            const float* __restrict__ vk = Vs2 + (16 * grp + 4 * kb) * vld2;
-#pragma unroll
-                            for (int dt = 0; dt < DTMAX; ++dt)
-                                if (dt < DT) {
-                                    float av[4];
-#pragma unroll
-                                    for (int t = 0; t < 4; ++t) av[t] = vk[t * vld2 + 16 * dt + nr];
-#pragma unroll
-                                    for (int t = 0; t < 4; ++t) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bq[t], o[dt], 0, 0, 0);
-                                }
-                        }
-                    }
-                }
-            }
-        }
-    });
+    wide_aggregate<KP, DTMAX, NTHRC>(acc, o, att, Vs2, Vw, a.ldv, 0, K, D, vld2, tid, wave, vfast);
     {
         const int row = i0 + nr;
         float* __restrict__ orow = a.out + win * a.so_w + (long)row * a.so_i;
@@ -743,11 +865,13 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
 // two per SIMD.  Same inputs, same output; the softmax rows never exist as a whole, so the training forward (which keeps them)
 // stays on k_gat_wide.
 // ---------------------------------------------------------------------------
-template <int DTMAX>
-__global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
+// NW waves per workgroup (8: one workgroup per CU, 128 query rows).
+template <int DTMAX, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void k_gat_wide_os(const GatWideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int IBL = 4, JPL = 8, RJ = 16, RI = 4, IBW = 16, KPB = 2, KB = KPB * 128, NW = 8;
-    const int tid = threadIdx.x, lane = tid & 63, nthr = 512;
+    constexpr int IBL = 4, JPL = 8, RJ = 16, RI = 4, IBW = 16, KPB = 2, KB = KPB * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int nthr = 64 * NW;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long blk = blockIdx.x;
     const long grp = blk / (8 * a.nblk);
@@ -777,15 +901,18 @@ __global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
     // aggregation-side layout (as k_gat_wide): the wave's softmax rows through its LDS slice, V through a shared 32-key tile
     const int vld2 = ((D + 15) & ~15) + 4;
     float* __restrict__ att = smem + wave * (IBW * GAT_APITCH);
-    float* __restrict__ Vs2 = smem + NW * IBW * GAT_APITCH;
-    const int agg_floats = NW * IBW * GAT_APITCH + 32 * vld2, pair_floats = (NW * IBW + KB) * GAT_LLD;
-    float* __restrict__ scl = smem + (agg_floats > pair_floats ? agg_floats : pair_floats) + wave * IBW;     // [16] per wave: row factors
+    // the two V tile buffers do NOT alias the pair-grid region: a key block's first tile is requested (LDS-DMA) before the
+    // block's softmax, while other waves may still be in the pair grid
+    const int att_floats = NW * IBW * GAT_APITCH, pair_floats = (NW * IBW + KB) * GAT_LLD;
+    float* __restrict__ Vs2 = smem + (att_floats > pair_floats ? att_floats : pair_floats);
+    float* __restrict__ scl = Vs2 + 2 * 32 * vld2 + wave * IBW;     // [16] per wave: row factors
     const int nr = lane & 15, kbq = lane >> 4;
     const int DT = (D + 15) >> 4;
     const float* __restrict__ Vw = a.V + (win * K) * (long)a.ldv;
     f32x4 o[DTMAX];
 #pragma unroll
     for (int dt = 0; dt < DTMAX; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool vfast = (a.ldv & 3) == 0 && (D & 3) == 0 && (reinterpret_cast<size_t>(a.V) & 15) == 0;
     float mrow[IBL], lrow[IBL];
 #pragma unroll
     for (int ii = 0; ii < IBL; ++ii) { mrow[ii] = -INFINITY; lrow[ii] = 0.f; }
@@ -802,41 +929,41 @@ __global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
             const int c0 = 32 * part;
             __syncthreads();                               // the previous users of Ls / Rs (pair grid, att / V tiles) are done
             {
-                constexpr int EL = 8;                      // (128 rows x 32 columns) / 512 threads
-                float v[EL];
+                // all loads of the part -- the block's L' rows and the key block's R' columns -- are issued before the first LDS
+                // store: ONE memory round trip per part (three when L' and the two halves of R' went one after the other)
+                constexpr int EL = 8;                      // (NW*16 rows x 32 columns) / (NW*64 threads)
+                constexpr int ER = KB * 32 / nthr;         // (256 keys x 32 columns) / (NW*64 threads)
+                float vl[EL], vr[ER];
+                // (the unit indices are re-derived from an opaque copy of the thread index in every part: as loop invariants the
+                // compiler kept them in registers, spilled them, and reloaded each one -- s_waitcnt vmcnt(0) -- between the loads)
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
 #pragma unroll
                 for (int n = 0; n < EL; ++n) {
-                    const int u = tid + n * nthr;
+                    const int u = tl + n * nthr;
                     const int r = u >> 5, c = u & 31;
                     const int row = i0b + r;
                     const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;
-                    v[n] = LCw[(long)rc * a.ldl + cc];
+                    vl[n] = LCw[(unsigned)(rc * a.ldl + cc)];          // (uniform base + 32-bit lane offset: no 64-bit address pairs)
+                }
+#pragma unroll
+                for (int n = 0; n < ER; ++n) {
+                    const int u = tl + n * nthr;
+                    const int c = u / KB, j = kb0 + (u - c * KB);      // key fastest: coalesced reads of the key-minor rows
+                    const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;
+                    vr[n] = RTw[(unsigned)(cc * a.Kp + jc)];
                 }
 #pragma unroll
                 for (int n = 0; n < EL; ++n) {
-                    const int u = tid + n * nthr;
+                    const int u = tl + n * nthr;
                     const int r = u >> 5, c = u & 31;
-                    Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? v[n] : 0.f;
+                    Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? vl[n] : 0.f;
                 }
-            }
-            {
-                constexpr int BATCH = 8;                   // (256 keys x 32 columns) / 512 threads, in two batches
-#pragma unroll 1
-                for (int hb = 0; hb < 2; ++hb) {
-                    float v[BATCH];
 #pragma unroll
-                    for (int n = 0; n < BATCH; ++n) {
-                        const int u = tid + (hb * BATCH + n) * nthr;
-                        const int c = u / KB, j = kb0 + (u - c * KB);      // key fastest: coalesced reads of the key-minor rows
-                        const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;
-                        v[n] = RTw[(long)cc * a.Kp + jc];
-                    }
-#pragma unroll
-                    for (int n = 0; n < BATCH; ++n) {
-                        const int u = tid + (hb * BATCH + n) * nthr;
-                        const int c = u / KB, jl = u - c * KB;
-                        Rs[jl * GAT_LLD + c] = (kb0 + jl < K && c0 + c < PT) ? v[n] : 0.f;
-                    }
+                for (int n = 0; n < ER; ++n) {
+                    const int u = tl + n * nthr;
+                    const int c = u / KB, jl = u - c * KB;
+                    Rs[jl * GAT_LLD + c] = (kb0 + jl < K && c0 + c < PT) ? vr[n] : 0.f;
                 }
             }
             __syncthreads();
@@ -871,22 +998,48 @@ __global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
                 }
             });
         }
+        // ---- the block's first V tile is requested here: its round trip runs under the softmax of the block (buffer 0 was last
+        // read by the previous block's aggregation, which every wave left before the barriers of this block's part loop)
+        wide_vtile_dma<DTMAX, nthr>(Vs2, Vw, a.ldv, kb0, K, D, vld2, wave, lane, vfast);
         // ---- scores of the block, running softmax statistics; acc becomes e^(s - m'), scl the factor of what was summed before
+        // (rank-1 terms and bias in batches of unconditional loads, as in k_gat_wide: one round trip each instead of two per score)
+        float dv[KPB][JPL], cvr4[IBL];
+#pragma unroll
+        for (int kp = 0; kp < KPB; ++kp)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = kb0 + kp * 128 + lj + RJ * jj;
+                dv[kp][jj] = RTw[(unsigned)(PT * a.Kp + (j < K ? j : K - 1))];
+            }
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii) {
+            const int irow = i0 + li + RI * ii;
+            cvr4[ii] = LCw[(unsigned)((irow < K ? irow : K - 1) * a.ldl + PT)];
+        }
+        const bool has_bias = a.bias != nullptr;
+        const float* __restrict__ bsrc = has_bias ? a.bias : LCw;
 #pragma unroll
         for (int ii = 0; ii < IBL; ++ii) {
             const int irow = i0 + li + RI * ii;
             const int irc = irow < K ? irow : K - 1;
-            const float cvr = LCw[(long)irc * a.ldl + PT];
+            const float cvr = cvr4[ii];
+            float bv[KPB][JPL];
+#pragma unroll
+            for (int kp = 0; kp < KPB; ++kp)
+#pragma unroll
+                for (int jj = 0; jj < JPL; ++jj) {
+                    const int j = kb0 + kp * 128 + lj + RJ * jj;
+                    bv[kp][jj] = bsrc[has_bias ? (unsigned)(irc * K + (j < K ? j : K - 1)) : 0u];
+                }
             float mb = -INFINITY;
 #pragma unroll
             for (int kp = 0; kp < KPB; ++kp)
 #pragma unroll
                 for (int jj = 0; jj < JPL; ++jj) {
                     const int j = kb0 + kp * 128 + lj + RJ * jj;
-                    const int jc = j < K ? j : K - 1;
-                    float v = acc[kp][ii][jj] + cvr + RTw[(long)PT * a.Kp + jc];
+                    float v = acc[kp][ii][jj] + cvr + dv[kp][jj];
                     if (a.v1) v = fmaxf(v, 0.f) + a.alpha * fminf(v, 0.f);
-                    if (a.bias) v += a.bias[(long)irc * K + jc];
+                    v += has_bias ? bv[kp][jj] : 0.f;
                     v = j < K ? v : -INFINITY;
                     acc[kp][ii][jj] = v;
                     mb = fmaxf(mb, v);
@@ -916,53 +1069,8 @@ __global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
             for (int dt = 0; dt < DTMAX; ++dt)
                 if (dt < DT) { o[dt][0] *= f; o[dt][1] *= f; o[dt][2] *= f; o[dt][3] *= f; }
         }
-        // ---- o += e V over the block's keys (k_gat_wide's aggregation loop)
-        static_for<0, 2 * KPB>([&](auto khc) {
-            {
-                constexpr int kp = decltype(khc)::value >> 1, half = decltype(khc)::value & 1;
-                const int k0 = kb0 + kp * 128 + half * 64;
-                if (k0 < K) {
-                    __syncthreads();
-#pragma unroll
-                    for (int ii = 0; ii < IBL; ++ii)
-#pragma unroll
-                        for (int j4 = 0; j4 < 4; ++j4) att[(li + RI * ii) * GAT_APITCH + lj + RJ * j4] = acc[kp][ii][4 * half + j4];
-                    for (int kq = 0; kq < 2; ++kq) {
-                        const int kv = k0 + 32 * kq;
-                        if (kq) __syncthreads();
-                        if (kv < K) {
-                            for (int u = tid; u < 32 * (vld2 >> 2); u += nthr) {
-                                const int r = u / (vld2 >> 2), c4 = (u - r * (vld2 >> 2)) * 4;
-                                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                                if (kv + r < K) {
-                                    const float* src = Vw + (long)(kv + r) * a.ldv + c4;
-#pragma unroll
-                                    for (int s4 = 0; s4 < 4; ++s4) v[s4] = (c4 + s4 < D) ? src[s4] : 0.f;
-                                }
-                                *reinterpret_cast<f32x4*>(Vs2 + r * vld2 + c4) = v;
-                            }
-                        }
-                        __syncthreads();
-                        if (kv < K) {
-#pragma unroll
-                            for (int g2 = 0; g2 < 2; ++g2) {
-                                const f32x4 bq = *reinterpret_cast<const f32x4*>(att + nr * GAT_APITCH + 32 * kq + 16 * g2 + 4 * kbq);
-                                const float* __restrict__ vk = Vs2 + (16 * g2 + 4 * kbq) * vld2;
-#pragma unroll
-                                for (int dt = 0; dt < DTMAX; ++dt)
-                                    if (dt < DT) {
-                                        float av[4];
-#pragma unroll
-                                        for (int t = 0; t < 4; ++t) av[t] = vk[t * vld2 + 16 * dt + nr];
-#pragma unroll
-                                        for (int t = 0; t < 4; ++t) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bq[t], o[dt], 0, 0, 0);
-                                    }
-                            }
-                        }
-                    }
-                }
-            }
-        });
+        // ---- o += e V over the block's keys (wide_aggregate: two V tile buffers, one barrier per tile)
+        wide_aggregate<KPB, DTMAX, nthr>(acc, o, att, Vs2, Vw, a.ldv, kb0, K, D, vld2, tid, wave, vfast);
     }
     // ---- h = sigmoid(o / l)
     __syncthreads();
@@ -986,16 +1094,17 @@ __global__ __launch_bounds__(512, 1) void k_gat_wide_os(const GatWideArgs a) {
     }
 }
 
-size_t gat_wide_os_lds(int D) {
-    const size_t pair = (size_t)(8 * 16 + 256) * GAT_LLD;
-    const size_t agg = (size_t)8 * 16 * GAT_APITCH + (size_t)32 * (((D + 15) & ~15) + 4);
-    return ((pair > agg ? pair : agg) + 8 * 16) * sizeof(float);
+size_t gat_wide_os_lds(int D, int nw) {
+    const size_t pair = (size_t)(nw * 16 + 256) * GAT_LLD;
+    const size_t att = (size_t)nw * 16 * GAT_APITCH;
+    // [pair grid | softmax slices] then two V tiles (WideAgg; D <= 256 here) that alias neither, then the row factors
+    return ((pair > att ? pair : att) + (size_t)2 * 32 * (((D + 15) & ~15) + 4) + nw * 16) * sizeof(float);
 }
 
 size_t gat_wide_lds(int K, int D, int nw) {
     const int KP = (K + 127) / 128;
     const size_t pair = (size_t)(nw * 16 + KP * 128) * GAT_LLD;
-    const size_t agg = (size_t)nw * 16 * GAT_APITCH + (size_t)32 * (((D + 15) & ~15) + 4);
+    const size_t agg = (size_t)nw * 16 * GAT_APITCH + (size_t)2 * (D <= 256 ? 32 : 16) * (((D + 15) & ~15) + 4);     // two V tiles (WideAgg)
     return (pair > agg ? pair : agg) * sizeof(float);
 }
 
@@ -1005,7 +1114,7 @@ int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int 
     if (nwin <= 0) return 0;
     if (K > 512 || D > 512) return -2;
     const int KP = (K + 127) / 128;
-    const int nw = KP == 4 ? 4 : (K >= 128 ? 8 : (K + 15) / 16);
+    const int nw = KP == 4 ? 4 : 8;          // (eight waves also below 128 keys: the staging helpers take the thread count at compile time; waves past K idle)
     GatWideArgs a{};
     a.LC = LC; a.RT = RT; a.ldl = ldl; a.rt_rows = rt_rows; a.Kp = Kp; a.PT = PT; a.P8 = P8; a.bias = bias;
     a.V = V; a.ldv = ldv; a.D = D; a.K = K; a.out = out; a.so_w = so_w; a.so_i = so_i; a.so_d = so_d; a.nwin = nwin;
@@ -1018,13 +1127,16 @@ int launch_gat_wide(const float* LC, const float* RT, int ldl, int rt_rows, int 
     if (K > 256 && dtmax == 16 && !att && !(drop && drop->thresh) && !os_off) {
         // more than 256 keys, node dimension up to 256, inference: key blocks of 256 with a running softmax (eight waves per
         // workgroup, two per SIMD; with 32 output tiles per lane -- D up to 512 -- the kernel spills and k_gat_wide stays)
-        a.nblk = (K + 127) / 128;
-        const size_t lds2 = gat_wide_os_lds(D);
+        // (NW = 4 -- 64 query rows per workgroup, two workgroups per CU, so that one's staging runs under the other's pair grid --
+        // was measured in round 6: config 4's attention 131 instead of 120 ms per 8 192 windows; each workgroup stages all of R')
+        constexpr int nw2 = 8;
+        a.nblk = (K + nw2 * 16 - 1) / (nw2 * 16);
+        const size_t lds2 = gat_wide_os_lds(D, nw2);
         if (lds2 <= 160 * 1024) {
             const unsigned grid2 = (unsigned)(((nwin + 7) / 8 * 8) * a.nblk);
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_wide_os<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_wide_os<16, nw2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             if (e_ != hipSuccess) return (int)e_;
-            hipLaunchKernelGGL((k_gat_wide_os<16>), dim3(grid2), dim3(512), lds2, s, a);
+            hipLaunchKernelGGL((k_gat_wide_os<16, nw2>), dim3(grid2), dim3(64 * nw2), lds2, s, a);
             LAUNCH_CHECK();
             return 0;
         }

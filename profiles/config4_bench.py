@@ -5,6 +5,9 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mtad-gat-pytorch_amd")); sys.path.insert(0, ROOT)
 import torch
+if os.environ.get("VARIANT"):           # a developer build of the library (profiles/build_variants.sh) instead of the in-tree one
+    import _native
+    _native._LIB_PATH = os.path.join(ROOT, "profiles", "bin", "variants", os.environ["VARIANT"], "libmtadgat.so")
 from mtad_gat import MTAD_GAT
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
@@ -20,7 +23,7 @@ with torch.no_grad():
     ref = None
     for chunk in chunks:
         if chunk: eng.set_chunk_windows(chunk)
-        for lanes in (0, 1, 0, 1):
+        for lanes in [int(v) for v in os.environ.get("LANES", "0,1,0,1").split(",")]:
             eng.set_option("lanes", lanes)
             out = m(x); torch.cuda.synchronize()
             t0 = time.perf_counter()
