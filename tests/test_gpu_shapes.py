@@ -19,6 +19,9 @@ SHAPES = [
     dict(n_features=20, window_size=128, out_dim=20, kernel_size=7, gru_hid_dim=256, recon_hid_dim=200, alpha=0.7),
     dict(n_features=129, window_size=40, out_dim=3, kernel_size=3, gru_hid_dim=40, recon_hid_dim=40),   # un-fused path (K > 128)
     # temporal layer fused with 6 keys per lane and a staging batch beyond the register budget, feature layer un-fused
+    # both layers un-fused with node rows that are NOT whole 16-byte words (the wide kernels' guarded V staging instead of the
+    # LDS-DMA tiles), an odd number of 16-column output tiles and a last key tile with a single real row (K = 129 + 16 k)
+    dict(n_features=145, window_size=150, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24),
     dict(n_features=128, window_size=96, out_dim=2, kernel_size=3, gru_hid_dim=24, recon_hid_dim=24),
     dict(n_features=10, window_size=100, out_dim=1, kernel_size=7, use_gatv2=False, gru_hid_dim=30, recon_hid_dim=30),
     dict(n_features=90, window_size=17, out_dim=4, kernel_size=5, gru_hid_dim=20, recon_hid_dim=20, feat_gat_embed_dim=7),
