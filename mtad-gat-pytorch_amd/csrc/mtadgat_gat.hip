@@ -866,6 +866,9 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
 // stays on k_gat_wide.
 // ---------------------------------------------------------------------------
 // NW waves per workgroup (8: one workgroup per CU, 128 query rows).
+// (Measured and not kept, round 6: key blocks of 128 -- 32 score registers per lane, no spills -- with the L' / R' words of part
+// p + 1 requested before part p's pair grid and stored behind it: 6.75-6.86 against 6.50-6.53 ms per 896-window chunk; the L' tile
+// is staged twice as often and the staging round trip is not what the kernel waits for.)
 template <int DTMAX, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void k_gat_wide_os(const GatWideArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -925,47 +928,54 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void k_gat_wide_os(cons
             for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
                 for (int jj = 0; jj < JPL; ++jj) acc[kp][ii][jj] = 0.f;
-        for (int part = 0; part < nparts; ++part) {
+        // Staging of a part: all loads -- the block's L' rows and the key block's R' columns -- are issued before the first LDS
+        // store: ONE memory round trip per part (three when L' and the two halves of R' went one after the other).  The unit
+        // indices are re-derived from an opaque copy of the thread index every time: as loop invariants the compiler kept them
+        // in registers, spilled them, and reloaded each one -- s_waitcnt vmcnt(0) -- between the loads.
+        constexpr int EL = 8;                              // (NW*16 rows x 32 columns) / (NW*64 threads)
+        constexpr int ER = KB * 32 / nthr;                 // (KB keys x 32 columns) / (NW*64 threads)
+        float vl[EL], vr[ER];
+        auto stage_issue = [&](const int part) {
             const int c0 = 32 * part;
-            __syncthreads();                               // the previous users of Ls / Rs (pair grid, att / V tiles) are done
-            {
-                // all loads of the part -- the block's L' rows and the key block's R' columns -- are issued before the first LDS
-                // store: ONE memory round trip per part (three when L' and the two halves of R' went one after the other)
-                constexpr int EL = 8;                      // (NW*16 rows x 32 columns) / (NW*64 threads)
-                constexpr int ER = KB * 32 / nthr;         // (256 keys x 32 columns) / (NW*64 threads)
-                float vl[EL], vr[ER];
-                // (the unit indices are re-derived from an opaque copy of the thread index in every part: as loop invariants the
-                // compiler kept them in registers, spilled them, and reloaded each one -- s_waitcnt vmcnt(0) -- between the loads)
-                int tl = tid;
-                asm volatile("" : "+v"(tl));
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
 #pragma unroll
-                for (int n = 0; n < EL; ++n) {
-                    const int u = tl + n * nthr;
-                    const int r = u >> 5, c = u & 31;
-                    const int row = i0b + r;
-                    const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;
-                    vl[n] = LCw[(unsigned)(rc * a.ldl + cc)];          // (uniform base + 32-bit lane offset: no 64-bit address pairs)
-                }
-#pragma unroll
-                for (int n = 0; n < ER; ++n) {
-                    const int u = tl + n * nthr;
-                    const int c = u / KB, j = kb0 + (u - c * KB);      // key fastest: coalesced reads of the key-minor rows
-                    const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;
-                    vr[n] = RTw[(unsigned)(cc * a.Kp + jc)];
-                }
-#pragma unroll
-                for (int n = 0; n < EL; ++n) {
-                    const int u = tl + n * nthr;
-                    const int r = u >> 5, c = u & 31;
-                    Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? vl[n] : 0.f;
-                }
-#pragma unroll
-                for (int n = 0; n < ER; ++n) {
-                    const int u = tl + n * nthr;
-                    const int c = u / KB, jl = u - c * KB;
-                    Rs[jl * GAT_LLD + c] = (kb0 + jl < K && c0 + c < PT) ? vr[n] : 0.f;
-                }
+            for (int n = 0; n < EL; ++n) {
+                const int u = tl + n * nthr;
+                const int r = u >> 5, c = u & 31;
+                const int row = i0b + r;
+                const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;
+                vl[n] = LCw[(unsigned)(rc * a.ldl + cc)];              // (uniform base + 32-bit lane offset: no 64-bit address pairs)
             }
+#pragma unroll
+            for (int n = 0; n < ER; ++n) {
+                const int u = tl + n * nthr;
+                const int c = u / KB, j = kb0 + (u - c * KB);          // key fastest: coalesced reads of the key-minor rows
+                const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;
+                vr[n] = RTw[(unsigned)(cc * a.Kp + jc)];
+            }
+        };
+        auto stage_store = [&](const int part) {
+            const int c0 = 32 * part;
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int n = 0; n < EL; ++n) {
+                const int u = tl + n * nthr;
+                const int r = u >> 5, c = u & 31;
+                Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? vl[n] : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < ER; ++n) {
+                const int u = tl + n * nthr;
+                const int c = u / KB, jl = u - c * KB;
+                Rs[jl * GAT_LLD + c] = (kb0 + jl < K && c0 + c < PT) ? vr[n] : 0.f;
+            }
+        };
+        for (int part = 0; part < nparts; ++part) {
+            __syncthreads();                               // the previous users of Ls / Rs (pair grid, att slices) are done
+            stage_issue(part);
+            stage_store(part);
             __syncthreads();
             int ntl = ntile - 4 * part;
             ntl = ntl > 4 ? 4 : ntl;
