@@ -450,6 +450,76 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gat(const GatArgs a) 
 }
 
 
+// ---- staging of one 32-column part of the wide kernels (round 6): the block's L' rows (row-major source) and the R' columns of KJ
+// keys (key-minor source) as 16-byte loads -- a thread takes 8 consecutive columns of one L' row (2 loads, 4 ds_write_b64) and, per
+// unit, 4 consecutive keys of a column PAIR (2 loads, 4 ds_write_b64: the 4 x 2 transpose is register naming) -- issued together
+// (one memory round trip per part) and stored without masks when the tile is interior (uniform test).  Before: 4-byte loads, one
+// element per load, ~17 vector instructions of index arithmetic and masking per element -- 414 per thread and part at config 4,
+// a tenth of the pair grid's count.  LC rows / RT rows are whole 16-byte words (ldl a multiple of 32, Kp of 4, bases aligned).
+template <int NTHR, int KJ>
+struct WideStage {
+    static constexpr int QN = KJ / 4;                  // key quads of the tile
+    static constexpr int RU = 4 * KJ / NTHR;           // (16 column pairs x QN quads) / threads
+    f32x4 l0, l1, ra[RU], rb[RU];
+    __device__ __forceinline__ void issue(const float* __restrict__ LCw, int ldl, const float* __restrict__ RTw, int Kp, int i0b, int kb0,
+                                          int c0, int K, int tid) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));                   // (indices re-derived per part: as loop invariants they were spilled)
+        {
+            const int r = tl >> 2, cq = (tl & 3) * 8;
+            const int row = i0b + r < K ? i0b + r : K - 1;
+            const float* __restrict__ p = LCw + (unsigned)(row * ldl + c0 + cq);
+            l0 = *reinterpret_cast<const f32x4*>(p);
+            l1 = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int n = 0; n < RU; ++n) {
+            const int u = tl + n * NTHR;
+            const int cp = u / QN, q = u - cp * QN;
+            const int j0 = kb0 + 4 * q < Kp - 4 ? kb0 + 4 * q : Kp - 4;       // (a quad past the keys is masked when it is stored)
+            const float* __restrict__ p = RTw + (unsigned)((c0 + 2 * cp) * Kp + j0);
+            ra[n] = *reinterpret_cast<const f32x4*>(p);
+            rb[n] = *reinterpret_cast<const f32x4*>(p + Kp);
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ Ls, float* __restrict__ Rs, int i0b, int kb0, int c0, int K, int PT, int tid) const {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const bool interior = i0b + NTHR / 4 <= K && kb0 + KJ <= K && c0 + 32 <= PT;      // (uniform)
+        {
+            const int r = tl >> 2, cq = (tl & 3) * 8;
+            f32x2* __restrict__ d = reinterpret_cast<f32x2*>(Ls + r * GAT_LLD + cq);
+            if (interior) {
+                d[0] = f32x2{l0[0], l0[1]}; d[1] = f32x2{l0[2], l0[3]}; d[2] = f32x2{l1[0], l1[1]}; d[3] = f32x2{l1[2], l1[3]};
+            } else {
+                const bool rok = i0b + r < K;
+                float e[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = (rok && c0 + cq + k < PT) ? e[k] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = f32x2{e[2 * k], e[2 * k + 1]};
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < RU; ++n) {
+            const int u = tl + n * NTHR;
+            const int cp = u / QN, q = u - cp * QN;
+            float* __restrict__ d = Rs + (4 * q) * GAT_LLD + 2 * cp;
+            if (interior) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x2*>(d + k * GAT_LLD) = f32x2{ra[n][k], rb[n][k]};
+            } else {
+                const bool cok = c0 + 2 * cp < PT;     // (PT is even: both columns of the pair are on one side of it)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool ok = cok && kb0 + 4 * q + k < K;
+                    *reinterpret_cast<f32x2*>(d + k * GAT_LLD) = f32x2{ok ? ra[n][k] : 0.f, ok ? rb[n][k] : 0.f};
+                }
+            }
+        }
+    }
+};
+
 // ---- aggregation o += att V of the wide kernels, software-pipelined (round 6).  The V rows of the window go through LDS in
 // tiles of VK keys (32; 16 when the node dimension exceeds 256 so that two tiles fit beside the softmax slices), TWO tile
 // buffers filled by LDS-DMA (global_load_lds_dwordx4: a 1-KiB piece of a V row per wave instruction, no staging registers):
@@ -659,55 +729,11 @@ __global__ __launch_bounds__((KP == 4 ? 256 : 512), 1) void k_gat_wide(const Gat
     const int ntile = PT >> 3, ptile = P8 >> 3;
     const int nparts = (ntile + 3) >> 2;
     for (int part = 0; part < nparts; ++part) {
-        // ---- stage this part: L' rows of the block (row-major source), R' columns of all keys (key-minor source).
-        // Every load is unconditional from a clamped address and all loads of a batch are issued before the first LDS
-        // store: one memory round trip per batch (a guarded load costs one per element)
-        const int c0 = 32 * part;
+        // ---- stage this part (WideStage): all loads issued together, one memory round trip
         {
-            // the block's L' loads are issued ahead of the first batch of R' loads and stored behind them: one memory round trip
-            // for both (a batch = one round trip: all its loads before its first LDS store)
-            constexpr int EL = 8;                                  // (NW*16 rows x 32 columns) / (NW*64 threads)
-            float vl[EL];
-            int tl = tid;                                          // (opaque per part: the unit indices are not kept -- and spilled -- as loop invariants)
-            asm volatile("" : "+v"(tl));
-#pragma unroll
-            for (int n = 0; n < EL; ++n) {
-                const int u = tl + n * nthr;
-                const int r = u >> 5, c = u & 31;
-                const int row = i0b + r;
-                const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;       // column PT (c_i) exists in every row
-                vl[n] = LCw[(unsigned)(rc * a.ldl + cc)];
-            }
-            constexpr int KJC = KP * 128;
-            constexpr int BATCH = 16;
-            const int total = KJC * 32;
-            for (int base = 0; base < total; base += BATCH * nthr) {
-                float v[BATCH];
-#pragma unroll
-                for (int n = 0; n < BATCH; ++n) {
-                    const int u = base + tl + n * nthr;
-                    const int uc = u < total ? u : total - 1;
-                    const int c = uc / KJC, j = uc - c * KJC;      // key fastest: coalesced reads of the key-minor rows
-                    const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;       // row PT (d_j) exists
-                    v[n] = RTw[(unsigned)(cc * a.Kp + jc)];
-                }
-                if (base == 0) {
-#pragma unroll
-                    for (int n = 0; n < EL; ++n) {
-                        const int u = tl + n * nthr;
-                        const int r = u >> 5, c = u & 31;
-                        Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? vl[n] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < BATCH; ++n) {
-                    const int u = base + tl + n * nthr;
-                    if (u < total) {
-                        const int c = u / KJC, j = u - c * KJC;
-                        Rs[j * GAT_LLD + c] = (j < K && c0 + c < PT) ? v[n] : 0.f;
-                    }
-                }
-            }
+            WideStage<(KP == 4 ? 256 : 512), KP * 128> st;
+            st.issue(LCw, a.ldl, RTw, a.Kp, i0b, 0, 32 * part, K, tid);
+            st.store(Ls, Rs, i0b, 0, 32 * part, K, PT, tid);
         }
         __syncthreads();
         int ntl = ntile - 4 * part;
@@ -928,54 +954,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : 1)) void k_gat_wide_os(cons
             for (int ii = 0; ii < IBL; ++ii)
 #pragma unroll
                 for (int jj = 0; jj < JPL; ++jj) acc[kp][ii][jj] = 0.f;
-        // Staging of a part: all loads -- the block's L' rows and the key block's R' columns -- are issued before the first LDS
-        // store: ONE memory round trip per part (three when L' and the two halves of R' went one after the other).  The unit
-        // indices are re-derived from an opaque copy of the thread index every time: as loop invariants the compiler kept them
-        // in registers, spilled them, and reloaded each one -- s_waitcnt vmcnt(0) -- between the loads.
-        constexpr int EL = 8;                              // (NW*16 rows x 32 columns) / (NW*64 threads)
-        constexpr int ER = KB * 32 / nthr;                 // (KB keys x 32 columns) / (NW*64 threads)
-        float vl[EL], vr[ER];
-        auto stage_issue = [&](const int part) {
-            const int c0 = 32 * part;
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-#pragma unroll
-            for (int n = 0; n < EL; ++n) {
-                const int u = tl + n * nthr;
-                const int r = u >> 5, c = u & 31;
-                const int row = i0b + r;
-                const int rc = row < K ? row : K - 1, cc = c0 + c < PT ? c0 + c : PT;
-                vl[n] = LCw[(unsigned)(rc * a.ldl + cc)];              // (uniform base + 32-bit lane offset: no 64-bit address pairs)
-            }
-#pragma unroll
-            for (int n = 0; n < ER; ++n) {
-                const int u = tl + n * nthr;
-                const int c = u / KB, j = kb0 + (u - c * KB);          // key fastest: coalesced reads of the key-minor rows
-                const int jc = j < K ? j : K - 1, cc = c0 + c < PT ? c0 + c : PT;
-                vr[n] = RTw[(unsigned)(cc * a.Kp + jc)];
-            }
-        };
-        auto stage_store = [&](const int part) {
-            const int c0 = 32 * part;
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-#pragma unroll
-            for (int n = 0; n < EL; ++n) {
-                const int u = tl + n * nthr;
-                const int r = u >> 5, c = u & 31;
-                Ls[r * GAT_LLD + c] = (i0b + r < K && c0 + c < PT) ? vl[n] : 0.f;
-            }
-#pragma unroll
-            for (int n = 0; n < ER; ++n) {
-                const int u = tl + n * nthr;
-                const int c = u / KB, jl = u - c * KB;
-                Rs[jl * GAT_LLD + c] = (kb0 + jl < K && c0 + c < PT) ? vr[n] : 0.f;
-            }
-        };
         for (int part = 0; part < nparts; ++part) {
             __syncthreads();                               // the previous users of Ls / Rs (pair grid, att slices) are done
-            stage_issue(part);
-            stage_store(part);
+            {
+                WideStage<nthr, KB> st;                    // all loads of the part issued together: one memory round trip
+                st.issue(LCw, a.ldl, RTw, a.Kp, i0b, kb0, 32 * part, K, tid);
+                st.store(Ls, Rs, i0b, kb0, 32 * part, K, PT, tid);
+            }
             __syncthreads();
             int ntl = ntile - 4 * part;
             ntl = ntl > 4 ? 4 : ntl;
