@@ -391,7 +391,9 @@ def sub_records(model, kw, dev, args_precision="fp32"):
                 (torch.sqrt(F.mse_loss(yt4, p_)) + torch.sqrt(F.mse_loss(xt4, r_))).backward()
                 opt4.step()
 
-            tt4 = _timed(step4, dev, 2, warm=1)
+            # (three warm-up steps: the first steps of a shape this size grow PyTorch's caching allocator by several GB -- with one
+            # warm-up the record read 106 ms for a step whose kernels take 51)
+            tt4 = _timed(step4, dev, 3, warm=3)
             out["config4_f512_w256"]["train_step_b256"] = {"ms": round(1e3 * tt4, 2), "windows_per_s": round(256 / tt4, 1),
                                                            "grad_path": getattr(m4, "grad_path", None)}
         except Exception as e:
