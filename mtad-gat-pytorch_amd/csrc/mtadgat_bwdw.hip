@@ -17,7 +17,7 @@
 //     k_bw_pair      GATv2 scores e_ij = sum_k a_k LeakyReLU(L_ik + R_jk) (modules.py:74-77 / :174-177):
 //                        d z_ijk = d e_ij a_k [u > 0 ? 1 : alpha],  d L_ik = sum_j d z,  d R_jk = sum_i d z,
 //                        d a_k = sum_ij d e_ij LeakyReLU(u)
-//                    in two passes over a 32-column block of the embedding (the second on the transposed d e), no atomics.
+//                    in ONE register-blocked pass over a 32-column block of the embedding (round 6), no atomics.
 // GAT (v1) layers of this size (round 6): the score backward e_ij = LeakyReLU(c_i + d_j) is linear in the node vectors below d s
 // (mtadgat_bwd.hip: k_gat_v1_prep / k_gat_bwd_v1 / k_gat_v1_finish); k_bw_v1 is k_gat_bwd_v1 with the node rows read from memory
 // instead of an LDS copy of the window -- same outputs (d V +=, per-window partials [p1 | p2 | sc sd]), so prep and finish are shared.
@@ -157,40 +157,21 @@ __global__ __launch_bounds__(256) void k_bw_softmax(const float* __restrict__ AT
     }
 }
 
-// ---- (B, K, K) -> transposed per window, 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void k_bw_transpose(const float* __restrict__ src, float* __restrict__ dst, long nwin, int K) {
-    __shared__ float tile[32][33];
-    const int tk = (K + 31) >> 5;
-    const long blk = blockIdx.x;
-    const long win = blk / (tk * tk);
-    const int t2 = (int)(blk - win * (tk * tk));
-    const int r0 = (t2 / tk) * 32, c0 = (t2 % tk) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 8 rows per pass
-    const float* __restrict__ s = src + win * (long)K * K;
-    float* __restrict__ d = dst + win * (long)K * K;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = r0 + ty + 8 * p, c = c0 + tx;
-        tile[ty + 8 * p][tx] = (r < K && c < K) ? s[(long)r * K + c] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int r = c0 + ty + 8 * p, c = r0 + tx;
-        if (r < K && c < K) d[(long)r * K + c] = tile[tx][ty + 8 * p];
-    }
-}
-
-// ---- GATv2 score backward for one window and one 32-column block of the embedding.
-// 256 threads: thread (k = tid & 31, q = tid >> 5) owns column k of the block and the rows i = q, q + 8, ... (pass 1: d L, d a)
-// resp. the keys j = q, q + 8, ... (pass 2: d R).  LDS: Ls [K][32] | Rs [K][32] | des [8][K] (the d e row / column a thread
-// group is working on: written and read by the same 32 lanes, i.e. within one wave).
+// ---- GATv2 score backward for one window and one 32-column block of the embedding (round 6: one pass, register-blocked).
+// u_ijk = L_ik + R_jk,  s_ijk = u > 0 ? 1 : alpha,  d L_ik = a_k sum_j d e_ij s_ijk,  d R_jk = a_k sum_i d e_ij s_ijk, and -- since
+// LeakyReLU(u) = s u is linear in (L, R) once s is fixed -- d a_k = sum_i L_ik dl_ik + sum_j R_jk dr_jk with the un-scaled sums dl, dr:
+// the pair loop is FIVE vector instructions per (i, j, k) for all three outputs (add, compare, select, two fma).
+// 32 G threads (G = 16 key groups up to 256 keys, 32 above): lane & 31 = column k, the half-waves are the key groups: group q keeps
+// R_jk and dr_jk of its JB = 4 QN <= 16 keys in registers across all rows (no transposed copy of d e, no second pass; <= 125
+// registers: four waves per SIMD).  Rows go in batches of eight: d e rows of the batch in LDS
+// (read as 16-byte broadcasts), the groups' partial dl through LDS, summed by 256 of the threads, which also take the L dl term of d a.
+// (The first version -- thread = (column, an eighth of the rows), one row at a time, three LDS reads and six instructions per pair and
+// pass, two passes -- took 12.2 ms per launch at config 4's shapes: 48 % of that shape's training step.)
 struct BwPairArgs {
     const float* LR;     // (B*K, ldlr): [L (Ep) | R (Ep)]
     int ldlr, Ep;
     const float* avec;   // (Ep) a, zero padded
     const float* DE;     // (B, K, K)
-    const float* DEt;    // (B, K, K) transposed per window
     int K;
     float alpha;
     float* DLR;          // (B*K, ldlr): [d L | d R]
@@ -198,66 +179,96 @@ struct BwPairArgs {
     long nwin;
 };
 
-__global__ __launch_bounds__(256) void k_bw_pair(const BwPairArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+template <int QN, int G>
+__global__ __launch_bounds__(32 * G) void k_bw_pair(const BwPairArgs a) {
+    constexpr int JB = 4 * QN, KP = G * JB, IB = 8, NT = 32 * G;
+    __shared__ __attribute__((aligned(16))) float des[IB * KP];      // d e rows of the batch, zero beyond K
+    __shared__ float red[G * IB * 32];                                // partial dl of the groups
+    __shared__ float Lb[IB * 32];                                     // L rows of the batch (this block's 32 columns)
     const int K = a.K, nkb = a.Ep >> 5;
     const long win = blockIdx.x / nkb;
     const int kb = (int)(blockIdx.x - win * nkb);
     const int tid = threadIdx.x, k = tid & 31, q = tid >> 5;
-    float* __restrict__ Ls = sm;
-    float* __restrict__ Rs = Ls + K * 32;
-    float* __restrict__ des = Rs + K * 32 + q * K;
-    float* __restrict__ red = Rs + K * 32 + 8 * K;               // [8][32]
-    const float* __restrict__ lr = a.LR + (win * K) * (long)a.ldlr + 32 * kb;
-    for (int u = tid; u < K * 32; u += 256) {
-        const int r = u >> 5, c = u & 31;
-        Ls[u] = lr[(long)r * a.ldlr + c];
-        Rs[u] = lr[(long)r * a.ldlr + a.Ep + c];
+    const int j0 = q * JB;
+    const float* __restrict__ lr = a.LR + (win * K) * (long)a.ldlr + 32 * kb + k;
+    const float* __restrict__ de = a.DE + win * (long)K * K;
+    float* __restrict__ dlr = a.DLR + (win * K) * (long)a.ldlr + 32 * kb + k;
+    const float alpha = a.alpha;
+    float R[JB], dr[JB];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+        const int j = j0 + jj;
+        const float v = lr[(long)(j < K ? j : K - 1) * a.ldlr + a.Ep];
+        R[jj] = j < K ? v : 0.f;
+        dr[jj] = 0.f;
+    }
+    float da = 0.f;
+    for (int i0 = 0; i0 < K; i0 += IB) {
+        __syncthreads();                                   // the previous batch's readers of des / red are done
+        // the batch's rows of d e (coalesced; rows and keys past K as zeros) and this thread's L values
+        {
+            float v[IB * KP / NT];
+#pragma unroll
+            for (int n = 0; n < IB * KP / NT; ++n) {
+                const int u = tid + n * NT;
+                const int r = u / KP, j = u - r * KP;
+                const int ic = i0 + r < K ? i0 + r : K - 1, jc = j < K ? j : K - 1;
+                v[n] = de[(long)ic * K + jc];
+            }
+#pragma unroll
+            for (int n = 0; n < IB * KP / NT; ++n) {
+                const int u = tid + n * NT;
+                const int r = u / KP, j = u - r * KP;
+                des[u] = (i0 + r < K && j < K) ? v[n] : 0.f;
+            }
+        }
+        if (tid < IB * 32) Lb[tid] = lr[(long)(i0 + (tid >> 5) < K ? i0 + (tid >> 5) : K - 1) * a.ldlr];      // (lr carries this thread's column k)
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < IB; ++r) {                     // (not unrolled: eight rows' d e quads at once spill the key registers)
+            const float lv = Lb[r * 32 + k];
+            float dl = 0.f;
+#pragma unroll
+            for (int qd = 0; qd < QN; ++qd) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(&des[r * KP + j0 + 4 * qd]);        // (one address per half-wave: broadcast)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = lv + R[4 * qd + e];
+                    const float sl = u > 0.f ? 1.f : alpha;
+                    dl = __builtin_fmaf(g4[e], sl, dl);
+                    dr[4 * qd + e] = __builtin_fmaf(g4[e], sl, dr[4 * qd + e]);
+                }
+            }
+            red[(q * IB + r) * 32 + k] = dl;
+        }
+        __syncthreads();
+        if (tid < IB * 32) {                               // thread (r = tid >> 5, k): the row's dl over all key groups
+            const int r = tid >> 5;
+            float dl = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) dl += red[(g2 * IB + r) * 32 + k];
+            if (i0 + r < K) {
+                da = __builtin_fmaf(Lb[tid], dl, da);
+                dlr[(long)(i0 + r) * a.ldlr] = dl * a.avec[32 * kb + k];
+            }
+        }
+    }
+    const float ak = a.avec[32 * kb + k];
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+        const int j = j0 + jj;
+        if (j < K) {
+            da = __builtin_fmaf(R[jj], dr[jj], da);
+            dlr[(long)j * a.ldlr + a.Ep] = dr[jj] * ak;
+        }
     }
     __syncthreads();
-    const float ak = a.avec[32 * kb + k];
-    const float alpha = a.alpha;
-    float* __restrict__ dlr = a.DLR + (win * K) * (long)a.ldlr + 32 * kb;
-    float da = 0.f;
-    // pass 1: rows i of this thread group; d L_ik and the group's share of d a_k
-    const float* __restrict__ de = a.DE + win * (long)K * K;
-    for (int i = q; i < K; i += 8) {
-        __builtin_amdgcn_wave_barrier();
-        for (int j = k; j < K; j += 32) des[j] = de[(long)i * K + j];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const float l = Ls[i * 32 + k];
-        float dl = 0.f;
-        for (int j = 0; j < K; ++j) {
-            const float gq = des[j];
-            const float u = l + Rs[j * 32 + k];
-            const float sl = u > 0.f ? 1.f : alpha;
-            dl = __builtin_fmaf(gq * sl, ak, dl);
-            da = __builtin_fmaf(gq * sl, u, da);
-        }
-        dlr[(long)i * a.ldlr + k] = dl;
-    }
-    // pass 2: keys j of this thread group; d R_jk
-    const float* __restrict__ det = a.DEt + win * (long)K * K;
-    for (int j = q; j < K; j += 8) {
-        __builtin_amdgcn_wave_barrier();
-        for (int i = k; i < K; i += 32) des[i] = det[(long)j * K + i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const float r = Rs[j * 32 + k];
-        float dr = 0.f;
-        for (int i = 0; i < K; ++i) {
-            const float u = Ls[i * 32 + k] + r;
-            dr = __builtin_fmaf(des[i] * (u > 0.f ? 1.f : alpha), ak, dr);
-        }
-        dlr[(long)j * a.ldlr + a.Ep + k] = dr;
-    }
     red[q * 32 + k] = da;
     __syncthreads();
     if (tid < 32) {
         float sacc = 0.f;
 #pragma unroll
-        for (int g2 = 0; g2 < 8; ++g2) sacc += red[g2 * 32 + tid];
+        for (int g2 = 0; g2 < G; ++g2) sacc += red[g2 * 32 + tid];
         a.DAp[win * a.Ep + 32 * kb + tid] = sacc;
     }
 }
@@ -363,30 +374,29 @@ int launch_bw_softmax(const float* ATT, float* DE, long nwin, int K, const DropA
     return 0;
 }
 
-int launch_bw_transpose(const float* src, float* dst, long nwin, int K, hipStream_t s) {
+int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const float* DE, int K, float alpha, float* DLR, float* DAp,
+                   long nwin, hipStream_t s) {
     if (nwin <= 0) return 0;
-    const long tk = (K + 31) / 32;
-    hipLaunchKernelGGL(k_bw_transpose, dim3((unsigned)(nwin * tk * tk)), dim3(256), 0, s, src, dst, nwin, K);
-    LAUNCH_CHECK();
-    return 0;
-}
-
-size_t bw_pair_lds(int K) { return ((size_t)2 * K * 32 + (size_t)8 * K + 8 * 32) * sizeof(float); }
-
-int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const float* DE, const float* DEt, int K, float alpha, float* DLR,
-                   float* DAp, long nwin, hipStream_t s) {
-    if (nwin <= 0) return 0;
-    const size_t lds = bw_pair_lds(K);
-    if ((Ep & 31) != 0 || K > 512 || lds > 160 * 1024) return -2;
-    if (lds > 64 * 1024) {      // per device and cheap: set on every launch that needs it (as launch_gat_wide does), no process-wide flag
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bw_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e_ != hipSuccess) return (int)e_;
-    }
+    if ((Ep & 31) != 0 || K > 512 || K < 1) return -2;
     BwPairArgs a{};
-    a.LR = LR; a.ldlr = ldlr; a.Ep = Ep; a.avec = avec; a.DE = DE; a.DEt = DEt; a.K = K; a.alpha = alpha; a.DLR = DLR; a.DAp = DAp; a.nwin = nwin;
+    a.LR = LR; a.ldlr = ldlr; a.Ep = Ep; a.avec = avec; a.DE = DE; a.K = K; a.alpha = alpha; a.DLR = DLR; a.DAp = DAp; a.nwin = nwin;
     const long blocks = nwin * (Ep / 32);
     if (blocks > 0x7fffffffL) return -2;
-    hipLaunchKernelGGL(k_bw_pair, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    if (K <= 256) {                                        // 16 key groups x 4 qn keys >= K
+        switch ((K + 63) / 64) {
+#define BWP_CASE(N) case N: hipLaunchKernelGGL((k_bw_pair<N, 16>), dim3((unsigned)blocks), dim3(512), 0, s, a); break;
+            BWP_CASE(1) BWP_CASE(2) BWP_CASE(3) BWP_CASE(4)
+#undef BWP_CASE
+            default: return -2;
+        }
+    } else {                                               // 32 key groups
+        switch ((K + 127) / 128) {
+#define BWP_CASE(N) case N: hipLaunchKernelGGL((k_bw_pair<N, 32>), dim3((unsigned)blocks), dim3(1024), 0, s, a); break;
+            BWP_CASE(3) BWP_CASE(4)
+#undef BWP_CASE
+            default: return -2;
+        }
+    }
     LAUNCH_CHECK();
     return 0;
 }

@@ -1883,7 +1883,6 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
             const int D = gp.D, ldS = round_up(D, 4), Ep = gb.Ep;
             float* dS = ws + w.wds;
             float* LR = ws + w.wlr;
-            float* det = ws + w.wdet;
             K_TRY(launch_bw_ds(hcat + colofs, dhcat + colofs, so_w, so_i, so_d, n, K, D, dS, ldS, s), "attention backward (d S)");
             // d V (aggregation path) = att'^T d S, att' = dropout(att)
             K_TRY(launch_bgemm(att, (long)K * K, 1, K, dS, (long)K * ldS, ldS, 1, dv, (long)K * lddv, lddv, K, D, K, n, &drop, dstream, K, s),
@@ -1910,7 +1909,6 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
                 K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
                 continue;
             }
-            K_TRY(launch_bw_transpose(de, det, n, K, s), "attention backward (d e transposed)");
             // un-scaled projections [L | R] of the node rows, then the score backward
             {
                 RowGemmArgs r{};
@@ -1921,7 +1919,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
                 r.R = (long)n * K; r.NT = 2 * gb.NTu; r.NT_rm = 2 * gb.NTu; r.group = 1; r.relu = 0;
                 K_TRY(launch_rowgemm(r, s), "attention backward (projection)");
             }
-            K_TRY(launch_bw_pair(LR, 2 * Ep, Ep, m.packed_dev + gb.a_off, de, det, K, m.cfg.alpha, dlr, dap, n, s), "attention backward (pairs)");
+            K_TRY(launch_bw_pair(LR, 2 * Ep, Ep, m.packed_dev + gb.a_off, de, K, m.cfg.alpha, dlr, dap, n, s), "attention backward (pairs)");
             const long RK = (long)n * K;
             if ((rc = run_rowgemm_T(m, gb.lrT, dlr, 2L * Ep, RK, dv, lddv, gp.D, true, nullptr, 0, 1.f, s))) return rc;
             WgradIn in;

@@ -254,7 +254,7 @@ struct Tape {
 struct BwdWorkspace {
     size_t da, dhcat, dhdec, dhend, dz0, dz1, de_f, de_t, dv_f, dv_t, dlr_f, dlr_t, dap_f, dap_t, dpre, wpart, sums, total;
     size_t v1s;          // GAT (v1): [u1 | u2 | k1 k2] and the batch sums [P1 | P2 | SC SD] of the two layers
-    size_t wds, wlr, wdet;   // wide attention layers (one layer at a time): d S (N K ldS), [L | R] (N K 2 Ep), d e transposed (N K K)
+    size_t wds, wlr;         // wide attention layers (one layer at a time): d S (N K ldS), [L | R] (N K 2 Ep)
     size_t wpart_floats;
 };
 

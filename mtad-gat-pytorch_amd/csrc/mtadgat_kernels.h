@@ -381,13 +381,11 @@ int launch_bw_ds(const float* H, const float* dH, long so_w, long so_i, long so_
 int launch_bgemm(const float* A, long sAb, long sAm, long sAk, const float* B, long sBb, long sBk, long sBn, float* C, long sCb, long ldc,
                  int M, int N, int Kc, long nb, const DropArgs* drop, unsigned drop_stream, int dropK, hipStream_t s);
 int launch_bw_softmax(const float* ATT, float* DE, long nwin, int K, const DropArgs& drop, unsigned drop_stream, hipStream_t s);
-int launch_bw_transpose(const float* src, float* dst, long nwin, int K, hipStream_t s);
-size_t bw_pair_lds(int K);
 // GAT (v1) score backward of a wide layer: k_gat_bwd_v1's outputs with the node rows read from memory (K <= 512)
 int launch_bw_v1(const float* Vn, long ldv, int D, int K, const float* u, const float* DE, float alpha, float* DV, int lddv, float* part,
                  long nwin, hipStream_t s);
-int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const float* DE, const float* DEt, int K, float alpha, float* DLR,
-                   float* DAp, long nwin, hipStream_t s);
+int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const float* DE, int K, float alpha, float* DLR, float* DAp,
+                   long nwin, hipStream_t s);
 int launch_gru(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);
 int launch_gru_train(const GruArgs& a, int ncg, int xmode, bool fc, hipStream_t s);     // always the hidden-tile-split kernel
 bool gru_cm_supported(int ncg, int xmode, bool fc, int out_dim);

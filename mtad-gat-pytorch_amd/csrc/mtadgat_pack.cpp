@@ -579,15 +579,14 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
     w.dap_t = take(N * b.gat[1].Ep);
     w.dpre = take(N * m.W * m.Fp);
     {   // wide attention layers (mtadgat_bwdw.hip), one layer at a time
-        size_t ds = 0, lr = 0, det = 0;
+        size_t ds = 0, lr = 0;
         for (int which = 0; which < 2; ++which) {
             const GatPlan& gp = which == 0 ? m.feat : m.temp;
             if (!b.gat[which].wide) continue;
             ds = std::max(ds, N * gp.K * (size_t)round_up(gp.D, 4));
             lr = std::max(lr, N * gp.K * 2 * (size_t)b.gat[which].Ep);
-            det = std::max(det, N * gp.K * (size_t)gp.K);
         }
-        w.wds = take(ds); w.wlr = take(lr); w.wdet = take(det);
+        w.wds = take(ds); w.wlr = take(lr);          // (no transposed copy of d e since round 6: the score backward is one pass)
     }
     // partial sums of the weight-gradient GEMMs (one at a time)
     size_t wp = 0;

@@ -46,6 +46,10 @@ CONFIGS = {
                            forecast_hid_dim=150, recon_hid_dim=150, dropout=0.3, alpha=0.2), 2),
     "wide_f150": (dict(n_features=150, window_size=40, out_dim=3, kernel_size=3, feat_gat_embed_dim=33, gru_hid_dim=40, forecast_n_layers=1,
                        forecast_hid_dim=32, recon_hid_dim=40, dropout=0.1, alpha=0.1), 5),
+    # GATv2 layers of 257 .. 384 nodes: the 32-key-group build of the one-pass score backward with three key quads per group
+    # (k_bw_pair<3, 32>; config 4's 512 nodes take <4, 32>, everything up to 256 the 16-group builds)
+    "wide_w300": (dict(n_features=9, window_size=300, out_dim=2, kernel_size=3, feat_gat_embed_dim=24, time_gat_embed_dim=12, gru_hid_dim=32,
+                       forecast_n_layers=1, forecast_hid_dim=16, recon_hid_dim=24, dropout=0.2, alpha=0.2), 3),
     # GAT (v1) on wide layers (round 6: k_bw_v1, csrc/mtadgat_bwdw.hip): temporal layer of 160 nodes; feature layer of 140 nodes with
     # 300-dimensional node vectors
     "v1_wide_w160": (dict(n_features=14, window_size=160, out_dim=3, kernel_size=3, use_gatv2=False, gru_hid_dim=40, forecast_n_layers=1,
@@ -169,7 +173,7 @@ def test_gradients_above_the_fp16_range_guard(gpu_device):
         assert model.conv(x[:64]).max().item() >= 32768.0            # the inputs do exceed the fp16 pieces' range
 
 
-@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape", "stacked", "stacked3_v1", "wide_w130", "wide_w256",
+@pytest.mark.parametrize("name", ["small_v2", "odd_shapes", "msl_shape", "v1_small", "v1_msl_shape", "stacked", "stacked3_v1", "wide_w130", "wide_w256", "wide_w300",
                                   "wide_f150", "v1_wide_w160", "v1_wide_f140"])
 def test_gradients_match_autograd_with_dropout(name, gpu_device):
     """train(): dropout inside the kernels; the same keep-masks (exported by the library) injected into the
