@@ -880,296 +880,10 @@ int launch_gat_v1_finish(const float* P, const float* Wm, const float* bv, const
     return 0;
 }
 
-// ---------------------------------------------------------------------------
-// graph attention backward, part 2 (GATv2 scores e_ij = sum_k a_k LeakyReLU(L_ik + R_jk), L = W_l v + b,
-// R = W_r v; modules.py:74-77 / :174-177).  With t = L_ik + R_jk and g = [t > 0]:
-//     d L_ik = a_k (1 - alpha) sum_j d e_ij g         (the alpha part vanishes: sum_j d e_ij = 0, softmax rows)
-//     d R_jk = a_k (alpha sum_i d e_ij + (1 - alpha) sum_i d e_ij g)
-//     d a_k  = sum_ij d e_ij LeakyReLU(t) = (1+alpha)/2 sum d e t + (1-alpha)/2 sum d e |t|
-// One workgroup per window.  L, R are re-projected 32 columns at a time on the MFMA (un-scaled weight tiles)
-// exactly as in the forward; in the pair phase a lane owns one embedding column k (so d L and the d a sums
-// stay in registers), a wave one query row at a time -- 16 columns of the part per pass, its four 16-lane quarters take
-// the four quarters of the keys --, and the d R partial sums of a lane's keys live in registers (the j loop is fully
-// unrolled) until they are merged through LDS float atomics.  d e is read from memory where it is used (rows are
-// wave-uniform: broadcast loads that hit the L1); with it out of the LDS and a quarter of the key accumulators per
-// lane (128 registers), two workgroups (temporal layer; three for the feature layer) share a CU instead of one.
-// ---------------------------------------------------------------------------
-constexpr int GP_LLD = 34;
-
-static inline int pair_nj8(int K) {
-    const int need = (K + 7) / 8;
-    const int opts[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16};
-    for (int o : opts)
-        if (o >= need) return o;
-    return -1;
-}
-
-static size_t pair_lds_base(int K, int vld) {
-    const int Kp16 = (K + 15) & ~15;
-    const int nj8 = pair_nj8(K);
-    if (nj8 < 0) return (size_t)1 << 30;
-    const int njq = (nj8 + 3) / 4;
-    const int NTn = (K + 31) >> 5;
-    const size_t sums = (size_t)4 * K + (size_t)8 * 32 * njq;          // rsq [K][4], csw [8 waves][key slots]
-    return ((size_t)Kp16 * vld + 2 * (size_t)NTn * 32 * GP_LLD + (size_t)32 * njq * 32 + 32 * njq + 64 + sums) * sizeof(float);
-}
-// the window's d e in LDS: row r = four blocks (one per 16-lane quarter of the keys) of 8 NJQ + 4 floats -- the quarters then
-// read different banks (the plain [K][K] layout put all four on the same ones: 47 % of the kernel's wave cycles were spent
-// waiting to issue LDS instructions) and every block starts 16-byte aligned (one ds_read_b128 per four keys)
-static size_t pair_lds_de(int K) {
-    const int nj8 = pair_nj8(K);
-    if (nj8 < 0) return (size_t)1 << 30;
-    const int njq = (nj8 + 3) / 4;
-    return (size_t)K * 4 * (8 * njq + 4) * sizeof(float);
-}
-static bool pair_stages_de(int K, int vld) { return pair_lds_base(K, vld) + pair_lds_de(K) <= 160 * 1024; }
-size_t gat_bwd_pair_lds(int K, int vld, int Ep) {
-    (void)Ep;
-    return pair_lds_base(K, vld) + (pair_stages_de(K, vld) ? pair_lds_de(K) : 0);     // (too large: d e is read from memory)
-}
-
-// (from 80 keys on -- NJ8 >= 10: 32 key accumulators per lane -- the 128-register budget of two workgroups per CU spills 27 / 81
-// registers; those instantiations take the 256-register budget and one workgroup per CU)
-template <int NJ8, bool DES = true>
-__global__ __launch_bounds__(512, (NJ8 >= 10 ? 2 : 4)) void k_gat_bwd_pair(const GatBwdPairArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NJQ = (NJ8 + 3) / 4;              // 8-key blocks per 16-lane quarter
-    constexpr int KJ = 32 * NJQ;                    // key slots (>= K; slots past K carry zeros)
-    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NW = nthr >> 6;
-    const long win = blockIdx.x;
-    const int K = a.K, D = a.D, vld = a.vld, Ep = a.Ep;
-    const int Kp16 = (K + 15) & ~15;
-    const int NTn = (K + 31) >> 5;
-    float* __restrict__ Vs = smem;
-    float* __restrict__ Ls = Vs + Kp16 * vld;
-    float* __restrict__ Rs = Ls + NTn * 32 * GP_LLD;
-    float* __restrict__ NS = Rs + NTn * 32 * GP_LLD;
-    float* __restrict__ cs = NS + KJ * 32;
-    float* __restrict__ daS = cs + KJ;
-    constexpr int DBS = 8 * NJQ + 4;                // floats per quarter block of a staged d e row
-    float* __restrict__ rsq = daS + 64;             // [K][4]: sums of a d e row over each quarter's keys
-    float* __restrict__ csw = rsq + 4 * K;          // [8][KJ]: sums of a d e column over the rows of each wave
-    float* __restrict__ des = csw + 8 * KJ;         // DES: [K][4][DBS]
-    const int i = lane & 31, g = lane >> 5;
-
-    // ---- stage V (+ the ones column D: the projection bias is weight row D), d e, clear the accumulators
-    {
-        const float* __restrict__ vsrc = a.V + win * (long)(a.vt ? D : K) * a.ldv;
-        const int total = Kp16 * vld;
-        if (!a.vt) {
-            for (int u = tid; u < total; u += nthr) {
-                const int node = u / vld, col = u - node * vld;
-                float v = 0.f;
-                if (node < K && col < D) v = vsrc[(long)node * a.ldv + col];
-                Vs[u] = (node < K && col == D) ? 1.f : v;
-            }
-        } else {
-            for (int u = tid; u < total; u += nthr) {
-                const int col = u / Kp16, node = u - col * Kp16;
-                float v = 0.f;
-                if (node < K && col < D) v = vsrc[(long)col * a.ldv + node];
-                Vs[node * vld + col] = (node < K && col == D) ? 1.f : v;
-            }
-        }
-        for (int u = tid; u < 2 * NTn * 32 * GP_LLD; u += nthr) Ls[u] = 0.f;      // Ls and Rs (rows >= K stay zero)
-        for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
-        if (tid < 64) daS[tid] = 0.f;
-    }
-    // d e of the window into LDS once (coalesced reads): the pair phase walks its rows once per embedding column and
-    // 16-column pass.  Keys past K are stored as zeros (no masks in the pair loop).
-    const float* __restrict__ deg = a.DE + win * (long)K * K;
-    if constexpr (DES) {
-        for (int u = tid; u < K * 4 * (DBS - 4); u += nthr) {
-            const int r = u / (4 * (DBS - 4)), jj = u - r * 4 * (DBS - 4);       // key slot jj = 8 NJQ q + (position in the block)
-            const int q = jj / (DBS - 4), pq = jj - q * (DBS - 4);
-            des[(r * 4 + q) * DBS + pq] = jj < K ? deg[(long)r * K + jj] : 0.f;
-        }
-        __syncthreads();
-    }
-    // Sums of d e the pair phase needs per embedding column k only through L and R (both linear in them):
-    //   s1_k = sum_{r,j} d_rj (L_rk + R_jk)        = sum_r L_rk rs_r + sum_j R_jk cs_j
-    //   A_k  = sum_{r,j} d_rj max(L_rk + R_jk, 0)  = sum_r L_rk M_rk + sum_j R_jk N_jk     (M, N: the d L / d R sums of the pair phase)
-    // and d a_k = alpha s1_k + (1 - alpha) A_k: no product per pair is needed for it.  rsq: row sums per quarter of the keys (a lane
-    // owns one quarter), csw: column sums per wave (a wave owns the rows r = wave, wave + NW, ...); cs = sum over the waves.
-    auto de_at = [&](int r, int j) -> float {
-        if (j >= K) return 0.f;
-        if constexpr (DES) return des[(r * 4 + j / (DBS - 4)) * DBS + (j % (DBS - 4))];
-        else return deg[(long)r * K + j];
-    };
-    for (int u = tid; u < 4 * K; u += nthr) {
-        const int r = u >> 2, q = u & 3;
-        float sum = 0.f;
-        for (int pq = 0; pq < DBS - 4; ++pq) sum += de_at(r, q * (DBS - 4) + pq);
-        rsq[u] = sum;
-    }
-    for (int u = tid; u < 8 * KJ; u += nthr) {
-        const int w = u / KJ, j = u - w * KJ;
-        float sum = 0.f;
-        if (w < NW)
-            for (int r = w; r < K; r += NW) sum += de_at(r, j);
-        csw[u] = sum;
-    }
-    __syncthreads();
-    for (int j = tid; j < KJ; j += nthr) {           // column sums of d e
-        float sum = 0.f;
-        for (int w = 0; w < 8; ++w) sum += csw[w * KJ + j];
-        cs[j] = sum;
-    }
-    __syncthreads();
-
-    const int NTu = a.NTu, Q = a.Q;
-    const int ntask = 2 * NTn;
-    const int k16 = lane & 15, quarter = lane >> 4;
-    const int j0 = 8 * NJQ * quarter;                // this quarter's keys: [j0, j0 + 8 NJQ)
-    // the 32-column parts are independent: small batches spread them over gridDim.y workgroups per window
-    for (int part = blockIdx.y; part < NTu; part += gridDim.y) {
-        // ---- MFMA phase: L, R columns [32 part, 32 part + 32) of all nodes
-        for (int task = wave; task < ntask; task += NW) {
-            const bool keyside = task >= NTn;
-            const int nt = keyside ? task - NTn : task;
-            const int wtile = keyside ? NTu + part : part;
-            const int node = nt * 32 + i;
-            const float* __restrict__ vrow = Vs + (node < K ? node : K - 1) * vld;
-            const f32x4* __restrict__ wp = a.Wp + ((long)wtile * Q) * 64 + lane;
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-            f32x4 w = wp[0];
-            for (int q = 0; q < Q; ++q) {
-                const f32x4 wn = wp[(long)(q + 1 < Q ? q + 1 : q) * 64];
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(vrow + 8 * q + 4 * g);
-                o = mfma4(w, xv, o);
-                w = wn;
-            }
-            if (node < K) {
-                float* __restrict__ dst = (keyside ? Rs : Ls) + node * GP_LLD + 4 * g;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    f32x2 v0, v1;
-                    v0[0] = o[4 * m + 0]; v0[1] = o[4 * m + 1]; v1[0] = o[4 * m + 2]; v1[1] = o[4 * m + 3];
-                    *reinterpret_cast<f32x2*>(dst + 8 * m) = v0;
-                    *reinterpret_cast<f32x2*>(dst + 8 * m + 2) = v1;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- pair phase: two passes of 16 columns
-        for (int cp = 0; cp < 2; ++cp) {
-            const int k = 16 * cp + k16;
-            const int col = 32 * part + k;
-            const float ak = a.avec[col];
-            const float cl = ak * (1.f - a.alpha);
-            float Nacc[8 * NJQ];
-#pragma unroll
-            for (int j = 0; j < 8 * NJQ; ++j) Nacc[j] = 0.f;
-            float s1 = 0.f, s2 = 0.f;                  // this lane's share of s1_k and A_k (see above)
-            const float* __restrict__ rsp = Rs + j0 * GP_LLD + k;
-            // the keys' R values of this column do not depend on the query row: registers, not one LDS read per pair
-            float Rv[8 * NJQ];
-#pragma unroll
-            for (int j = 0; j < 8 * NJQ; ++j) Rv[j] = rsp[j * GP_LLD];
-#pragma unroll
-            for (int j = 0; j < 8 * NJQ; ++j) s1 = __builtin_fmaf(Rv[j], csw[wave * KJ + j0 + j], s1);
-            for (int r = wave; r < K; r += NW) {
-                const float L = Ls[r * GP_LLD + k];
-                // the row's d e values of this quarter's keys: its block of the staged row (aligned, conflict free, zeros past K), or
-                // -- d e not staged -- from memory (dword aligned rows; slots past K read on into the next row / region and are masked)
-                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-                f32x4 dq[2 * NJQ];
-                if constexpr (DES) {
-                    const f32x4* __restrict__ dblk = reinterpret_cast<const f32x4*>(des + (r * 4 + quarter) * DBS);
-#pragma unroll
-                    for (int jb = 0; jb < 2 * NJQ; ++jb) dq[jb] = dblk[jb];
-                } else {
-                    const float* __restrict__ drow = deg + (long)r * K + j0;
-#pragma unroll
-                    for (int jb = 0; jb < 2 * NJQ; ++jb) {
-                        const f32x4u t4 = *reinterpret_cast<const f32x4u*>(drow + 4 * jb);
-                        dq[jb] = f32x4{t4[0], t4[1], t4[2], t4[3]};
-                    }
-                }
-                float Macc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8 * NJQ; ++j) {
-                    const float dvv = dq[j >> 2][j & 3];
-                    const float d = (DES || j0 + j < K) ? dvv : 0.f;
-                    const float t = L + Rv[j];
-                    const float mm = t > 0.f ? d : 0.f;
-                    Macc += mm;
-                    Nacc[j] += mm;
-                }
-                s1 = __builtin_fmaf(L, rsq[4 * r + quarter], s1);
-                s2 = __builtin_fmaf(L, Macc, s2);          // (this lane's keys only: the quarters are summed with s2 below)
-                Macc += __shfl_xor(Macc, 16);
-                Macc += __shfl_xor(Macc, 32);
-                if (quarter == 0) a.DLR[(win * K + r) * (long)(2 * Ep) + col] = cl * Macc;
-            }
-            // the waves' partial sums into NS / daS, one wave after the other (plain read-add-write between barriers): LDS float
-            // atomics from all eight waves at once cost 5.6 of this kernel's 9.0 ms at 100 keys (~180 cycles per wave instruction);
-            // the order of the sums is fixed as well
-#pragma unroll
-            for (int j = 0; j < 8 * NJQ; ++j) s2 = __builtin_fmaf(Rv[j], Nacc[j], s2);
-            for (int wq = 0; wq < NW; ++wq) {
-                if (wave == wq) {
-#pragma unroll
-                    for (int j = 0; j < 8 * NJQ; ++j) NS[(j0 + j) * 32 + k] += Nacc[j];
-                    // s1 / s2: the four quarters of a column share daS[k]
-                    float t1 = s1, t2 = s2;
-                    t1 += __shfl_xor(t1, 16); t1 += __shfl_xor(t1, 32);
-                    t2 += __shfl_xor(t2, 16); t2 += __shfl_xor(t2, 32);
-                    if (quarter == 0) { daS[k] += t1; daS[32 + k] += t2; }
-                }
-                __syncthreads();
-            }
-        }
-        for (int u = tid; u < K * 32; u += nthr) {
-            const int j = u >> 5, kk = u & 31;
-            const int col = 32 * part + kk;
-            const float ak = a.avec[col];
-            a.DLR[(win * K + j) * (long)(2 * Ep) + Ep + col] = ak * (a.alpha * cs[j] + (1.f - a.alpha) * NS[u]);
-        }
-        if (tid < 32) {
-            const int col = 32 * part + tid;
-            a.DApart[win * Ep + col] = a.alpha * daS[tid] + (1.f - a.alpha) * daS[32 + tid];
-        }
-        __syncthreads();
-        for (int u = tid; u < KJ * 32; u += nthr) NS[u] = 0.f;
-        if (tid < 64) daS[tid] = 0.f;
-        // (the next part's MFMA phase ends in a barrier before anybody adds to NS / daS again)
-    }
-}
-
-int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s) {
-    if (a.nwin <= 0) return 0;
-    const int nj8 = pair_nj8(a.K);
-    if (nj8 < 0 || lds_bytes > 160 * 1024) return -2;
-    const unsigned grid = (unsigned)a.nwin;
-    // few windows: one workgroup per (window, group of parts) so that the launch still covers the machine twice
-    const long want = (2L * cu_count() + a.nwin - 1) / a.nwin;
-    const unsigned split = (unsigned)(want < 1 ? 1 : (want > a.NTu ? a.NTu : want));
-    const bool des = pair_stages_de(a.K, a.vld);
-#define GBP_LAUNCH(N, D)                                                                                               \
-    {                                                                                                                  \
-        if (lds_bytes > 64 * 1024) {                                                                                   \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_pair<N, D>),                  \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
-            if (e_ != hipSuccess) return (int)e_;                                                                      \
-        }                                                                                                              \
-        hipLaunchKernelGGL((k_gat_bwd_pair<N, D>), dim3(grid, split), dim3(512), lds_bytes, s, a);                     \
-    }
-#define GBP_CASE(N)                                                                                                    \
-    if (nj8 == N) {                                                                                                    \
-        if (des) GBP_LAUNCH(N, true) else if (N >= 10) GBP_LAUNCH((N >= 10 ? N : 16), false)                           \
-        else return -2;            /* (up to 64 keys the staged rows always fit) */                                    \
-    }
-    GBP_CASE(1) GBP_CASE(2) GBP_CASE(3) GBP_CASE(4) GBP_CASE(5) GBP_CASE(6) GBP_CASE(7) GBP_CASE(8) GBP_CASE(10) GBP_CASE(13) GBP_CASE(16)
-#undef GBP_CASE
-#undef GBP_LAUNCH
-    LAUNCH_CHECK();
-    return 0;
-}
+// (graph attention backward, part 2 -- the GATv2 score backward -- is k_bw_pair in mtadgat_bwdw.hip since round 6: the un-scaled
+// projections come from a row GEMM and one register-blocked pass serves fused and wide layers alike.  The per-window kernel that
+// re-projected L, R on the fp32 MFMA inside the workgroup, k_gat_bwd_pair, took 4.07 + 2.21 ms per 8 192 MSL windows against
+// 1.7 + 1.1 + 2 x 0.25 for projection GEMM + k_bw_pair, and is gone.)
 
 // ---------------------------------------------------------------------------
 // small kernels

@@ -2,7 +2,8 @@
 // mtadgat_bwd.hip keep a whole window in LDS and stop there).  Reference: FeatureAttentionLayer.forward modules.py:65-95,
 // TemporalAttentionLayer.forward modules.py:166-193 under loss.backward(), training.py:126 -- the reference trains any shape.
 //
-// Same outputs as k_gat_bwd_att + k_gat_bwd_pair, so everything downstream is shared (mtadgat_capi.cpp: the data-gradient row
+// Same outputs as the fused layers' k_gat_bwd_att (+ the score backward, which since round 6 is this file's k_bw_pair for every
+// GATv2 layer), so everything downstream is shared (mtadgat_capi.cpp: the data-gradient row
 // GEMM d V += [dL | dR] [W_l ; W_r], the weight-gradient GEMM, the batch sums of d e and d a):
 //     DE  (B, K, K)        d e_ij, the gradient of the attention scores (= of the layer's bias before the sum over windows)
 //     DV  (B*K, lddv)      the aggregation path's d V
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void k_bw_softmax(const float* __restrict__ AT
 // LeakyReLU(u) = s u is linear in (L, R) once s is fixed -- d a_k = sum_i L_ik dl_ik + sum_j R_jk dr_jk with the un-scaled sums dl, dr:
 // the pair loop is FIVE vector instructions per (i, j, k) for all three outputs (add, compare, select, two fma).
 // 32 G threads (G = 16 key groups up to 256 keys, 32 above): lane & 31 = column k, the half-waves are the key groups: group q keeps
-// R_jk and dr_jk of its JB = 4 QN <= 16 keys in registers across all rows (no transposed copy of d e, no second pass; <= 125
+// R_jk and dr_jk of its JB = ceil(K / G) <= 16 keys in registers across all rows (no transposed copy of d e, no second pass; <= 125
 // registers: four waves per SIMD).  Rows go in batches of eight: d e rows of the batch in LDS
 // (read as 16-byte broadcasts), the groups' partial dl through LDS, summed by 256 of the threads, which also take the L dl term of d a.
 // (The first version -- thread = (column, an eighth of the rows), one row at a time, three LDS reads and six instructions per pair and
@@ -179,9 +180,10 @@ struct BwPairArgs {
     long nwin;
 };
 
-template <int QN, int G>
+template <int JB, int G>
 __global__ __launch_bounds__(32 * G) void k_bw_pair(const BwPairArgs a) {
-    constexpr int JB = 4 * QN, KP = G * JB, IB = 8, NT = 32 * G;
+    constexpr int QN = (JB + 3) / 4, JBP = 4 * QN;                    // keys per group; slots of a group in a staged d e row (whole 16-byte words)
+    constexpr int KP = G * JBP, IB = 8, NT = 32 * G;
     __shared__ __attribute__((aligned(16))) float des[IB * KP];      // d e rows of the batch, zero beyond K
     __shared__ float red[G * IB * 32];                                // partial dl of the groups
     __shared__ float Lb[IB * 32];                                     // L rows of the batch (this block's 32 columns)
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(32 * G) void k_bw_pair(const BwPairArgs a) {
     const long win = blockIdx.x / nkb;
     const int kb = (int)(blockIdx.x - win * nkb);
     const int tid = threadIdx.x, k = tid & 31, q = tid >> 5;
-    const int j0 = q * JB;
+    const int j0 = q * JB;                                            // this group's keys: [j0, j0 + JB)
     const float* __restrict__ lr = a.LR + (win * K) * (long)a.ldlr + 32 * kb + k;
     const float* __restrict__ de = a.DE + win * (long)K * K;
     float* __restrict__ dlr = a.DLR + (win * K) * (long)a.ldlr + 32 * kb + k;
@@ -211,15 +213,17 @@ __global__ __launch_bounds__(32 * G) void k_bw_pair(const BwPairArgs a) {
 #pragma unroll
             for (int n = 0; n < IB * KP / NT; ++n) {
                 const int u = tid + n * NT;
-                const int r = u / KP, j = u - r * KP;
+                const int r = u / KP, sl = u - r * KP;
+                const int j = (sl / JBP) * JB + (sl % JBP);            // slot -> key (positions JB .. JBP - 1 of a group: padding)
                 const int ic = i0 + r < K ? i0 + r : K - 1, jc = j < K ? j : K - 1;
                 v[n] = de[(long)ic * K + jc];
             }
 #pragma unroll
             for (int n = 0; n < IB * KP / NT; ++n) {
                 const int u = tid + n * NT;
-                const int r = u / KP, j = u - r * KP;
-                des[u] = (i0 + r < K && j < K) ? v[n] : 0.f;
+                const int r = u / KP, sl = u - r * KP;
+                const int j = (sl / JBP) * JB + (sl % JBP);
+                des[u] = (i0 + r < K && sl % JBP < JB && j < K) ? v[n] : 0.f;
             }
         }
         if (tid < IB * 32) Lb[tid] = lr[(long)(i0 + (tid >> 5) < K ? i0 + (tid >> 5) : K - 1) * a.ldlr];      // (lr carries this thread's column k)
@@ -230,14 +234,15 @@ __global__ __launch_bounds__(32 * G) void k_bw_pair(const BwPairArgs a) {
             float dl = 0.f;
 #pragma unroll
             for (int qd = 0; qd < QN; ++qd) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(&des[r * KP + j0 + 4 * qd]);        // (one address per half-wave: broadcast)
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(&des[r * KP + q * JBP + 4 * qd]);   // (one address per half-wave: broadcast)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u = lv + R[4 * qd + e];
-                    const float sl = u > 0.f ? 1.f : alpha;
-                    dl = __builtin_fmaf(g4[e], sl, dl);
-                    dr[4 * qd + e] = __builtin_fmaf(g4[e], sl, dr[4 * qd + e]);
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (4 * qd + e < JB) {
+                        const float u = lv + R[4 * qd + e];
+                        const float sl = u > 0.f ? 1.f : alpha;
+                        dl = __builtin_fmaf(g4[e], sl, dl);
+                        dr[4 * qd + e] = __builtin_fmaf(g4[e], sl, dr[4 * qd + e]);
+                    }
             }
             red[(q * IB + r) * 32 + k] = dl;
         }
@@ -382,17 +387,18 @@ int launch_bw_pair(const float* LR, int ldlr, int Ep, const float* avec, const f
     a.LR = LR; a.ldlr = ldlr; a.Ep = Ep; a.avec = avec; a.DE = DE; a.K = K; a.alpha = alpha; a.DLR = DLR; a.DAp = DAp; a.nwin = nwin;
     const long blocks = nwin * (Ep / 32);
     if (blocks > 0x7fffffffL) return -2;
-    if (K <= 256) {                                        // 16 key groups x 4 qn keys >= K
-        switch ((K + 63) / 64) {
+    if (K <= 256) {                                        // 16 key groups x jb keys >= K
+        switch ((K + 15) / 16) {
 #define BWP_CASE(N) case N: hipLaunchKernelGGL((k_bw_pair<N, 16>), dim3((unsigned)blocks), dim3(512), 0, s, a); break;
-            BWP_CASE(1) BWP_CASE(2) BWP_CASE(3) BWP_CASE(4)
+            BWP_CASE(1) BWP_CASE(2) BWP_CASE(3) BWP_CASE(4) BWP_CASE(5) BWP_CASE(6) BWP_CASE(7) BWP_CASE(8)
+            BWP_CASE(9) BWP_CASE(10) BWP_CASE(11) BWP_CASE(12) BWP_CASE(13) BWP_CASE(14) BWP_CASE(15) BWP_CASE(16)
 #undef BWP_CASE
             default: return -2;
         }
     } else {                                               // 32 key groups
-        switch ((K + 127) / 128) {
+        switch ((K + 31) / 32) {
 #define BWP_CASE(N) case N: hipLaunchKernelGGL((k_bw_pair<N, 32>), dim3((unsigned)blocks), dim3(1024), 0, s, a); break;
-            BWP_CASE(3) BWP_CASE(4)
+            BWP_CASE(9) BWP_CASE(10) BWP_CASE(11) BWP_CASE(12) BWP_CASE(13) BWP_CASE(14) BWP_CASE(15) BWP_CASE(16)
 #undef BWP_CASE
             default: return -2;
         }

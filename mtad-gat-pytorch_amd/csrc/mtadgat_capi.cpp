@@ -991,6 +991,8 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
         for (const LinTPlan& p : m.bw.fcT) add(p.w3_off, (size_t)p.NT * p.Q16 * 3 * 256);
         add(m.bw.recfcT.w3_off, (size_t)m.bw.recfcT.NT * m.bw.recfcT.Q16 * 3 * 256);
         for (int k = 0; k < 2; ++k) add(m.bw.gat[k].lrT.w3_off, (size_t)m.bw.gat[k].lrT.NT * m.bw.gat[k].lrT.Q16 * 3 * 256);
+        for (int k = 0; k < 2; ++k)
+            if (m.bw.gat[k].wu3_off) add(m.bw.gat[k].wu3_off, (size_t)2 * m.bw.gat[k].NTu * (((k == 0 ? m.feat : m.temp).Q + 1) / 2) * 3 * 256);
     }
     for (const GruPlan& g : m.gru)
         if (g.has_xproj && g.xproj.w3_off) add(g.xproj.w3_off, (size_t)g.xproj.NT * g.xproj.Q16 * 3 * 256);
@@ -1528,6 +1530,28 @@ int run_rowgemm_T(Model& m, const LinTPlan& p, const float* X, long ldx, long R,
     return 0;
 }
 
+// the un-scaled projections [L | R] = V [W_l ; W_r]^T + [b | 0] of the node rows (GATv2 score backward): one row GEMM over the backward
+// plan's pack, on three bf16 pieces per operand from 65 536 rows (as the data-gradient GEMMs; the pack is split on first use after an upload)
+int run_bwd_projection(Model& m, const GatPlan& gp, const GatBwdPlan& gb, const float* Vn, long ldv, long rows, float* LR, hipStream_t s) {
+    RowGemmArgs r{};
+    r.X = Vn; r.ldx = ldv; r.Kvalid = gp.D; r.Q = gp.Q;
+    r.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + gb.wu_off);
+    r.bias = m.packed_dev + gb.bu_off;
+    r.Y = LR; r.ldy = 2L * gb.Ep; r.Nvalid = 2 * gb.Ep; r.vec_store = 1;
+    r.R = rows; r.NT = 2 * gb.NTu; r.NT_rm = 2 * gb.NTu; r.group = 1; r.relu = 0;
+    if (gb.wu3_off && ((m.precision == 2 && m.rowgemm_kernel != 1 && rows >= 65536) || m.rowgemm_kernel == 2)) {
+        const int Q16 = (gp.Q + 1) / 2;
+        if (gb.wu3_version != m.weights_version) {
+            K_TRY(launch_split3(m.packed_dev + gb.wu_off, m.packed_dev + gb.wu3_off, 2 * gb.NTu, gp.Q, Q16, 1, nullptr, s), "split-bf16 projection weights (backward)");
+            gb.wu3_version = m.weights_version;
+        }
+        r.x3 = 1; r.Q16 = Q16;
+        r.Wp3 = reinterpret_cast<const f32x4*>(m.packed_dev + gb.wu3_off);
+    }
+    K_TRY(launch_rowgemm(r, s), "attention backward (projection)");
+    return 0;
+}
+
 struct WgradIn {
     const float* A = nullptr; long lda = 0;
     const float* B = nullptr; long ldb = 0; int bmode = 0; int bshift = 0;
@@ -1910,15 +1934,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
                 continue;
             }
             // un-scaled projections [L | R] of the node rows, then the score backward
-            {
-                RowGemmArgs r{};
-                r.X = Vn; r.ldx = ldv; r.Kvalid = D; r.Q = gp.Q;
-                r.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + gb.wu_off);
-                r.bias = m.packed_dev + gb.bu_off;
-                r.Y = LR; r.ldy = 2L * Ep; r.Nvalid = 2 * Ep; r.vec_store = 1;
-                r.R = (long)n * K; r.NT = 2 * gb.NTu; r.NT_rm = 2 * gb.NTu; r.group = 1; r.relu = 0;
-                K_TRY(launch_rowgemm(r, s), "attention backward (projection)");
-            }
+            if ((rc = run_bwd_projection(m, gp, gb, Vn, ldv, (long)n * K, LR, s))) return rc;
             K_TRY(launch_bw_pair(LR, 2 * Ep, Ep, m.packed_dev + gb.a_off, de, K, m.cfg.alpha, dlr, dap, n, s), "attention backward (pairs)");
             const long RK = (long)n * K;
             if ((rc = run_rowgemm_T(m, gb.lrT, dlr, 2L * Ep, RK, dv, lddv, gp.D, true, nullptr, 0, 1.f, s))) return rc;
@@ -1954,13 +1970,13 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
             K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
             continue;
         }
-        GatBwdPairArgs pa{};
-        pa.V = hcat; pa.ldv = m.Dp; pa.D = gp.D; pa.K = K; pa.vt = aa.vt; pa.vld = gp.f_vld;
-        pa.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + gb.wu_off);
-        pa.NTu = gb.NTu; pa.Q = gp.Q; pa.E = gp.E; pa.Ep = gb.Ep;
-        pa.avec = m.packed_dev + gb.a_off;
-        pa.DE = de; pa.DLR = dlr; pa.DApart = dap; pa.nwin = n; pa.alpha = m.cfg.alpha;
-        K_TRY(launch_gat_bwd_pair(pa, gb.pair_lds, s), "attention backward (pairs)");
+        // round 6: the un-scaled projections [L | R] of the node rows as one row GEMM, then the one-pass score backward (k_bw_pair,
+        // mtadgat_bwdw.hip) -- for fused layers too: the per-window kernel that re-projected L, R inside the workgroup is gone
+        {
+            float* LR = ws + w.wlr;
+            if ((rc = run_bwd_projection(m, gp, gb, which == 0 ? T + t.xct : hcat, which == 0 ? m.Wp : m.Dp, (long)n * K, LR, s))) return rc;
+            K_TRY(launch_bw_pair(LR, 2 * gb.Ep, gb.Ep, m.packed_dev + gb.a_off, de, K, m.cfg.alpha, dlr, dap, n, s), "attention backward (pairs)");
+        }
         const long RK = (long)n * K;
         if ((rc = run_rowgemm_T(m, gb.lrT, dlr, 2L * gb.Ep, RK, dv, lddv, gp.D, true, nullptr, 0, 1.f, s))) return rc;
         WgradIn in;

@@ -114,6 +114,8 @@ struct WgradPlan {
 struct GatBwdPlan {
     int Ep = 0, NTu = 0;            // E rounded up to 32, tiles per side
     size_t wu_off = 0;              // un-scaled projection tiles [2*NTu][Q][64]
+    size_t wu3_off = 0;             // ... as three bf16 pieces [2*NTu][(Q + 1) / 2][3][64], derived on first use after an upload (k_rowgemm_x3, GATv2)
+    mutable uint64_t wu3_version = 0;
     size_t a_off = 0;               // a (Ep floats, zero padded)
     LinTPlan lrT;                   // d V += [dL | dR] [W_l ; W_r]
     WgradPlan wg;                   // lin.weight / lin.bias

@@ -175,21 +175,6 @@ struct GatBwdAttArgs {
     unsigned drop_stream;
 };
 
-// part 2 (per window, GATv2): from d e_ij to the gradients of the projected L, R (written per node for the
-// weight-gradient GEMM and the d V rowgemm) and of `a` (per-window partials)
-struct GatBwdPairArgs {
-    const float* V;
-    int ldv, D, K, vt, vld;
-    const f32x4* Wp;     // un-scaled projection tiles [2*NTu][Q][64]: query-side tiles (bias = weight row D) then key-side
-    int NTu, Q, E, Ep;   // Ep = 32*NTu
-    const float* avec;   // a (E, zero padded to Ep)
-    const float* DE;     // (B, K, K)
-    float* DLR;          // (B*K, 2*Ep): [dL | dR]
-    float* DApart;       // (B, Ep): this window's share of d a
-    long nwin;
-    float alpha;
-};
-
 struct GruBwdArgs {
     const float* Gates;  // (B*T, 4*Hp): r | z | n | q (= W_hn h + b_hn) kept by the forward
     const float* Seq;    // (B*T, Hp): h_t
@@ -413,9 +398,7 @@ int launch_gru16_bwd(const Gru16BwdArgs& a, hipStream_t s);
 int launch_xproj_dec(const float* hend, long ldh, int Hin, const float* fold, const int* m0, const float* bias, int Hp, int T, long B,
                      float* XP, hipStream_t s);
 int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s);
-int launch_gat_bwd_pair(const GatBwdPairArgs& a, size_t lds_bytes, hipStream_t s);
 size_t gat_bwd_att_lds(int K, int D, int vld, int nwa);
-size_t gat_bwd_pair_lds(int K, int vld, int Ep);
 int launch_wgrad(const WgradArgs& a, hipStream_t s);
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s);
 // dst[n] += sum_r src[r*ld + n]  (n < N), two-stage through `scratch` (>= sum_rows_scratch(R, N) floats)

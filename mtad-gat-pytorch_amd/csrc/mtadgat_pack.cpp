@@ -381,6 +381,7 @@ std::string validate_and_plan(Model& m) {
                 }
                 if (gb.wide) {
                     gb.wu_off = take((size_t)2 * gb.NTu * g.Q * 256);
+                    gb.wu3_off = take((size_t)2 * gb.NTu * ((g.Q + 1) / 2) * 3 * 256);
                     gb.bu_off = take((size_t)2 * gb.Ep);
                     gb.a_off = take((size_t)gb.Ep);
                     lint(gb.lrT, 2 * gb.Ep, g.D);
@@ -398,11 +399,12 @@ std::string validate_and_plan(Model& m) {
                     continue;
                 }
                 gb.wu_off = take((size_t)2 * gb.NTu * g.Q * 256);
+                gb.wu3_off = take((size_t)2 * gb.NTu * ((g.Q + 1) / 2) * 3 * 256);
+                gb.bu_off = take((size_t)2 * gb.Ep);         // (round 6: the score backward's projections are a row GEMM here too)
                 gb.a_off = take((size_t)gb.Ep);
                 lint(gb.lrT, 2 * gb.Ep, g.D);
                 wg(gb.wg, 2 * gb.Ep, g.D, true);
-                gb.pair_lds = gat_bwd_pair_lds(g.K, g.f_vld, gb.Ep);
-                if (gb.att_lds > 160 * 1024 || gb.pair_lds > 160 * 1024) { b.supported = false; b.why = "attention backward tiles exceed the LDS"; }
+                if (gb.att_lds > 160 * 1024) { b.supported = false; b.why = "attention backward tiles exceed the LDS"; }
             }
             auto gru_b = [&](GruBwdPlan& gb, const GruPlan& g) {
                 gb.whT_off = take((size_t)g.NCG * 12 * g.NCG * 256);
@@ -582,9 +584,11 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
         size_t ds = 0, lr = 0;
         for (int which = 0; which < 2; ++which) {
             const GatPlan& gp = which == 0 ? m.feat : m.temp;
+            // (round 6: the un-scaled projections [L | R] go through memory for EVERY GATv2 layer -- the one-pass score backward
+            // k_bw_pair serves the fused layers too)
+            if (m.cfg.use_gatv2 || b.gat[which].wide) lr = std::max(lr, N * gp.K * 2 * (size_t)b.gat[which].Ep);
             if (!b.gat[which].wide) continue;
             ds = std::max(ds, N * gp.K * (size_t)round_up(gp.D, 4));
-            lr = std::max(lr, N * gp.K * 2 * (size_t)b.gat[which].Ep);
         }
         w.wds = take(ds); w.wlr = take(lr);          // (no transposed copy of d e since round 6: the score backward is one pass)
     }
@@ -889,8 +893,7 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
                 return (k == D && side == 0) ? lb[e] : 0.f;
             });
             for (int e = 0; e < E; ++e) out[gb.a_off + e] = av[e];
-            if (gb.wide)       // (the row GEMM takes the projection bias as a vector: a wide D leaves no spare weight row for it)
-                for (int e = 0; e < E; ++e) out[gb.bu_off + e] = lb[e];
+            for (int e = 0; e < E; ++e) out[gb.bu_off + e] = lb[e];      // (the row GEMM takes the projection bias as a vector)
             pack_tiles(out.data() + gb.lrT.w_off, gb.lrT.NT, gb.lrT.Q, [&](int n, int k) -> float {
                 const int side = k / Ep, e = k % Ep;
                 return (n < D && e < E && side < 2) ? lw[(size_t)e * 2 * D + (size_t)side * D + n] : 0.f;
