@@ -524,46 +524,43 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
     float* __restrict__ atts = dVacc + Kp16 * vld;
     const int lj = lane % RJ, li = lane / RJ;
 
-    // ---- stage V, d S (zero padded), clear the d V accumulators
+    // ---- stage V, d S (zero padded), clear the d V accumulators.  Unconditional loads from clamped addresses in batches of eight,
+    // every load of a batch issued before its first LDS store (round 6).  The first version guarded each load (`in range ? src[..] : 0`):
+    // a branch with s_waitcnt vmcnt(0) at the join per element, i.e. 13 + 13 serial memory round trips per window at the MSL shape.
     {
         const float* __restrict__ vsrc = a.V + win * (long)(a.vt ? D : K) * a.ldv;
-        const int total = Kp16 * vld;
-        if (!a.vt) {
-            for (int u = tid; u < total; u += nthr) {
-                const int node = u / vld, col = u - node * vld;
-                Vs[u] = (node < K && col < D) ? vsrc[(long)node * a.ldv + col] : 0.f;
-                dVacc[u] = 0.f;
-            }
-        } else {
-            for (int u = tid; u < total; u += nthr) {            // node fastest: coalesced reads of the transposed source
-                const int col = u / Kp16, node = u - col * Kp16;
-                Vs[node * vld + col] = (node < K && col < D) ? vsrc[(long)col * a.ldv + node] : 0.f;
-                dVacc[node * vld + col] = 0.f;
-            }
-        }
         const float* __restrict__ hsrc = a.H + win * a.so_w;
         const float* __restrict__ dsrc = a.dH + win * a.so_w;
-        if (a.so_d == 1) {
-            for (int u = tid; u < total; u += nthr) {
-                const int node = u / vld, col = u - node * vld;
-                float v = 0.f;
-                if (node < K && col < D) {
-                    const long o = (long)node * a.so_i + col;
-                    const float h = hsrc[o];
-                    v = dsrc[o] * h * (1.f - h);
-                }
-                dSs[u] = v;
+        const int total = Kp16 * vld;
+        const bool vfast = a.vt != 0, sfast = a.so_d != 1;       // the element order that walks the unit stride of each source
+        constexpr int MAXU = 8;
+        for (int base = 0; base < total; base += MAXU * nthr) {
+            float vv[MAXU], hv[MAXU], dv[MAXU];
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n) {
+                const int u = base + tid + n * nthr;
+                const int uc = u < total ? u : total - 1;
+                int node, col;
+                if (vfast) { col = uc / Kp16; node = uc - col * Kp16; } else { node = uc / vld; col = uc - node * vld; }
+                const int nc = node < K ? node : K - 1, cc = col < D ? col : D - 1;
+                vv[n] = vsrc[vfast ? (long)cc * a.ldv + nc : (long)nc * a.ldv + cc];       // (ONE load from a selected address: two loads behind a select are a branch)
+                if (sfast) { col = uc / Kp16; node = uc - col * Kp16; } else { node = uc / vld; col = uc - node * vld; }
+                const int n2 = node < K ? node : K - 1, c2 = col < D ? col : D - 1;
+                const long o = (long)n2 * a.so_i + (long)c2 * a.so_d;
+                hv[n] = hsrc[o];
+                dv[n] = dsrc[o];
             }
-        } else {
-            for (int u = tid; u < total; u += nthr) {
-                const int col = u / Kp16, node = u - col * Kp16;
-                float v = 0.f;
-                if (node < K && col < D) {
-                    const long o = (long)node * a.so_i + (long)col * a.so_d;
-                    const float h = hsrc[o];
-                    v = dsrc[o] * h * (1.f - h);
+#pragma unroll
+            for (int n = 0; n < MAXU; ++n) {
+                const int u = base + tid + n * nthr;
+                if (u < total) {
+                    int node, col;
+                    if (vfast) { col = u / Kp16; node = u - col * Kp16; } else { node = u / vld; col = u - node * vld; }
+                    Vs[node * vld + col] = (node < K && col < D) ? vv[n] : 0.f;
+                    dVacc[node * vld + col] = 0.f;
+                    if (sfast) { col = u / Kp16; node = u - col * Kp16; } else { node = u / vld; col = u - node * vld; }
+                    dSs[node * vld + col] = (node < K && col < D) ? dv[n] * hv[n] * (1.f - hv[n]) : 0.f;
                 }
-                dSs[node * vld + col] = v;
             }
         }
     }
@@ -614,7 +611,8 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
                 const int j = lj + RJ * jj;
                 const int jc = j < K ? j : K - 1;
                 const bool valid = irow < K && j < K;
-                const float av = valid ? ap[jc] : 0.f;
+                const float avl = ap[jc];                  // (unconditional from the clamped address: the row's loads go out together)
+                const float av = valid ? avl : 0.f;
                 float sc = 1.f;
                 if (a.drop.thresh) sc = drop_keep(key, (unsigned)(irc * K + jc), a.drop.thresh) ? a.drop.keep_scale : 0.f;
                 const float datt = acc[ii][jj] * sc;
