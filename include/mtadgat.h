@@ -276,10 +276,11 @@ int mtadgat_heads(mtadgat_handle h, const float* hend_dev, int64_t batch,
  * Gradients are ACCUMULATED (+=) into `grads_dev`, a flat float32 buffer of mtadgat_grad_floats()
  * entries holding the reference's parameters' gradients in their own shapes, in the field order of
  * mtadgat_params (offsets: mtadgat_grad_offsets); zero it before the first chunk of a step.
- * Not every configuration has a HIP backward (mtadgat_backward_supported: GATv2 and GAT (v1), any number of stacked
- * GRU / decoder layers; attention layers with more than 128 nodes or features -- up to 512, GATv2 -- run the generic kernels of
- * csrc/mtadgat_bwdw.hip with every matrix through memory; GAT (v1) layers of that size and layers beyond 512 do not).  `batch` windows are processed as one
- * chunk: tape and workspace grow linearly with it (~0.85 + 0.75 MB per window at W=100, F=55). */
+ * Every configuration the forward accepts has a HIP backward (mtadgat_backward_supported: GATv2 and GAT (v1), any number of stacked
+ * GRU / decoder layers; attention layers with more than 128 nodes or features -- up to 512 -- run the kernels of
+ * csrc/mtadgat_bwdw.hip with every matrix through memory; the GATv2 score backward of ALL layers is that file's one-pass k_bw_pair
+ * behind a projection row GEMM since round 6).  `batch` windows are processed as one
+ * chunk: tape and workspace grow linearly with it (~0.85 + 0.85 MB per window at W=100, F=55). */
 int     mtadgat_backward_supported(mtadgat_handle h);
 size_t  mtadgat_tape_bytes(mtadgat_handle h, int64_t batch);
 size_t  mtadgat_backward_workspace_bytes(mtadgat_handle h, int64_t batch);
