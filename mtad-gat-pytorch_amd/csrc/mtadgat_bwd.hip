@@ -488,12 +488,13 @@ int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
 //     d e_ij = att_ij (d att_ij - sum_j att_ij d att_ij)              -> DE   (also d bias before the batch sum)
 //     d V_j (aggregation path) = sum_i att'_ij d S_i                     -> DV   (MFMA 16x16x4 + LDS float atomics)
 // ---------------------------------------------------------------------------
-constexpr int GB_APITCH = 68;
 
+// LDS: d S [Kp16][vld] | { V [Kp16][vld] (d att phase)  /  att'^T [Kp16 keys][Kp16 + 4 rows] (d V phase) }
 size_t gat_bwd_att_lds(int K, int D, int vld, int nwa) {
-    (void)D;
+    (void)D; (void)nwa;
     const int Kp16 = (K + 15) & ~15;
-    return ((size_t)3 * Kp16 * vld + (size_t)nwa * 16 * GB_APITCH) * sizeof(float);
+    const size_t v = (size_t)Kp16 * vld, t = (size_t)Kp16 * (Kp16 + 4);
+    return (v + (v > t ? v : t)) * sizeof(float);
 }
 
 template <int RJ>
@@ -505,8 +506,7 @@ __device__ __forceinline__ float bw_row_sum(float v) {
     return v;
 }
 
-// DTM: 16-feature blocks of d V a wave keeps per 64-key pass (4: D <= 64, 8: D <= 128)
-template <int IBL, int JPL, int RJ, int DTM = 8>
+template <int IBL, int JPL, int RJ>
 __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RI = 64 / RJ;
@@ -518,13 +518,13 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
     const int K = a.K, D = a.D, vld = a.vld;
     const int Kp16 = (K + 15) & ~15;
     const int NWA = Kp16 >> 4;
-    float* __restrict__ Vs = smem;
-    float* __restrict__ dSs = Vs + Kp16 * vld;
-    float* __restrict__ dVacc = dSs + Kp16 * vld;
-    float* __restrict__ atts = dVacc + Kp16 * vld;
+    float* __restrict__ dSs = smem;
+    float* __restrict__ Vs = dSs + Kp16 * vld;           // d att phase
+    float* __restrict__ attT = Vs;                        // d V phase (aliases V: a barrier separates the phases)
+    const int AP = Kp16 + 4;                              // pitch of an att'^T row (one key, the query rows)
     const int lj = lane % RJ, li = lane / RJ;
 
-    // ---- stage V, d S (zero padded), clear the d V accumulators.  Unconditional loads from clamped addresses in batches of eight,
+    // ---- stage V, d S (zero padded).  Unconditional loads from clamped addresses in batches of eight,
     // every load of a batch issued before its first LDS store (round 6).  The first version guarded each load (`in range ? src[..] : 0`):
     // a branch with s_waitcnt vmcnt(0) at the join per element, i.e. 13 + 13 serial memory round trips per window at the MSL shape.
     {
@@ -557,7 +557,6 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
                     int node, col;
                     if (vfast) { col = u / Kp16; node = u - col * Kp16; } else { node = u / vld; col = u - node * vld; }
                     Vs[node * vld + col] = (node < K && col < D) ? vv[n] : 0.f;
-                    dVacc[node * vld + col] = 0.f;
                     if (sfast) { col = u / Kp16; node = u - col * Kp16; } else { node = u / vld; col = u - node * vld; }
                     dSs[node * vld + col] = (node < K && col < D) ? dv[n] * hv[n] * (1.f - hv[n]) : 0.f;
                 }
@@ -630,96 +629,71 @@ __global__ __launch_bounds__(512) void k_gat_bwd_att(const GatBwdAttArgs a) {
             }
         }
     }
-    // ---- d V (aggregation path): out[key][feature] += sum over a wave's 16 rows att'[row][key] d S[row][feature]
-    //   v_mfma_f32_16x16x4_f32: A[m = key][k = row], B[k = row][n = feature]; lane (nr = lane & 15, kb = lane >> 4)
-    //   holds A[nr][kb], B[kb][nr] of rows 4 s + kb for instruction s; D register q of lane (nr, kb) = out[4 kb + q][nr]
-    // A wave keeps its 16 x 16 blocks of a 64-key pass in registers; the waves then add them into dVacc one after the other
-    // (plain read-add-write between barriers: LDS float atomics from all waves at once cost ~180 cycles per wave instruction,
-    // most of this kernel's time; the order of the sums is fixed as well).
+    // ---- d V (aggregation path): d V[key][feature] = sum over ALL query rows att'[row][key] d S[row][feature]  (round 6).
+    // The waves' att' rows go through LDS transposed (att'^T over the V tile, which is dead now); then a wave owns 16 KEYS and
+    // contracts over every row on v_mfma_f32_16x16x4_f32 -- A[m = key][k], B[k][n = feature], the contraction index of lane
+    // group kb running over rows kb Kp16/4 + s so that a lane's A words are contiguous (16-byte reads, kept across the feature
+    // tiles) -- and writes its block of d V straight to memory.  Before: a wave contracted over ITS 16 rows only and the waves
+    // added their partial [K][D] blocks into an LDS accumulator one after the other (2 x 7 barrier-separated steps per window),
+    // with 111 KB of LDS per workgroup (one per CU; now 79 KB at the MSL temporal layer, 53 KB at the feature layer: two / three).
+    __syncthreads();                                       // every wave is done with V
+    if (rows_owner) {
+#pragma unroll
+        for (int ii = 0; ii < IBL; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < JPL; ++jj) {
+                const int j = lj + RJ * jj;
+                if (j < Kp16) attT[j * AP + i0 + li + RI * ii] = acc[ii][jj];        // (rows / keys past K carry zeros)
+            }
+    }
+    __syncthreads();
     {
-        float* __restrict__ att = atts + (rows_owner ? wave : 0) * (IBW * GB_APITCH);
         const int nr = lane & 15, kb = lane >> 4;
-        constexpr int JPP = 64 / RJ;
-        constexpr int PASSES = (JPL + JPP - 1) / JPP;
+        const int NW = nthr >> 6, NKT = Kp16 >> 4, S4 = Kp16 >> 4;       // S4: 16-byte words of a lane's share of an att'^T row (Kp16 / 4 rows)
         const int DT = (D + 15) >> 4;
+        const int rbase = kb * (Kp16 >> 2);                // this lane group's rows: rbase + s, s < Kp16 / 4
+        for (int kt = wave; kt < NKT; kt += NW) {
+            constexpr int S4M = 8;                         // K <= 128
+            f32x4 aw[S4M];
+            const f32x4* __restrict__ ap4 = reinterpret_cast<const f32x4*>(attT + (16 * kt + nr) * AP + rbase);
 #pragma unroll
-        for (int pass = 0; pass < PASSES; ++pass) {
-            if (pass * 64 < K) {                           // (uniform over the workgroup)
-                const int jn = min(64, Kp16 - pass * 64);
-                f32x4 oacc[4][DTM];
-                if (rows_owner) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
+            for (int w4 = 0; w4 < S4M; ++w4)
+                if (w4 < S4) aw[w4] = ap4[w4];
+            for (int dt = 0; dt < DT; ++dt) {
+                const int dcol = 16 * dt + nr;
+                const float* __restrict__ bp = dSs + rbase * vld + (dcol < vld ? dcol : vld - 1);
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ii = 0; ii < IBL; ++ii)
+                for (int w4 = 0; w4 < S4M; ++w4)
+                    if (w4 < S4) {
+                        float bv[4];
 #pragma unroll
-                        for (int j4 = 0; j4 < JPP; ++j4)   // every column of the pass (stale LDS contents must not reach the MFMA)
-                            att[(li + RI * ii) * GB_APITCH + lj + RJ * j4] = (JPP * pass + j4 < JPL) ? acc[ii][(JPP * pass + j4 < JPL) ? JPP * pass + j4 : 0] : 0.f;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
+                        for (int e = 0; e < 4; ++e) bv[e] = bp[(4 * w4 + e) * vld];
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        if (jt < (jn >> 4)) {
-                            float av[4];
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) av[s] = att[(4 * s + kb) * GB_APITCH + 16 * jt + nr];
-#pragma unroll
-                            for (int dt = 0; dt < DTM; ++dt) {
-                                if (dt < DT) {
-                                    const int dcol = 16 * dt + nr;
-                                    const int dcc = dcol < vld ? dcol : vld - 1;
-                                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                    for (int s = 0; s < 4; ++s) {
-                                        const float bv = dSs[(i0 + 4 * s + kb) * vld + dcc];
-                                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, o, 0, 0, 0);
-                                    }
-                                    oacc[jt][dt] = o;
-                                }
-                            }
-                        }
+                        for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[w4][e], bv[e], o, 0, 0, 0);
                     }
-                }
-                for (int wq = 0; wq < NWA; ++wq) {
-                    if (wave == wq) {
+                // D register q of lane (nr, kb) = out[key 4 kb + q][feature nr] of the block
+                if (dcol < D) {
 #pragma unroll
-                        for (int jt = 0; jt < 4; ++jt)
-                            if (jt < (jn >> 4)) {
-#pragma unroll
-                                for (int dt = 0; dt < DTM; ++dt) {
-                                    const int dcol = 16 * dt + nr;
-                                    if (dt < DT && dcol < D) {
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q) dVacc[(pass * 64 + 16 * jt + 4 * kb + q) * vld + dcol] += oacc[jt][dt][q];
-                                    }
-                                }
-                            }
+                    for (int q = 0; q < 4; ++q) {
+                        const int key = 16 * kt + 4 * kb + q;
+                        if (key < K) a.DV[(win * K + key) * (long)a.lddv + dcol] = o[q];
                     }
-                    __syncthreads();
                 }
             }
         }
     }
-    __syncthreads();
-    for (int u = tid; u < K * D; u += nthr) {
-        const int node = u / D, col = u - node * D;
-        a.DV[(win * K + node) * (long)a.lddv + col] = dVacc[node * vld + col];
-    }
 }
 
-#define GBA_LAUNCH(I, J, RJ_, DT_)                                                                              \
-    {                                                                                                            \
+#define GBA_CASE(I, J, RJ_)                                                                                      \
+    if (IBL == I && JPL == J && rj == RJ_) {                                                                     \
         if (lds_bytes > 64 * 1024) {                                                                             \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_att<I, J, RJ_, DT_>),   \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gat_bwd_att<I, J, RJ_>),        \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);     \
             if (e_ != hipSuccess) return (int)e_;                                                                \
         }                                                                                                        \
-        hipLaunchKernelGGL((k_gat_bwd_att<I, J, RJ_, DT_>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);         \
+        hipLaunchKernelGGL((k_gat_bwd_att<I, J, RJ_>), dim3(grid), dim3(64 * nw), lds_bytes, s, a);              \
         launched = true;                                                                                         \
-    }
-#define GBA_CASE(I, J, RJ_)                                                                                      \
-    if (IBL == I && JPL == J && rj == RJ_) {                                                                     \
-        if (a.D <= 64) GBA_LAUNCH(I, J, RJ_, 4) else GBA_LAUNCH(I, J, RJ_, 8)                                    \
     }
 
 int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw, size_t lds_bytes, hipStream_t s) {
