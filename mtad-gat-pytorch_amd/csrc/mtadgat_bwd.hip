@@ -354,10 +354,14 @@ int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, fl
 // ---------------------------------------------------------------------------
 // (Rounds 2-5 carried a bf16-operand build of the transposed recurrent product as an opt-in "bf16 training step"; it lost to this
 // fp32 step at every batch size -- 7.98 vs 2.32 ms at 256 windows, 33.9 vs 28.5 at 8 192 -- and is gone: a bf16 request trains here.)
+// X3 (round 6, the default arithmetic): the transposed recurrent product on three bf16 pieces per operand (mfma_s3: six
+// v_mfma_f32_32x32x16_bf16 per 16 features instead of eight v_mfma_f32_32x32x2_f32 -- 2.7x less matrix time, fp32-class results;
+// the gradient blocks are split where they are published, the weights once per upload: whT3).
+template <bool X3>
 __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
     constexpr bool BF = false;
     extern __shared__ __attribute__((aligned(16))) float gsm[];
-    f32x4* __restrict__ das = reinterpret_cast<f32x4*>(gsm);          // fp32: [3][NCG][4][64] float4; bf16: [3][NCG][2][64] containers
+    f32x4* __restrict__ das = reinterpret_cast<f32x4*>(gsm);          // fp32: [3][NCG][4][64] float4; X3: [3][NCG][2][3 pieces][64] containers
     const int lane = threadIdx.x & 63;
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NCG = a.NCG;
@@ -365,10 +369,11 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
     const long win = (long)blockIdx.x * 32 + i;
     const long winc = win < a.B ? win : a.B - 1;
     const int T = a.T, Hp = a.Hp;
-    constexpr int CPT = BF ? 2 : 4;                                   // chunks per 32-unit tile
-    constexpr int RING = BF ? 3 : 4;
+    constexpr int CPT = (BF || X3) ? 2 : 4;                           // chunks per 32-unit tile
+    constexpr int RING = X3 ? 6 : (BF ? 3 : 4);                       // chunks in flight (a divisor of NQ = 3 CPT NCG)
+    constexpr int WPC = X3 ? 3 : 1;                                   // 16-byte words per weight chunk and lane
     const int NQ = 3 * CPT * NCG;
-    const f32x4* __restrict__ W = a.WhT + (long)c * NQ * 64 + lane;
+    const f32x4* __restrict__ W = a.WhT + (long)c * NQ * (64 * WPC) + lane;
     const int col0 = 32 * c + 4 * g;
 
     f32x16 dh;
@@ -383,9 +388,11 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
             for (int s4 = 0; s4 < 4; ++s4) dh[4 * m + s4] = v[s4];
         }
     }
-    f32x4 wr[RING];
+    f32x4 wr[RING][WPC];
 #pragma unroll
-    for (int u = 0; u < RING; ++u) wr[u] = W[u * 64];
+    for (int u = 0; u < RING; ++u)
+#pragma unroll
+        for (int pc = 0; pc < WPC; ++pc) wr[u][pc] = W[(u * WPC + pc) * 64];
 
     for (int t = T - 1; t >= 0; --t) {
         const long row = winc * T + t;
@@ -435,7 +442,19 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
                 *reinterpret_cast<f32x4*>(op + 3 * Hp + 8 * m) = dnh4[m];
             }
         }
-        if (BF) {
+        if (X3) {
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                f32x4 p3[3][3];
+                split3(dar4[2 * mm], dar4[2 * mm + 1], p3[0][0], p3[0][1], p3[0][2]);
+                split3(daz4[2 * mm], daz4[2 * mm + 1], p3[1][0], p3[1][1], p3[1][2]);
+                split3(dnh4[2 * mm], dnh4[2 * mm + 1], p3[2][0], p3[2][1], p3[2][2]);
+#pragma unroll
+                for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) das[(((gt * NCG + c) * 2 + mm) * 3 + pc) * 64 + lane] = p3[gt][pc];
+            }
+        } else if (BF) {
 #pragma unroll
             for (int mm = 0; mm < 2; ++mm) {
                 das[((0 * NCG + c) * 2 + mm) * 64 + lane] = cvt8(dar4[2 * mm], dar4[2 * mm + 1]);
@@ -455,11 +474,19 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
         for (int q0 = 0; q0 < NQ; q0 += RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) {
-                const f32x4 xv = das[(q0 + u) * 64 + lane];
-                acc = BF ? mfma_bf(wr[u], xv, acc) : mfma4(wr[u], xv, acc);
+                if constexpr (X3) {
+                    f32x4 x3[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) x3[pc] = das[((q0 + u) * 3 + pc) * 64 + lane];
+                    acc = mfma_s3(wr[u], x3, acc);
+                } else {
+                    const f32x4 xv = das[(q0 + u) * 64 + lane];
+                    acc = BF ? mfma_bf(wr[u][0], xv, acc) : mfma4(wr[u][0], xv, acc);
+                }
                 int qn = q0 + u + RING;
                 qn = qn >= NQ ? qn - NQ : qn;
-                wr[u] = W[qn * 64];
+#pragma unroll
+                for (int pc = 0; pc < WPC; ++pc) wr[u][pc] = W[(qn * WPC + pc) * 64];
             }
         }
         dh = acc;
@@ -469,14 +496,16 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const GruBwdArgs a) {
 
 int launch_gru_bwd(const GruBwdArgs& a, hipStream_t s) {
     if (a.B <= 0) return 0;
-    const size_t lds = (size_t)3 * a.NCG * 4 * 64 * sizeof(f32x4);
+    const size_t lds = (size_t)3 * a.NCG * (a.x3 ? 6 : 4) * 64 * sizeof(f32x4);
     if (a.NCG < 1 || a.NCG > 8 || lds > 160 * 1024) return -2;
+    if (a.bf16) return -2;
+    const void* fn = a.x3 ? reinterpret_cast<const void*>(&k_gru_bwd<true>) : reinterpret_cast<const void*>(&k_gru_bwd<false>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gru_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (a.bf16) return -2;
-    hipLaunchKernelGGL(k_gru_bwd, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
+    if (a.x3) hipLaunchKernelGGL(k_gru_bwd<true>, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
+    else hipLaunchKernelGGL(k_gru_bwd<false>, dim3((unsigned)((a.B + 31) / 32)), dim3(64 * a.NCG), lds, s, a);
     LAUNCH_CHECK();
     return 0;
 }

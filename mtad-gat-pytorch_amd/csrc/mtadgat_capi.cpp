@@ -988,6 +988,10 @@ int mtadgat_derived_regions(mtadgat_handle h, int64_t* out, int max_pairs) {
     if (m.bw.supported) {
         for (const GruBwdPlan& gb : m.bw.gru) add(gb.wihT.w3_off, (size_t)gb.wihT.NT * gb.wihT.Q16 * 3 * 256);
         for (const GruBwdPlan& gb : m.bw.rec) add(gb.wihT.w3_off, (size_t)gb.wihT.NT * gb.wihT.Q16 * 3 * 256);
+        for (size_t l = 0; l < m.bw.gru.size(); ++l)
+            if (m.bw.gru[l].whT3_off) add(m.bw.gru[l].whT3_off, (size_t)m.gru[l].NCG * 6 * m.gru[l].NCG * 3 * 256);
+        for (size_t l = 0; l < m.bw.rec.size(); ++l)
+            if (m.bw.rec[l].whT3_off) add(m.bw.rec[l].whT3_off, (size_t)m.rec[l].NCG * 6 * m.rec[l].NCG * 3 * 256);
         for (const LinTPlan& p : m.bw.fcT) add(p.w3_off, (size_t)p.NT * p.Q16 * 3 * 256);
         add(m.bw.recfcT.w3_off, (size_t)m.bw.recfcT.NT * m.bw.recfcT.Q16 * 3 * 256);
         for (int k = 0; k < 2; ++k) add(m.bw.gat[k].lrT.w3_off, (size_t)m.bw.gat[k].lrT.NT * m.bw.gat[k].lrT.Q16 * 3 * 256);
@@ -1829,6 +1833,15 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
             GruBwdArgs ga{};
             ga.Gates = gates; ga.Seq = seq; ga.DHseq = dhseq; ga.lddh = q.Hp; ga.DHend = dhend_; ga.ldde = q.Hp;
             ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + qb.whT_off);
+            if (m.precision == 2 && qb.whT3_off) {       // default arithmetic: three bf16 pieces per operand (split on first use after an upload)
+                if (qb.whT3_version != m.weights_version) {
+                    K_TRY(launch_split3(m.packed_dev + qb.whT_off, m.packed_dev + qb.whT3_off, q.NCG, 12 * q.NCG, 6 * q.NCG, 1, nullptr, s),
+                          "split-bf16 transposed recurrent weights");
+                    qb.whT3_version = m.weights_version;
+                }
+                ga.WhT = reinterpret_cast<const f32x4*>(m.packed_dev + qb.whT3_off);
+                ga.x3 = 1;
+            }
             ga.DA = da; ga.Hp = q.Hp; ga.H = q.H; ga.T = W; ga.NCG = q.NCG; ga.B = n;
             K_TRY(launch_gru_bwd(ga, s), what);
         }

@@ -129,7 +129,8 @@ struct GatBwdPlan {
 };
 struct GruBwdPlan {
     size_t whT_off = 0;             // W_hh^T tiles for k_gru_bwd
-    size_t whT16_off = 0;           // ... as a bf16 pack (bf16 training)
+    size_t whT3_off = 0;            // ... as three bf16 pieces [NCG][6*NCG][3][64], derived on first use after an upload (k_gru_bwd<true>)
+    mutable uint64_t whT3_version = 0;
     LinTPlan wihT;                  // d x = d a W_ih
     WgradPlan wg_ih, wg_hh;
 };

@@ -186,7 +186,8 @@ struct GruBwdArgs {
     float* DA;           // (B*T, 4*Hp) out: dn_x | dr | dz | dn_h  (pre-activation gradients)
     int Hp, H, T, NCG;
     long B;
-    int bf16;            // 1: WhT is the bf16 pack [NCG][6*NCG][64] of 16-feature chunks
+    int bf16;            // (unused: the bf16 training recurrences are gone; a launch with bf16 != 0 is refused)
+    int x3;              // 1: WhT is the split-bf16 pack [NCG][6*NCG][3 pieces][64] of 16-feature chunks (k_gru_bwd<true>)
 };
 
 // dW[m][n] = sum_rows A[row][m] * B[row][n]   (+ a virtual all-ones column n == N: bias gradients)

@@ -408,7 +408,7 @@ std::string validate_and_plan(Model& m) {
             }
             auto gru_b = [&](GruBwdPlan& gb, const GruPlan& g) {
                 gb.whT_off = take((size_t)g.NCG * 12 * g.NCG * 256);
-                gb.whT16_off = take((size_t)g.NCG * 6 * g.NCG * 256);
+                gb.whT3_off = take((size_t)g.NCG * 6 * g.NCG * 3 * 256);
                 lint(gb.wihT, 3 * g.Hp, g.in_dim);
                 wg(gb.wg_ih, 3 * g.Hp, g.in_dim, true);
                 wg(gb.wg_hh, 3 * g.Hp, g.H, true);
@@ -907,11 +907,6 @@ std::string pack_weights(Model& m, const mtadgat_params& p, std::vector<float>& 
                 const int blk = k / Hp, u = k % Hp;
                 return (n < H && u < H && blk < 3) ? w_hh[((size_t)blk * H + u) * H + n] : 0.f;
             });
-            if (m.precision == 1)
-                pack_tiles_bf16(out.data() + gb.whT16_off, g.NCG, 6 * g.NCG, [&](int n, int k) -> float {
-                    const int blk = k / Hp, u = k % Hp;
-                    return (n < H && u < H && blk < 3) ? w_hh[((size_t)blk * H + u) * H + n] : 0.f;
-                });
             auto gate_ih = [](int blk) { return blk == 0 ? 2 : blk - 1; };                            // blocks n | r | z
             pack_tiles(out.data() + gb.wihT.w_off, gb.wihT.NT, gb.wihT.Q, [&](int n, int k) -> float {
                 const int blk = k / Hp, u = k % Hp;
