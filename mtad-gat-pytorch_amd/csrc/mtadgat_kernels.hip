@@ -656,19 +656,29 @@ __global__ __launch_bounds__(256) void k_conv_lds(const ConvArgs a) {
         // one element per lane and row; every load is unconditional (clamped column, a valid row for rows
         // outside the batch) and all of them are issued before the first LDS store: one memory round trip
         // per wave instead of one per row (a guarded load compiles to a branch + s_waitcnt vmcnt(0))
+        // (round 6: the rows' source offsets first -- wave-uniform, with the gather mode's `starts` loads and position updates --, then
+        // nothing but the loads, in one loop per input type: with the offset arithmetic, the gather branch and the bf16 / fp32
+        // choice inside the load loop every row was a control-flow region of its own with s_waitcnt vmcnt(0) at its join, 38 serial
+        // memory round trips per wave -- the whole 38 - 51 us of this kernel at 256 windows)
         constexpr int MAXR = 40;
         float v[MAXR];
+        long srcs[MAXR];
+        bool oks[MAXR];
         const int colc = lane < a.F ? lane : a.F - 1;
 #pragma unroll
         for (int rr = 0; rr < MAXR; ++rr) {
-            v[rr] = 0.f;
-            if (rr < nrow) {                              // wave-uniform
-                bool ok;
-                const long src = src_row(rr, ok);
-                const float t = xload(src + colc);
-                v[rr] = (ok && lane < a.F) ? t : 0.f;
-            }
+            srcs[rr] = 0; oks[rr] = false;
+            if (rr < nrow) srcs[rr] = src_row(rr, oks[rr]);       // wave-uniform
         }
+        if (a.x_bf16) {
+#pragma unroll
+            for (int rr = 0; rr < MAXR; ++rr) v[rr] = __builtin_bit_cast(float, (unsigned)Xh[srcs[rr] + colc] << 16);
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < MAXR; ++rr) v[rr] = a.X[srcs[rr] + colc];
+        }
+#pragma unroll
+        for (int rr = 0; rr < MAXR; ++rr) v[rr] = (oks[rr] && lane < a.F) ? v[rr] : 0.f;
 #pragma unroll
         for (int rr = 0; rr < MAXR; ++rr)
             if (rr < nrow) {
