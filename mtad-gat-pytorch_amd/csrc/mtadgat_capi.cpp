@@ -763,6 +763,7 @@ static void free_device_tables(Model& m) {
     if (sw) (void)hipSetDevice(t.device);
     if (t.gidx_dev) (void)hipFree(t.gidx_dev);
     if (t.foldcode_dev) (void)hipFree(t.foldcode_dev);
+    if (t.foldsum_dev) (void)hipFree(t.foldsum_dev);
     for (int i = 0; i < 2; ++i) {
         if (t.gatcode_dev[i]) (void)hipFree(t.gatcode_dev[i]);
         if (t.colk_dev[i]) (void)hipFree(t.colk_dev[i]);
@@ -771,6 +772,7 @@ static void free_device_tables(Model& m) {
     if (t.pin) (void)hipHostFree(t.pin);
     if (sw) (void)hipSetDevice(cur);
     t.gidx_dev = t.foldcode_dev = nullptr;
+    t.foldsum_dev = nullptr;
     t.pin = nullptr;
     t.ready = false;
     t.device = -1;
@@ -938,6 +940,8 @@ int mtadgat_update_weights_device(mtadgat_handle h, const float* flat_dev, int64
         a.flat = flat_dev; a.wih = t.fo.rec_wih[0]; a.Hin = g.in_dim; a.T = m.W; a.H = g.H; a.Hp = g.Hp; a.NMp = 8 * g.Qx;
         a.code = t.foldcode_dev; a.tile_floats = (long)g.NCG * g.Qxp * 3 * 256;
         a.tiles_out = m.packed_dev + g.wx_off; a.fold_out = g.has16 ? m.packed_dev + g.fold_off : nullptr;
+        if (!t.foldsum_dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t.foldsum_dev), (size_t)3 * g.H * (g.in_dim + 1) * sizeof(double)));
+        a.prefix = t.foldsum_dev;
         K_TRY(launch_pack_fold(a, s), "decoder input fold");
     }
     { int rc = run_split3(m, s); if (rc) return rc; }      // the split packs follow the fp32 packs they are derived from

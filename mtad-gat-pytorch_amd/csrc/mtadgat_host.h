@@ -176,6 +176,7 @@ struct DevTables {
     int* gidx_dev = nullptr;
     int* gatcode_dev[2] = {nullptr, nullptr};
     int* foldcode_dev = nullptr;
+    double* foldsum_dev = nullptr;    // [3 H][Hin + 1] running sums of the decoder's W_ih rows (k_fold_prefix -> k_pack_fold), rebuilt per re-pack
     int* colk_dev[2] = {nullptr, nullptr};
     float* pin = nullptr;             // pinned staging: the two a vectors coming down, the column orders going up
     size_t pin_floats = 0;

@@ -321,6 +321,7 @@ struct PackFoldArgs {
     long tile_floats;
     float* tiles_out;    // [T][tile_floats]
     float* fold_out;     // [T][3][Hp][8] or null
+    double* prefix;      // [3 H][Hin + 1] scratch: prefix[R][j] = sum_{j' < j} W_ih[R][j'] (filled by the launcher's first kernel)
 };
 
 constexpr int FINGERPRINT_MAX_TENSORS = 48;

@@ -109,20 +109,31 @@ __global__ void k_pack_gru_bias(const float* __restrict__ flat, long bih, long b
 
 // decoder input x_t[j] = h_end[(t Hin + j) / T] (reference modules.py:279): the columns of W_ih that share an h_end
 // entry summed per step (double), into the per-step tiles of k_gru's folded input and the plain array of k_gru16
-__device__ float fold_value(const float* __restrict__ wih, int Hin, int T, int R, int t, int k) {
-#pragma clang fp contract(off)
+// Round 6: the column sums come from per-row running sums in double (k_fold_prefix, one pass over W_ih per re-pack) -- every one of
+// the T x (tile slots) outputs used to walk its own up-to-T columns (60 us per optimizer step at the reference's shapes, 3 % of a
+// 256-window training step); a difference of two double prefix sums rounds to the same float as the direct double sum except on
+// rounding ties (the device image was never bit-identical to the host packer's in this one pack: other summation order).
+__device__ float fold_value(const double* __restrict__ prefix, int Hin, int T, int R, int t, int k) {
     const int lo = (int)(((long)t * Hin) / T);
     long j0 = (long)(lo + k) * T - (long)t * Hin, j1 = j0 + T;
     j0 = j0 < 0 ? 0 : j0;
     j1 = j1 > Hin ? Hin : j1;
+    if (j1 <= j0) return 0.f;
+    const double* __restrict__ pr = prefix + (long)R * (Hin + 1);
+    return (float)(pr[j1] - pr[j0]);
+}
+__global__ void k_fold_prefix(const float* __restrict__ wih, int rows, int Hin, double* __restrict__ prefix) {
+#pragma clang fp contract(off)
+    const int R = blockIdx.x * blockDim.x + threadIdx.x;
+    if (R >= rows) return;
     double acc = 0.0;
-    for (long j = j0; j < j1; ++j) acc += (double)wih[(long)R * Hin + j];
-    return (float)acc;
+    double* __restrict__ pr = prefix + (long)R * (Hin + 1);
+    pr[0] = 0.0;
+    for (int j = 0; j < Hin; ++j) { acc += (double)wih[(long)R * Hin + j]; pr[j + 1] = acc; }
 }
 
 __global__ void k_pack_fold(const PackFoldArgs a) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const float* __restrict__ wih = a.flat + a.wih;
     const long n_tiles = (long)a.T * a.tile_floats;
     if (i < n_tiles) {
         const int t = (int)(i / a.tile_floats);
@@ -130,7 +141,7 @@ __global__ void k_pack_fold(const PackFoldArgs a) {
         float v = 0.f;
         if (c > 0) {
             const int R = (c - 1) / a.NMp, k = (c - 1) - R * a.NMp;
-            v = fold_value(wih, a.Hin, a.T, R, t, k);
+            v = fold_value(a.prefix, a.Hin, a.T, R, t, k);
         }
         a.tiles_out[i] = v;
         return;
@@ -142,7 +153,7 @@ __global__ void k_pack_fold(const PackFoldArgs a) {
         const int u = (int)(q % a.Hp);
         const long q2 = q / a.Hp;
         const int st = (int)(q2 % 3), t = (int)(q2 / 3);
-        a.fold_out[j] = u < a.H ? fold_value(wih, a.Hin, a.T, st * a.H + u, t, k) : 0.f;
+        a.fold_out[j] = u < a.H ? fold_value(a.prefix, a.Hin, a.T, st * a.H + u, t, k) : 0.f;
     }
 }
 
@@ -386,6 +397,8 @@ int launch_pack_gru_bias(const float* flat, long bih, long bhh, int H, int Hp, f
 int launch_pack_fold(const PackFoldArgs& a, hipStream_t s) {
     const long n = (long)a.T * a.tile_floats + (a.fold_out ? (long)a.T * 3 * a.Hp * 8 : 0);
     if (n <= 0) return 0;
+    if (!a.prefix) return -2;
+    hipLaunchKernelGGL(k_fold_prefix, dim3((unsigned)((3 * a.H + 63) / 64)), dim3(64), 0, s, a.flat + a.wih, 3 * a.H, a.Hin, a.prefix);
     hipLaunchKernelGGL(k_pack_fold, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return 0;
