@@ -242,10 +242,10 @@ __global__ __launch_bounds__(256, (VEC || BMODE == 1) ? 3 : 2) void k_wgrad_lds(
 // 64 outputs per workgroup, four threads per output (slabs g, g + 4, ...; the four partial sums are added in a fixed order through
 // LDS): with one thread per output the 64 .. 128 slab reads of an element were one chain on a launch of ~1 workgroup per CU
 // (14 us for 20 MB at 256 windows, twelve launches per training step)
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceArgs& a, const unsigned block) {
     __shared__ float part[4][64];
     const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const long idx = (long)blockIdx.x * 64 + e;
+    const long idx = (long)block * 64 + e;
     const int NN = a.N + 1;
     const bool ok = idx < (long)a.M * NN;
     int m = 0, n = 0;
@@ -266,6 +266,15 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduceArgs a) {
         const int ro = a.rowmapB[m];
         if (ro >= 0) a.outB[ro] += v;
     }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradReduceArgs a) { wgrad_reduce_block(a, blockIdx.x); }
+// every reduction of a training step in one launch (round 6): workgroups [first_block[i], first_block[i + 1]) serve entry i
+__global__ __launch_bounds__(256) void k_wgrad_reduce_batch(const WgradReduceBatch b) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < b.n && blockIdx.x >= b.first_block[i + 1]) ++i;                // (uniform, <= 15 steps)
+    wgrad_reduce_block(b.e[i], blockIdx.x - b.first_block[i]);
 }
 
 int launch_wgrad(const WgradArgs& a, hipStream_t s) {
@@ -292,6 +301,28 @@ int launch_wgrad(const WgradArgs& a, hipStream_t s) {
         else
             hipLaunchKernelGGL((k_wgrad_lds<0, false>), grid, dim3(256), 0, s, a);
     }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_wgrad_reduce_batch(const WgradReduceArgs* e, int n, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (n > WGRAD_BATCH_MAX) return -2;
+    WgradReduceBatch b{};
+    unsigned blocks = 0;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        const long total = (long)e[i].M * (e[i].N + 1);
+        if (total <= 0) continue;
+        b.e[k] = e[i];
+        b.first_block[k] = blocks;
+        blocks += (unsigned)((total + 63) / 64);
+        ++k;
+    }
+    b.first_block[k] = blocks;
+    b.n = k;
+    if (k == 0) return 0;
+    hipLaunchKernelGGL(k_wgrad_reduce_batch, dim3(blocks), dim3(256), 0, s, b);
     LAUNCH_CHECK();
     return 0;
 }

@@ -1565,7 +1565,29 @@ struct WgradIn {
     const float* B = nullptr; long ldb = 0; int bmode = 0; int bshift = 0;
     long R = 0; int T = 1;
 };
-int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, float* wpart, float* outW, float* outB, hipStream_t s) {
+// The weight-gradient GEMMs of a backward leave their slab partials in consecutive regions of `base`; the reductions into the flat
+// gradient buffer are queued and run as ONE launch (flush) -- at the end of the backward, or earlier when the region is full.
+struct WgradQueue {
+    float* base = nullptr;
+    size_t cap = 0, used = 0;
+    WgradReduceArgs pend[WGRAD_BATCH_MAX];
+    int n = 0;
+    hipStream_t s = nullptr;
+    int flush() {
+        if (n == 0) return 0;
+        K_TRY(launch_wgrad_reduce_batch(pend, n, s), "weight-gradient reductions");
+        n = 0; used = 0;
+        return 0;
+    }
+};
+int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, WgradQueue& wq, float* outW, float* outB, hipStream_t s) {
+    const int nslab_ = wgrad_slabs(in.R, p.Mp, p.Np);
+    const size_t need_ = ((size_t)nslab_ * p.Mp * p.Np + 63) & ~(size_t)63;
+    if (need_ > wq.cap) return fail(MTADGAT_ERR_WORKSPACE, "internal: weight-gradient partial region too small");
+    if (wq.used + need_ > wq.cap || wq.n == WGRAD_BATCH_MAX)
+        if (int rc_ = wq.flush()) return rc_;
+    float* wpart = wq.base + wq.used;
+    wq.used += need_;
     WgradArgs a{};
     a.A = in.A; a.lda = in.lda; a.M = p.M;
     a.B = in.B; a.ldb = in.ldb; a.N = p.N; a.bmode = in.bmode; a.bshift = in.bshift;
@@ -1585,7 +1607,7 @@ int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, float* wpart, flo
     r.colmap = reinterpret_cast<const int*>(m.packed_dev + p.col_off);
     r.rowmapB = p.has_bias && outB ? reinterpret_cast<const int*>(m.packed_dev + p.rowB_off) : nullptr;
     r.outW = outW; r.outB = outB;
-    K_TRY(launch_wgrad_reduce(r, s), "weight-gradient reduction");
+    wq.pend[wq.n++] = r;
     return 0;
 }
 
@@ -1797,7 +1819,8 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
     const GruPlan& r = m.rec.back();                 // the decoder layer under the per-step Linear
     const float* hcat = T + t.hcat;
     const float* hend = T + t.hend;
-    float* wpart = ws + w.wpart;
+    WgradQueue wpart;
+    wpart.base = ws + w.wpart; wpart.cap = w.wpart_floats; wpart.s = s;
     float* dhend = ws + w.dhend;
 
     // ---- 1. forecasting head (modules.py:307-311)
@@ -2011,7 +2034,7 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         in.A = dpre; in.lda = m.Fp; in.B = x; in.bmode = 1; in.R = RW; in.T = W;
         if ((rc = run_wgrad(m, b.conv_wg, in, wpart, grads + gl.conv_w, grads + gl.conv_b, s))) return rc;
     }
-    return 0;
+    return wpart.flush();            // every weight-gradient reduction of the step, one launch
 }
 
 /* The keep-masks of nn.GRU's dropout between stacked layers (reference modules.py:233 / :253): mask_gru (gru_n_layers - 1, batch, W, H),

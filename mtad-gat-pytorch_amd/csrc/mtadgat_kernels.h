@@ -224,6 +224,14 @@ struct WgradReduceArgs {
     float* outB;
 };
 
+// several reductions in ONE launch (round 6: a training step had twelve of them, 5 - 7 us each, every one behind its GEMM)
+constexpr int WGRAD_BATCH_MAX = 16;
+struct WgradReduceBatch {
+    WgradReduceArgs e[WGRAD_BATCH_MAX];
+    unsigned first_block[WGRAD_BATCH_MAX + 1];     // workgroups [first_block[i], first_block[i + 1]) serve entry i
+    int n;
+};
+
 struct GruArgs {
     const float* X;      // XMODE 0: (B*T, ldx) input rows; XMODE 1: (B, ldx) hin rows
     long ldx;
@@ -403,6 +411,7 @@ int launch_gat_bwd_att(const GatBwdAttArgs& a, int IBL, int JPL, int rj, int nw,
 size_t gat_bwd_att_lds(int K, int D, int vld, int nwa);
 int launch_wgrad(const WgradArgs& a, hipStream_t s);
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s);
+int launch_wgrad_reduce_batch(const WgradReduceArgs* e, int n, hipStream_t s);
 // dst[n] += sum_r src[r*ld + n]  (n < N), two-stage through `scratch` (>= sum_rows_scratch(R, N) floats)
 size_t sum_rows_scratch(long R, int N);
 int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, float* dst, hipStream_t s);

@@ -592,9 +592,10 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
         }
         w.wds = take(ds); w.wlr = take(lr);          // (no transposed copy of d e since round 6: the score backward is one pass)
     }
-    // partial sums of the weight-gradient GEMMs (one at a time)
+    // partial sums of the weight-gradient GEMMs: one region each (round 6), so that their reductions can wait for ONE batched launch
+    // at the end of the backward (the GEMMs used to share a region, each followed by its own reduction launch: twelve per step)
     size_t wp = 0;
-    auto need = [&](const WgradPlan& p, long R) { wp = std::max(wp, (size_t)wgrad_slabs(R, p.Mp, p.Np) * p.Mp * p.Np); };
+    auto need = [&](const WgradPlan& p, long R) { wp += align64((size_t)wgrad_slabs(R, p.Mp, p.Np) * p.Mp * p.Np); };
     const long RW = (long)n * m.W;
     need(b.conv_wg, RW);
     if (m.cfg.use_gatv2) {
