@@ -58,27 +58,46 @@ __device__ float gat_row_value(const PackGatArgs& a, int n, int k) {
 
 // Column order of a GATv2 layer's folded projection (gat_column_order, mtadgat_pack.cpp, on the device): embedding columns with
 // a'_k = (1 - alpha) / 2 a_k >= 0 first, in their own order, padded to a multiple of 8; then the negative ones, likewise.
-// colk[n] = embedding column of sorted column n or -1; ord = [P8, PT, number of non-negative columns].  One workgroup; the
-// embedding has at most a few hundred columns, so one thread walks it.
-__global__ void k_gat_colorder(const float* __restrict__ av, int E, double alpha, int* __restrict__ colk, int ncolk, int* __restrict__ ord) {
+// colk[n] = embedding column of sorted column n or -1; ord = [P8, PT, number of non-negative columns].  One workgroup of 256
+// threads: a counting pass, then a placement pass whose ranks come from wave ballots + the per-wave counts in LDS (both groups keep
+// ascending embedding order, as the host packer writes them).
+__global__ void __launch_bounds__(256) k_gat_colorder(const float* __restrict__ av, int E, double alpha, int* __restrict__ colk, int ncolk, int* __restrict__ ord) {
+    __shared__ int s_cnt[4];
     __shared__ int s_np;
-    const int tid = threadIdx.x;
-    for (int n = tid; n < ncolk; n += blockDim.x) colk[n] = -1;
-    if (tid == 0) {
-        int np = 0;
-        for (int k = 0; k < E; ++k) np += ((1.0 - alpha) * 0.5 * (double)av[k]) >= 0.0 ? 1 : 0;
-        s_np = np;
-    }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int n = tid; n < ncolk; n += 256) colk[n] = -1;
+    int np_local = 0;
+    for (int k = tid; k < E; k += 256) np_local += ((1.0 - alpha) * 0.5 * (double)av[k]) >= 0.0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) np_local += __shfl_xor(np_local, o);
+    if (lane == 0) s_cnt[wv] = np_local;
     __syncthreads();
-    if (tid == 0) {
-        const int np = s_np, P8 = (np + 7) / 8 * 8, N8 = (E - np + 7) / 8 * 8;
-        int ip = 0, in = 0;
-        for (int k = 0; k < E; ++k) {
-            if (((1.0 - alpha) * 0.5 * (double)av[k]) >= 0.0) colk[ip++] = k;
-            else colk[P8 + in++] = k;
+    if (tid == 0) s_np = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+    const int np = s_np, P8 = (np + 7) / 8 * 8, N8 = (E - np + 7) / 8 * 8;
+    int basep = 0, basen = 0;                           // columns of each group placed by the chunks before this one
+    for (int k0 = 0; k0 < E; k0 += 256) {
+        const int k = k0 + tid;
+        const bool in = k < E;
+        const bool pos = in && ((1.0 - alpha) * 0.5 * (double)av[k]) >= 0.0;
+        const unsigned long long bp = __ballot(pos), bi = __ballot(in);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        __syncthreads();                                // the previous chunk's counts have been read
+        if (lane == 0) s_cnt[wv] = __popcll(bp);
+        __syncthreads();
+        int wp = 0, tp = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = s_cnt[w]; if (w < wv) wp += c; tp += c; }
+        const int nin = min(256, E - k0);
+        const int rp = wp + __popcll(bp & below);                                   // non-negative columns of this chunk before k
+        const int rn = (64 * wv - wp) + __popcll((bi & ~bp) & below);               // negative ones (every wave before this one is full)
+        if (in) {
+            if (pos) colk[basep + rp] = k;
+            else colk[P8 + basen + rn] = k;
         }
-        ord[0] = P8; ord[1] = P8 + N8; ord[2] = np; ord[3] = 0;
+        basep += tp; basen += nin - tp;
     }
+    if (tid == 0) { ord[0] = P8; ord[1] = P8 + N8; ord[2] = np; ord[3] = 0; }
 }
 
 __global__ void k_pack_gat(const PackGatArgs a) {
