@@ -253,13 +253,16 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceArgs& a, con
     if (ok) {
         m = (int)(idx / NN);
         n = (int)(idx - (long)m * NN);
-        for (int s = g; s < a.nslab; s += 4) v += a.P[((long)s * a.Mp + m) * a.Np + n];
+        if (a.rowmapW || n < a.N)
+            for (int s = g; s < a.nslab; s += 4) v += a.P[((long)s * a.Mp + m) * a.Np + n];
     }
     part[g][e] = v;
     __syncthreads();
     if (g != 0 || !ok) return;
     v = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
-    if (n < a.N) {
+    if (!a.rowmapW) {
+        if (n < a.N) a.outW[n] += v;                    // a queued column sum (launch_sum_rows_part)
+    } else if (n < a.N) {
         const int ro = a.rowmapW[m], co = a.colmap[n];
         if (ro >= 0 && co >= 0) a.outW[ro + co] += v;
     } else if (a.rowmapB) {
@@ -361,6 +364,16 @@ __global__ __launch_bounds__(256) void k_sum_rows2(const float* __restrict__ par
     ps[g][e] = v;
     __syncthreads();
     if (g == 0 && n < N) dst[n] += (ps[0][e] + ps[1][e]) + (ps[2][e] + ps[3][e]);
+}
+int launch_sum_rows_part(const float* src, long ld, long R, int N, float* scratch, int* nslab, hipStream_t s) {
+    *nslab = 0;
+    if (R <= 0 || N <= 0) return 0;
+    const int S = sum_rows_slabs(R);
+    const long rps = (R + S - 1) / S;
+    hipLaunchKernelGGL(k_sum_rows1, dim3((unsigned)((N + 255) / 256), (unsigned)S), dim3(256), 0, s, src, ld, R, N, rps, scratch);
+    LAUNCH_CHECK();
+    *nslab = S;
+    return 0;
 }
 int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, float* dst, hipStream_t s) {
     if (R <= 0 || N <= 0) return 0;

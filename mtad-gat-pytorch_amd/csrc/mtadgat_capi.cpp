@@ -1610,6 +1610,19 @@ int run_wgrad(Model& m, const WgradPlan& p, const WgradIn& in, WgradQueue& wq, f
     wq.pend[wq.n++] = r;
     return 0;
 }
+// column sums over the windows (d bias / d a of a GATv2 layer): the first stage now, the reduction in the step's batched launch
+int run_sum_rows_queued(const float* src, long ld, long R, int N, float* scratch, float* dst, WgradQueue& wq, hipStream_t s) {
+    if (wq.n == WGRAD_BATCH_MAX)
+        if (int rc_ = wq.flush()) return rc_;
+    int nslab = 0;
+    K_TRY(launch_sum_rows_part(src, ld, R, N, scratch, &nslab, s), "column sums");
+    if (nslab == 0) return 0;
+    WgradReduceArgs r{};
+    r.P = scratch; r.nslab = nslab; r.Mp = 1; r.Np = N; r.M = 1; r.N = N;
+    r.outW = dst;
+    wq.pend[wq.n++] = r;
+    return 0;
+}
 
 }  // namespace
 
@@ -1981,8 +1994,8 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
             WgradIn in;
             in.A = dlr; in.lda = 2L * Ep; in.R = RK; in.T = 1; in.B = Vn; in.ldb = ldv;
             if ((rc = run_wgrad(m, gb.wg, in, wpart, grads + gl.lin_w[which], grads + gl.lin_b[which], s))) return rc;
-            K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
-            K_TRY(launch_sum_rows(dap, Ep, n, gp.E, ws + w.sums, grads + gl.a[which], s), "attention vector gradient");
+            if ((rc = run_sum_rows_queued(de, (long)K * K, n, K * K, ws + w.sums_q[2 * which], grads + gl.bias[which], wpart, s))) return rc;
+            if ((rc = run_sum_rows_queued(dap, Ep, n, gp.E, ws + w.sums_q[2 * which + 1], grads + gl.a[which], wpart, s))) return rc;
             continue;
         }
         GatBwdAttArgs aa{};
@@ -2023,8 +2036,8 @@ int mtadgat_backward(mtadgat_handle h, const float* x, int64_t batch, int64_t wi
         in.A = dlr; in.lda = 2L * gb.Ep; in.R = RK; in.T = 1;
         if (which == 0) { in.B = T + t.xct; in.ldb = m.Wp; } else { in.B = hcat; in.ldb = m.Dp; }
         if ((rc = run_wgrad(m, gb.wg, in, wpart, grads + gl.lin_w[which], grads + gl.lin_b[which], s))) return rc;
-        K_TRY(launch_sum_rows(de, (long)K * K, n, K * K, ws + w.sums, grads + gl.bias[which], s), "attention bias gradient");
-        K_TRY(launch_sum_rows(dap, gb.Ep, n, gp.E, ws + w.sums, grads + gl.a[which], s), "attention vector gradient");
+        if ((rc = run_sum_rows_queued(de, (long)K * K, n, K * K, ws + w.sums_q[2 * which], grads + gl.bias[which], wpart, s))) return rc;
+        if ((rc = run_sum_rows_queued(dap, gb.Ep, n, gp.E, ws + w.sums_q[2 * which + 1], grads + gl.a[which], wpart, s))) return rc;
     }
     // ---- 5. convolution (modules.py:18-22)
     {

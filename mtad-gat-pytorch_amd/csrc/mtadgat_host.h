@@ -257,6 +257,7 @@ struct Tape {
 // scratch of the backward
 struct BwdWorkspace {
     size_t da, dhcat, dhdec, dhend, dz0, dz1, de_f, de_t, dv_f, dv_t, dlr_f, dlr_t, dap_f, dap_t, dpre, wpart, sums, total;
+    size_t sums_q[4];    // GATv2: first-stage column sums of d e / d a' of the two layers, reduced in the step's batched reduction launch
     size_t v1s;          // GAT (v1): [u1 | u2 | k1 k2] and the batch sums [P1 | P2 | SC SD] of the two layers
     size_t wds, wlr;         // wide attention layers (one layer at a time): d S (N K ldS), [L | R] (N K 2 Ep)
     size_t wpart_floats;

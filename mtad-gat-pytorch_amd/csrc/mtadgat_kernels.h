@@ -217,7 +217,7 @@ struct WgradArgs {
 struct WgradReduceArgs {
     const float* P;
     int nslab, Mp, Np, M, N;
-    const int* rowmapW;  // element offset of row m in outW, or -1
+    const int* rowmapW;  // element offset of row m in outW, or -1.  null: a plain vector sum (M = 1): outW[n] += sum_s P[s*Np + n]
     const int* colmap;   // element offset of column n, or -1
     const int* rowmapB;  // element offset in outB, or -1  (null: no bias output)
     float* outW;
@@ -415,6 +415,8 @@ int launch_wgrad_reduce_batch(const WgradReduceArgs* e, int n, hipStream_t s);
 // dst[n] += sum_r src[r*ld + n]  (n < N), two-stage through `scratch` (>= sum_rows_scratch(R, N) floats)
 size_t sum_rows_scratch(long R, int N);
 int launch_sum_rows(const float* src, long ld, long R, int N, float* scratch, float* dst, hipStream_t s);
+// the first stage alone: partial sums [*nslab][N] into `scratch`; the caller queues their reduction (WgradReduceArgs with null maps)
+int launch_sum_rows_part(const float* src, long ld, long R, int N, float* scratch, int* nslab, hipStream_t s);
 // GAT (v1) score backward (mtadgat_bwd.hip)
 size_t gat_bwd_v1_lds(int K, int D);
 int launch_gat_v1_prep(const float* Wm, const float* bv, const float* av, int E, int D, float* u, hipStream_t s);

@@ -612,6 +612,11 @@ void plan_bwd_workspace(const Model& m, int64_t n, BwdWorkspace& w) {
     w.v1s = take(4 * pv);
     const size_t smax = std::max(std::max((size_t)m.W * m.W, pv), std::max((size_t)m.F * m.F, (size_t)std::max(b.gat[0].Ep, b.gat[1].Ep)));
     w.sums = take(sum_rows_scratch(n, (int)smax));
+    for (int which = 0; which < 2; ++which) {
+        const size_t K = which == 0 ? (size_t)m.F : (size_t)m.W;
+        w.sums_q[2 * which] = m.cfg.use_gatv2 ? take(sum_rows_scratch(n, (int)(K * K))) : 0;
+        w.sums_q[2 * which + 1] = m.cfg.use_gatv2 ? take(sum_rows_scratch(n, b.gat[which].Ep)) : 0;
+    }
     w.total = off;
 }
 
