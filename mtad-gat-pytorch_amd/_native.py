@@ -9,6 +9,26 @@ import os
 
 import torch  # must be imported before the library: both bind libamdhip64.so.7, torch's copy wins
 
+# Debugging aid (tests/test_gpu_fuzz.py): every scratch buffer handed to the library (workspace, training tape) is
+# filled with a large finite value before each call, so a kernel that USES scratch it did not write shows up in the outputs of a
+# single call instead of depending on what the caching allocator left in the block (finite, inside the fp16 range: padding that
+# is read and multiplied by zero weights is legitimate and stays harmless).
+_POISON_SCRATCH = bool(os.environ.get("MTADGAT_POISON_SCRATCH"))
+_POISON_VALUE = 7777.0
+
+
+def _empty(*shape, **kw):
+    """torch.empty, poisoned under MTADGAT_POISON_SCRATCH (outputs included: a kernel that accumulates into an output it was
+    supposed to write, or leaves part of it unwritten, shows up the same way)."""
+    t = torch.empty(*shape, **kw)
+    if _POISON_SCRATCH and t.is_floating_point() and t.device.type == "cuda":
+        t.fill_(_POISON_VALUE)
+    return t
+
+
+def _empty_like(x):
+    return _empty(x.shape, dtype=x.dtype, device=x.device)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmtadgat.so")
 MAX_LAYERS = 8
@@ -183,12 +203,14 @@ class Engine:
         v = list(offs)
         return dict(zip(self.TAPE_FIELDS, v[:len(self.TAPE_FIELDS)])), dict(zip(self.WS_FIELDS, v[len(self.TAPE_FIELDS):]))
 
-    def _buf(self, name, nbytes, device):
+    def _buf(self, name, nbytes, device, fresh=True):
         cur = getattr(self, name, None)
         if cur is None or cur.device != device or cur.numel() * 4 < nbytes:
             setattr(self, name, None)
-            cur = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            cur = _empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
             setattr(self, name, cur)
+        if _POISON_SCRATCH and fresh:
+            cur.fill_(_POISON_VALUE)
         return cur
 
     def forward_train(self, x, p, seed, window0=0, tape=None):
@@ -196,13 +218,15 @@ class Engine:
         c = self.cfg
         b = x.shape[0]
         xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
-        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=x.device)
-        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=x.device)
+        preds = _empty((b, c.out_dim), dtype=torch.float32, device=x.device)
+        recons = _empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=x.device)
         if b == 0:
             return preds, recons, None
         need = self.lib.mtadgat_tape_bytes(self.handle, b)
         if tape is None or tape.numel() * 4 < need:
-            tape = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+            tape = _empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        if _POISON_SCRATCH:
+            tape.fill_(_POISON_VALUE)
         self._call(self.lib.mtadgat_forward_train, "forward_train", x.device, xp, b, int(window0), float(p), int(seed),
                    _dev_ptr(preds, "preds"), _dev_ptr(recons, "recons"), _dev_ptr(tape, "tape"), need)
         return preds, recons, tape
@@ -225,28 +249,28 @@ class Engine:
         """d loss / d x of the chunk mtadgat_backward just processed (same stream, same workspace): (b, W, F)."""
         c = self.cfg
         b = x_like.shape[0]
-        dx = torch.empty((b, c.window_size, c.n_features), dtype=torch.float32, device=x_like.device)
+        dx = _empty((b, c.window_size, c.n_features), dtype=torch.float32, device=x_like.device)
         if b == 0:
             return dx
         need_w = self.lib.mtadgat_backward_workspace_bytes(self.handle, b)
-        ws = self._buf("_bws", need_w, x_like.device)
+        ws = self._buf("_bws", need_w, x_like.device, fresh=False)      # (mtadgat_backward's d pre-activations are read from it)
         self._call(self.lib.mtadgat_backward_input, "backward_input", x_like.device, b, _dev_ptr(ws, "workspace"), need_w, _dev_ptr(dx, "dx"))
         return dx
 
     def dropout_masks(self, batch, p, seed, device, window0=0):
         """The keep-masks the kernels apply: {"feat": (b,F,F), "temp": (b,W,W), "fc": [(b,hid)] * hidden layers}."""
         c = self.cfg
-        mf = torch.empty((batch, c.n_features, c.n_features), dtype=torch.float32, device=device)
-        mt = torch.empty((batch, c.window_size, c.window_size), dtype=torch.float32, device=device)
+        mf = _empty((batch, c.n_features, c.n_features), dtype=torch.float32, device=device)
+        mt = _empty((batch, c.window_size, c.window_size), dtype=torch.float32, device=device)
         nh = c.forecast_n_linear - 1
-        mfc = torch.empty((max(nh, 1), batch, c.forecast_hid_dim), dtype=torch.float32, device=device)
+        mfc = _empty((max(nh, 1), batch, c.forecast_hid_dim), dtype=torch.float32, device=device)
         self._call(self.lib.mtadgat_dropout_masks, "dropout_masks", device, batch, int(window0), float(p), int(seed),
                    _dev_ptr(mf, "mask"), _dev_ptr(mt, "mask"), _dev_ptr(mfc, "mask"))
         out = {"feat": mf, "temp": mt, "fc": [mfc[i] for i in range(nh)]}
         lg, ld = c.gru_n_layers - 1, c.recon_n_layers - 1
         if lg > 0 or ld > 0:      # nn.GRU's dropout between stacked layers
-            mg = torch.empty((max(lg, 1), batch, c.window_size, c.gru_hid_dim), dtype=torch.float32, device=device)
-            mr = torch.empty((max(ld, 1), batch, c.window_size, c.recon_hid_dim), dtype=torch.float32, device=device)
+            mg = _empty((max(lg, 1), batch, c.window_size, c.gru_hid_dim), dtype=torch.float32, device=device)
+            mr = _empty((max(ld, 1), batch, c.window_size, c.recon_hid_dim), dtype=torch.float32, device=device)
             self._call(self.lib.mtadgat_dropout_masks_rnn, "dropout_masks_rnn", device, batch, int(window0), float(p), int(seed),
                        _dev_ptr(mg, "mask") if lg > 0 else None, _dev_ptr(mr, "mask") if ld > 0 else None)
             out["gru"] = [mg[i] for i in range(lg)]
@@ -343,7 +367,7 @@ class Engine:
     def read_packed(self, device):
         """Diagnostic: the packed weight image as a CPU tensor."""
         n = self.lib.mtadgat_packed_floats(self.handle)
-        out = torch.empty(n, dtype=torch.float32)
+        out = _empty(n, dtype=torch.float32)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream().cuda_stream
             _check(self.lib.mtadgat_read_packed(self.handle, ctypes.c_void_p(out.data_ptr()), n, ctypes.c_void_p(stream)), "read_packed")
@@ -400,8 +424,10 @@ class Engine:
         ws = self._ws
         if ws is None or ws.device != device or ws.numel() * 4 < need:
             self._ws = None
-            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+            ws = _empty((need + 3) // 4, dtype=torch.float32, device=device)
             self._ws = ws
+        if _POISON_SCRATCH:
+            ws.fill_(_POISON_VALUE)
         return ws, need
 
     def set_precision(self, mode):
@@ -451,9 +477,9 @@ class Engine:
             xp, fn = ctypes.c_void_p(x.data_ptr()), self.lib.mtadgat_forward_xbf16
         else:
             xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
-        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=x.device)
-        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=x.device)
-        hend = torch.empty((b, c.gru_hid_dim), dtype=torch.float32, device=x.device) if want_hend else None
+        preds = _empty((b, c.out_dim), dtype=torch.float32, device=x.device)
+        recons = _empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=x.device)
+        hend = _empty((b, c.gru_hid_dim), dtype=torch.float32, device=x.device) if want_hend else None
         ws, need = self._workspace(b, x.device)
         self._call(fn, "forward", x.device, xp, b, _dev_ptr(preds, "preds"),
                    _dev_ptr(recons, "recons"), _dev_ptr(hend, "hend") if want_hend else None,
@@ -479,9 +505,9 @@ class Engine:
             b = count if count is not None else max(0, (n_rows - c.window_size - start0) // max(stride, 1) + 1)
             stp = None
         dev = series.device
-        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=dev)
-        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=dev) if want_recons else None
-        last = torch.empty((b, c.out_dim), dtype=torch.float32, device=dev) if want_last else None
+        preds = _empty((b, c.out_dim), dtype=torch.float32, device=dev)
+        recons = _empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=dev) if want_recons else None
+        last = _empty((b, c.out_dim), dtype=torch.float32, device=dev) if want_last else None
         ws, need = self._workspace(b, dev)
         self._call(self.lib.mtadgat_forward_series, "forward_series", dev, sp, n_rows, stp, int(start0), int(stride), b,
                    _dev_ptr(preds, "preds"), _dev_ptr(recons, "recons") if want_recons else None,
@@ -492,7 +518,7 @@ class Engine:
         c = self.cfg
         b = x.shape[0]
         xp = _dev_ptr(x, "x", (b, c.window_size, c.n_features))
-        y = torch.empty_like(x)
+        y = _empty_like(x)
         self._call(self.lib.mtadgat_conv, "conv", x.device, xp, b, _dev_ptr(y, "y"), None, 0)
         return y
 
@@ -500,7 +526,7 @@ class Engine:
         c = self.cfg
         b = xc.shape[0]
         xp = _dev_ptr(xc, "x", (b, c.window_size, c.n_features))
-        y = torch.empty_like(xc)
+        y = _empty_like(xc)
         ws, need = self._workspace(b, xc.device)
         self._call(self.lib.mtadgat_gat, "gat", xc.device, which, xp, b, _dev_ptr(y, "y"), _dev_ptr(ws, "workspace"), need)
         return y
@@ -509,7 +535,7 @@ class Engine:
         c = self.cfg
         b = hcat.shape[0]
         xp = _dev_ptr(hcat, "h_cat", (b, c.window_size, 3 * c.n_features))
-        hend = torch.empty((b, c.gru_hid_dim), dtype=torch.float32, device=hcat.device)
+        hend = _empty((b, c.gru_hid_dim), dtype=torch.float32, device=hcat.device)
         ws, need = self._workspace(b, hcat.device)
         self._call(self.lib.mtadgat_gru, "gru", hcat.device, xp, b, _dev_ptr(hend, "h_end"), _dev_ptr(ws, "workspace"), need)
         return hend
@@ -518,8 +544,8 @@ class Engine:
         c = self.cfg
         b = hend.shape[0]
         hp = _dev_ptr(hend, "h_end", (b, c.gru_hid_dim))
-        preds = torch.empty((b, c.out_dim), dtype=torch.float32, device=hend.device) if want_preds else None
-        recons = torch.empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=hend.device) if want_recons else None
+        preds = _empty((b, c.out_dim), dtype=torch.float32, device=hend.device) if want_preds else None
+        recons = _empty((b, c.window_size, c.out_dim), dtype=torch.float32, device=hend.device) if want_recons else None
         ws, need = self._workspace(b, hend.device)
         self._call(self.lib.mtadgat_heads, "heads", hend.device, hp, b,
                    _dev_ptr(preds, "preds") if want_preds else None,

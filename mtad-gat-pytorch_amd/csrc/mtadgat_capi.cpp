@@ -1782,21 +1782,35 @@ int mtadgat_forward_train(mtadgat_handle h, const float* x, int64_t batch, int64
         K_TRY(launch_rowgemm(a, s), "reconstruction Linear (training)");
     } else {
         // layer 0 reads the repeated h_end (modules.py:279), the layers above the (dropped-out) states of the one below; the
-        // per-step Linear (modules.py:282) rides in the last layer
+        // per-step Linear (modules.py:282) rides in the last layer while its weights fit beside the state in 64 KB of LDS
+        // (launch_gru_split), otherwise it is a row GEMM over the kept states -- as in the small-batch branch above
         const float* xin = hend;
         long ldin = g.Hp;
         int kx = m.cfg.gru_hid_dim;
+        const GruPlan& rlast = m.rec[Ld - 1];
+        const bool fc_rides = ((size_t)rlast.NCG * 1024 + (size_t)rlast.NCG * m.rec_fc.out_dim * 32) * sizeof(float) <= 64 * 1024;
         for (int l = 0; l < Ld; ++l) {
             const GruPlan& rl = m.rec[l];
-            const bool last = l == Ld - 1;
+            const bool last = l == Ld - 1, fused = last && fc_rides;
             float* seq = T + (l == 0 ? t.seq_d : t.seq_du[l - 1]);
             float* gates = T + (l == 0 ? t.gates_d : t.gates_du[l - 1]);
-            if ((rc = run_gru_layer(m, S_RECON, rl, xin, ldin, kx, n, nullptr, 0, seq, last ? &m.rec_fc : nullptr, last ? recons : nullptr, nullptr, s,
+            if ((rc = run_gru_layer(m, S_RECON, rl, xin, ldin, kx, n, nullptr, 0, seq, fused ? &m.rec_fc : nullptr, fused ? recons : nullptr, nullptr, s,
                                     gates))) return rc;
             if (!last) {
                 float* dr = T + t.drop_d[l];
                 K_TRY(launch_seq_dropout(seq, dr, n, W, rl.H, rl.Hp, drop, DROP_REC0 + (unsigned)l, s), "decoder inter-layer dropout");
                 xin = dr; ldin = rl.Hp; kx = rl.H;
+            } else if (!fused) {
+                Scope sc(m, S_RECON, s);
+                const LinPlan& p = m.rec_fc;
+                RowGemmArgs a{};
+                a.X = seq; a.ldx = rl.Hp; a.Kvalid = rl.H; a.Q = p.Q;
+                a.Wp = reinterpret_cast<const f32x4*>(m.packed_dev + p.w_off);
+                a.bias = m.packed_dev + p.b_off;
+                a.Y = recons; a.ldy = p.out_dim; a.Nvalid = p.out_dim;
+                a.vec_store = (p.out_dim % 4 == 0 && aligned16(recons)) ? 1 : 0;
+                a.R = n * (int64_t)W; a.NT = p.NT; a.NT_rm = p.NT; a.group = 1; a.relu = 0;
+                K_TRY(launch_rowgemm(a, s), "reconstruction Linear (training)");
             }
         }
     }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256 / CW_RT, CW_RT == 1 ? 4 : 3) void k_conv_win(co
                     if (f0 + 2 * e2 < total) { Xh[(pad + r0) * pvh + c0] = (unsigned short)hw_; Xl[(pad + r0) * pvh + c0] = (unsigned short)lw_; }
                     if (f0 + 2 * e2 + 1 < total) { Xh[(pad + r1) * pvh + c1] = (unsigned short)(hw_ >> 16); Xl[(pad + r1) * pvh + c1] = (unsigned short)(lw_ >> 16); }
                     col += 2;
-                    if (col >= F) { col -= F; ++row; }
+                    if (col >= F) { col -= F; ++row; if (col >= F) { col -= F; ++row; } }      // (F = 1: a pair is two rows)
                 }
             }
         }

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512, MTADGAT_GAT_MINW) void k_gath(const GatArgs a)
                         if (fl0 + 2 * e2 < total) { Xh[(pad + r0) * pvx + c0] = (unsigned short)hw_; Xl[(pad + r0) * pvx + c0] = (unsigned short)lw_; }
                         if (fl0 + 2 * e2 + 1 < total) { Xh[(pad + r1) * pvx + c1] = (unsigned short)(hw_ >> 16); Xl[(pad + r1) * pvx + c1] = (unsigned short)(lw_ >> 16); }
                         col += 2;
-                        if (col >= F) { col -= F; ++row; }
+                        if (col >= F) { col -= F; ++row; if (col >= F) { col -= F; ++row; } }      // (F = 1: a pair is two rows)
                     }
                 }
             }

@@ -21,6 +21,9 @@ CONFIGS = {
                         forecast_n_layers=1, forecast_hid_dim=8),          # decoder input folds more than 8 entries per step
     "many_nodes": dict(n_features=5, window_size=140, out_dim=5, kernel_size=3, gru_hid_dim=16, recon_hid_dim=16,
                        forecast_n_layers=1, forecast_hid_dim=8),           # temporal layer beyond the fused kernel
+    "long_embedding": dict(n_features=4, window_size=300, out_dim=4, kernel_size=3, gru_hid_dim=16, recon_hid_dim=16,
+                           forecast_n_layers=1, forecast_hid_dim=8),       # feature layer: 600 embedding columns = three chunks of
+                                                                           # k_gat_colorder's ballot ranks, the last one partial
 }
 
 
