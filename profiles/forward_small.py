@@ -5,6 +5,9 @@ import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mtad-gat-pytorch_amd")); sys.path.insert(0, ROOT)
 import torch
+if os.environ.get("VARIANT"):           # a developer build of the library (profiles/build_variants.sh) instead of the in-tree one
+    import _native
+    _native._LIB_PATH = os.path.join(ROOT, "profiles", "bin", "variants", os.environ["VARIANT"], "libmtadgat.so")
 from mtad_gat import MTAD_GAT
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
