@@ -2,7 +2,9 @@
 the kernel-selection thresholds, series scoring, the training step's gradients, the forward after optimizer steps (device-side
 re-pack) -- against the package's torch-op algebra on the same device (pinned to the oracle / the reference by the CPU tests).
 
-Round 6 ran this generator over ~600 configurations (scratch runs, seeds 1..11).  It found two defects the hand-picked shapes had
+Round 6 ran this generator over ~900 configurations (scratch runs: the shapes below, an edge-value generator -- dims at 1 / 2 / tile
+boundaries, batches at every kernel-selection threshold +-1 --, dropout-mode and large-batch gradients, bf16 / fp16 / non-contiguous /
+empty inputs, strided series).  It found two defects the hand-picked shapes had
 missed, both kept below as explicit cases:
   * a univariate series (n_features = 1) at 4 096 windows or more: the window-per-workgroup convolution staged its input pairs with
     a single row wrap (k_conv_win / k_gath<CONV>), i.e. wrong and run-to-run varying results for F = 1;
@@ -127,7 +129,9 @@ def _check_case(kw, batches, series, seed, dev, train=True):
             bad.append(f"{n}: diff {dd:.3e} scale {sc:.3e}")
     assert not bad, f"gradients (b={b}): " + "; ".join(bad)
     # two optimizer steps with sign flips of the attention vectors (device-side re-pack, new column order), then the forward
-    opt = torch.optim.Adam(m.parameters(), lr=3e-2)
+    # (lr 1e-2: two Adam steps of 3e-2 can push a 256-unit GRU over 256 time steps into a chaotic regime where torch's own fp32 and
+    # fp64 results differ by O(10) on the CPU -- seen once in the scratch runs; nothing to compare there)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
     for _ in range(2):
         opt.zero_grad()
         p, r = m(x)
