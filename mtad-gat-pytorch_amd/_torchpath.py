@@ -22,6 +22,8 @@ reproduces the reference's masks exactly.  `masks` (optional) injects explicit k
 {"feat": (b,F,F), "temp": (b,W,W), "fc": [(b,hid), ...]} of 0/1 floats, scaled by 1/(1-p) here; with stacked recurrences also
 "gru" / "rec": [(b,W,H), ...] for nn.GRU's dropout between the layers.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -71,6 +73,13 @@ def temporal_gat_stage(model, xc, training=False, mask=None):
     return graph_attention(xc, model.temporal_gat, training, mask)
 
 
+def _no_miopen_rnn(t):
+    """On the GPU nn.GRU dispatches to MIOpen's fused RNN, which returned wrong, call-order dependent results for some shape
+    sequences in round 6's random-shape runs (tests/test_gpu_fuzz.py; 0.1 .. 0.5 off, gone with the fused RNN disabled): the
+    torch-op route uses aten's own GRU there.  (The CPU route is unaffected.)"""
+    return torch.backends.cudnn.flags(enabled=False) if t.device.type == "cuda" else contextlib.nullcontext()
+
+
 def _layered_gru(rnn, x, masks):
     """nn.GRU evaluated layer by layer (single-layer aten::gru calls on the module's own parameters), with the given keep-masks
     (b, W, H) applied -- scaled by 1 / (1 - p) -- to the outputs of every layer but the last: nn.GRU's inter-layer dropout
@@ -80,7 +89,8 @@ def _layered_gru(rnn, x, masks):
     for l in range(rnn.num_layers):
         w = [getattr(rnn, f"{k}_l{l}") for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
         h0 = out.new_zeros(1, out.shape[0], rnn.hidden_size)
-        out, _ = torch._VF.gru(out, h0, w, True, 1, 0.0, False, False, True)
+        with _no_miopen_rnn(out):
+            out, _ = torch._VF.gru(out, h0, w, True, 1, 0.0, False, False, True)
         if l + 1 < rnn.num_layers:
             out = out * masks[l] * (1.0 / (1.0 - p))
     return out
@@ -89,7 +99,8 @@ def _layered_gru(rnn, x, masks):
 def gru_stage(model, h_cat, masks=None):
     if masks:
         return _layered_gru(model.gru.gru, h_cat, masks)[:, -1, :]
-    _, h = model.gru.gru(h_cat)                                 # nn.GRU: h0 = 0, inter-layer dropout in train()
+    with _no_miopen_rnn(h_cat):
+        _, h = model.gru.gru(h_cat)                             # nn.GRU: h0 = 0, inter-layer dropout in train()
     return h[-1]
 
 
@@ -107,7 +118,8 @@ def recon_stage(model, h_end, masks=None):
     if masks:
         dec = _layered_gru(model.recon_model.decoder.rnn, rep, masks)
     else:
-        dec, _ = model.recon_model.decoder.rnn(rep)
+        with _no_miopen_rnn(rep):
+            dec, _ = model.recon_model.decoder.rnn(rep)
     return model.recon_model.fc(dec)
 
 
