@@ -162,6 +162,54 @@ def test_seeded_random_shapes(ci, gpu_device):
     _check_case(kw, batches, series, 7000 + ci, gpu_device)
 
 
+@pytest.mark.parametrize("ci", range(5))
+def test_input_variants_on_random_shapes(ci, gpu_device):
+    """Non-contiguous inputs (a transposed view, a strided slice), an empty batch, bf16 / fp16 tensors (answered in their dtype),
+    and d loss / d x, on seeded random shapes against the CPU checker."""
+    import copy
+    from mtad_gat import MTAD_GAT
+    import _torchpath
+    dev = gpu_device
+    kw, batches, _ = _rand_case(random.Random(4100003 + ci))
+    torch.manual_seed(41000 + ci)
+    m = MTAD_GAT(**kw)
+    with torch.no_grad():
+        m.feature_gat.bias.normal_()
+        m.temporal_gat.bias.normal_()
+    m.eval()
+    ref_model = copy.deepcopy(m)
+    m = m.to(dev)
+    w, f, b = kw["window_size"], kw["n_features"], batches[1]
+    x_nc = torch.rand(b, f, w, device=dev).transpose(1, 2)
+    x_sl = torch.rand(2 * b, w, f, device=dev)[::2]
+    with torch.no_grad():
+        for xx in (x_nc, x_sl):
+            assert not xx.is_contiguous()
+            p, r = m(xx)
+            ph, rh = _torchpath.forward(ref_model, xx.cpu().contiguous(), None)
+            d = max((p.cpu() - ph).abs().max().item(), (r.cpu() - rh).abs().max().item())
+            assert d <= 1e-5, f"non-contiguous input: {d:.2e}"
+        pe, re_ = m(torch.empty(0, w, f, device=dev))
+        assert pe.shape == (0, kw["out_dim"]) and re_.shape == (0, w, kw["out_dim"])
+        for dt, tol in ((torch.bfloat16, 8e-2), (torch.float16, 2e-3)):
+            xh = torch.rand(b, w, f, device=dev).to(dt)
+            p, r = m(xh)
+            assert p.dtype == dt and r.dtype == dt
+            ph, rh = _torchpath.forward(ref_model, xh.float().cpu(), None)
+            d = max((p.float().cpu() - ph).abs().max().item(), (r.float().cpu() - rh).abs().max().item())
+            assert d <= tol, f"{dt} input: {d:.2e}"
+    if w * f * 4 <= 64 * 1024:                                  # (mtadgat_backward_input: one window per workgroup's LDS)
+        x = torch.rand(b, w, f, device=dev, requires_grad=True)
+        y = torch.rand(b, kw["out_dim"], device=dev)
+        p, r = m(x)
+        _loss(p, r, x, y).backward()
+        xc = x.detach().cpu().requires_grad_(True)
+        ph, rh = _torchpath.forward(ref_model, xc, None)
+        _loss(ph, rh, xc, y.cpu()).backward()
+        dd, sc = (x.grad.cpu() - xc.grad).abs().max().item(), xc.grad.abs().max().item()
+        assert dd <= 1e-6 + 1e-4 * sc, f"d loss / d x: {dd:.2e} of {sc:.2e}"
+
+
 def test_poisoned_scratch_and_outputs():
     """The same checks in a fresh process whose scratch buffers and outputs start out as 7777.0 instead of a new allocation's zeros."""
     code = (
