@@ -2,7 +2,7 @@
 the kernel-selection thresholds, series scoring, the training step's gradients, the forward after optimizer steps (device-side
 re-pack) -- against the package's torch-op algebra on the same device (pinned to the oracle / the reference by the CPU tests).
 
-Round 6 ran this generator over ~900 configurations (scratch runs: the shapes below, an edge-value generator -- dims at 1 / 2 / tile
+Round 6 ran this generator over ~1 000 configurations (scratch runs: the shapes below, 100 wide shapes of up to 512 nodes, an edge-value generator -- dims at 1 / 2 / tile
 boundaries, batches at every kernel-selection threshold +-1 --, dropout-mode and large-batch gradients, bf16 / fp16 / non-contiguous /
 empty inputs, strided series).  It found two defects the hand-picked shapes had
 missed, both kept below as explicit cases:
